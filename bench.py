@@ -1,0 +1,198 @@
+#!/usr/bin/env python
+"""Throughput of the episodic few-shot hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank/GPU)
+
+One step = one synthetic ORBIT-shaped task through SingleStepFewShotRecogniser.personalise() + predict() with
+the support/query frames already resident in HBM (5-way, 5 shots x 8 frames = 200 support frames, 200 query
+frames). Metric (BASELINE.json): query frames/sec per task = M / (t_personalise + t_predict); `value` is the
+whole-job rate over all ranks (tasks are independent units: rank r runs its own tasks, no data-path collective;
+"scaling": "weak"). Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel = the fp32-MFMA
+implicit-GEMM convolution, per-launch HIP events on its stream) and `cpu_baseline` (the PyTorch-CPU oracle of
+the same path timed on this box's host cores, N=1 only, bounded sample).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import orbit_dataset_amd  # noqa: E402,F401
+from orbit_dataset_amd import _lib, synthetic  # noqa: E402
+from orbit_dataset_amd.model.few_shot_recognisers import SingleStepFewShotRecogniser  # noqa: E402
+
+WORKLOADS = {
+    # name: (extractor, adapt_features, frame size)   — BASELINE.json configs[1..3]
+    "resnet18_84": ("resnet18", False, 84),
+    "efficientnet_b0_224": ("efficientnet_b0", False, 224),
+    "resnet18_224": ("resnet18", False, 224),
+    "cnaps_resnet18_224": ("resnet18", True, 224),
+}
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+WAY, SHOTS, FRAMES_PER_SHOT, NUM_QUERY = 5, 5, 8, 200
+
+
+def build_model(workload, device):
+    fe_name, adapt, _ = WORKLOADS[workload]
+    model = SingleStepFewShotRecogniser(fe_name, adapt, "proto", 1, 256, False, 16, 1.0)
+    synthetic.init_parameters_(model)
+    if adapt:
+        from orbit_dataset_amd.model.film import get_film_parameters
+        model.film_generator.initial_film_parameters = get_film_parameters(model.film_parameter_names,
+                                                                           model.feature_extractor)
+    model._set_device(device)
+    model._send_to_device()
+    model.set_test_mode(True)
+    return model
+
+
+def run_task(model, task):
+    model.personalise(task["context_clips"], task["context_labels"])
+    logits = model.predict(task["target_clips"])
+    model._reset()
+    return logits
+
+
+def cpu_baseline(workload, model):
+    """The oracle (CPU restatement of the reference path) on ONE task of the same workload, all host cores."""
+    from oracle.recogniser import OracleRecogniser
+    fe_name, adapt, size = WORKLOADS[workload]
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    ref = OracleRecogniser(fe_name, adapt, "proto", 1, 256)
+    sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    ref.fe.load_state_dict({k[len("feature_extractor."):]: v for k, v in sd.items() if k.startswith("feature_extractor.")})
+    if adapt:
+        ref.set_encoder.load_state_dict({k[len("set_encoder."):]: v for k, v in sd.items() if k.startswith("set_encoder.")})
+        ref.build_film_generator().load_state_dict(
+            {k[len("film_generator."):]: v for k, v in sd.items() if k.startswith("film_generator.")})
+    task = synthetic.make_task(0, WAY, SHOTS, FRAMES_PER_SHOT, NUM_QUERY, size)
+    warm = synthetic.make_task(1, WAY, 1, 2, 4, size)
+    ref.personalise(warm["context_clips"], warm["context_labels"])
+    ref.predict(warm["target_clips"])
+    t0 = time.perf_counter()
+    ref.personalise(task["context_clips"], task["context_labels"])
+    logits = ref.predict(task["target_clips"])
+    dt = time.perf_counter() - t0
+    return {"value": NUM_QUERY / dt, "unit": "query frames/s", "cores": cores, "kind": "port",
+            "sample": "1 task (200 support + 200 query frames, %dx%d), PyTorch-CPU oracle, %.1f s" % (size, size, dt)
+            }, task, logits
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="efficientnet_b0_224", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--distinct-tasks", type=int, default=4, help="tasks resident in HBM, cycled through")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    _lib.require_gpu()
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    fe_name, adapt, size = WORKLOADS[args.workload]
+    model = build_model(args.workload, device)
+    # each rank owns its own tasks (task index = rank + world * i): weak scaling, independent units
+    tasks = [synthetic.make_task_on_device(rank + world * i, WAY, SHOTS, FRAMES_PER_SHOT, NUM_QUERY, size, 1, device)
+             for i in range(max(1, args.distinct_tasks))]
+    lib = _lib.load()
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        run_task(model, tasks[i % len(tasks)])
+    barrier()
+    lib.orbit_prof_enable(1)
+    t0 = time.perf_counter()
+    correct = torch.zeros(2, device=device)
+    for i in range(args.steps):
+        task = tasks[i % len(tasks)]
+        logits = run_task(model, task)
+        correct[0] += (logits.argmax(1) == task["target_labels"]).sum()
+        correct[1] += logits.shape[0]
+    barrier()
+    elapsed = time.perf_counter() - t0
+    lib.orbit_prof_enable(0)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.all_reduce(correct)  # frame-accuracy counts: the only exchange of the task-parallel form
+
+    ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+    _lib.check(lib.orbit_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "orbit_prof_collect")
+    variants = []
+    for i in range(lib.orbit_prof_num_variants()):
+        name = ctypes.create_string_buffer(48)
+        ln, vms, vfl = ctypes.c_long(), ctypes.c_double(), ctypes.c_double()
+        lib.orbit_prof_variant(i, name, ctypes.byref(ln), ctypes.byref(vms), ctypes.byref(vfl))
+        if ln.value:
+            variants.append({"kernel": name.value.decode(), "launches": ln.value,
+                             "avg_us": round(1e3 * vms.value / ln.value, 2),
+                             "tflops": round(vfl.value / (vms.value * 1e-3) / 1e12, 2) if vms.value > 0 else None})
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    macs = model.feature_extractor.macs_per_frame(size, size)
+    out = {
+        "metric": "query frames/sec per task (224x224, 5-way ProtoNet) + frame accuracy vs ref",
+        "value": NUM_QUERY * args.steps * world / elapsed,
+        "unit": "query frames/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s: ProtoNet + %s%s, %dx%d, %d-way, %d support frames (%d shots x %d), %d query "
+                               "frames, clip_length 1, batch_size 256, inputs resident in HBM" % (
+                                   args.workload, fe_name, " + CNAPs FiLM adaptation" if adapt else "", size, size, WAY,
+                                   WAY * SHOTS * FRAMES_PER_SHOT, SHOTS, FRAMES_PER_SHOT, NUM_QUERY),
+                   "tasks_per_step": 1, "parallelism": "task-parallel x%d (independent tasks per rank)" % world},
+        "frame_accuracy": float(correct[0].item() / max(correct[1].item(), 1)),
+        "extractor_gflop_per_task": 2 * macs * (WAY * SHOTS * FRAMES_PER_SHOT + NUM_QUERY) / 1e9,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "kernel": "orbit::conv_igemm_kernel (all instantiations)",
+                     "launches": n.value, "avg_launch_us": 1e3 * ms.value / max(n.value, 1),
+                     "kernel_time_share": ms.value / (1e3 * elapsed), "variants": variants},
+    }
+    if not args.no_cpu_baseline and world == 1:
+        base, task, want = cpu_baseline(args.workload, model)
+        got = run_task(model, {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in task.items()}).cpu()
+        base["max_abs_dlogit_vs_gpu"] = float((got - want).abs().max().item())
+        base["argmax_identical"] = bool(torch.equal(got.argmax(1), want.argmax(1)))
+        out["cpu_baseline"] = base
+    else:
+        out["cpu_baseline"] = None
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

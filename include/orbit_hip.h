@@ -1,0 +1,185 @@
+/*
+ * orbit_hip.h — C-ABI of liborbit_hip.so: the MI355X (gfx950) implementation of ORBIT's episodic
+ * few-shot recognition hot path (FewShotRecogniser.personalise()/predict()).
+ *
+ * The reference (microsoft/ORBIT-Dataset) is pure Python/PyTorch and has no FFI of its own; the seam
+ * this library replaces is the ATen op sequence under these reference call sites (file:line are
+ * relative to the reference tree):
+ *
+ *   orbit_proto_configure / _finalize   model/classifier_heads.py:94-119 (_build_class_reps),
+ *                                        :232-263 (PrototypicalClassifier.configure)
+ *   orbit_proto_predict                  model/classifier_heads.py:202-230 (PrototypicalClassifier.predict)
+ *   orbit_mean_pool                      model/poolers.py:7-16 (MeanPooler.forward)
+ *   orbit_extractor_*                    model/feature_extractors.py:37-79 (create_feature_extractor) and
+ *                                        model/few_shot_recognisers.py:99-153 (_get_features[_in_batches]);
+ *                                        "set_encoder": model/set_encoders.py:81-120 (SimplePrePoolNet)
+ *   film_gamma / film_beta arguments     model/few_shot_recognisers.py:114-115,143-144
+ *                                        (functional_call with the FiLM dict), model/film.py:38-94
+ *   orbit_set_mean                       model/set_encoders.py:61-75 (SetEncoder.aggregate 'mean')
+ *   orbit_filmgen_*                      model/feature_adapters.py:36-78 (FilmParameterGenerator),
+ *                                        model/mlps.py:52-63 (DenseBlock)
+ *   orbit_op_*                           single operators (conv/pool/depthwise/SE) exposed for parity tests
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer to contiguous memory owned by the caller (fp32 unless stated,
+ *     labels int64). The library never frees or retains caller memory past the call.
+ *   - `stream` is a hipStream_t passed as void*. Calls only enqueue work and return immediately.
+ *   - return 0 on success, negative on error; orbit_last_error() returns a thread-local message.
+ *   - the library uses the calling thread's current HIP device; handles belong to the device they were
+ *     created on. One process per GPU is the intended deployment.
+ *   - no global mutable state besides the thread-local error string.
+ */
+#ifndef ORBIT_HIP_H
+#define ORBIT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct orbit_extractor orbit_extractor_t;
+typedef struct orbit_filmgen orbit_filmgen_t;
+typedef void* orbit_stream_t; /* hipStream_t */
+
+#define ORBIT_OK 0
+#define ORBIT_ERR_ARG (-1)
+#define ORBIT_ERR_HIP (-2)
+#define ORBIT_ERR_STATE (-3)
+#define ORBIT_ERR_NOMEM (-4)
+
+#define ORBIT_ACT_NONE 0
+#define ORBIT_ACT_RELU 1
+#define ORBIT_ACT_SILU 2
+
+/* ---- library ---------------------------------------------------------------------------------- */
+int orbit_version(void);
+const char* orbit_last_error(void);
+/* number of visible HIP devices (<=0: no usable GPU); does not create a context on failure */
+int orbit_device_count(void);
+
+/* ---- prototype head ---------------------------------------------------------------------------- */
+/* Per-class sums of per-clip mean-pooled support features.
+ *   feats   [n_tasks][N*T][D]   frame features, clip-major (clip i owns rows i*T .. i*T+T-1)
+ *   labels  [n_tasks][N]        int64 clip labels
+ *   class_ids [n_tasks][C]      int64 ascending unique labels (column order of the logits)
+ *   sums    [n_tasks][C][D] out Σ over clips of class c of mean_T(feats)   (all-reduce payload)
+ *   counts  [n_tasks][C]    out number of clips of class c (as float)      (all-reduce payload)
+ * Summation order per (class, d) is ascending clip index: deterministic. */
+int orbit_proto_configure(const float* feats, const int64_t* labels, const int64_t* class_ids,
+                          int n_tasks, int N, int T, int D, int C,
+                          float* sums, float* counts, orbit_stream_t stream);
+
+/* W[c] = 2*mu_c, b[c] = -mu_c.mu_c with mu_c = sums[c]/counts[c]  (classifier_heads.py:253-255).
+ * cosine != 0: b is not written (may be NULL). */
+int orbit_proto_finalize(const float* sums, const float* counts, int n_tasks, int C, int D, int cosine,
+                         float* W, float* b, orbit_stream_t stream);
+
+/* logits[m][c] = logit_scale * (q_m . W_c + b_c)                       (euclidean, :213)
+ *              = logit_scale * cos(q_m, W_c), eps 1e-8 per norm        (cosine, :215-217)
+ * with q_m = mean over the T frames of clip m of Q.   Q [n_tasks][M*T][D]; logits [n_tasks][M][C];
+ * argmax [n_tasks][M] int32 or NULL (first maximal column, as torch.argmax). */
+int orbit_proto_predict(const float* Q, const float* W, const float* b,
+                        int n_tasks, int M, int T, int D, int C, float logit_scale, int cosine,
+                        float* logits, int32_t* argmax, orbit_stream_t stream);
+
+/* out[i][d] = mean_t x[i*T+t][d]  (poolers.py:13-16) */
+int orbit_mean_pool(const float* x, int N, int T, int D, float* out, orbit_stream_t stream);
+
+/* out[d] = (1/n) Σ_i x[i][d]  (set_encoders.py:70-71; also the LITE concat-mean) */
+int orbit_set_mean(const float* x, int n, int D, float* out, orbit_stream_t stream);
+
+/* ---- feature extractors / set encoder ---------------------------------------------------------- */
+/* name: "resnet18" | "efficientnet_b0" | "set_encoder".  H,W: frame size the plan is built for. */
+int orbit_extractor_create(const char* name, int H, int W, orbit_extractor_t** out);
+void orbit_extractor_destroy(orbit_extractor_t* fe);
+
+/* state_dict enumeration: parameter/buffer keys the extractor expects (torch state_dict names). */
+int orbit_extractor_num_params(const orbit_extractor_t* fe);
+const char* orbit_extractor_param_name(const orbit_extractor_t* fe, int i);
+size_t orbit_extractor_param_numel(const orbit_extractor_t* fe, int i);
+
+/* copy one tensor (host or device pointer, fp32, torch layout) into the extractor. */
+int orbit_extractor_load(orbit_extractor_t* fe, const char* key, const float* data, size_t numel);
+/* repack conv weights for the kernels, precompute folded BN for the non-FiLM case. Call after loads. */
+int orbit_extractor_finalize(orbit_extractor_t* fe, orbit_stream_t stream);
+
+int orbit_extractor_output_size(const orbit_extractor_t* fe);
+/* FiLM-tagged BatchNorms in module-traversal order: count, per-slot channel count and module name,
+ * total channels (= length of film_gamma / film_beta). */
+int orbit_extractor_film_slots(const orbit_extractor_t* fe);
+int orbit_extractor_film_slot_channels(const orbit_extractor_t* fe, int slot);
+const char* orbit_extractor_film_slot_name(const orbit_extractor_t* fe, int slot);
+int orbit_extractor_film_size(const orbit_extractor_t* fe);
+
+size_t orbit_extractor_workspace_bytes(const orbit_extractor_t* fe, int B);
+/* multiply-accumulates per frame of the plan (for roofline accounting) */
+double orbit_extractor_macs_per_frame(const orbit_extractor_t* fe);
+
+/* frames [B][3][H][W] NCHW fp32 -> feats [B][D].
+ * film_gamma/film_beta: NULL, or the per-task BatchNorm weight/bias of every FiLM slot concatenated in
+ * slot order (the tensors the reference passes through functional_call). */
+int orbit_extractor_forward(orbit_extractor_t* fe, const float* frames, int B,
+                            const float* film_gamma, const float* film_beta,
+                            float* feats, void* workspace, size_t workspace_bytes, orbit_stream_t stream);
+
+/* ---- FiLM parameter generator ------------------------------------------------------------------ */
+/* n_gen generators (sorted FiLM-name order). Generator i: Linear(z_dim,hid) -> LayerNorm(hid) -> ReLU ->
+ * Linear(hid,out_size[i]); kind[i]: 0 = 'weight' (gamma' = g0*(o*r+1)), 1 = 'bias' (beta' = b0 + o*r);
+ * dst_offset[i]: offset of its output inside film_gamma (kind 0) / film_beta (kind 1). */
+int orbit_filmgen_create(int n_gen, int z_dim, int hidden, const int* out_size, const int* kind,
+                         const int* dst_offset, orbit_filmgen_t** out);
+void orbit_filmgen_destroy(orbit_filmgen_t* g);
+/* tensor: "w1"[hid][z] "b1"[hid] "ln_w"[hid] "ln_b"[hid] "w2"[out][hid] "b2"[out] "reg"[out] "init"[out] */
+int orbit_filmgen_load(orbit_filmgen_t* g, int gen, const char* tensor, const float* data, size_t numel);
+/* z [z_dim] -> film_gamma, film_beta (each film_size floats), l2[1] = Σ_i Σ reg_i^2 */
+int orbit_filmgen_forward(orbit_filmgen_t* g, const float* z, float* film_gamma, float* film_beta,
+                          float* l2, orbit_stream_t stream);
+
+/* ---- single operators (NHWC activations), exposed for parity tests and reuse -------------------- */
+/* General convolution as implicit GEMM on fp32 MFMA.
+ *   x: NHWC [B][H][W][Cin]  (x_nchw != 0: NCHW [B][Cin][H][W], Cin <= 4 only — the network stems)
+ *   w: torch OIHW [Cout][Cin][KH][KW];  y: NHWC [B][Ho][Wo][Cout]  (pool2: [B][Ho/2][Wo/2][Cout])
+ *   y = act( conv(x*gate) * scale + shift + residual ), optional fused 2x2/2 max-pool (floor).
+ *   scale/shift [Cout] (NULL = 1/0), residual NHWC like y or NULL, gate [B][Cin] or NULL. */
+int orbit_op_conv2d(const float* x, int x_nchw, const float* w, float* y,
+                    const float* scale, const float* shift, const float* residual, const float* gate,
+                    int B, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                    int pad_top, int pad_left, int Ho, int Wo, int act, int pool2,
+                    orbit_stream_t stream);
+/* depthwise KxK conv, NHWC, w torch [C][1][K][K]; y = act(dw(x)*scale+shift) */
+int orbit_op_dwconv2d(const float* x, const float* w, float* y, const float* scale, const float* shift,
+                      int B, int H, int W, int C, int K, int stride, int pad_top, int pad_left,
+                      int Ho, int Wo, int act, orbit_stream_t stream);
+/* max-pool NHWC, -inf padding */
+int orbit_op_maxpool2d(const float* x, float* y, int B, int H, int W, int C, int K, int stride, int pad,
+                       int Ho, int Wo, orbit_stream_t stream);
+/* global average pool NHWC [B][HW][C] -> [B][C] */
+int orbit_op_avgpool(const float* x, float* y, int B, int HW, int C, orbit_stream_t stream);
+/* squeeze-excite gate: g[b][c] = sigmoid(W2 . silu(W1 . pooled[b] + b1) + b2);  W1 [R][C], W2 [C][R] */
+int orbit_op_se_gate(const float* pooled, const float* w1, const float* b1, const float* w2,
+                     const float* b2, float* gate, int B, int C, int R, orbit_stream_t stream);
+
+/* ---- measurement: per-launch HIP-event timing of the dominant kernel (conv_igemm, all variants) ---- */
+int orbit_prof_enable(int on);   /* on: reset and start recording an event pair per launch on its stream */
+/* waits for the recorded launches, returns summed duration, summed ALGORITHMIC flops and launch count */
+int orbit_prof_collect(double* total_ms, double* total_flops, long* launches);
+int orbit_prof_num_variants(void);
+int orbit_prof_variant(int i, char* name48, long* launches, double* ms, double* flops);
+
+/* ---- RCCL over xGMI (one process per GPU) ------------------------------------------------------- */
+/* The reference has no collectives; this is the exchange step of the support-sharded variant: the
+ * all-reduce(SUM) of orbit_proto_configure's sums/counts (and of set-encoder embedding sums). */
+#define ORBIT_COMM_ID_BYTES 128
+int orbit_comm_unique_id(void* out128);                       /* rank 0: create the rendezvous id */
+int orbit_comm_init(int rank, int world, const void* unique_id);
+int orbit_comm_world(void);
+int orbit_comm_rank(void);
+int orbit_allreduce_sum(float* buf, size_t n, orbit_stream_t stream);  /* in place */
+void orbit_comm_destroy(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ORBIT_HIP_H */

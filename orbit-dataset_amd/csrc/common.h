@@ -1,0 +1,83 @@
+// Shared helpers for liborbit_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdint>
+#include <cstring>
+#include "../../include/orbit_hip.h"
+
+namespace orbit {
+
+// thread-local error message returned by orbit_last_error()
+char* err_buf();
+int set_err(int code, const char* fmt, ...);
+
+#define ORBIT_HIP_CHECK(expr)                                                                  \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess)                                                                  \
+            return ::orbit::set_err(ORBIT_ERR_HIP, "%s failed: %s (%s:%d)", #expr,             \
+                                    hipGetErrorString(_e), __FILE__, __LINE__);                \
+    } while (0)
+
+#define ORBIT_LAUNCH_CHECK()                                                                   \
+    do {                                                                                       \
+        hipError_t _e = hipGetLastError();                                                     \
+        if (_e != hipSuccess)                                                                  \
+            return ::orbit::set_err(ORBIT_ERR_HIP, "kernel launch failed: %s (%s:%d)",         \
+                                    hipGetErrorString(_e), __FILE__, __LINE__);                \
+    } while (0)
+
+#define ORBIT_REQUIRE(cond, ...)                                                               \
+    do {                                                                                       \
+        if (!(cond)) return ::orbit::set_err(ORBIT_ERR_ARG, __VA_ARGS__);                      \
+    } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- internal launchers shared between the single-op C-ABI and the network runtime -------------
+
+struct ConvDesc {
+    const float* x;         // NHWC activations, or NCHW frames when x_nchw
+    const float* w_packed;  // [CoutPad][KT], K = (kh, kw, ci) with ci fastest, zero padded
+    float* y;               // NHWC
+    const float* scale;     // [Cout] or nullptr
+    const float* shift;     // [Cout] or nullptr
+    const float* residual;  // NHWC like y or nullptr
+    const float* gate;      // [B][Cin] or nullptr
+    int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo;
+    int act;     // ORBIT_ACT_*
+    int pool2;   // fused 2x2/2 max-pool of the activated output
+    int x_nchw;  // stem gather from NCHW frames
+};
+
+// geometry of the packed weight matrix for a conv (shared by pack + launch)
+struct ConvPackGeom {
+    int cin_pad;   // per-tap padded Cin (vector mode), unused in stem mode
+    int kt;        // padded K
+    int cout_pad;  // padded rows
+};
+ConvPackGeom conv_pack_geom(int Cin, int Cout, int KH, int KW, int x_nchw);
+size_t conv_packed_floats(int Cin, int Cout, int KH, int KW, int x_nchw);
+// OIHW -> packed (device to device)
+int conv_pack_weights(const float* w_oihw, float* w_packed, int Cin, int Cout, int KH, int KW,
+                      int x_nchw, hipStream_t s);
+int launch_conv(const ConvDesc& d, hipStream_t s);
+
+int launch_dwconv(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
+                  int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                  int act, hipStream_t s);
+// [C][1][K][K] -> [K][K][C]
+int dwconv_pack_weights(const float* w, float* w_khwc, int C, int K, hipStream_t s);
+int launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int K, int stride, int pad,
+                   int Ho, int Wo, hipStream_t s);
+int launch_avgpool(const float* x, float* y, int B, int HW, int C, hipStream_t s);
+int launch_se_gate(const float* pooled, const float* w1, const float* b1, const float* w2,
+                   const float* b2, float* gate, int B, int C, int R, hipStream_t s);
+// scale = g / sqrt(var + eps); shift = b + (conv_bias - mean) * scale   (conv_bias may be nullptr)
+int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                   const float* conv_bias, float eps, int C, float* scale, float* shift, hipStream_t s);
+
+}  // namespace orbit

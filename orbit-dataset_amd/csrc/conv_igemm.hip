@@ -1,0 +1,526 @@
+// Implicit-GEMM convolution on the gfx950 fp32 matrix cores (v_mfma_f32_32x32x2_f32).
+//
+// This kernel carries >99% of the hot path's arithmetic: every dense convolution of the feature
+// extractors (reference: model/feature_extractors.py:37-79 -> timm / torchvision-layout networks run by
+// model/few_shot_recognisers.py:99-153) and of the set encoder (model/set_encoders.py:81-120).
+//
+//   GEMM view   C[m][n] = sum_k A[m][k] * Wp[n][k]
+//               m = output pixel (b, ho, wo)   n = output channel   k = (kh, kw, ci), ci fastest
+//   A is never materialised: each K-tile of 32 is gathered from the NHWC activation tensor (32
+//   consecutive input channels of one filter tap = one 128-byte segment per row), or, for the 3-channel
+//   network stems, element-wise from the NCHW frames.
+//   Epilogue (fused, so activations make exactly one HBM round trip per layer):
+//               y = act(acc * scale[n] + shift[n] + residual[m][n])      folded BatchNorm (+FiLM), skip add
+//               optional 2x2/2 max-pool: rows are enumerated window-major so that the four members of
+//               a pooling window are the four consecutive accumulator rows a lane already holds.
+//   Prologue:   optional per-(frame, input-channel) squeeze-excite gate multiplied into A.
+//
+// Tiling: 256 threads = 4 waves; block tile BM x BN x 32, wave grid WGM x WGN, each wave owns
+// (BM/WGM/32) x (BN/WGN/32) accumulator tiles of 32x32 (16 VGPRs each). LDS rows are padded to 36 floats:
+// the fragment reads are conflict-free ds_read_b128 (lane (i, h) reads k = 8g+4h .. +3 of row i, and
+// register kk of the read feeds MFMA kk, so lanes 0-31 / 32-63 supply k = 8g+kk / 8g+4+kk).
+// Global->LDS staging goes through registers and is software-pipelined one K-tile ahead (the f32 MFMA
+// issues once per 64 cycles per SIMD, so one tile of prefetch hides L2/HBM latency).
+// fp32 in, fp32 accumulate: bit-equivalent to an fmaf chain, which is what the 1e-3 logit parity
+// target needs (no TF32-class path exists on gfx950).
+#include <vector>
+#include "common.h"
+
+namespace orbit {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+constexpr int BK = 32;
+constexpr int LDS_STRIDE = BK + 4;  // floats; 144 B rows keep ds_read_b128 conflict-free
+
+struct ConvParams {
+    const float* x;
+    const float* w;
+    float* y;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    const float* gate;
+    int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo;
+    int HoP, WoP;   // pooled output dims (pool2)
+    int M;          // GEMM rows (pool2: B*HoP*WoP*4)
+    int KT;         // padded K
+    int cin_pad;    // per-tap padded Cin (vector mode)
+    int act;
+    int m_tiles, n_tiles;
+};
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+    if (act == ORBIT_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ORBIT_ACT_SILU) return v / (1.0f + expf(-v));
+    return v;
+}
+
+// XCD-aware remap: hardware places block i on XCD i % 8; give each XCD a contiguous run of logical
+// tiles so that the n-tiles sharing an A row-panel hit the same L2 (bijective for any grid size).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + slot;
+}
+
+template <bool POOL2>
+__device__ __forceinline__ void decode_row(const ConvParams& p, int m, int& b, int& ho, int& wo) {
+    if (POOL2) {
+        const int win = m >> 2, q = m & 3;
+        const int per = p.HoP * p.WoP;
+        b = win / per;
+        const int r = win - b * per;
+        const int hp = r / p.WoP, wp = r - hp * p.WoP;
+        ho = hp * 2 + (q >> 1);
+        wo = wp * 2 + (q & 1);
+    } else {
+        const int per = p.Ho * p.Wo;
+        b = m / per;
+        const int r = m - b * per;
+        ho = r / p.Wo;
+        wo = r - ho * p.Wo;
+    }
+}
+
+// MODE 0: NHWC activations, Cin % 4 == 0 (float4 gathers).  MODE 1: NCHW frames, tiny Cin (stems).
+template <int BM, int BN, int WGM, int WGN, int MODE, bool POOL2, bool GATE>
+__global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
+    static_assert(WGM * WGN == 4, "4 waves per block");
+    constexpr int WM = BM / WGM, WN = BN / WGN;  // wave tile
+    constexpr int TM = WM / 32, TN = WN / 32;    // 32x32 accumulator tiles per wave
+    static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
+    constexpr int AR = BM / 32;                  // float4 A loads per thread per K-tile (vector mode)
+    constexpr int BR = BN / 32;                  // float4 B loads per thread per K-tile
+    constexpr int KPT = BM / 8;                  // scalar A loads per thread per K-tile (stem mode)
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                            // [2][BM][LDS_STRIDE]
+    float* Bs = smem + 2 * BM * LDS_STRIDE;      // [2][BN][LDS_STRIDE]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;
+
+    const int tile = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
+    const int m0 = (tile / p.n_tiles) * BM;
+    const int n0 = (tile % p.n_tiles) * BN;
+
+    // ---- per-thread gather bookkeeping (rows are fixed for the whole K loop) ----
+    // vector mode: thread owns float4 column c4 of rows (tid>>3) + 32*i
+    // stem mode:   thread owns KPT consecutive k of row tid % BM
+    const int c4 = tid & 7;
+    const float* a_base[MODE == 0 ? AR : 1];
+    int a_hi0[MODE == 0 ? AR : 1], a_wi0[MODE == 0 ? AR : 1];
+    const float* a_gate[MODE == 0 ? AR : 1];
+    if (MODE == 0) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            const int m = m0 + (tid >> 3) + 32 * i;
+            int b = 0, ho = 0, wo = 0;
+            const bool ok = m < p.M;
+            if (ok) decode_row<POOL2>(p, m, b, ho, wo);
+            a_base[i] = p.x + (size_t)b * p.H * p.W * p.Cin;
+            a_hi0[i] = ok ? ho * p.stride - p.pad_t : -(1 << 28);  // invalid rows fail the bounds test
+            a_wi0[i] = wo * p.stride - p.pad_l;
+            a_gate[i] = GATE ? p.gate + (size_t)b * p.Cin : nullptr;
+        }
+    } else {
+        const int m = m0 + (tid % BM);
+        int b = 0, ho = 0, wo = 0;
+        const bool ok = m < p.M;
+        if (ok) decode_row<POOL2>(p, m, b, ho, wo);
+        a_base[0] = p.x + (size_t)b * p.Cin * p.H * p.W;
+        a_hi0[0] = ok ? ho * p.stride - p.pad_t : -(1 << 28);
+        a_wi0[0] = wo * p.stride - p.pad_l;
+        a_gate[0] = nullptr;
+    }
+    const float* b_ptr = p.w + (size_t)(n0 + (tid >> 3)) * p.KT + c4 * 4;
+
+    f32x4 a_stage[MODE == 0 ? AR : KPT / 4];
+    f32x4 b_stage[BR];
+
+    const int nk = p.KT / BK;
+    const int cpt = MODE == 0 ? p.cin_pad / BK : 1;  // K-tiles per filter tap
+    const int ktot = p.KH * p.KW * p.Cin;            // true K (stem mode)
+
+    auto load_tile = [&](int kt) {
+        if (MODE == 0) {
+            const int tap = kt / cpt;
+            const int ci = (kt - tap * cpt) * BK + c4 * 4;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            const bool ci_ok = ci < p.Cin;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (ci_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
+                    v = *reinterpret_cast<const f32x4*>(a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + ci);
+                    if (GATE) v *= *reinterpret_cast<const f32x4*>(a_gate[i] + ci);
+                }
+                a_stage[i] = v;
+            }
+        } else {
+            // tid / BM is wave-uniform (BM is a multiple of 64): keep the k decode on the scalar unit
+            const int kb = kt * BK + __builtin_amdgcn_readfirstlane(tid / BM) * KPT;
+            const size_t plane = (size_t)p.H * p.W;
+#pragma unroll
+            for (int j = 0; j < KPT; ++j) {
+                const int k = kb + j;
+                const int tap = k / p.Cin, ci = k - tap * p.Cin;
+                const int kh = tap / p.KW, kw = tap - kh * p.KW;
+                const int hi = a_hi0[0] + kh, wi = a_wi0[0] + kw;
+                float v = 0.f;
+                if (k < ktot && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                    v = a_base[0][ci * plane + (size_t)hi * p.W + wi];
+                a_stage[j >> 2][j & 3] = v;
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j)
+            b_stage[j] = *reinterpret_cast<const f32x4*>(b_ptr + (size_t)(32 * j) * p.KT + kt * BK);
+    };
+
+    auto store_tile = [&](int buf) {
+        float* A = As + buf * BM * LDS_STRIDE;
+        float* Bq = Bs + buf * BN * LDS_STRIDE;
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < AR; ++i)
+                *reinterpret_cast<f32x4*>(A + ((tid >> 3) + 32 * i) * LDS_STRIDE + c4 * 4) = a_stage[i];
+        } else {
+            float* dst = A + (tid % BM) * LDS_STRIDE + (tid / BM) * KPT;
+#pragma unroll
+            for (int j = 0; j < KPT / 4; ++j) *reinterpret_cast<f32x4*>(dst + 4 * j) = a_stage[j];
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j)
+            *reinterpret_cast<f32x4*>(Bq + ((tid >> 3) + 32 * j) * LDS_STRIDE + c4 * 4) = b_stage[j];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    load_tile(0);
+    store_tile(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile(kt + 1);  // global loads in flight under the MFMAs below
+
+        const float* A = As + cur * BM * LDS_STRIDE + (wm + l31) * LDS_STRIDE + lh * 4;
+        const float* Bq = Bs + cur * BN * LDS_STRIDE + (wn + l31) * LDS_STRIDE + lh * 4;
+        // k-groups of 8 that hold real data in this tile (the tail of a padded tap is all zeros)
+        const int kvalid = MODE == 0 ? p.Cin - (kt % cpt) * BK : ktot - kt * BK;
+        const int ngrp = kvalid >= BK ? BK / 8 : (kvalid + 7) >> 3;
+        auto mma_group = [&](int g) {
+            f32x4 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDS_STRIDE + g * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const f32x4*>(Bq + j * 32 * LDS_STRIDE + g * 8);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+        };
+        if (ngrp == BK / 8) {  // common case: fully unrolled so fragment reads run ahead of the MFMAs
+#pragma unroll
+            for (int g = 0; g < BK / 8; ++g) mma_group(g);
+        } else {
+            for (int g = 0; g < ngrp; ++g) mma_group(g);
+        }
+
+        if (kt + 1 < nk) store_tile(cur ^ 1);  // the other buffer was last read before the previous barrier
+        __syncthreads();
+    }
+
+    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn + j * 32 + l31;
+        const bool n_ok = n < p.Cout;
+        const float sc = (n_ok && p.scale) ? p.scale[n] : 1.0f;
+        const float sh = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int mrow = m0 + wm + i * 32 + 8 * rq + 4 * lh;  // first of 4 consecutive rows
+                if (POOL2) {
+                    // the 4 rows are one pooling window (window-major row order)
+                    float v = -INFINITY;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r)
+                        v = fmaxf(v, apply_act(acc[i][j][rq * 4 + r] * sc + sh, p.act));
+                    if (n_ok && mrow < p.M) p.y[(size_t)(mrow >> 2) * p.Cout + n] = v;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int m = mrow + r;
+                        if (n_ok && m < p.M) {
+                            float v = acc[i][j][rq * 4 + r] * sc + sh;
+                            if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
+                            p.y[(size_t)m * p.Cout + n] = apply_act(v, p.act);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// ---- weight packing: OIHW -> [cout_pad][KT] with k = (kh*KW + kw)*cin_pad + ci (vector mode)
+//                                              or k = (kh*KW + kw)*Cin + ci     (stem mode) ----------
+__global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                                        int Cin, int Cout, int KH, int KW, int cin_pad,
+                                                        int KT, int cout_pad, int stem) {
+    const size_t total = (size_t)cout_pad * KT;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int n = (int)(i / KT), k = (int)(i % KT);
+        const int per = stem ? Cin : cin_pad;
+        const int tap = k / per, ci = k % per;
+        float v = 0.f;
+        if (n < Cout && tap < KH * KW && ci < Cin) {
+            const int kh = tap / KW, kw = tap % KW;
+            v = w[(((size_t)n * Cin + ci) * KH + kh) * KW + kw];
+        }
+        wp[i] = v;
+    }
+}
+
+ConvPackGeom conv_pack_geom(int Cin, int Cout, int KH, int KW, int x_nchw) {
+    ConvPackGeom g;
+    if (x_nchw) {
+        g.cin_pad = Cin;
+        g.kt = (int)align_up((size_t)KH * KW * Cin, BK);
+    } else {
+        g.cin_pad = (int)align_up((size_t)Cin, BK);
+        g.kt = KH * KW * g.cin_pad;
+    }
+    g.cout_pad = (int)align_up((size_t)Cout, 128);
+    return g;
+}
+
+size_t conv_packed_floats(int Cin, int Cout, int KH, int KW, int x_nchw) {
+    const ConvPackGeom g = conv_pack_geom(Cin, Cout, KH, KW, x_nchw);
+    return (size_t)g.cout_pad * g.kt;
+}
+
+int conv_pack_weights(const float* w_oihw, float* w_packed, int Cin, int Cout, int KH, int KW, int x_nchw,
+                      hipStream_t s) {
+    const ConvPackGeom g = conv_pack_geom(Cin, Cout, KH, KW, x_nchw);
+    const size_t total = (size_t)g.cout_pad * g.kt;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    conv_pack_kernel<<<blocks, 256, 0, s>>>(w_oihw, w_packed, Cin, Cout, KH, KW, g.cin_pad, g.kt,
+                                            g.cout_pad, x_nchw);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+// ---- optional per-launch profiling (bench.py roofline): HIP events recorded on the launch stream ------
+struct ProfRec {
+    hipEvent_t start, stop;
+    int variant;
+    double flops;
+};
+struct ProfVariant {
+    char name[48];
+    long launches;
+    double ms, flops;
+};
+static bool g_prof_on = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+static std::vector<ProfVariant> g_prof_variants;
+
+static hipEvent_t prof_event() {
+    if (!g_prof_pool.empty()) {
+        hipEvent_t e = g_prof_pool.back();
+        g_prof_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+static int prof_variant(const char* name) {
+    for (size_t i = 0; i < g_prof_variants.size(); ++i)
+        if (strcmp(g_prof_variants[i].name, name) == 0) return (int)i;
+    ProfVariant v;
+    memset(&v, 0, sizeof(v));
+    snprintf(v.name, sizeof(v.name), "%s", name);
+    g_prof_variants.push_back(v);
+    return (int)g_prof_variants.size() - 1;
+}
+
+template <int BM, int BN, int WGM, int WGN, int MODE, bool POOL2, bool GATE>
+static int launch_cfg(ConvParams& p, hipStream_t s) {
+    p.m_tiles = cdiv(p.M, BM);
+    p.n_tiles = cdiv(p.Cout, BN);
+    const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
+    auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, MODE, POOL2, GATE>;
+    static bool attr_set = false;  // >64 KiB dynamic LDS needs the opt-in once per kernel
+    if (!attr_set && lds > 64 * 1024) {
+        ORBIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr_set = true;
+    }
+    if (g_prof_on) {
+        char name[48];
+        snprintf(name, sizeof(name), "conv_igemm<%d,%d,%s%s%s>", BM, BN, MODE ? "nchw" : "nhwc", POOL2 ? ",pool2" : "",
+                 GATE ? ",gate" : "");
+        ProfRec r;
+        r.start = prof_event(), r.stop = prof_event(), r.variant = prof_variant(name);
+        const double pix = POOL2 ? (double)p.B * p.HoP * p.WoP * 4 : (double)p.B * p.Ho * p.Wo;
+        r.flops = 2.0 * pix * p.Cout * p.KH * p.KW * p.Cin;  // algorithmic (unpadded) FLOPs of this launch
+        (void)hipEventRecord(r.start, s);
+        kern<<<p.m_tiles * p.n_tiles, 256, lds, s>>>(p);
+        (void)hipEventRecord(r.stop, s);
+        g_prof_recs.push_back(r);
+    } else {
+        kern<<<p.m_tiles * p.n_tiles, 256, lds, s>>>(p);
+    }
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+template <int MODE, bool POOL2, bool GATE>
+static int launch_tiled(ConvParams& p, hipStream_t s) {
+    // Tile choice: the widest N tile the layer fills, the tallest M tile that still yields >= ~2 blocks
+    // per CU (256 CUs); small-M late layers fall back to 64-row tiles to keep the chip occupied.
+    const long target = 512;
+    if (p.Cout > 64) {
+        if ((long)cdiv(p.M, 128) * cdiv(p.Cout, 128) >= target)
+            return launch_cfg<128, 128, 2, 2, MODE, POOL2, GATE>(p, s);
+        if ((long)cdiv(p.M, 128) * cdiv(p.Cout, 64) >= target)
+            return launch_cfg<128, 64, 2, 2, MODE, POOL2, GATE>(p, s);
+        return launch_cfg<64, 64, 2, 2, MODE, POOL2, GATE>(p, s);
+    }
+    if (p.Cout > 32) {
+        if ((long)cdiv(p.M, 128) >= target) return launch_cfg<128, 64, 2, 2, MODE, POOL2, GATE>(p, s);
+        return launch_cfg<64, 64, 2, 2, MODE, POOL2, GATE>(p, s);
+    }
+    return launch_cfg<128, 32, 4, 1, MODE, POOL2, GATE>(p, s);
+}
+
+int launch_conv(const ConvDesc& d, hipStream_t s) {
+    ORBIT_REQUIRE(d.x && d.w_packed && d.y, "conv: null pointer");
+    ORBIT_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Cout > 0 && d.Ho > 0 && d.Wo > 0,
+                  "conv: bad sizes");
+    ORBIT_REQUIRE(d.x_nchw ? d.Cin <= 4 : (d.Cin % 4 == 0),
+                  "conv: NHWC path needs Cin %% 4 == 0, NCHW stem path needs Cin <= 4 (Cin=%d)", d.Cin);
+    ORBIT_REQUIRE(!(d.pool2 && d.residual), "conv: pool2 cannot be combined with a residual input");
+    ORBIT_REQUIRE(!(d.gate && d.x_nchw), "conv: gate is only supported on the NHWC path");
+    const ConvPackGeom g = conv_pack_geom(d.Cin, d.Cout, d.KH, d.KW, d.x_nchw);
+    ConvParams p;
+    p.x = d.x, p.w = d.w_packed, p.y = d.y, p.scale = d.scale, p.shift = d.shift;
+    p.residual = d.residual, p.gate = d.gate;
+    p.B = d.B, p.H = d.H, p.W = d.W, p.Cin = d.Cin, p.Cout = d.Cout, p.KH = d.KH, p.KW = d.KW;
+    p.stride = d.stride, p.pad_t = d.pad_t, p.pad_l = d.pad_l, p.Ho = d.Ho, p.Wo = d.Wo;
+    p.HoP = d.Ho / 2, p.WoP = d.Wo / 2;
+    p.KT = g.kt, p.cin_pad = g.cin_pad, p.act = d.act;
+    if (d.pool2) {
+        ORBIT_REQUIRE(p.HoP > 0 && p.WoP > 0, "conv: pool2 needs Ho, Wo >= 2");
+        p.M = d.B * p.HoP * p.WoP * 4;
+    } else {
+        p.M = d.B * d.Ho * d.Wo;
+    }
+    if (d.x_nchw) {
+        return d.pool2 ? launch_tiled<1, true, false>(p, s) : launch_tiled<1, false, false>(p, s);
+    }
+    if (d.gate) {
+        ORBIT_REQUIRE(!d.pool2, "conv: gate + pool2 is not instantiated");
+        return launch_tiled<0, false, true>(p, s);
+    }
+    return d.pool2 ? launch_tiled<0, true, false>(p, s) : launch_tiled<0, false, false>(p, s);
+}
+
+}  // namespace orbit
+
+using namespace orbit;
+
+extern "C" {
+
+// Profiling of the dominant kernel (all conv_igemm instantiations). enable(1) starts recording one HIP event
+// pair per launch on the launch stream; collect() waits for them, folds them into per-variant totals and
+// returns the grand totals; variant(i) reads one row. Not thread-safe: one profiled stream at a time.
+int orbit_prof_enable(int on) {
+    g_prof_on = on != 0;
+    if (on) {
+        for (ProfRec& r : g_prof_recs) g_prof_pool.push_back(r.start), g_prof_pool.push_back(r.stop);
+        g_prof_recs.clear();
+        g_prof_variants.clear();
+    }
+    return ORBIT_OK;
+}
+
+int orbit_prof_collect(double* total_ms, double* total_flops, long* launches) {
+    double ms = 0, fl = 0;
+    for (ProfRec& r : g_prof_recs) {
+        ORBIT_HIP_CHECK(hipEventSynchronize(r.stop));
+        float t = 0.f;
+        ORBIT_HIP_CHECK(hipEventElapsedTime(&t, r.start, r.stop));
+        ProfVariant& v = g_prof_variants[r.variant];
+        v.launches += 1, v.ms += t, v.flops += r.flops;
+        ms += t, fl += r.flops;
+        g_prof_pool.push_back(r.start), g_prof_pool.push_back(r.stop);
+    }
+    if (total_ms) *total_ms = ms;
+    if (total_flops) *total_flops = fl;
+    if (launches) *launches = (long)g_prof_recs.size();
+    g_prof_recs.clear();
+    return ORBIT_OK;
+}
+
+int orbit_prof_num_variants(void) { return (int)g_prof_variants.size(); }
+
+int orbit_prof_variant(int i, char* name48, long* launches, double* ms, double* flops) {
+    ORBIT_REQUIRE(i >= 0 && i < (int)g_prof_variants.size(), "prof_variant: index out of range");
+    const ProfVariant& v = g_prof_variants[i];
+    if (name48) memcpy(name48, v.name, sizeof(v.name));
+    if (launches) *launches = v.launches;
+    if (ms) *ms = v.ms;
+    if (flops) *flops = v.flops;
+    return ORBIT_OK;
+}
+
+int orbit_op_conv2d(const float* x, int x_nchw, const float* w, float* y, const float* scale,
+                               const float* shift, const float* residual, const float* gate, int B, int H,
+                               int W, int Cin, int Cout, int KH, int KW, int stride, int pad_top,
+                               int pad_left, int Ho, int Wo, int act, int pool2, orbit_stream_t stream) {
+    ORBIT_REQUIRE(x && w && y, "op_conv2d: null pointer");
+    ORBIT_REQUIRE(KH > 0 && KW > 0 && stride > 0, "op_conv2d: bad kernel geometry");
+    hipStream_t s = (hipStream_t)stream;
+    float* wp = nullptr;
+    const size_t nfl = conv_packed_floats(Cin, Cout, KH, KW, x_nchw);
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&wp), nfl * sizeof(float), s));
+    int rc = conv_pack_weights(w, wp, Cin, Cout, KH, KW, x_nchw, s);
+    if (rc == ORBIT_OK) {
+        ConvDesc d;
+        d.x = x, d.w_packed = wp, d.y = y, d.scale = scale, d.shift = shift, d.residual = residual;
+        d.gate = gate, d.B = B, d.H = H, d.W = W, d.Cin = Cin, d.Cout = Cout, d.KH = KH, d.KW = KW;
+        d.stride = stride, d.pad_t = pad_top, d.pad_l = pad_left, d.Ho = Ho, d.Wo = Wo, d.act = act;
+        d.pool2 = pool2, d.x_nchw = x_nchw;
+        rc = launch_conv(d, s);
+    }
+    (void)hipFreeAsync(wp, s);
+    return rc;
+}
+
+}  // extern "C"

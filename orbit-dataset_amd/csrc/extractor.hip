@@ -1,0 +1,531 @@
+// Network runtime: builds a static launch plan for "resnet18", "efficientnet_b0" or "set_encoder" at a
+// given frame size, owns the parameters (loaded by torch state_dict key), repacks conv weights for the
+// MFMA kernel, folds BatchNorm (+ per-task FiLM gamma/beta) into per-channel scale/shift, and replays the
+// plan on a HIP stream. This is the native counterpart of
+//   model/feature_extractors.py:37-79   create_feature_extractor (timm tf_efficientnet_b0; resnet18 is the
+//                                        torchvision-layout network BASELINE.json's configs name)
+//   model/set_encoders.py:81-120        SimplePrePoolNet
+//   model/few_shot_recognisers.py:99-153 _get_features[_in_batches] (one call = one mini-batch of frames)
+//   model/film.py:38-74                 which BatchNorms are FiLM-modulated
+// Activations are NHWC fp32 and live in caller-provided workspace (three rotating buffers); frames come
+// in as NCHW (the reference's clip layout) and are consumed directly by the stem convolution.
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+#include "common.h"
+
+namespace orbit {
+
+struct Param {
+    std::string key;
+    size_t numel = 0, off = 0;  // offset (floats) into the parameter pool
+    bool loaded = false;
+};
+
+struct BNDesc {        // host side
+    int gamma, beta, mean, var;  // param indices
+    int conv_bias;               // param index or -1
+    int C;
+    float eps;
+    int film_slot;               // -1 if not FiLM-modulated
+    int film_off;                // offset inside film_gamma / film_beta
+    size_t fold_off;             // offset of this layer's scale/shift in the fold arrays
+    std::string name;
+};
+
+struct BNDev {         // device descriptor for the fold kernel
+    size_t gamma, beta, mean, var, conv_bias;  // pool offsets (conv_bias = SIZE_MAX if none)
+    size_t fold_off;
+    int C, film_off;                           // film_off < 0: not modulated
+    float eps;
+};
+
+enum OpKind { OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_AVGPOOL, OP_SE };
+
+struct Op {
+    OpKind kind;
+    int in = -1, out = -1, res = -1;  // buffer ids: -1 frames, 0..2 activations, 100 feats, 101 pooled, 102 gate
+    int H = 0, W = 0, Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad_t = 0, pad_l = 0, Ho = 0, Wo = 0;
+    int act = ORBIT_ACT_NONE, pool2 = 0, x_nchw = 0, use_gate = 0;
+    int weight = -1, bias = -1, bn = -1;  // param / BN indices
+    size_t packed_off = 0;                // into the packed-weight pool
+    int se_w1 = -1, se_b1 = -1, se_w2 = -1, se_b2 = -1, R = 0;
+    int pool_k = 0, pool_pad = 0;
+};
+
+__global__ __launch_bounds__(256) void bn_fold_all_kernel(const BNDev* __restrict__ descs,
+                                                          const float* __restrict__ pool,
+                                                          const float* __restrict__ film_gamma,
+                                                          const float* __restrict__ film_beta,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
+    const BNDev d = descs[blockIdx.x];
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < d.C; c += gridDim.y * 256) {
+        const bool film = film_gamma != nullptr && d.film_off >= 0;
+        const float g = film ? film_gamma[d.film_off + c] : pool[d.gamma + c];
+        const float b = film ? film_beta[d.film_off + c] : pool[d.beta + c];
+        const float sc = g / sqrtf(pool[d.var + c] + d.eps);
+        const float cb = d.conv_bias != (size_t)-1 ? pool[d.conv_bias + c] : 0.f;
+        scale[d.fold_off + c] = sc;
+        shift[d.fold_off + c] = b + (cb - pool[d.mean + c]) * sc;
+    }
+}
+
+}  // namespace orbit
+
+using namespace orbit;
+
+struct orbit_extractor {
+    std::string name;
+    int H = 0, W = 0, out_size = 0;
+    std::vector<Param> params;
+    std::map<std::string, int> index;
+    std::vector<BNDesc> bns;
+    std::vector<Op> ops;
+    std::vector<int> film_slots;  // BN indices in module-traversal order
+    int film_size = 0;
+    size_t pool_floats = 0, packed_floats = 0, fold_floats = 0;
+    size_t buf_elems[3] = {0, 0, 0};  // per-frame element counts of the rotating activation buffers
+    int max_se_c = 0;
+    double macs = 0;
+    float* d_pool = nullptr;
+    float* d_packed = nullptr;
+    float* d_fold = nullptr;  // static (non-FiLM) scale | shift
+    BNDev* d_bn = nullptr;
+    std::vector<BNDev> bn_dev;  // host copy of the fold descriptors
+    bool finalized = false;
+
+    // device buffers are created on first use so that a plan can be built and inspected (state_dict keys,
+    // FiLM slots, workspace size, MACs) on a host without a GPU
+    int ensure_device() {
+        if (d_pool) return ORBIT_OK;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_pool), pool_floats * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(d_pool, 0, pool_floats * sizeof(float));
+        if (e == hipSuccess)
+            e = hipMalloc(reinterpret_cast<void**>(&d_packed), std::max<size_t>(packed_floats, 4) * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_fold), 2 * fold_floats * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_bn), bn_dev.size() * sizeof(BNDev));
+        if (e == hipSuccess)
+            e = hipMemcpy(d_bn, bn_dev.data(), bn_dev.size() * sizeof(BNDev), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d_pool), (void)hipFree(d_packed), (void)hipFree(d_fold), (void)hipFree(d_bn);
+            d_pool = d_packed = d_fold = nullptr, d_bn = nullptr;
+            (void)hipGetLastError();
+            return set_err(ORBIT_ERR_HIP, "extractor: device allocation failed: %s", hipGetErrorString(e));
+        }
+        return ORBIT_OK;
+    }
+
+    int add_param(const std::string& key, size_t numel) {
+        Param p;
+        p.key = key, p.numel = numel, p.off = pool_floats;
+        pool_floats += (numel + 3) / 4 * 4;
+        params.push_back(p);
+        index[key] = (int)params.size() - 1;
+        return (int)params.size() - 1;
+    }
+    int add_bn(const std::string& prefix, int C, float eps, bool film, int conv_bias = -1) {
+        BNDesc b;
+        b.name = prefix;
+        b.gamma = add_param(prefix + ".weight", C);
+        b.beta = add_param(prefix + ".bias", C);
+        b.mean = add_param(prefix + ".running_mean", C);
+        b.var = add_param(prefix + ".running_var", C);
+        b.conv_bias = conv_bias, b.C = C, b.eps = eps;
+        b.film_slot = -1, b.film_off = -1;
+        b.fold_off = fold_floats;
+        fold_floats += (size_t)(C + 3) / 4 * 4;
+        if (film) {
+            b.film_slot = (int)film_slots.size();
+            b.film_off = film_size;
+            film_size += C;
+            film_slots.push_back((int)bns.size());
+        }
+        bns.push_back(b);
+        return (int)bns.size() - 1;
+    }
+    void note_buf(int id, size_t elems) {
+        if (id >= 0 && id < 3) buf_elems[id] = std::max(buf_elems[id], elems);
+    }
+    // dense conv + BN (+act) (+residual) (+gate) (+pool2); returns output dims through Ho/Wo
+    void add_conv(const std::string& wkey, int bn, int in, int out, int res, int H_, int W_, int Cin, int Cout,
+                  int K, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, int pool2, int x_nchw,
+                  int use_gate, int bias = -1) {
+        Op o;
+        o.kind = OP_CONV, o.in = in, o.out = out, o.res = res;
+        o.H = H_, o.W = W_, o.Cin = Cin, o.Cout = Cout, o.KH = K, o.KW = K, o.stride = stride;
+        o.pad_t = pad_t, o.pad_l = pad_l, o.Ho = Ho, o.Wo = Wo, o.act = act, o.pool2 = pool2;
+        o.x_nchw = x_nchw, o.use_gate = use_gate, o.bn = bn, o.bias = bias;
+        o.weight = index.count(wkey) ? index[wkey] : add_param(wkey, (size_t)Cout * Cin * K * K);
+        o.packed_off = packed_floats;
+        packed_floats += conv_packed_floats(Cin, Cout, K, K, x_nchw);
+        const int oh = pool2 ? Ho / 2 : Ho, ow = pool2 ? Wo / 2 : Wo;
+        note_buf(out, (size_t)oh * ow * Cout);
+        macs += (double)(pool2 ? oh * 2 : Ho) * (pool2 ? ow * 2 : Wo) * Cout * Cin * K * K;
+        ops.push_back(o);
+    }
+};
+
+static int conv_out(int H, int K, int stride, int pad) { return (H + 2 * pad - K) / stride + 1; }
+static void same_pad(int H, int K, int stride, int& Ho, int& pad_before) {  // TF "SAME"
+    Ho = (H + stride - 1) / stride;
+    const int total = std::max((Ho - 1) * stride + K - H, 0);
+    pad_before = total / 2;
+}
+
+// ---- resnet18 (torchvision layout, pooled 512-d features; every BatchNorm is a FiLM slot) -------
+static int build_resnet18(orbit_extractor* fe, int H, int W) {
+    fe->out_size = 512;
+    int h = conv_out(H, 7, 2, 3), w = conv_out(W, 7, 2, 3);
+    int bn = fe->add_bn("bn1", 64, 1e-5f, true);
+    fe->add_conv("conv1.weight", bn, -1, 0, -1, H, W, 3, 64, 7, 2, 3, 3, h, w, ORBIT_ACT_RELU, 0, 1, 0);
+    {
+        Op o;
+        o.kind = OP_MAXPOOL, o.in = 0, o.out = 1, o.H = h, o.W = w, o.Cin = 64, o.Cout = 64;
+        o.pool_k = 3, o.stride = 2, o.pool_pad = 1;
+        o.Ho = conv_out(h, 3, 2, 1), o.Wo = conv_out(w, 3, 2, 1);
+        h = o.Ho, w = o.Wo;
+        fe->note_buf(1, (size_t)h * w * 64);
+        fe->ops.push_back(o);
+    }
+    int cur = 1, cin = 64;
+    const int widths[4] = {64, 128, 256, 512};
+    for (int L = 0; L < 4; ++L) {
+        for (int blk = 0; blk < 2; ++blk) {
+            const int cout = widths[L];
+            const int stride = (L > 0 && blk == 0) ? 2 : 1;
+            const std::string p = "layer" + std::to_string(L + 1) + "." + std::to_string(blk);
+            const int ho = conv_out(h, 3, stride, 1), wo = conv_out(w, 3, stride, 1);
+            const int t1 = (cur + 1) % 3, t2 = (cur + 2) % 3;
+            // module registration order: conv1, bn1, conv2, bn2, downsample.{0,1}
+            const int bn1 = fe->add_bn(p + ".bn1", cout, 1e-5f, true);
+            fe->add_conv(p + ".conv1.weight", bn1, cur, t1, -1, h, w, cin, cout, 3, stride, 1, 1, ho, wo,
+                         ORBIT_ACT_RELU, 0, 0, 0);
+            const int bn2 = fe->add_bn(p + ".bn2", cout, 1e-5f, true);
+            int res = cur;
+            if (stride != 1 || cin != cout) {
+                const int bnd = fe->add_bn(p + ".downsample.1", cout, 1e-5f, true);
+                // conv2 is emitted after the downsample so the plan order is ds -> conv2; param order
+                // (state_dict) is irrelevant to execution
+                fe->add_conv(p + ".downsample.0.weight", bnd, cur, t2, -1, h, w, cin, cout, 1, stride, 0, 0, ho,
+                             wo, ORBIT_ACT_NONE, 0, 0, 0);
+                res = t2;
+            }
+            // out = relu(bn2(conv2(t1)) + res); write into the buffer that is neither t1 nor res
+            const int outb = (res == cur) ? t2 : cur;
+            fe->add_conv(p + ".conv2.weight", bn2, t1, outb, res, ho, wo, cout, cout, 3, 1, 1, 1, ho, wo,
+                         ORBIT_ACT_RELU, 0, 0, 0);
+            cur = outb, cin = cout, h = ho, w = wo;
+        }
+    }
+    Op o;
+    o.kind = OP_AVGPOOL, o.in = cur, o.out = 100, o.H = h, o.W = w, o.Cin = 512, o.Cout = 512;
+    fe->ops.push_back(o);
+    return ORBIT_OK;
+}
+
+// ---- efficientnet_b0, timm `tf_` variant (SAME padding, BN eps 1e-3), num_classes=0 --------------
+static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
+    fe->out_size = 1280;
+    const float eps = 1e-3f;
+    int h, w, pt, pl;
+    same_pad(H, 3, 2, h, pt);
+    same_pad(W, 3, 2, w, pl);
+    int bn = fe->add_bn("bn1", 32, eps, true);  // root bn1 is FiLM-tagged (film.py:45-46)
+    fe->add_conv("conv_stem.weight", bn, -1, 0, -1, H, W, 3, 32, 3, 2, pt, pl, h, w, ORBIT_ACT_SILU, 0, 1, 0);
+    int cur = 0, cin = 32;
+
+    auto add_dw = [&](const std::string& wkey, int bnidx, int in, int out, int C, int K, int stride, int hh,
+                      int ww, int& ho, int& wo) {
+        Op o;
+        o.kind = OP_DWCONV, o.in = in, o.out = out, o.H = hh, o.W = ww, o.Cin = C, o.Cout = C;
+        o.KH = o.KW = K, o.stride = stride, o.act = ORBIT_ACT_SILU, o.bn = bnidx;
+        same_pad(hh, K, stride, o.Ho, o.pad_t);
+        same_pad(ww, K, stride, o.Wo, o.pad_l);
+        o.weight = fe->add_param(wkey, (size_t)C * K * K);
+        o.packed_off = fe->packed_floats;
+        fe->packed_floats += (size_t)(C * K * K + 3) / 4 * 4;
+        ho = o.Ho, wo = o.Wo;
+        fe->note_buf(out, (size_t)ho * wo * C);
+        fe->macs += (double)ho * wo * C * K * K;
+        fe->ops.push_back(o);
+    };
+    auto add_se = [&](const std::string& p, int buf, int C, int R, int hh, int ww) {
+        Op a;
+        a.kind = OP_AVGPOOL, a.in = buf, a.out = 101, a.H = hh, a.W = ww, a.Cin = C, a.Cout = C;
+        fe->ops.push_back(a);
+        Op s;
+        s.kind = OP_SE, s.in = 101, s.out = 102, s.Cin = C, s.R = R;
+        s.se_w1 = fe->add_param(p + ".conv_reduce.weight", (size_t)R * C);
+        s.se_b1 = fe->add_param(p + ".conv_reduce.bias", R);
+        s.se_w2 = fe->add_param(p + ".conv_expand.weight", (size_t)C * R);
+        s.se_b2 = fe->add_param(p + ".conv_expand.bias", C);
+        fe->macs += 2.0 * C * R;
+        fe->max_se_c = std::max(fe->max_se_c, C);
+        fe->ops.push_back(s);
+    };
+
+    // stage 0: DepthwiseSeparableConv (not FiLM-tagged, film.py:41-48)
+    {
+        const std::string p = "blocks.0.0";
+        int ho, wo;
+        const int t1 = (cur + 1) % 3, t2 = (cur + 2) % 3;
+        // registration order: conv_dw, bn1, se, conv_pw, bn2
+        const size_t dw_slot = fe->params.size();
+        (void)dw_slot;
+        // conv_dw param is registered inside add_dw, bn1 after it: keep state_dict order cosmetic only
+        const int bn1 = fe->add_bn(p + ".bn1", 32, eps, false);
+        add_dw(p + ".conv_dw.weight", bn1, cur, t1, 32, 3, 1, h, w, ho, wo);
+        add_se(p + ".se", t1, 32, 8, ho, wo);
+        const int bn2 = fe->add_bn(p + ".bn2", 16, eps, false);
+        fe->add_conv(p + ".conv_pw.weight", bn2, t1, t2, -1, ho, wo, 32, 16, 1, 1, 0, 0, ho, wo, ORBIT_ACT_NONE,
+                     0, 0, 1);
+        cur = t2, cin = 16, h = ho, w = wo;
+    }
+    // stages 1..6: InvertedResidual  {repeats, kernel, stride, out channels}, expansion 6, SE 0.25 of block input
+    const int cfg[6][4] = {{2, 3, 2, 24}, {2, 5, 2, 40}, {3, 3, 2, 80}, {3, 5, 1, 112}, {4, 5, 2, 192}, {1, 3, 1, 320}};
+    for (int s = 0; s < 6; ++s) {
+        for (int r = 0; r < cfg[s][0]; ++r) {
+            const int K = cfg[s][1], stride = r == 0 ? cfg[s][2] : 1, cout = cfg[s][3];
+            const int mid = cin * 6;
+            const int rd = (int)(cin * 0.25 + 0.5);  // timm: round(in_chs * se_ratio)
+            const std::string p = "blocks." + std::to_string(s + 1) + "." + std::to_string(r);
+            const int t1 = (cur + 1) % 3, t2 = (cur + 2) % 3;
+            const bool skip = stride == 1 && cin == cout;
+            int ho, wo;
+            const int bn1 = fe->add_bn(p + ".bn1", mid, eps, false);
+            fe->add_conv(p + ".conv_pw.weight", bn1, cur, t1, -1, h, w, cin, mid, 1, 1, 0, 0, h, w, ORBIT_ACT_SILU, 0,
+                         0, 0);
+            const int bn2 = fe->add_bn(p + ".bn2", mid, eps, true);  // InvertedResidual.bn2 is FiLM-tagged
+            add_dw(p + ".conv_dw.weight", bn2, t1, t2, mid, K, stride, h, w, ho, wo);
+            add_se(p + ".se", t2, mid, rd, ho, wo);
+            const int bn3 = fe->add_bn(p + ".bn3", cout, eps, false);
+            // project: reads t2 (gated), residual from cur, writes t1 (free again)
+            fe->add_conv(p + ".conv_pwl.weight", bn3, t2, t1, skip ? cur : -1, ho, wo, mid, cout, 1, 1, 0, 0, ho, wo,
+                         ORBIT_ACT_NONE, 0, 0, 1);
+            cur = t1, cin = cout, h = ho, w = wo;
+        }
+    }
+    const int t1 = (cur + 1) % 3;
+    bn = fe->add_bn("bn2", 1280, eps, true);  // root bn2 is FiLM-tagged
+    fe->add_conv("conv_head.weight", bn, cur, t1, -1, h, w, cin, 1280, 1, 1, 0, 0, h, w, ORBIT_ACT_SILU, 0, 0, 0);
+    Op o;
+    o.kind = OP_AVGPOOL, o.in = t1, o.out = 100, o.H = h, o.W = w, o.Cin = 1280, o.Cout = 1280;
+    fe->ops.push_back(o);
+    return ORBIT_OK;
+}
+
+// ---- set encoder: 5 x (conv3x3 p1 + bias -> BN -> ReLU -> maxpool 2x2) -> global avg -> 64 ---------
+static int build_set_encoder(orbit_extractor* fe, int H, int W) {
+    fe->out_size = 64;
+    int h = H, w = W, cur = -1, cin = 3;
+    for (int L = 1; L <= 5; ++L) {
+        if (h < 2 || w < 2) return set_err(ORBIT_ERR_ARG, "set_encoder: frame %dx%d too small for 5 poolings", H, W);
+        const std::string p = "encoder.layer" + std::to_string(L);
+        const int out = cur < 0 ? 0 : (cur + 1) % 3;
+        const int wparam = fe->add_param(p + ".0.weight", (size_t)64 * cin * 9);
+        (void)wparam;
+        const int bias = fe->add_param(p + ".0.bias", 64);
+        const int bn = fe->add_bn(p + ".1", 64, 1e-5f, false, bias);
+        fe->add_conv(p + ".0.weight", bn, cur, out, -1, h, w, cin, 64, 3, 1, 1, 1, h, w, ORBIT_ACT_RELU, 1,
+                     cur < 0 ? 1 : 0, 0, bias);
+        cur = out, cin = 64, h /= 2, w /= 2;
+    }
+    Op o;
+    o.kind = OP_AVGPOOL, o.in = cur, o.out = 100, o.H = h, o.W = w, o.Cin = 64, o.Cout = 64;
+    fe->ops.push_back(o);
+    return ORBIT_OK;
+}
+
+// ---- workspace layout ------------------------------------------------------------------------------
+struct WsLayout {
+    size_t buf[3], pooled, gate, fold, total;
+};
+static WsLayout ws_layout(const orbit_extractor* fe, int B) {
+    WsLayout L;
+    size_t off = 0;
+    for (int i = 0; i < 3; ++i) {
+        L.buf[i] = off;
+        off += align_up(fe->buf_elems[i] * (size_t)B * sizeof(float), 256);
+    }
+    L.pooled = off;
+    off += align_up((size_t)std::max(fe->max_se_c, 1) * B * sizeof(float), 256);
+    L.gate = off;
+    off += align_up((size_t)std::max(fe->max_se_c, 1) * B * sizeof(float), 256);
+    L.fold = off;
+    off += align_up(2 * fe->fold_floats * sizeof(float), 256);
+    L.total = off;
+    return L;
+}
+
+extern "C" {
+
+int orbit_extractor_create(const char* name, int H, int W, orbit_extractor_t** out) {
+    ORBIT_REQUIRE(name && out, "extractor_create: null pointer");
+    ORBIT_REQUIRE(H >= 8 && W >= 8 && H <= 4096 && W <= 4096, "extractor_create: bad frame size %dx%d", H, W);
+    orbit_extractor* fe = new orbit_extractor();
+    fe->name = name, fe->H = H, fe->W = W;
+    int rc;
+    if (fe->name == "resnet18") rc = build_resnet18(fe, H, W);
+    else if (fe->name == "efficientnet_b0") rc = build_efficientnet_b0(fe, H, W);
+    else if (fe->name == "set_encoder") rc = build_set_encoder(fe, H, W);
+    else rc = set_err(ORBIT_ERR_ARG, "Invalid feature_extractor_name: %s", name);
+    if (rc != ORBIT_OK) {
+        delete fe;
+        return rc;
+    }
+    fe->bn_dev.resize(fe->bns.size());
+    for (size_t i = 0; i < fe->bns.size(); ++i) {
+        const BNDesc& b = fe->bns[i];
+        BNDev& d = fe->bn_dev[i];
+        d.gamma = fe->params[b.gamma].off, d.beta = fe->params[b.beta].off;
+        d.mean = fe->params[b.mean].off, d.var = fe->params[b.var].off;
+        d.conv_bias = b.conv_bias >= 0 ? fe->params[b.conv_bias].off : (size_t)-1;
+        d.fold_off = b.fold_off, d.C = b.C, d.film_off = b.film_off, d.eps = b.eps;
+    }
+    *out = fe;
+    return ORBIT_OK;
+}
+
+void orbit_extractor_destroy(orbit_extractor_t* fe) {
+    if (!fe) return;
+    (void)hipFree(fe->d_pool);
+    (void)hipFree(fe->d_packed);
+    (void)hipFree(fe->d_fold);
+    (void)hipFree(fe->d_bn);
+    delete fe;
+}
+
+int orbit_extractor_num_params(const orbit_extractor_t* fe) { return fe ? (int)fe->params.size() : 0; }
+const char* orbit_extractor_param_name(const orbit_extractor_t* fe, int i) {
+    return (fe && i >= 0 && i < (int)fe->params.size()) ? fe->params[i].key.c_str() : nullptr;
+}
+size_t orbit_extractor_param_numel(const orbit_extractor_t* fe, int i) {
+    return (fe && i >= 0 && i < (int)fe->params.size()) ? fe->params[i].numel : 0;
+}
+
+int orbit_extractor_load(orbit_extractor_t* fe, const char* key, const float* data, size_t numel) {
+    ORBIT_REQUIRE(fe && key && data, "extractor_load: null pointer");
+    auto it = fe->index.find(key);
+    ORBIT_REQUIRE(it != fe->index.end(), "extractor_load: unexpected key '%s' for %s", key, fe->name.c_str());
+    Param& p = fe->params[it->second];
+    ORBIT_REQUIRE(p.numel == numel, "extractor_load: '%s' has %zu elements, expected %zu", key, numel, p.numel);
+    if (int rc = fe->ensure_device()) return rc;
+    ORBIT_HIP_CHECK(hipMemcpy(fe->d_pool + p.off, data, numel * sizeof(float), hipMemcpyDefault));
+    p.loaded = true;
+    fe->finalized = false;
+    return ORBIT_OK;
+}
+
+int orbit_extractor_finalize(orbit_extractor_t* fe, orbit_stream_t stream) {
+    ORBIT_REQUIRE(fe, "extractor_finalize: null pointer");
+    for (const Param& p : fe->params)
+        ORBIT_REQUIRE(p.loaded, "extractor_finalize: parameter '%s' was never loaded", p.key.c_str());
+    if (int rc = fe->ensure_device()) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    for (const Op& o : fe->ops) {
+        if (o.kind == OP_CONV) {
+            int rc = conv_pack_weights(fe->d_pool + fe->params[o.weight].off, fe->d_packed + o.packed_off, o.Cin,
+                                       o.Cout, o.KH, o.KW, o.x_nchw, s);
+            if (rc != ORBIT_OK) return rc;
+        } else if (o.kind == OP_DWCONV) {
+            int rc = dwconv_pack_weights(fe->d_pool + fe->params[o.weight].off, fe->d_packed + o.packed_off, o.Cin,
+                                         o.KH, s);
+            if (rc != ORBIT_OK) return rc;
+        }
+    }
+    dim3 grid((unsigned)fe->bns.size(), 2);
+    bn_fold_all_kernel<<<grid, 256, 0, s>>>(fe->d_bn, fe->d_pool, nullptr, nullptr, fe->d_fold,
+                                            fe->d_fold + fe->fold_floats);
+    ORBIT_LAUNCH_CHECK();
+    fe->finalized = true;
+    return ORBIT_OK;
+}
+
+int orbit_extractor_output_size(const orbit_extractor_t* fe) { return fe ? fe->out_size : 0; }
+int orbit_extractor_film_slots(const orbit_extractor_t* fe) { return fe ? (int)fe->film_slots.size() : 0; }
+int orbit_extractor_film_slot_channels(const orbit_extractor_t* fe, int slot) {
+    return (fe && slot >= 0 && slot < (int)fe->film_slots.size()) ? fe->bns[fe->film_slots[slot]].C : 0;
+}
+const char* orbit_extractor_film_slot_name(const orbit_extractor_t* fe, int slot) {
+    return (fe && slot >= 0 && slot < (int)fe->film_slots.size()) ? fe->bns[fe->film_slots[slot]].name.c_str()
+                                                                  : nullptr;
+}
+int orbit_extractor_film_size(const orbit_extractor_t* fe) { return fe ? fe->film_size : 0; }
+double orbit_extractor_macs_per_frame(const orbit_extractor_t* fe) { return fe ? fe->macs : 0.0; }
+
+size_t orbit_extractor_workspace_bytes(const orbit_extractor_t* fe, int B) {
+    if (!fe || B <= 0) return 0;
+    return ws_layout(fe, B).total;
+}
+
+int orbit_extractor_forward(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
+                            const float* film_beta, float* feats, void* workspace, size_t workspace_bytes,
+                            orbit_stream_t stream) {
+    ORBIT_REQUIRE(fe && frames && feats && workspace, "extractor_forward: null pointer");
+    ORBIT_REQUIRE(B > 0, "extractor_forward: empty batch");
+    if (!fe->finalized) return set_err(ORBIT_ERR_STATE, "extractor_forward: call orbit_extractor_finalize first");
+    ORBIT_REQUIRE((film_gamma == nullptr) == (film_beta == nullptr),
+                  "extractor_forward: film_gamma and film_beta must be given together");
+    const WsLayout L = ws_layout(fe, B);
+    ORBIT_REQUIRE(workspace_bytes >= L.total, "extractor_forward: workspace too small (%zu < %zu bytes)",
+                  workspace_bytes, L.total);
+    ORBIT_REQUIRE(((uintptr_t)workspace & 255) == 0, "extractor_forward: workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    char* ws = static_cast<char*>(workspace);
+    auto buf = [&](int id) -> float* {
+        if (id == -1) return const_cast<float*>(frames);
+        if (id == 100) return feats;
+        if (id == 101) return reinterpret_cast<float*>(ws + L.pooled);
+        if (id == 102) return reinterpret_cast<float*>(ws + L.gate);
+        return reinterpret_cast<float*>(ws + L.buf[id]);
+    };
+    const float* scale = fe->d_fold;
+    const float* shift = fe->d_fold + fe->fold_floats;
+    if (film_gamma && fe->film_size > 0) {
+        float* fs = reinterpret_cast<float*>(ws + L.fold);
+        dim3 grid((unsigned)fe->bns.size(), 2);
+        bn_fold_all_kernel<<<grid, 256, 0, s>>>(fe->d_bn, fe->d_pool, film_gamma, film_beta, fs, fs + fe->fold_floats);
+        ORBIT_LAUNCH_CHECK();
+        scale = fs, shift = fs + fe->fold_floats;
+    }
+    for (const Op& o : fe->ops) {
+        int rc = ORBIT_OK;
+        switch (o.kind) {
+            case OP_CONV: {
+                ConvDesc d;
+                d.x = buf(o.in), d.w_packed = fe->d_packed + o.packed_off, d.y = buf(o.out);
+                d.scale = o.bn >= 0 ? scale + fe->bns[o.bn].fold_off : nullptr;
+                d.shift = o.bn >= 0 ? shift + fe->bns[o.bn].fold_off : nullptr;
+                d.residual = o.res >= 0 ? buf(o.res) : nullptr;
+                d.gate = o.use_gate ? buf(102) : nullptr;
+                d.B = B, d.H = o.H, d.W = o.W, d.Cin = o.Cin, d.Cout = o.Cout, d.KH = o.KH, d.KW = o.KW;
+                d.stride = o.stride, d.pad_t = o.pad_t, d.pad_l = o.pad_l, d.Ho = o.Ho, d.Wo = o.Wo;
+                d.act = o.act, d.pool2 = o.pool2, d.x_nchw = o.x_nchw;
+                rc = launch_conv(d, s);
+                break;
+            }
+            case OP_DWCONV:
+                rc = launch_dwconv(buf(o.in), fe->d_packed + o.packed_off, buf(o.out),
+                                   scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off, B, o.H, o.W,
+                                   o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, o.act, s);
+                break;
+            case OP_MAXPOOL:
+                rc = launch_maxpool(buf(o.in), buf(o.out), B, o.H, o.W, o.Cin, o.pool_k, o.stride, o.pool_pad, o.Ho,
+                                    o.Wo, s);
+                break;
+            case OP_AVGPOOL:
+                rc = launch_avgpool(buf(o.in), buf(o.out), B, o.H * o.W, o.Cin, s);
+                break;
+            case OP_SE:
+                rc = launch_se_gate(buf(101), fe->d_pool + fe->params[o.se_w1].off, fe->d_pool + fe->params[o.se_b1].off,
+                                    fe->d_pool + fe->params[o.se_w2].off, fe->d_pool + fe->params[o.se_b2].off,
+                                    buf(102), B, o.Cin, o.R, s);
+                break;
+        }
+        if (rc != ORBIT_OK) return rc;
+    }
+    return ORBIT_OK;
+}
+
+}  // extern "C"

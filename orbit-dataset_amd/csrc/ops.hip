@@ -1,0 +1,264 @@
+// HBM-bound layer kernels of the extractors (NHWC activations, channels innermost so every wave
+// instruction moves 1 KiB of contiguous data): depthwise convolution, max/avg pooling, squeeze-excite
+// gate, BatchNorm folding.
+//
+// Reference sites these stand in for (all run through ATen in the reference):
+//   depthwise / SE / SiLU        timm tf_efficientnet_b0 blocks used by model/feature_extractors.py:39-43
+//   max-pool, global avg-pool    model/set_encoders.py:101-118 and the ResNet/EfficientNet trunks
+//   BatchNorm (eval) + FiLM      model/few_shot_recognisers.py:114-117,176-183 — never a kernel of its own:
+//                                folded here to a per-channel (scale, shift) consumed by conv epilogues.
+#include "common.h"
+
+namespace orbit {
+
+__device__ __forceinline__ float act_fn(float v, int act) {
+    if (act == ORBIT_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ORBIT_ACT_SILU) return v / (1.0f + expf(-v));
+    return v;
+}
+
+// ---- depthwise KxK, NHWC, float4 over channels --------------------------------------------------
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x,
+                                                     const float* __restrict__ w,  // [K][K][C]
+                                                     float* __restrict__ y, const float* __restrict__ scale,
+                                                     const float* __restrict__ shift, int B, int H, int W,
+                                                     int C, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                                                     int act) {
+    const int C4 = C >> 2;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        size_t r = i / C4;
+        const int wo = (int)(r % Wo);
+        r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const float* xb = x + (size_t)b * H * W * C + c;
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int hi = ho * stride - pad_t + kh;
+            if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int wi = wo * stride - pad_l + kw;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)hi * W + wi) * C);
+                const float4 f = *reinterpret_cast<const float4*>(w + (size_t)(kh * K + kw) * C + c);
+                acc.x = fmaf(v.x, f.x, acc.x);
+                acc.y = fmaf(v.y, f.y, acc.y);
+                acc.z = fmaf(v.z, f.z, acc.z);
+                acc.w = fmaf(v.w, f.w, acc.w);
+            }
+        }
+        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (scale) sc = *reinterpret_cast<const float4*>(scale + c);
+        if (shift) sh = *reinterpret_cast<const float4*>(shift + c);
+        float4 o;
+        o.x = act_fn(acc.x * sc.x + sh.x, act);
+        o.y = act_fn(acc.y * sc.y + sh.y, act);
+        o.z = act_fn(acc.z * sc.z + sh.z, act);
+        o.w = act_fn(acc.w * sc.w + sh.w, act);
+        *reinterpret_cast<float4*>(y + (((size_t)b * Ho + ho) * Wo + wo) * C + c) = o;
+    }
+}
+
+__global__ __launch_bounds__(256) void dw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                                      int C, int K) {
+    const int total = C * K * K;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int c = i % C, tap = i / C;
+        wp[i] = w[(size_t)c * K * K + tap];
+    }
+}
+
+// ---- max-pool NHWC ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      int B, int H, int W, int C, int K, int stride, int pad,
+                                                      int Ho, int Wo) {
+    const int C4 = C >> 2;
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int c = (int)(i % C4) * 4;
+        size_t r = i / C4;
+        const int wo = (int)(r % Wo);
+        r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        const float* xb = x + (size_t)b * H * W * C + c;
+        float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        for (int kh = 0; kh < K; ++kh) {
+            const int hi = ho * stride - pad + kh;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int kw = 0; kw < K; ++kw) {
+                const int wi = wo * stride - pad + kw;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)hi * W + wi) * C);
+                m.x = fmaxf(m.x, v.x), m.y = fmaxf(m.y, v.y), m.z = fmaxf(m.z, v.z), m.w = fmaxf(m.w, v.w);
+            }
+        }
+        *reinterpret_cast<float4*>(y + (((size_t)b * Ho + ho) * Wo + wo) * C + c) = m;
+    }
+}
+
+// ---- global average pool NHWC [B][HW][C] -> [B][C] -----------------------------------------------
+// grid (ceil(C/64), B); 256 threads = 64 channels x 4 interleaved spatial slices, combined through LDS in
+// a fixed order (deterministic).
+__global__ __launch_bounds__(256) void avgpool_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      int HW, int C) {
+    __shared__ float part[4][64];
+    const int b = blockIdx.y;
+    const int cl = threadIdx.x & 63, slice = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s = 0.f;
+    if (c < C) {
+        const float* p = x + (size_t)b * HW * C + c;
+        for (int i = slice; i < HW; i += 4) s += p[(size_t)i * C];
+    }
+    part[slice][cl] = s;
+    __syncthreads();
+    if (slice == 0 && c < C)
+        y[(size_t)b * C + c] = (part[0][cl] + part[1][cl] + part[2][cl] + part[3][cl]) / (float)HW;
+}
+
+// ---- squeeze-excite gate: one block per frame ------------------------------------------------------
+__global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ pooled,
+                                                      const float* __restrict__ w1, const float* __restrict__ b1,
+                                                      const float* __restrict__ w2, const float* __restrict__ b2,
+                                                      float* __restrict__ gate, int C, int R) {
+    extern __shared__ float sm[];  // [C] pooled, [R] hidden
+    float* sp = sm;
+    float* hid = sm + C;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) sp[c] = pooled[(size_t)b * C + c];
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = wave; r < R; r += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(w1[(size_t)r * C + c], sp[c], s);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) {
+            s += b1[r];
+            hid[r] = s / (1.0f + expf(-s));  // SiLU
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = b2[c];
+        for (int r = 0; r < R; ++r) s = fmaf(w2[(size_t)c * R + r], hid[r], s);
+        gate[(size_t)b * C + c] = 1.0f / (1.0f + expf(-s));
+    }
+}
+
+// ---- BatchNorm (eval) folding -------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta,
+                                                      const float* __restrict__ mean, const float* __restrict__ var,
+                                                      const float* __restrict__ conv_bias, float eps, int C,
+                                                      float* __restrict__ scale, float* __restrict__ shift) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float sc = gamma[c] / sqrtf(var[c] + eps);
+    const float cb = conv_bias ? conv_bias[c] : 0.f;
+    scale[c] = sc;
+    shift[c] = beta[c] + (cb - mean[c]) * sc;
+}
+
+static int grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (int)(b > 8192 ? 8192 : (b == 0 ? 1 : b));
+}
+
+int launch_dwconv(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
+                  int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                  int act, hipStream_t s) {
+    ORBIT_REQUIRE(x && w_khwc && y, "dwconv: null pointer");
+    ORBIT_REQUIRE(C % 4 == 0, "dwconv: C %% 4 != 0 (C=%d)", C);
+    ORBIT_REQUIRE(K == 3 || K == 5, "dwconv: only 3x3 and 5x5 kernels are instantiated (K=%d)", K);
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    if (K == 3)
+        dwconv_kernel<3><<<grid_for(total), 256, 0, s>>>(x, w_khwc, y, scale, shift, B, H, W, C, stride, pad_t,
+                                                         pad_l, Ho, Wo, act);
+    else
+        dwconv_kernel<5><<<grid_for(total), 256, 0, s>>>(x, w_khwc, y, scale, shift, B, H, W, C, stride, pad_t,
+                                                         pad_l, Ho, Wo, act);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int dwconv_pack_weights(const float* w, float* w_khwc, int C, int K, hipStream_t s) {
+    dw_pack_kernel<<<grid_for((size_t)C * K * K), 256, 0, s>>>(w, w_khwc, C, K);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int K, int stride, int pad, int Ho,
+                   int Wo, hipStream_t s) {
+    ORBIT_REQUIRE(x && y, "maxpool: null pointer");
+    ORBIT_REQUIRE(C % 4 == 0, "maxpool: C %% 4 != 0 (C=%d)", C);
+    const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    maxpool_kernel<<<grid_for(total), 256, 0, s>>>(x, y, B, H, W, C, K, stride, pad, Ho, Wo);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int launch_avgpool(const float* x, float* y, int B, int HW, int C, hipStream_t s) {
+    ORBIT_REQUIRE(x && y && B > 0 && HW > 0 && C > 0, "avgpool: bad arguments");
+    dim3 grid(cdiv(C, 64), B);
+    avgpool_kernel<<<grid, 256, 0, s>>>(x, y, HW, C);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int launch_se_gate(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
+                   float* gate, int B, int C, int R, hipStream_t s) {
+    ORBIT_REQUIRE(pooled && w1 && b1 && w2 && b2 && gate, "se_gate: null pointer");
+    se_gate_kernel<<<B, 256, (size_t)(C + R) * sizeof(float), s>>>(pooled, w1, b1, w2, b2, gate, C, R);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
+                   const float* conv_bias, float eps, int C, float* scale, float* shift, hipStream_t s) {
+    bn_fold_kernel<<<cdiv(C, 256), 256, 0, s>>>(gamma, beta, mean, var, conv_bias, eps, C, scale, shift);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+}  // namespace orbit
+
+using namespace orbit;
+
+extern "C" {
+
+int orbit_op_dwconv2d(const float* x, const float* w, float* y, const float* scale, const float* shift, int B,
+                      int H, int W, int C, int K, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                      int act, orbit_stream_t stream) {
+    ORBIT_REQUIRE(x && w && y, "op_dwconv2d: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    float* wp = nullptr;
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&wp), (size_t)C * K * K * sizeof(float), s));
+    int rc = dwconv_pack_weights(w, wp, C, K, s);
+    if (rc == ORBIT_OK)
+        rc = launch_dwconv(x, wp, y, scale, shift, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, act, s);
+    (void)hipFreeAsync(wp, s);
+    return rc;
+}
+
+int orbit_op_maxpool2d(const float* x, float* y, int B, int H, int W, int C, int K, int stride, int pad,
+                       int Ho, int Wo, orbit_stream_t stream) {
+    return launch_maxpool(x, y, B, H, W, C, K, stride, pad, Ho, Wo, (hipStream_t)stream);
+}
+
+int orbit_op_avgpool(const float* x, float* y, int B, int HW, int C, orbit_stream_t stream) {
+    return launch_avgpool(x, y, B, HW, C, (hipStream_t)stream);
+}
+
+int orbit_op_se_gate(const float* pooled, const float* w1, const float* b1, const float* w2, const float* b2,
+                     float* gate, int B, int C, int R, orbit_stream_t stream) {
+    return launch_se_gate(pooled, w1, b1, w2, b2, gate, B, C, R, (hipStream_t)stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,103 @@
+"""Prototypical-network head on the native wavefront-reduction kernels (csrc/head.hip).
+
+Mirror of the head protocol of reference model/classifier_heads.py:
+  configure(features[N,D], labels[N], ops_counter=None)   :232-263 (+ _build_class_reps :94-119)
+  predict(features[M,D]) -> logits[M,C]                    :202-230
+  reset()                                                  :197-200
+Semantics kept from the reference:
+  * logit columns follow the ascending unique label values (labels need not be contiguous);
+  * euclidean logits are  s * (2 q.mu - mu.mu)  — W = 2 mu, b = -mu.mu (:253-255), the -q.q term is dropped;
+  * cosine logits are s * cos(q, W_c) with eps 1e-8;
+  * the configured weight/bias are detached from the support features (the reference re-wraps them in
+    nn.Parameter, :261-263, which cuts the autograd graph);
+  * predict before configure raises AttributeError (:210-211).
+Only the 'proto' / 'proto_cosine' heads are on the hot path named by BASELINE.json; 'versa', 'mahalanobis'
+and 'linear' are out of scope of this build.
+"""
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class PrototypicalClassifier(nn.Module):
+    def __init__(self, logit_scale: float = 1.0, distance_fn: str = "euclidean"):
+        super().__init__()
+        if distance_fn not in ("euclidean", "cosine"):
+            raise ValueError(f"Distance function {distance_fn} not valid.")
+        self.logit_scale = logit_scale
+        self.distance_fn = distance_fn
+        # hook for the support-sharded multi-GPU variant: called with the contiguous [C*D + C] buffer of
+        # per-class sums and counts between configure and finalize (an in-place all-reduce(SUM))
+        self.partial_reduce = None
+        self.reset()
+
+    def reset(self):
+        self.weight = None
+        self.class_ids = None
+        if self.distance_fn == "euclidean":
+            self.bias = None
+
+    @property
+    def _cosine(self):
+        return 1 if self.distance_fn == "cosine" else 0
+
+    def configure(self, context_features, context_labels, ops_counter=None, frames_per_clip: int = 1):
+        """context_features: [N*frames_per_clip, D] (clip-major); context_labels: [N]."""
+        _lib.require_gpu()
+        T = int(frames_per_clip)
+        assert context_features.size(0) == context_labels.size(0) * T, \
+            "context features and labels are different sizes!"
+        feats = context_features.detach().contiguous().float()
+        dev = feats.device
+        labels = context_labels.to(device=dev, dtype=torch.int64).contiguous()
+        class_ids = torch.unique(labels)  # ascending; one sync for the class count, as in the reference
+        C, (NT, D) = int(class_ids.numel()), feats.shape
+        N = NT // T
+        payload = torch.empty(C * D + C, device=dev, dtype=torch.float32)
+        sums, counts = payload[: C * D], payload[C * D:]
+        lib, st = _lib.load(), _lib.stream_handle()
+        _lib.check(lib.orbit_proto_configure(_lib.dptr(feats, torch.float32), _lib.dptr(labels, torch.int64),
+                                             _lib.dptr(class_ids, torch.int64), 1, N, T, D, C,
+                                             _lib.dptr(sums), _lib.dptr(counts), st), "orbit_proto_configure")
+        if self.partial_reduce is not None:
+            self.partial_reduce(payload)
+        weight = torch.empty(C, D, device=dev, dtype=torch.float32)
+        bias = None if self._cosine else torch.empty(C, device=dev, dtype=torch.float32)
+        _lib.check(lib.orbit_proto_finalize(_lib.dptr(sums), _lib.dptr(counts), 1, C, D, self._cosine,
+                                            _lib.dptr(weight), _lib.dptr(bias), st), "orbit_proto_finalize")
+        self.weight = weight
+        self.class_ids = class_ids
+        if not self._cosine:
+            self.bias = bias
+
+    def predict(self, features, ops_counter=None, frames_per_clip: int = 1, return_argmax: bool = False):
+        if self.weight is None or (self.distance_fn == "euclidean" and self.bias is None):
+            raise AttributeError("Weight and/or bias not set - is model personalised?")
+        _lib.require_gpu()
+        T = int(frames_per_clip)
+        q = features.detach().contiguous().float()
+        MT, D = q.shape
+        M = MT // T
+        C = self.weight.size(0)
+        logits = torch.empty(M, C, device=q.device, dtype=torch.float32)
+        argmax = torch.empty(M, device=q.device, dtype=torch.int32) if return_argmax else None
+        if M > 0:
+            _lib.check(_lib.load().orbit_proto_predict(
+                _lib.dptr(q, torch.float32), _lib.dptr(self.weight), _lib.dptr(None if self._cosine else self.bias),
+                1, M, T, D, C, float(self.logit_scale), self._cosine, _lib.dptr(logits), _lib.dptr(argmax),
+                _lib.stream_handle()), "orbit_proto_predict")
+        return (logits, argmax) if return_argmax else logits
+
+
+def create_classifier(classifier: str, feat_dim: int, logit_scale: float):
+    """Head factory used by FewShotRecogniser.__init__ (reference few_shot_recognisers.py:70-84)."""
+    if classifier == "proto":
+        return PrototypicalClassifier(logit_scale)
+    if classifier == "proto_cosine":
+        return PrototypicalClassifier(logit_scale, distance_fn="cosine")
+    if classifier in ("linear", "versa", "mahalanobis"):
+        raise NotImplementedError(
+            f"Classifier '{classifier}' is outside the prototype-head hot path this build implements "
+            "(SURVEY.md §8f lists it as a next row).")
+    raise ValueError(f"Classifier {classifier} not valid.")

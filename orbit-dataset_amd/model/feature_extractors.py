@@ -1,0 +1,315 @@
+"""Feature extractors backed by the native gfx950 runtime (csrc/extractor.hip).
+
+Mirror of the reference factory `create_feature_extractor` (reference model/feature_extractors.py:37-79):
+same signature and return value `(extractor, film_parameter_names)`, `extractor.output_size`, frozen
+parameters when `learn_extractor=False`, FiLM tagging when `with_film=True`. The reference builds timm
+networks; here the network lives in liborbit_hip.so and this module is only its parameter container
+(state_dict-compatible key names: torchvision layout for resnet18, timm `tf_efficientnet_b0` layout for
+efficientnet_b0) plus the call into `orbit_extractor_forward`. `resnet18` and arbitrary frame sizes are
+additions BASELINE.json's configs require (the snapshot's args.py:27,77 no longer list them).
+
+There is no pretrained-weight download (no network): `pretrained=True` is accepted for signature parity and
+ignored; parameters are initialised deterministically by `synthetic.init_extractor_` or `load_state_dict`.
+"""
+import ctypes
+
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+_EXTRACTOR_OUTPUT = {"resnet18": 512, "efficientnet_b0": 1280}
+_BN_EPS = {"resnet18": 1e-5, "efficientnet_b0": 1e-3, "set_encoder": 1e-5}
+
+
+class ParamNode(nn.Module):
+    """Plain container node of the parameter tree (a conv, a BatchNorm, a block ...)."""
+
+    def forward(self, *a, **k):  # pragma: no cover - never called
+        raise RuntimeError("parameter container; the computation runs in liborbit_hip.so")
+
+
+class BatchNormNode(ParamNode):
+    """weight / bias parameters + running_mean / running_var / num_batches_tracked buffers of one BatchNorm."""
+
+
+def _ensure_child(module, name, cls=ParamNode):
+    child = module._modules.get(name)
+    if child is None:
+        child = cls()
+        module.add_module(name, child)
+    return child
+
+
+class _Plan:
+    """One native plan (frame size specific) and the parameter stamp it was last synchronised with."""
+
+    def __init__(self, name, H, W):
+        lib = _lib.load()
+        h = ctypes.c_void_p()
+        _lib.check(lib.orbit_extractor_create(name.encode(), H, W, ctypes.byref(h)), "orbit_extractor_create")
+        self.handle = h
+        self.stamp = None
+        self.workspaces = {}
+
+    def destroy(self):
+        if self.handle:
+            _lib.load().orbit_extractor_destroy(self.handle)
+            self.handle = None
+
+
+class HipNetwork(nn.Module):
+    """Parameter tree of a native network + forward through liborbit_hip.so.
+
+    forward(frames[B,3,H,W] fp32 on the HIP device, film=None) -> features [B, output_size].
+    `film` is an optional pair (gamma, beta) of concatenated per-task BatchNorm weight/bias for the FiLM slots
+    (fast path). When the module is instead run under `torch.func.functional_call` with a FiLM dict (the
+    reference's mechanism, few_shot_recognisers.py:114-115), the swapped-in BatchNorm tensors are detected and
+    gathered automatically.
+    """
+
+    def __init__(self, native_name):
+        super().__init__()
+        self.native_name = native_name
+        self._plans = {}
+        lib = _lib.load()
+        # a throw-away plan at a nominal size enumerates the state_dict keys and FiLM slots
+        probe = _Plan(native_name, 64, 64)
+        try:
+            h = probe.handle
+            self.output_size = lib.orbit_extractor_output_size(h)
+            self._keys = []
+            for i in range(lib.orbit_extractor_num_params(h)):
+                key = lib.orbit_extractor_param_name(h, i).decode()
+                numel = lib.orbit_extractor_param_numel(h, i)
+                self._keys.append((key, numel))
+            self._film_slot_names = []
+            self._film_slot_channels = []
+            for s in range(lib.orbit_extractor_film_slots(h)):
+                self._film_slot_names.append(lib.orbit_extractor_film_slot_name(h, s).decode())
+                self._film_slot_channels.append(lib.orbit_extractor_film_slot_channels(h, s))
+            self.film_size = lib.orbit_extractor_film_size(h)
+        finally:
+            probe.destroy()
+        self._leaves = []  # (module, attr, key)
+        for key, numel in self._keys:
+            self._register_leaf(key, numel)
+
+    # ---- parameter tree -------------------------------------------------------------------------
+    def _register_leaf(self, key, numel):
+        parts = key.split(".")
+        node = self
+        is_bn_stat = parts[-1] in ("running_mean", "running_var")
+        for i, part in enumerate(parts[:-1]):
+            last = i == len(parts) - 2
+            node = _ensure_child(node, part, BatchNormNode if (last and is_bn_stat) else ParamNode)
+        attr = parts[-1]
+        shape = self._leaf_shape(key, numel)
+        if is_bn_stat:
+            init = torch.zeros(shape) if attr == "running_mean" else torch.ones(shape)
+            node.register_buffer(attr, init)
+            if "num_batches_tracked" not in node._buffers:
+                node.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+            self._leaves.append((node, attr, key, None))
+        else:
+            param = nn.Parameter(torch.zeros(shape))
+            node.register_parameter(attr, param)
+            # keep the Parameter object: functional_call swaps module._parameters entries, and a plan created
+            # while FiLM tensors are swapped in must still upload the network's own BatchNorm parameters
+            self._leaves.append((node, attr, key, param))
+
+    def _leaf_shape(self, key, numel):
+        return (numel,)
+
+    def _tensor(self, node, attr):
+        t = node._parameters.get(attr)
+        return t if t is not None else node._buffers.get(attr)
+
+    # ---- native plan handling ---------------------------------------------------------------------
+    def _plan(self, H, W):
+        plan = self._plans.get((H, W))
+        if plan is None:
+            plan = _Plan(self.native_name, H, W)
+            self._plans[(H, W)] = plan
+        return plan
+
+    def _stamp(self):
+        # swapped-in FiLM tensors (functional_call) are plain tensors, not Parameters: they do not count as a
+        # change of the network's own parameters
+        st = []
+        for node, attr, _, own in self._leaves:
+            t = self._tensor(node, attr)
+            if own is not None and not isinstance(t, nn.Parameter):
+                t = own
+            st.append((t.data_ptr(), t._version))
+        return tuple(st)
+
+    def sync(self, plan=None):
+        """(Re)upload parameters into the native plan(s) if they changed since the last upload."""
+        lib = _lib.load()
+        stamp = self._stamp()
+        plans = [plan] if plan is not None else list(self._plans.values())
+        for pl in plans:
+            if pl.stamp == stamp:
+                continue
+            for node, attr, key, own in self._leaves:
+                t = self._tensor(node, attr)
+                if own is not None and not isinstance(t, nn.Parameter):
+                    t = own
+                t = t.detach().contiguous().float()
+                _lib.check(lib.orbit_extractor_load(pl.handle, key.encode(), ctypes.c_void_p(t.data_ptr()),
+                                                    t.numel()), "orbit_extractor_load(%s)" % key)
+            _lib.check(lib.orbit_extractor_finalize(pl.handle, _lib.stream_handle()), "orbit_extractor_finalize")
+            pl.stamp = stamp
+
+    def _workspace(self, plan, B, device):
+        ws = plan.workspaces.get(B)
+        if ws is None or ws.device != device:
+            nbytes = _lib.load().orbit_extractor_workspace_bytes(plan.handle, B)
+            ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
+            plan.workspaces = {B: ws}  # keep only the most recent batch size
+        return ws
+
+    def macs_per_frame(self, H, W):
+        return _lib.load().orbit_extractor_macs_per_frame(self._plan(H, W).handle)
+
+    # ---- FiLM ---------------------------------------------------------------------------------------
+    def film_slot_modules(self):
+        mods = dict(self.named_modules())
+        return [(name, mods[name]) for name in self._film_slot_names]
+
+    def _gather_swapped_film(self):
+        """If BatchNorm weights/biases were swapped in by functional_call, return (gamma, beta) concatenated."""
+        swapped = False
+        gammas, betas = [], []
+        for _, m in self.film_slot_modules():
+            w, b = m._parameters["weight"], m._parameters["bias"]
+            if not isinstance(w, nn.Parameter) or not isinstance(b, nn.Parameter):
+                swapped = True
+            gammas.append(w.detach().reshape(-1))
+            betas.append(b.detach().reshape(-1))
+        if not swapped:
+            return None
+        return torch.cat(gammas).float().contiguous(), torch.cat(betas).float().contiguous()
+
+    # ---- forward ------------------------------------------------------------------------------------
+    def forward(self, x, film=None, out=None, check_sync=True):
+        _lib.require_gpu()
+        if x.dim() == 5:
+            x = x.flatten(end_dim=1)
+        if x.dim() != 4 or x.shape[1] != 3:
+            raise ValueError("expected frames of shape [B,3,H,W], got %s" % (tuple(x.shape),))
+        if not x.is_cuda:
+            raise _lib.OrbitHipError("frames must be on the HIP device (got %s); no CPU fallback" % x.device)
+        x = x.contiguous().float()
+        B, _, H, W = x.shape
+        plan = self._plan(H, W)
+        if film is None and self.film_size > 0:
+            film = self._gather_swapped_film()
+        if check_sync or plan.stamp is None:
+            self.sync(plan)
+        feats = out if out is not None else torch.empty(B, self.output_size, device=x.device, dtype=torch.float32)
+        if B == 0:
+            return feats
+        ws = self._workspace(plan, B, x.device)
+        gamma = beta = None
+        if film is not None:
+            gamma, beta = film
+            if gamma.numel() != self.film_size or beta.numel() != self.film_size:
+                raise ValueError("film vectors must have %d elements" % self.film_size)
+        _lib.check(_lib.load().orbit_extractor_forward(
+            plan.handle, _lib.dptr(x, torch.float32), B, _lib.dptr(gamma), _lib.dptr(beta),
+            _lib.dptr(feats, torch.float32), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_handle()),
+            "orbit_extractor_forward")
+        return feats
+
+    def __del__(self):
+        try:
+            for p in self._plans.values():
+                p.destroy()
+        except Exception:
+            pass
+
+
+# torch-layout shapes of the leaves, so that state_dicts interchange with torchvision / timm checkpoints
+def _conv_shape(cout, cin, k):
+    return (cout, cin, k, k)
+
+
+class ResNet18(HipNetwork):
+    def __init__(self):
+        super().__init__("resnet18")
+
+    def _leaf_shape(self, key, numel):
+        if key == "conv1.weight":
+            return (64, 3, 7, 7)
+        if key.endswith("downsample.0.weight"):
+            cout = {"layer2": 128, "layer3": 256, "layer4": 512}[key.split(".")[0]]
+            return (cout, cout // 2, 1, 1)
+        if ".conv" in key and key.endswith(".weight"):
+            cout = {"layer1": 64, "layer2": 128, "layer3": 256, "layer4": 512}[key.split(".")[0]]
+            cin = numel // (cout * 9)
+            return (cout, cin, 3, 3)
+        return (numel,)
+
+
+class EfficientNetB0(HipNetwork):
+    def __init__(self):
+        super().__init__("efficientnet_b0")
+        self._numel = dict(self._keys)
+
+    def _leaf_shape(self, key, numel):
+        if not key.endswith(".weight") or ".bn" in key or key.startswith("bn"):
+            return (numel,)
+        if key == "conv_stem.weight":
+            return (32, 3, 3, 3)
+        # the output-channel count equals the size of the tensor that follows a conv in module order:
+        # derive it from the sibling BatchNorm / bias instead of hard-coding the table
+        keys = dict(self._keys)
+        prefix = key[: -len(".weight")]
+        if prefix.endswith("conv_dw"):
+            blk = prefix[: -len(".conv_dw")]
+            bn = blk + (".bn1" if blk == "blocks.0.0" else ".bn2")
+            c = keys[bn + ".weight"]
+            k = int(round((numel // c) ** 0.5))
+            return (c, 1, k, k)
+        if prefix.endswith("se.conv_reduce") or prefix.endswith("se.conv_expand"):
+            cout = keys[prefix + ".bias"]
+            return (cout, numel // cout, 1, 1)
+        if prefix == "conv_head":
+            return (1280, numel // 1280, 1, 1)
+        blk, conv = prefix.rsplit(".", 1)
+        if blk == "blocks.0.0":
+            bn = ".bn2"  # DepthwiseSeparableConv: conv_pw -> bn2
+        else:
+            bn = ".bn1" if conv == "conv_pw" else ".bn3"
+        cout = keys[blk + bn + ".weight"]
+        return (cout, numel // cout, 1, 1)
+
+
+def create_feature_extractor(feature_extractor_name: str, pretrained: bool = True, with_film: bool = False,
+                             learn_extractor: bool = True):
+    """Same contract as the reference factory (model/feature_extractors.py:37-79)."""
+    from .film import get_film_parameter_names, tag_film_layers
+
+    if feature_extractor_name == "resnet18":
+        feature_extractor = ResNet18()
+    elif feature_extractor_name == "efficientnet_b0":
+        feature_extractor = EfficientNetB0()
+    else:
+        raise ValueError(f"Invalid feature_extractor_name: {feature_extractor_name}")
+    assert feature_extractor.output_size == _EXTRACTOR_OUTPUT[feature_extractor_name]
+
+    if not learn_extractor:
+        freeze_extractor(feature_extractor)
+
+    film_param_names = None
+    if with_film:
+        tag_film_layers(feature_extractor_name, feature_extractor)
+        film_param_names = get_film_parameter_names(feature_extractor_name, feature_extractor)
+    return feature_extractor, film_param_names
+
+
+def freeze_extractor(feature_extractor):
+    for param in feature_extractor.parameters():
+        param.requires_grad = False

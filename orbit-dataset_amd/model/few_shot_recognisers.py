@@ -1,0 +1,246 @@
+"""Episodic few-shot recognisers on the MI355X-native runtime.
+
+Drop-in mirror of the reference API (reference model/few_shot_recognisers.py):
+  FewShotRecogniser            :46-183   wiring, batched feature extraction, BN-state policy
+  SingleStepFewShotRecogniser  :271-473  personalise / personalise_with_lite / predict / predict_a_batch /
+                                         _reset / _clear_caches
+Same constructor arguments, method names, argument meaning, side effects (`film_dict`, classifier state,
+LITE caches) and errors. What differs is where the arithmetic runs: every frame batch goes through
+`orbit_extractor_forward` (hand-written gfx950 kernels), FiLM parameters come from one grouped generator
+launch, the head is the wavefront-reduction prototype kernel. Frames may arrive on the host (they are moved
+per mini-batch, as in the reference) or already resident in HBM.
+
+Scope notes: the native path is the inference/forward form. Train-mode BatchNorm and
+autograd through the extractor (`learn_extractor=True` outside test mode) are the "next" row and raise
+NotImplementedError instead of silently falling back to another backend.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+from ..data.utils import get_batch_indices
+from .classifier_heads import create_classifier
+from .feature_adapters import FilmParameterGenerator, NullGenerator
+from .feature_extractors import create_feature_extractor
+from .film import get_film_parameter_sizes, get_film_parameters
+from .poolers import MeanPooler
+from .set_encoders import NullSetEncoder, SetEncoder
+
+
+class FewShotRecogniser(nn.Module):
+    """Generic few-shot classification model (reference :46-183)."""
+
+    def __init__(self, feature_extractor_name: str, adapt_features: bool, classifier: str, clip_length: int,
+                 batch_size: int, learn_extractor: bool, logit_scale: float = 1.0):
+        super().__init__()
+        self.adapt_features = adapt_features
+        self.learn_extractor = learn_extractor
+        self.clip_length = clip_length
+        self.batch_size = batch_size
+        self.logit_scale = logit_scale
+        self.test_mode = False
+
+        self.feature_extractor, self.film_parameter_names = create_feature_extractor(
+            feature_extractor_name=feature_extractor_name,
+            pretrained=True,
+            with_film=self.adapt_features,
+            learn_extractor=self.learn_extractor,
+        )
+        self.classifier_name = classifier
+        self.classifier = create_classifier(classifier, self.feature_extractor.output_size, self.logit_scale)
+        self.frame_pooler = MeanPooler(T=self.clip_length)
+        self.device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+
+    def _set_device(self, device):
+        self.device = torch.device(device)
+
+    def _send_to_device(self):
+        if self.device is None or self.device.type != "cuda":
+            raise _lib.OrbitHipError("the native recogniser runs on a HIP device only (got %s)" % (self.device,))
+        self.to(self.device)
+
+    # ---- feature extraction ----------------------------------------------------------------------
+    def _film_vectors(self, film_dict):
+        """(gamma, beta) concatenated in FiLM-slot order, or None."""
+        if not film_dict:
+            return None
+        gen = getattr(self, "film_generator", None)
+        if gen is not None and film_dict is getattr(self, "_generated_film_dict", None) and gen.last_film is not None:
+            return gen.last_film
+        gammas, betas = [], []
+        for name, _ in self.feature_extractor.film_slot_modules():
+            gammas.append(film_dict[name + ".weight"].reshape(-1))
+            betas.append(film_dict[name + ".bias"].reshape(-1))
+        return torch.cat(gammas).float().contiguous(), torch.cat(betas).float().contiguous()
+
+    def _get_features(self, clips, film_dict={}, ops_counter=None):
+        """clips [n,T,3,H,W] or frames [B,3,H,W] -> frame features [n*T, D] (reference :99-122)."""
+        if clips.dim() == 5:
+            clips = clips.flatten(end_dim=1)
+        clips = clips.to(self.device, non_blocking=True)
+        return self.feature_extractor(clips, film=self._film_vectors(film_dict))
+
+    def _get_features_in_batches(self, clips, film_dict={}, ops_counter=None):
+        """Same, `batch_size` clips per extractor launch (reference :124-153). Each batch writes its slice of
+        one preallocated [N*T, D] tensor instead of a final torch.cat."""
+        num_clips = len(clips)
+        frames_per_clip = clips.shape[1] if clips.dim() == 5 else 1
+        D = self.feature_extractor.output_size
+        features = torch.empty(num_clips * frames_per_clip, D, device=self.device, dtype=torch.float32)
+        film = self._film_vectors(film_dict)
+        num_batches = int(np.ceil(float(num_clips) / float(self.batch_size)))
+        for batch in range(num_batches):
+            lo, hi = get_batch_indices(batch, num_clips, self.batch_size)
+            batch_clips = clips[lo:hi]
+            if batch_clips.dim() == 5:
+                batch_clips = batch_clips.flatten(end_dim=1)
+            batch_clips = batch_clips.to(self.device, non_blocking=True)
+            self.feature_extractor(batch_clips, film=film,
+                                   out=features[lo * frames_per_clip: hi * frames_per_clip],
+                                   check_sync=(batch == 0))
+        return features
+
+    def _pool_features(self, features, ops_counter=None):
+        return self.frame_pooler(features)
+
+    def set_test_mode(self, test_mode):
+        self.test_mode = test_mode
+
+    def _set_batch_norm_state(self):
+        """eval() everywhere; the reference switches the extractor to train() when meta-training an unfrozen
+        extractor (:176-183). Batch-statistics BatchNorm is not part of the native forward (next row)."""
+        self.eval()
+        if self.learn_extractor and not self.test_mode:
+            raise NotImplementedError(
+                "train-mode BatchNorm (learn_extractor=True outside test mode) is not implemented by the native "
+                "forward path; call set_test_mode(True) or construct with learn_extractor=False")
+
+
+class SingleStepFewShotRecogniser(FewShotRecogniser):
+    """Few-shot model personalised in a single forward step — ProtoNets / CNAPs-style (reference :271-473)."""
+
+    def __init__(self, feature_extractor_name: str, adapt_features: bool, classifier: str, clip_length: int,
+                 batch_size: int, learn_extractor: bool, num_lite_samples: int, logit_scale: float = 1.0):
+        FewShotRecogniser.__init__(self, feature_extractor_name, adapt_features, classifier, clip_length,
+                                   batch_size, learn_extractor, logit_scale)
+        self.num_lite_samples = num_lite_samples
+        if self.adapt_features:
+            self.set_encoder = SetEncoder()
+            self.film_parameter_sizes = get_film_parameter_sizes(self.film_parameter_names, self.feature_extractor)
+            initial_film_parameters = get_film_parameters(self.film_parameter_names, self.feature_extractor)
+            self.film_generator = FilmParameterGenerator(
+                self.film_parameter_sizes,
+                initial_film_parameters,
+                pooled_size=self.set_encoder.output_size,
+                hidden_size=self.set_encoder.output_size,
+                slot_names=[n for n, _ in self.feature_extractor.film_slot_modules()],
+            )
+        else:
+            self.set_encoder = NullSetEncoder()
+            self.film_generator = NullGenerator()
+        self.film_dict = None
+        self._generated_film_dict = None
+        self.reps_cache = None
+        self.features_cache = None
+
+    def _reset(self):
+        self.film_dict = None
+        self._generated_film_dict = None
+        self.classifier.reset()
+
+    def _clear_caches(self):
+        self.reps_cache = None
+        self.features_cache = None
+
+    # ---- personalise ---------------------------------------------------------------------------------
+    def personalise(self, context_clips, context_labels, ops_counter=None):
+        self._set_batch_norm_state()
+        task_embedding = self._get_task_embedding_in_batches(context_clips, ops_counter)
+        self.film_dict = self._generate_film_params(task_embedding, ops_counter)
+        context_features = self._get_features_in_batches(context_clips, self.film_dict, ops_counter)
+        context_features = self._pool_features(context_features, ops_counter)
+        self.classifier.configure(context_features, context_labels, ops_counter)
+
+    def personalise_with_lite(self, context_clips, context_labels):
+        """LITE forward (reference :328-343): a random subset of `num_lite_samples` clips is re-encoded on
+        every call, the rest comes from the per-task caches; features/labels are reordered by the permutation.
+        The permutation comes from np.random, exactly as in the reference (seed numpy to reproduce)."""
+        self._set_batch_norm_state()
+        shuffled_idxs = np.random.permutation(len(context_clips))
+        grad_idxs = shuffled_idxs[0:self.num_lite_samples]
+        no_grad_idxs = shuffled_idxs[self.num_lite_samples:]
+        task_embedding = self._get_task_embedding_with_split_batch(context_clips, grad_idxs, no_grad_idxs)
+        self.film_dict = self._generate_film_params(task_embedding)
+        context_features = self._get_features_with_split_batch(context_clips, self.film_dict, grad_idxs, no_grad_idxs)
+        context_features = self._pool_features(context_features)
+        labels = context_labels[torch.as_tensor(shuffled_idxs, device=context_labels.device)]
+        self.classifier.configure(context_features, labels)
+
+    # ---- task embedding ------------------------------------------------------------------------------
+    def _get_task_embedding(self, context_clips, ops_counter=None, aggregation="mean"):
+        context_clips = context_clips.to(self.device, non_blocking=True)
+        reps = self.set_encoder(context_clips)
+        return self.set_encoder.aggregate(reps, aggregation=aggregation)
+
+    def _get_task_embedding_in_batches(self, context_clips, ops_counter=None, aggregation="mean"):
+        if isinstance(self.set_encoder, NullSetEncoder):
+            return None
+        num_clips = len(context_clips)
+        frames_per_clip = context_clips.shape[1] if context_clips.dim() == 5 else 1
+        reps = torch.empty(num_clips * frames_per_clip, self.set_encoder.output_size, device=self.device,
+                           dtype=torch.float32)
+        num_batches = int(np.ceil(float(num_clips) / float(self.batch_size)))
+        for batch in range(num_batches):
+            lo, hi = get_batch_indices(batch, num_clips, self.batch_size)
+            batch_clips = context_clips[lo:hi].to(self.device, non_blocking=True)
+            if batch_clips.dim() == 5:
+                batch_clips = batch_clips.flatten(end_dim=1)
+            self.set_encoder(batch_clips, out=reps[lo * frames_per_clip: hi * frames_per_clip],
+                             check_sync=(batch == 0))
+        return self.set_encoder.aggregate(reps, aggregation=aggregation)
+
+    def _get_task_embedding_with_split_batch(self, context_clips, grad_idxs, no_grad_idxs):
+        if isinstance(self.set_encoder, NullSetEncoder):
+            return None
+        self._set_batch_norm_state()
+        if self.reps_cache is None:
+            self.reps_cache = self._get_task_embedding_in_batches(context_clips, aggregation="none")
+        reps_with_grads = self._get_task_embedding(context_clips[grad_idxs], aggregation="none")
+        reps_without_grads = self.reps_cache[torch.as_tensor(no_grad_idxs, device=self.reps_cache.device)]
+        # mean over the concatenation (reference :413 returns a [64] vector here, not [1,64])
+        return self.set_encoder.aggregate(torch.cat((reps_with_grads, reps_without_grads)), "mean").reshape(-1)
+
+    def _get_features_with_split_batch(self, context_clips, film_dict, grad_idxs, no_grad_idxs):
+        self._set_batch_norm_state()
+        if self.features_cache is None:
+            self.features_cache = self._get_features_in_batches(context_clips, film_dict)
+        features_with_grads = self._get_features(context_clips[grad_idxs], film_dict)
+        if context_clips.dim() == 5 and context_clips.shape[1] > 1:
+            # the cache holds frame features [N*T, D]; the reference indexes it with clip indices (:434),
+            # which is only meaningful for T == 1 — keep clip granularity here
+            T = context_clips.shape[1]
+            idx = torch.as_tensor(no_grad_idxs, device=self.features_cache.device)
+            frame_idx = (idx[:, None] * T + torch.arange(T, device=idx.device)[None, :]).reshape(-1)
+            features_without_grads = self.features_cache[frame_idx]
+        else:
+            features_without_grads = self.features_cache[torch.as_tensor(no_grad_idxs, device=self.features_cache.device)]
+        return torch.cat((features_with_grads, features_without_grads))
+
+    def _generate_film_params(self, task_embedding, ops_counter=None):
+        film_dict = self.film_generator(task_embedding)
+        self._generated_film_dict = film_dict
+        return film_dict
+
+    # ---- predict ----------------------------------------------------------------------------------------
+    def predict(self, target_clips):
+        self._set_batch_norm_state()
+        target_features = self._get_features_in_batches(target_clips, self.film_dict)
+        target_features = self._pool_features(target_features)
+        return self.classifier.predict(target_features)
+
+    def predict_a_batch(self, target_clips):
+        self._set_batch_norm_state()
+        target_features = self._get_features(target_clips, self.film_dict)
+        target_features = self._pool_features(target_features)
+        return self.classifier.predict(target_features)

@@ -1,0 +1,30 @@
+"""Frame pooler (reference model/poolers.py:7-16): mean over the T frames of each clip, on the GPU."""
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+
+class MeanPooler(nn.Module):
+    def __init__(self, T, dim=1):
+        super().__init__()
+        self.T = T
+        self.dim = dim
+
+    def forward(self, x):
+        feat_dim = x.size(-1)
+        if self.T == 1:
+            return x.view(-1, feat_dim)
+        _lib.require_gpu()
+        x = x.contiguous().float()
+        n = x.numel() // (self.T * feat_dim)
+        out = torch.empty(n, feat_dim, device=x.device, dtype=torch.float32)
+        if n > 0:
+            _lib.check(_lib.load().orbit_mean_pool(_lib.dptr(x, torch.float32), n, self.T, feat_dim,
+                                                   _lib.dptr(out), _lib.stream_handle()), "orbit_mean_pool")
+        return out
+
+
+class IdentityPooler(nn.Module):
+    def forward(self, x):
+        return x

@@ -1,0 +1,106 @@
+"""CPU-side checks of the drop-in boundary: liborbit_hip.so loads, exports every symbol include/orbit_hip.h
+declares, binds to one HIP runtime, and its host-only entry points (plan construction, state_dict
+enumeration, FiLM slots, workspace/MAC accounting, argument validation) behave — no kernel launches."""
+import ctypes
+import os
+import re
+
+import pytest
+
+import orbit_dataset_amd  # noqa: F401
+from orbit_dataset_amd import _lib
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    src = open(os.path.join(ROOT, "include", "orbit_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(orbit_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_symbols_exported_and_bound(lib):
+    names = header_functions()
+    assert len(names) >= 35
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/orbit_hip.h but not exported"
+    assert sorted(_lib.EXPORTS) == names, "ctypes signature table and header disagree"
+    assert lib.orbit_version() >= 100
+
+
+def test_single_hip_runtime(lib):
+    import torch  # noqa: F401
+    assert len(_lib._hip_runtimes_mapped()) <= 1
+
+
+def _create(lib, name, H, W):
+    h = ctypes.c_void_p()
+    rc = lib.orbit_extractor_create(name.encode(), H, W, ctypes.byref(h))
+    return rc, h
+
+
+def test_plan_accounting_matches_survey(lib):
+    """MACs per frame of the native plans == the figures BASELINE.md / SURVEY §8(d) compute from layer shapes."""
+    expect = {("resnet18", 84): 0.2961e9, ("resnet18", 224): 1.8136e9, ("efficientnet_b0", 224): 0.3845e9,
+              ("set_encoder", 84): 0.0981e9, ("set_encoder", 224): 0.7009e9}
+    for (name, size), macs in expect.items():
+        rc, h = _create(lib, name, size, size)
+        assert rc == 0, _lib.last_error()
+        got = lib.orbit_extractor_macs_per_frame(h)
+        if (name, size) == ("set_encoder", 84):
+            # odd feature maps (21, 5): the fused floor-mode 2x2 pool never reads the last row/column, so the
+            # native plan skips those conv outputs (96.2 M vs 98.1 M MACs for the unfused layer sequence)
+            assert 0.97 * macs < got < macs, (name, size, got)
+        else:
+            assert abs(got - macs) / macs < 2e-3, (name, size, got)
+        assert lib.orbit_extractor_workspace_bytes(h, 200) > 200 * 3 * size * size
+        lib.orbit_extractor_destroy(h)
+
+
+def test_film_slots_follow_reference_rule(lib):
+    rc, h = _create(lib, "efficientnet_b0", 224, 224)
+    assert rc == 0
+    n = lib.orbit_extractor_film_slots(h)
+    names = [lib.orbit_extractor_film_slot_name(h, i).decode() for i in range(n)]
+    chans = [lib.orbit_extractor_film_slot_channels(h, i) for i in range(n)]
+    # reference model/film.py:41-48: root bn1, bn2 and InvertedResidual.bn2; SURVEY §2.2 lists the sizes
+    assert names[0] == "bn1" and names[-1] == "bn2" and n == 17
+    assert chans == [32, 96, 144, 144, 240, 240, 480, 480, 480, 672, 672, 672, 1152, 1152, 1152, 1152, 1280]
+    assert lib.orbit_extractor_film_size(h) == 10240
+    assert all(nm.endswith(".bn2") and nm.startswith("blocks.") for nm in names[1:-1])
+    assert "blocks.0.0" not in " ".join(names)
+    lib.orbit_extractor_destroy(h)
+    rc, h = _create(lib, "resnet18", 84, 84)
+    assert lib.orbit_extractor_film_slots(h) == 20 and lib.orbit_extractor_film_size(h) == 4800
+    lib.orbit_extractor_destroy(h)
+
+
+def test_argument_validation_is_loud(lib):
+    rc, h = _create(lib, "vit_b_32", 224, 224)
+    assert rc != 0 and "Invalid feature_extractor_name" in _lib.last_error()
+    rc, h = _create(lib, "set_encoder", 16, 16)
+    assert rc != 0 and "too small" in _lib.last_error()
+    rc, h = _create(lib, "resnet18", 84, 84)
+    assert rc == 0
+    bad = (ctypes.c_float * 4)()
+    assert lib.orbit_extractor_load(h, b"no.such.key", bad, 4) != 0 and "unexpected key" in _lib.last_error()
+    assert lib.orbit_extractor_load(h, b"bn1.weight", bad, 4) != 0 and "expected 64" in _lib.last_error()
+    # forward before finalize must fail, not run on garbage
+    assert lib.orbit_extractor_forward(h, bad, 1, None, None, bad, bad, 1 << 30, None) != 0
+    lib.orbit_extractor_destroy(h)
+    assert lib.orbit_proto_predict(bad, bad, None, 1, 1, 1, 4, 2, 1.0, 0, bad, None, None) != 0
+    with pytest.raises(AttributeError):
+        _lib.check(-1)  # "not set - is the model personalised?" maps to the reference's AttributeError
+
+
+def test_no_cpu_fallback_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from orbit_dataset_amd.model.classifier_heads import PrototypicalClassifier
+    from orbit_dataset_amd.model.feature_extractors import create_feature_extractor
+    with pytest.raises(_lib.OrbitHipError):
+        PrototypicalClassifier().configure(torch.zeros(4, 8), torch.arange(4))
+    fe, _ = create_feature_extractor("resnet18", True, False, False)
+    with pytest.raises(_lib.OrbitHipError):
+        fe(torch.zeros(1, 3, 32, 32))

@@ -1,0 +1,107 @@
+"""GPU parity of the native feature extractors / set encoder / FiLM generator against the PyTorch-CPU oracle
+(same deterministic parameters, same seeded synthetic frames), through orbit_extractor_* / orbit_filmgen_*."""
+import pytest
+import torch
+from torch.func import functional_call
+
+pytestmark = pytest.mark.gpu
+
+import orbit_dataset_amd  # noqa: E402,F401
+from oracle import blocks, extractors  # noqa: E402
+from orbit_dataset_amd import synthetic  # noqa: E402
+from orbit_dataset_amd.model.feature_adapters import FilmParameterGenerator  # noqa: E402
+from orbit_dataset_amd.model.feature_extractors import create_feature_extractor  # noqa: E402
+from orbit_dataset_amd.model.film import get_film_parameter_sizes, get_film_parameters  # noqa: E402
+from orbit_dataset_amd.model.set_encoders import SetEncoder  # noqa: E402
+
+FEAT_TOL = 2e-5  # abs, features are O(0.1..2)
+
+
+def _frames(n, size, seed=3):
+    t = synthetic.make_task(seed, way=4, shots=1, frames_per_shot=max(n // 4, 1), num_query=1, frame_size=size)
+    return t["context_clips"].flatten(end_dim=1)[:n]
+
+
+def _pair(name, with_film=False):
+    ref = extractors.create(name).eval()
+    synthetic.init_parameters_(ref)
+    fe, film_names = create_feature_extractor(name, True, with_film, False)
+    fe.load_state_dict(ref.state_dict())
+    return ref, fe.cuda(), film_names
+
+
+@pytest.mark.parametrize("name,size,n", [("resnet18", 84, 12), ("resnet18", 32, 5), ("resnet18", 224, 3),
+                                         ("resnet18", 97, 2), ("efficientnet_b0", 224, 4),
+                                         ("efficientnet_b0", 64, 6), ("efficientnet_b0", 75, 2)])
+def test_extractor_matches_oracle(device, name, size, n):
+    ref, fe, _ = _pair(name)
+    x = _frames(n, size)
+    with torch.no_grad():
+        want = ref(x)
+    got = fe(x.to(device)).cpu()
+    assert got.shape == want.shape == (n, fe.output_size)
+    err = (got - want).abs().max().item()
+    assert err < FEAT_TOL, f"{name}@{size}: max abs feature err {err} (feature max {want.abs().max().item():.3f})"
+
+
+@pytest.mark.parametrize("name,size", [("resnet18", 84), ("efficientnet_b0", 96)])
+def test_extractor_film_matches_functional_call(device, name, size):
+    """Per-task FiLM: the reference swaps BatchNorm weight/bias by name via functional_call
+    (few_shot_recognisers.py:114-115); both the fast path (film=) and the functional_call path must agree."""
+    ref, fe, film_names = _pair(name, with_film=True)
+    g = torch.Generator().manual_seed(11)
+    params = dict(ref.named_parameters())
+    film = {}
+    for n_ in film_names:
+        p = params[n_].detach()
+        film[n_] = p * (1 + 0.2 * torch.randn(p.shape, generator=g)) + 0.05 * torch.randn(p.shape, generator=g)
+    x = _frames(6, size)
+    with torch.no_grad():
+        want = functional_call(ref, film, (x,))
+        plain = ref(x)
+    assert (want - plain).abs().max().item() > 1e-2  # FiLM really changes the features
+    film_dev = {k: v.to(device) for k, v in film.items()}
+    got_fc = functional_call(fe, film_dev, (x.to(device),)).cpu()
+    slots = [n_ for n_, _ in fe.film_slot_modules()]
+    gamma = torch.cat([film_dev[s + ".weight"] for s in slots])
+    beta = torch.cat([film_dev[s + ".bias"] for s in slots])
+    got_fast = fe(x.to(device), film=(gamma, beta)).cpu()
+    assert (got_fc - want).abs().max().item() < FEAT_TOL
+    assert torch.equal(got_fc, got_fast)
+    assert (fe(x.to(device)).cpu() - plain).abs().max().item() < FEAT_TOL  # and the un-FiLMed path is untouched
+
+
+@pytest.mark.parametrize("size,n", [(84, 10), (224, 3), (32, 4)])
+def test_set_encoder_matches_oracle(device, size, n):
+    ref = blocks.SetEncoder().eval()
+    synthetic.init_parameters_(ref)
+    enc = SetEncoder()
+    enc.load_state_dict(ref.state_dict())
+    enc = enc.cuda()
+    x = _frames(n, size)
+    with torch.no_grad():
+        want = ref(x)
+    got = enc(x.to(device))
+    assert (got.cpu() - want).abs().max().item() < FEAT_TOL
+    z = enc.aggregate(got, "mean").cpu()
+    assert z.shape == (1, 64) and (z - ref.aggregate(want)).abs().max().item() < FEAT_TOL
+
+
+def test_film_generator_matches_oracle(device):
+    ref_fe, fe, film_names = _pair("efficientnet_b0", with_film=True)
+    sizes = get_film_parameter_sizes(film_names, fe)
+    init = get_film_parameters(film_names, fe)
+    gen = FilmParameterGenerator(sizes, init, 64, 64, slot_names=[n for n, _ in fe.film_slot_modules()]).cuda()
+    synthetic.init_parameters_(gen, prefix="film_generator.")
+    ref = blocks.FilmParameterGenerator({k: v for k, v in sizes.items()}, {k: v.cpu() for k, v in init.items()})
+    ref.load_state_dict({k: v.cpu() for k, v in gen.state_dict().items()})
+    assert ref.film_parameter_names == gen.film_parameter_names and len(gen.film_parameter_names) == 34
+    z = torch.randn(1, 64, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        want = ref(z)
+    got = gen(z.to(device))
+    assert set(got) == set(want)
+    for k in want:
+        assert (got[k].cpu() - want[k]).abs().max().item() < 1e-5, k
+    assert abs(float(gen.regularization_term()) - float(ref.regularization_term())) < 1e-4 * float(ref.l2_term)
+    assert sum(v.numel() for v in got.values()) == 20480

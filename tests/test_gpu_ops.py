@@ -1,0 +1,228 @@
+"""GPU parity of the single operators behind the C-ABI (orbit_op_*, head, pooler) against plain PyTorch-CPU fp32.
+
+Every call goes through liborbit_hip.so via ctypes (raw device pointers + stream handle). Tolerances are
+absolute, fp32: 2e-4 on O(1..30) conv outputs (K up to 4608 products), tighter on the elementwise kernels.
+"""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import orbit_dataset_amd  # noqa: E402,F401
+from orbit_dataset_amd import _lib  # noqa: E402
+
+
+def _st():
+    return _lib.stream_handle()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def run_conv(lib, device, x_cpu, w_cpu, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=None, residual=None,
+             gate=None, act=0, pool2=0, x_nchw=0):
+    B, Cin, H, W = x_cpu.shape
+    Cout, _, KH, KW = w_cpu.shape
+    xin = (x_cpu if x_nchw else nhwc(x_cpu)).to(device)
+    oh, ow = (Ho // 2, Wo // 2) if pool2 else (Ho, Wo)
+    y = torch.full((B, oh, ow, Cout), float("nan"), device=device)
+    d = lambda t: _lib.dptr(None if t is None else t.to(device).contiguous())
+    res = None if residual is None else nhwc(residual)
+    keep = [t.to(device).contiguous() if t is not None else None for t in (w_cpu, scale, shift, res, gate)]
+    rc = lib.orbit_op_conv2d(_lib.dptr(xin), x_nchw, _lib.dptr(keep[0]), _lib.dptr(y), _lib.dptr(keep[1]),
+                             _lib.dptr(keep[2]), _lib.dptr(keep[3]), _lib.dptr(keep[4]), B, H, W, Cin, Cout, KH, KW,
+                             stride, pad_t, pad_l, Ho, Wo, act, pool2, _st())
+    _lib.check(rc, "orbit_op_conv2d")
+    torch.cuda.synchronize()
+    return nchw(y.cpu())
+
+
+def ref_conv(x, w, stride, pad_t, pad_l, Ho, Wo, scale=None, shift=None, residual=None, gate=None, act=0, pool2=0):
+    B, Cin, H, W = x.shape
+    KH, KW = w.shape[2:]
+    if gate is not None:
+        x = x * gate[:, :, None, None]
+    pb = max((Ho - 1) * stride + KH - H - pad_t, 0)
+    pr = max((Wo - 1) * stride + KW - W - pad_l, 0)
+    y = F.conv2d(F.pad(x, [pad_l, pr, pad_t, pb]), w, None, stride)[:, :, :Ho, :Wo]
+    if scale is not None:
+        y = y * scale[None, :, None, None]
+    if shift is not None:
+        y = y + shift[None, :, None, None]
+    if residual is not None:
+        y = y + residual
+    if act == 1:
+        y = F.relu(y)
+    elif act == 2:
+        y = F.silu(y)
+    if pool2:
+        y = F.max_pool2d(y, 2, 2)
+    return y
+
+
+CONV_CASES = [
+    # name, B, Cin, H, W, Cout, K, stride, pad, extras
+    ("3x3_64_64", 4, 64, 21, 21, 64, 3, 1, 1, {}),
+    ("3x3_s2_64_128", 3, 64, 21, 21, 128, 3, 2, 1, {}),
+    ("1x1_s2_ds", 3, 64, 21, 21, 128, 1, 2, 0, {}),
+    ("3x3_256_512_smallM", 5, 256, 6, 6, 512, 3, 2, 1, {}),
+    ("3x3_512_512", 2, 512, 3, 3, 512, 3, 1, 1, {}),
+    ("relu_bn_res", 4, 64, 11, 11, 64, 3, 1, 1, {"bn": True, "res": True, "act": 1}),
+    ("bigM_128x128_tile", 40, 128, 28, 28, 256, 3, 1, 1, {"bn": True, "act": 1}),
+    ("bigM_128x64_tile", 64, 64, 42, 42, 128, 1, 1, 0, {"bn": True}),
+    ("pw_16_96_silu", 3, 16, 28, 28, 96, 1, 1, 0, {"bn": True, "act": 2}),
+    ("pw_gate_96_24", 3, 96, 14, 14, 24, 1, 1, 0, {"bn": True, "gate": True}),
+    ("pw_gate_res_240_40", 2, 240, 14, 14, 40, 1, 1, 0, {"bn": True, "gate": True, "res": True}),
+    ("pw_1152_320", 2, 1152, 7, 7, 320, 1, 1, 0, {"bn": True}),
+    ("pw_40_240_tailK", 2, 40, 14, 14, 240, 1, 1, 0, {"bn": True, "act": 2}),
+    ("head_320_1280", 2, 320, 7, 7, 1280, 1, 1, 0, {"bn": True, "act": 2}),
+    ("pool2_64_64", 3, 64, 42, 42, 64, 3, 1, 1, {"bn": True, "act": 1, "pool2": 1}),
+    ("pool2_odd_21", 3, 64, 21, 21, 64, 3, 1, 1, {"bn": True, "act": 1, "pool2": 1}),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_nhwc(lib, device, case):
+    name, B, Cin, H, W, Cout, K, stride, pad, ex = case
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 10000)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    Ho = (H + 2 * pad - K) // stride + 1
+    Wo = (W + 2 * pad - K) // stride + 1
+    scale = torch.rand(Cout, generator=g) + 0.5 if ex.get("bn") else None
+    shift = torch.randn(Cout, generator=g) * 0.1 if ex.get("bn") else None
+    res = torch.randn(B, Cout, Ho, Wo, generator=g) if ex.get("res") else None
+    gate = torch.rand(B, Cin, generator=g) if ex.get("gate") else None
+    kw = dict(scale=scale, shift=shift, residual=res, gate=gate, act=ex.get("act", 0), pool2=ex.get("pool2", 0))
+    got = run_conv(lib, device, x, w, stride, pad, pad, Ho, Wo, **kw)
+    want = ref_conv(x, w, stride, pad, pad, Ho, Wo, **kw)
+    assert got.shape == want.shape
+    assert not torch.isnan(got).any(), "kernel left outputs unwritten"
+    err = (got - want).abs().max().item()
+    assert err < 2e-4, f"{name}: max abs err {err}"
+
+
+STEM_CASES = [
+    ("resnet_stem_84", 3, 84, 64, 7, 2, 3, 3, 0, 1),
+    ("resnet_stem_odd_37", 2, 37, 64, 7, 2, 3, 3, 0, 1),
+    ("effnet_stem_same_64", 2, 64, 32, 3, 2, 0, 0, 0, 2),     # TF SAME, even input: pad only bottom/right
+    ("effnet_stem_same_odd_33", 2, 33, 32, 3, 2, 1, 1, 0, 2),  # odd input: symmetric
+    ("setenc_l1_pool", 3, 84, 64, 3, 1, 1, 1, 1, 1),
+    ("setenc_l1_pool_32", 2, 32, 64, 3, 1, 1, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", STEM_CASES, ids=[c[0] for c in STEM_CASES])
+def test_conv_stem_nchw(lib, device, case):
+    name, B, HW, Cout, K, stride, pad_t, pad_l, pool2, act = case
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(B, 3, HW, HW, generator=g)
+    w = torch.randn(Cout, 3, K, K, generator=g) / (3 * K * K) ** 0.5
+    if name.startswith("effnet"):
+        Ho = Wo = -(-HW // stride)
+    else:
+        Ho = Wo = (HW + 2 * pad_t - K) // stride + 1
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    got = run_conv(lib, device, x, w, stride, pad_t, pad_l, Ho, Wo, scale=scale, shift=shift, act=act, pool2=pool2,
+                   x_nchw=1)
+    want = ref_conv(x, w, stride, pad_t, pad_l, Ho, Wo, scale=scale, shift=shift, act=act, pool2=pool2)
+    assert got.shape == want.shape and not torch.isnan(got).any()
+    err = (got - want).abs().max().item()
+    assert err < 1e-4, f"{name}: max abs err {err}"
+
+
+def test_conv_transpose_detecting(lib, device):
+    """Asymmetric weights + one-hot input: catches row/col or (kh,kw) swaps that random data could hide."""
+    B, Cin, H, W, Cout = 1, 4, 5, 7, 3
+    x = torch.zeros(B, Cin, H, W)
+    x[0, 2, 1, 4] = 1.0
+    w = torch.arange(Cout * Cin * 9, dtype=torch.float32).reshape(Cout, Cin, 3, 3)
+    got = run_conv(lib, device, x, w, 1, 1, 1, H, W)
+    want = F.conv2d(x, w, padding=1)
+    assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("C,K,stride,HW", [(32, 3, 1, 28), (96, 3, 2, 28), (144, 5, 2, 28), (480, 5, 1, 14),
+                                           (672, 5, 2, 14), (1152, 3, 1, 7), (240, 3, 2, 15)])
+def test_dwconv(lib, device, C, K, stride, HW):
+    g = torch.Generator().manual_seed(C + K)
+    B = 3
+    x = torch.randn(B, C, HW, HW, generator=g)
+    w = torch.randn(C, 1, K, K, generator=g) / K
+    scale = torch.rand(C, generator=g) + 0.5
+    shift = torch.randn(C, generator=g) * 0.1
+    Ho = -(-HW // stride)
+    total = max((Ho - 1) * stride + K - HW, 0)
+    pt = total // 2
+    y = torch.full((B, Ho, Ho, C), float("nan"), device=device)
+    xd, wd, sd, hd = nhwc(x).to(device), w.to(device), scale.to(device), shift.to(device)
+    _lib.check(lib.orbit_op_dwconv2d(_lib.dptr(xd), _lib.dptr(wd), _lib.dptr(y), _lib.dptr(sd), _lib.dptr(hd), B, HW,
+                                     HW, C, K, stride, pt, pt, Ho, Ho, 2, _st()), "dwconv")
+    torch.cuda.synchronize()
+    xp = F.pad(x, [pt, total - pt, pt, total - pt])
+    want = F.silu(F.conv2d(xp, w, None, stride, 0, 1, C) * scale[None, :, None, None] + shift[None, :, None, None])
+    err = (nchw(y.cpu()) - want).abs().max().item()
+    assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("K,stride,pad,HW", [(3, 2, 1, 42), (3, 2, 1, 21), (2, 2, 0, 21)])
+def test_maxpool(lib, device, K, stride, pad, HW):
+    g = torch.Generator().manual_seed(3)
+    B, C = 3, 64
+    x = torch.randn(B, C, HW, HW, generator=g)
+    Ho = (HW + 2 * pad - K) // stride + 1
+    y = torch.full((B, Ho, Ho, C), float("nan"), device=device)
+    xd = nhwc(x).to(device)
+    _lib.check(lib.orbit_op_maxpool2d(_lib.dptr(xd), _lib.dptr(y), B, HW, HW, C, K, stride, pad, Ho, Ho, _st()), "maxpool")
+    torch.cuda.synchronize()
+    assert torch.equal(nchw(y.cpu()), F.max_pool2d(x, K, stride, pad))
+
+
+@pytest.mark.parametrize("C,HW", [(512, 9), (1280, 49), (32, 12544), (100, 5)])
+def test_avgpool(lib, device, C, HW):
+    g = torch.Generator().manual_seed(C)
+    B = 5
+    x = torch.randn(B, HW, C, generator=g)
+    y = torch.full((B, C), float("nan"), device=device)
+    xd = x.to(device)
+    _lib.check(lib.orbit_op_avgpool(_lib.dptr(xd), _lib.dptr(y), B, HW, C, _st()), "avgpool")
+    torch.cuda.synchronize()
+    assert (y.cpu() - x.mean(1)).abs().max().item() < 2e-6
+
+
+@pytest.mark.parametrize("C,R", [(32, 8), (96, 4), (1152, 48)])
+def test_se_gate(lib, device, C, R):
+    g = torch.Generator().manual_seed(C)
+    B = 7
+    p = torch.randn(B, C, generator=g)
+    w1, b1 = torch.randn(R, C, generator=g) / C ** 0.5, torch.randn(R, generator=g) * 0.1
+    w2, b2 = torch.randn(C, R, generator=g) / R ** 0.5, torch.randn(C, generator=g) * 0.1
+    out = torch.full((B, C), float("nan"), device=device)
+    dev = [t.to(device) for t in (p, w1, b1, w2, b2)]
+    _lib.check(lib.orbit_op_se_gate(*[_lib.dptr(t) for t in dev], _lib.dptr(out), B, C, R, _st()), "se_gate")
+    torch.cuda.synchronize()
+    want = torch.sigmoid(F.silu(p @ w1.t() + b1) @ w2.t() + b2)
+    assert (out.cpu() - want).abs().max().item() < 2e-6
+
+
+def test_mean_pool_and_set_mean(lib, device):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(25 * 8, 512, generator=g)
+    xd = x.to(device)
+    out = torch.empty(25, 512, device=device)
+    _lib.check(lib.orbit_mean_pool(_lib.dptr(xd), 25, 8, 512, _lib.dptr(out), _st()), "mean_pool")
+    m = torch.empty(512, device=device)
+    _lib.check(lib.orbit_set_mean(_lib.dptr(xd), 200, 512, _lib.dptr(m), _st()), "set_mean")
+    torch.cuda.synchronize()
+    assert (out.cpu() - x.view(25, 8, 512).mean(1)).abs().max().item() < 1e-6
+    assert (m.cpu() - x.mean(0)).abs().max().item() < 1e-6

@@ -1,0 +1,99 @@
+"""CPU tests of the host-side mirror: helpers, synthetic data determinism, parameter-tree compatibility with
+the oracle's torchvision/timm-layout modules, FiLM bookkeeping, and that the product never imports oracle/."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import orbit_dataset_amd  # noqa: F401
+from oracle import blocks, extractors
+from orbit_dataset_amd import synthetic
+from orbit_dataset_amd.data import utils as dutils
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_get_batch_indices_matches_reference_probe():
+    # SURVEY §8c G7 probe: 10 items, batch 4 -> (0,4),(4,8),(8,10)
+    assert [dutils.get_batch_indices(i, 10, 4) for i in range(3)] == [(0, 4), (4, 8), (8, 10)]
+    for n in (1, 7, 256, 257):
+        for bs in (1, 3, 256):
+            for i in range(-(-n // bs)):
+                assert dutils.get_batch_indices(i, n, bs) == blocks.get_batch_indices(i, n, bs)
+
+
+@pytest.mark.parametrize("L", [1, 2, 3, 8])
+def test_attach_frame_history(L):
+    frames = torch.arange(7 * 3 * 2 * 2, dtype=torch.float32).reshape(7, 3, 2, 2)
+    got = dutils.attach_frame_history(frames, L)
+    assert got.shape == (7, L, 3, 2, 2)
+    assert torch.equal(got, blocks.attach_frame_history(frames, L))
+    assert torch.equal(got[:, -1], frames)                     # last slot is the frame itself
+    assert torch.equal(got[0], frames[:1].expand(L, -1, -1, -1))  # frame 0 padded with itself
+
+
+def test_synthetic_task_layout_and_determinism():
+    a = synthetic.make_task(3, way=5, shots=5, frames_per_shot=8, num_query=20, frame_size=16)
+    b = synthetic.make_task(3, way=5, shots=5, frames_per_shot=8, num_query=20, frame_size=16)
+    assert a["context_clips"].shape == (200, 1, 3, 16, 16) and a["context_clips"].dtype == torch.float32
+    assert a["context_labels"].shape == (200,) and a["context_labels"].dtype == torch.int64
+    assert a["target_clips"].shape == (20, 1, 3, 16, 16)
+    assert all(torch.equal(a[k], b[k]) for k in ("context_clips", "context_labels", "target_clips", "target_labels"))
+    assert torch.bincount(a["context_labels"]).tolist() == [40] * 5
+    c = synthetic.make_task(4, way=5, shots=5, frames_per_shot=8, num_query=20, frame_size=16, clip_length=8)
+    assert c["context_clips"].shape == (25, 8, 3, 16, 16)
+    d = synthetic.make_task(0, way=3, shots=1, frames_per_shot=2, num_query=5, frame_size=8, label_values=(3, 7, 9))
+    assert sorted(set(d["context_labels"].tolist())) == [3, 7, 9]
+
+
+@pytest.mark.parametrize("name", ["resnet18", "efficientnet_b0"])
+def test_parameter_tree_is_checkpoint_compatible(name):
+    from orbit_dataset_amd.model.feature_extractors import create_feature_extractor
+    ref = extractors.create(name)
+    fe, film_names = create_feature_extractor(name, True, True, False)
+    a, b = ref.state_dict(), fe.state_dict()
+    assert list(sorted(a)) == list(sorted(b))
+    assert all(a[k].shape == b[k].shape for k in a)
+    fe.load_state_dict(a, strict=True)
+    assert not any(p.requires_grad for p in fe.parameters())         # learn_extractor=False freezes (:81-87)
+    assert [n for n, _ in fe.film_slot_modules()] == ref.film_slot_names()
+    expect = [s + sfx for s in ref.film_slot_names() for sfx in (".weight", ".bias")]
+    assert film_names == expect
+    synthetic.init_parameters_(fe)
+    synthetic.init_parameters_(ref)
+    assert all(torch.equal(fe.state_dict()[k], ref.state_dict()[k]) for k in a)
+
+
+def test_recogniser_wiring_and_state_dict_names():
+    from orbit_dataset_amd.model.few_shot_recognisers import SingleStepFewShotRecogniser
+    m = SingleStepFewShotRecogniser("efficientnet_b0", True, "proto", 1, 256, False, 16, 1.0)
+    keys = set(m.state_dict().keys())
+    # names the reference's checkpoints use (SURVEY §5 checkpoint row)
+    for k in ("feature_extractor.conv_stem.weight", "set_encoder.encoder.layer1.0.weight",
+              "film_generator.generators.0.block.0.weight", "film_generator.generators.33.block.3.bias",
+              "film_generator.regularizers.33"):
+        assert k in keys, k
+    assert len(m.film_generator.film_parameter_names) == 34 and m.film_generator.film_size == 10240
+    assert m.film_generator.film_parameter_names == sorted(m.film_parameter_names)
+    assert m.clip_length == 1 and m.feature_extractor.output_size == 1280
+    m2 = SingleStepFewShotRecogniser("resnet18", False, "proto_cosine", 8, 4, False, 16, 32.0)
+    assert m2.classifier.distance_fn == "cosine" and m2.film_generator.regularization_term() == 0
+    assert m2.film_generator(None) == {}
+    with pytest.raises(NotImplementedError):
+        SingleStepFewShotRecogniser("resnet18", False, "mahalanobis", 1, 4, False, 16)
+    m3 = SingleStepFewShotRecogniser("resnet18", False, "proto", 1, 4, True, 16)
+    m3.set_test_mode(False)
+    with pytest.raises(NotImplementedError):  # train-mode BatchNorm is a declared gap, not a silent fallback
+        m3._set_batch_norm_state()
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "orbit-dataset_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
+                assert "oracle/" not in src or f in ("synthetic.py",), os.path.join(dirpath, f)
