@@ -128,12 +128,19 @@ def check(rc, what=""):
         raise OrbitHipError("%s failed (code %d): %s" % (what or "liborbit_hip call", rc, msg))
 
 
+_gpu_ok = False
+
+
 def require_gpu():
-    """Fail loudly unless a HIP device is usable through torch."""
+    """Fail loudly unless a HIP device is usable through torch (checked once: is_available() costs ~0.4 ms)."""
+    global _gpu_ok
+    if _gpu_ok:
+        return
     import torch
     load()
     if not torch.cuda.is_available():
         raise OrbitHipError("no HIP device is visible to torch; the ORBIT hot path has no CPU fallback")
+    _gpu_ok = True
 
 
 def stream_handle():

@@ -42,8 +42,20 @@ class PrototypicalClassifier(nn.Module):
     def _cosine(self):
         return 1 if self.distance_fn == "cosine" else 0
 
-    def configure(self, context_features, context_labels, ops_counter=None, frames_per_clip: int = 1):
-        """context_features: [N*frames_per_clip, D] (clip-major); context_labels: [N]."""
+    @staticmethod
+    def unique_labels(context_labels, device):
+        """Ascending unique label values on `device` (column order of the logits, classifier_heads.py:246-248).
+        Host-resident labels are reduced on the host (no device sync); device labels need one sync for the class
+        count, exactly like the reference's torch.unique(...).item() loop (:96-100)."""
+        if context_labels.is_cuda:
+            return torch.unique(context_labels.to(torch.int64))
+        return torch.unique(context_labels.to(torch.int64)).to(device, non_blocking=True)
+
+    def configure(self, context_features, context_labels, ops_counter=None, frames_per_clip: int = 1,
+                  class_ids=None):
+        """context_features: [N*frames_per_clip, D] (clip-major); context_labels: [N].
+        class_ids: optional precomputed `unique_labels` (lets the caller take the count before it queues the
+        extractor work, and gives the global label set when the support set is sharded over ranks)."""
         _lib.require_gpu()
         T = int(frames_per_clip)
         assert context_features.size(0) == context_labels.size(0) * T, \
@@ -51,7 +63,8 @@ class PrototypicalClassifier(nn.Module):
         feats = context_features.detach().contiguous().float()
         dev = feats.device
         labels = context_labels.to(device=dev, dtype=torch.int64).contiguous()
-        class_ids = torch.unique(labels)  # ascending; one sync for the class count, as in the reference
+        if class_ids is None:
+            class_ids = self.unique_labels(labels, dev)
         C, (NT, D) = int(class_ids.numel()), feats.shape
         N = NT // T
         payload = torch.empty(C * D + C, device=dev, dtype=torch.float32)

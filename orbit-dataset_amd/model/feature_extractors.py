@@ -175,21 +175,21 @@ class HipNetwork(nn.Module):
 
     # ---- FiLM ---------------------------------------------------------------------------------------
     def film_slot_modules(self):
-        mods = dict(self.named_modules())
-        return [(name, mods[name]) for name in self._film_slot_names]
+        cached = self.__dict__.get("_film_slot_cache")
+        if cached is None:
+            mods = dict(self.named_modules())
+            cached = [(name, mods[name]) for name in self._film_slot_names]
+            self.__dict__["_film_slot_cache"] = cached
+        return cached
 
     def _gather_swapped_film(self):
         """If BatchNorm weights/biases were swapped in by functional_call, return (gamma, beta) concatenated."""
-        swapped = False
-        gammas, betas = [], []
-        for _, m in self.film_slot_modules():
-            w, b = m._parameters["weight"], m._parameters["bias"]
-            if not isinstance(w, nn.Parameter) or not isinstance(b, nn.Parameter):
-                swapped = True
-            gammas.append(w.detach().reshape(-1))
-            betas.append(b.detach().reshape(-1))
-        if not swapped:
-            return None
+        slots = self.film_slot_modules()
+        if all(isinstance(m._parameters["weight"], nn.Parameter) and isinstance(m._parameters["bias"], nn.Parameter)
+               for _, m in (slots[0], slots[-1])):
+            return None  # functional_call with a FiLM dict swaps every slot; first and last suffice as a probe
+        gammas = [m._parameters["weight"].detach().reshape(-1) for _, m in slots]
+        betas = [m._parameters["bias"].detach().reshape(-1) for _, m in slots]
         return torch.cat(gammas).float().contiguous(), torch.cat(betas).float().contiguous()
 
     # ---- forward ------------------------------------------------------------------------------------

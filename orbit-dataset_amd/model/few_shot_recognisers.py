@@ -110,7 +110,8 @@ class FewShotRecogniser(nn.Module):
     def _set_batch_norm_state(self):
         """eval() everywhere; the reference switches the extractor to train() when meta-training an unfrozen
         extractor (:176-183). Batch-statistics BatchNorm is not part of the native forward (next row)."""
-        self.eval()
+        if self.training or self.feature_extractor.training:
+            self.eval()
         if self.learn_extractor and not self.test_mode:
             raise NotImplementedError(
                 "train-mode BatchNorm (learn_extractor=True outside test mode) is not implemented by the native "
@@ -156,11 +157,14 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
     # ---- personalise ---------------------------------------------------------------------------------
     def personalise(self, context_clips, context_labels, ops_counter=None):
         self._set_batch_norm_state()
+        # the label set does not depend on the features: resolve it (and its one possible sync) before the
+        # extractor work is queued, so nothing below waits on the device
+        class_ids = self.classifier.unique_labels(context_labels, self.device)
         task_embedding = self._get_task_embedding_in_batches(context_clips, ops_counter)
         self.film_dict = self._generate_film_params(task_embedding, ops_counter)
         context_features = self._get_features_in_batches(context_clips, self.film_dict, ops_counter)
         context_features = self._pool_features(context_features, ops_counter)
-        self.classifier.configure(context_features, context_labels, ops_counter)
+        self.classifier.configure(context_features, context_labels, ops_counter, class_ids=class_ids)
 
     def personalise_with_lite(self, context_clips, context_labels):
         """LITE forward (reference :328-343): a random subset of `num_lite_samples` clips is re-encoded on
