@@ -32,8 +32,10 @@ namespace orbit {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-constexpr int BK = 32;
-constexpr int LDS_STRIDE = BK + 4;  // floats; 144 B rows keep ds_read_b128 conflict-free
+// K-tile width BK is a template parameter (8, 16 or 32): the tile of a 1x1/3x3 conv must lie inside one filter
+// tap, so EfficientNet's narrow layers (Cin = 16, 24, 40, 80, 112, 144, 240) get an exact-fit BK instead of a
+// zero-padded 32. LDS rows are padded to BK + 4 floats: for 12/20/36-float strides the 16-lane groups of a
+// ds_read_b128 land on 16 distinct 16-byte bank slots (conflict-free).
 
 struct ConvParams {
     const float* x;
@@ -87,15 +89,21 @@ __device__ __forceinline__ void decode_row(const ConvParams& p, int m, int& b, i
 }
 
 // MODE 0: NHWC activations, Cin % 4 == 0 (float4 gathers).  MODE 1: NCHW frames, tiny Cin (stems).
-template <int BM, int BN, int WGM, int WGN, int MODE, bool POOL2, bool GATE>
+template <int BM, int BN, int WGM, int WGN, int BK, int MODE, bool POOL2, bool GATE>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     static_assert(WGM * WGN == 4, "4 waves per block");
+    static_assert(BK == 8 || BK == 16 || BK == 32, "BK");
+    static_assert(MODE == 0 || BK == 32, "the stem gather is written for BK = 32");
+    constexpr int LDS_STRIDE = BK + 4;
     constexpr int WM = BM / WGM, WN = BN / WGN;  // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;    // 32x32 accumulator tiles per wave
     static_assert(TM >= 1 && TN >= 1, "wave tile must hold at least one 32x32 MFMA tile");
-    constexpr int AR = BM / 32;                  // float4 A loads per thread per K-tile (vector mode)
-    constexpr int BR = BN / 32;                  // float4 B loads per thread per K-tile
+    constexpr int TPR = BK / 4;                  // threads (float4s) per tile row
+    constexpr int RPP = 256 / TPR;               // tile rows filled per pass of the 256 threads
+    constexpr int AR = (BM + RPP - 1) / RPP;     // float4 A loads per thread per K-tile (vector mode)
+    constexpr int BR = (BN + RPP - 1) / RPP;     // float4 B loads per thread per K-tile
     constexpr int KPT = BM / 8;                  // scalar A loads per thread per K-tile (stem mode)
+    constexpr int NG = BK / 8;                   // k-groups of 8 per K-tile
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                            // [2][BM][LDS_STRIDE]
@@ -113,16 +121,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // ---- per-thread gather bookkeeping (rows are fixed for the whole K loop) ----
     // vector mode: thread owns float4 column c4 of rows (tid>>3) + 32*i
     // stem mode:   thread owns KPT consecutive k of row tid % BM
-    const int c4 = tid & 7;
+    const int c4 = tid % TPR, lrow = tid / TPR;  // this thread's float4 column / first row of the tile
     const float* a_base[MODE == 0 ? AR : 1];
     int a_hi0[MODE == 0 ? AR : 1], a_wi0[MODE == 0 ? AR : 1];
     const float* a_gate[MODE == 0 ? AR : 1];
     if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const int m = m0 + (tid >> 3) + 32 * i;
+            const int m = m0 + lrow + RPP * i;
             int b = 0, ho = 0, wo = 0;
-            const bool ok = m < p.M;
+            const bool ok = m < p.M && (BM % RPP == 0 || lrow + RPP * i < BM);
             if (ok) decode_row<POOL2>(p, m, b, ho, wo);
             a_base[i] = p.x + (size_t)b * p.H * p.W * p.Cin;
             a_hi0[i] = ok ? ho * p.stride - p.pad_t : -(1 << 28);  // invalid rows fail the bounds test
@@ -139,7 +147,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         a_wi0[0] = wo * p.stride - p.pad_l;
         a_gate[0] = nullptr;
     }
-    const float* b_ptr = p.w + (size_t)(n0 + (tid >> 3)) * p.KT + c4 * 4;
+    const bool b_row_ok = BN % RPP == 0 || lrow < BN;  // BK = 8 with BN = 64: half of the threads stage B
+    const float* b_ptr = p.w + (size_t)(n0 + (b_row_ok ? lrow : 0)) * p.KT + c4 * 4;
 
     f32x4 a_stage[MODE == 0 ? AR : KPT / 4];
     f32x4 b_stage[BR];
@@ -147,6 +156,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int nk = p.KT / BK;
     const int cpt = MODE == 0 ? p.cin_pad / BK : 1;  // K-tiles per filter tap
     const int ktot = p.KH * p.KW * p.Cin;            // true K (stem mode)
+    (void)ktot;
 
     auto load_tile = [&](int kt) {
         if (MODE == 0) {
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j)
-            b_stage[j] = *reinterpret_cast<const f32x4*>(b_ptr + (size_t)(32 * j) * p.KT + kt * BK);
+            b_stage[j] = *reinterpret_cast<const f32x4*>(b_ptr + (size_t)(RPP * j) * p.KT + kt * BK);
     };
 
     auto store_tile = [&](int buf) {
@@ -191,7 +201,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < AR; ++i)
-                *reinterpret_cast<f32x4*>(A + ((tid >> 3) + 32 * i) * LDS_STRIDE + c4 * 4) = a_stage[i];
+                if (BM % RPP == 0 || lrow + RPP * i < BM)
+                    *reinterpret_cast<f32x4*>(A + (lrow + RPP * i) * LDS_STRIDE + c4 * 4) = a_stage[i];
         } else {
             float* dst = A + (tid % BM) * LDS_STRIDE + (tid / BM) * KPT;
 #pragma unroll
@@ -199,7 +210,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j)
-            *reinterpret_cast<f32x4*>(Bq + ((tid >> 3) + 32 * j) * LDS_STRIDE + c4 * 4) = b_stage[j];
+            if (BN % RPP == 0 || lrow + RPP * j < BN)
+                *reinterpret_cast<f32x4*>(Bq + (lrow + RPP * j) * LDS_STRIDE + c4 * 4) = b_stage[j];
     };
 
     f32x16 acc[TM][TN];
@@ -220,30 +232,39 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
         const float* A = As + cur * BM * LDS_STRIDE + (wm + l31) * LDS_STRIDE + lh * 4;
         const float* Bq = Bs + cur * BN * LDS_STRIDE + (wn + l31) * LDS_STRIDE + lh * 4;
-        // k-groups of 8 that hold real data in this tile (the tail of a padded tap is all zeros)
-        const int kvalid = MODE == 0 ? p.Cin - (kt % cpt) * BK : ktot - kt * BK;
-        const int ngrp = kvalid >= BK ? BK / 8 : (kvalid + 7) >> 3;
-        auto mma_group = [&](int g) {
-            f32x4 af[TM], bf[TN];
+        // fragment reads are register double-buffered: group g+1 is fetched from LDS while the MFMAs of group g
+        // issue, so only the first read of a K-tile is exposed
+        f32x4 af[2][TM], bf[2][TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDS_STRIDE + g * 8);
+        for (int i = 0; i < TM; ++i) af[0][i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDS_STRIDE);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-                bf[j] = *reinterpret_cast<const f32x4*>(Bq + j * 32 * LDS_STRIDE + g * 8);
+        for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bq + j * 32 * LDS_STRIDE);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDS_STRIDE + (g + 1) * 8);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[(g + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Bq + j * 32 * LDS_STRIDE + (g + 1) * 8);
+            }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
-        };
-        if (ngrp == BK / 8) {  // common case: fully unrolled so fragment reads run ahead of the MFMAs
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[g & 1][i][kk], bf[g & 1][j][kk],
+                                                                         acc[i][j], 0, 0, 0);
+        }
+        // pin the issue order the code above spells out: reads(g0) | reads(g+1), MFMAs(g) | ... (0x100 = DS read,
+        // 0x008 = MFMA); without it the scheduler batches the reads behind all issued MFMAs and exposes LDS latency
+        __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
-            for (int g = 0; g < BK / 8; ++g) mma_group(g);
-        } else {
-            for (int g = 0; g < ngrp; ++g) mma_group(g);
+        for (int g = 0; g < NG; ++g) {
+            if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
         }
 
         if (kt + 1 < nk) store_tile(cur ^ 1);  // the other buffer was last read before the previous barrier
@@ -304,13 +325,21 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
     }
 }
 
+// K-tile width for a layer: the widest of 32/16/8 that divides Cin (stems: 32)
+static int choose_bk(int Cin, int x_nchw) {
+    if (x_nchw || Cin % 32 == 0) return 32;
+    if (Cin % 16 == 0) return 16;
+    return 8;
+}
+
 ConvPackGeom conv_pack_geom(int Cin, int Cout, int KH, int KW, int x_nchw) {
     ConvPackGeom g;
+    const int bk = choose_bk(Cin, x_nchw);
     if (x_nchw) {
         g.cin_pad = Cin;
-        g.kt = (int)align_up((size_t)KH * KW * Cin, BK);
+        g.kt = (int)align_up((size_t)KH * KW * Cin, bk);
     } else {
-        g.cin_pad = (int)align_up((size_t)Cin, BK);
+        g.cin_pad = (int)align_up((size_t)Cin, bk);
         g.kt = KH * KW * g.cin_pad;
     }
     g.cout_pad = (int)align_up((size_t)Cout, 128);
@@ -370,12 +399,12 @@ static int prof_variant(const char* name) {
     return (int)g_prof_variants.size() - 1;
 }
 
-template <int BM, int BN, int WGM, int WGN, int MODE, bool POOL2, bool GATE>
+template <int BM, int BN, int WGM, int WGN, int BK, int MODE, bool POOL2, bool GATE>
 static int launch_cfg(ConvParams& p, hipStream_t s) {
     p.m_tiles = cdiv(p.M, BM);
     p.n_tiles = cdiv(p.Cout, BN);
-    const size_t lds = (size_t)2 * (BM + BN) * LDS_STRIDE * sizeof(float);
-    auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, MODE, POOL2, GATE>;
+    const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+    auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, BK, MODE, POOL2, GATE>;
     static bool attr_set = false;  // >64 KiB dynamic LDS needs the opt-in once per kernel
     if (!attr_set && lds > 64 * 1024) {
         ORBIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -384,8 +413,8 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
     }
     if (g_prof_on) {
         char name[48];
-        snprintf(name, sizeof(name), "conv_igemm<%d,%d,%s%s%s>", BM, BN, MODE ? "nchw" : "nhwc", POOL2 ? ",pool2" : "",
-                 GATE ? ",gate" : "");
+        snprintf(name, sizeof(name), "conv_igemm<%d,%d,%d,%s%s%s>", BM, BN, BK, MODE ? "nchw" : "nhwc",
+                 POOL2 ? ",pool2" : "", GATE ? ",gate" : "");
         ProfRec r;
         r.start = prof_event(), r.stop = prof_event(), r.variant = prof_variant(name);
         const double pix = POOL2 ? (double)p.B * p.HoP * p.WoP * 4 : (double)p.B * p.Ho * p.Wo;
@@ -401,30 +430,37 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
     return ORBIT_OK;
 }
 
-template <int MODE, bool POOL2, bool GATE>
+template <int BK, int MODE, bool POOL2, bool GATE>
 static int launch_tiled(ConvParams& p, hipStream_t s) {
     // Tile choice: the widest N tile the layer fills, the tallest M tile that still yields >= ~2 blocks
     // per CU (256 CUs); small-M late layers fall back to 64-row tiles to keep the chip occupied.
     const long target = 512;
     static const char* force = getenv("ORBIT_CONV_TILE");  // tuning experiments only: 128x128|128x64|64x64|128x32
     if (force) {
-        if (!strcmp(force, "128x128")) return launch_cfg<128, 128, 2, 2, MODE, POOL2, GATE>(p, s);
-        if (!strcmp(force, "128x64")) return launch_cfg<128, 64, 2, 2, MODE, POOL2, GATE>(p, s);
-        if (!strcmp(force, "64x64")) return launch_cfg<64, 64, 2, 2, MODE, POOL2, GATE>(p, s);
-        if (!strcmp(force, "128x32")) return launch_cfg<128, 32, 4, 1, MODE, POOL2, GATE>(p, s);
+        if (!strcmp(force, "128x128")) return launch_cfg<128, 128, 2, 2, BK, MODE, POOL2, GATE>(p, s);
+        if (!strcmp(force, "128x64")) return launch_cfg<128, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
+        if (!strcmp(force, "64x64")) return launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
+        if (!strcmp(force, "128x32")) return launch_cfg<128, 32, 4, 1, BK, MODE, POOL2, GATE>(p, s);
     }
     if (p.Cout > 64) {
         if ((long)cdiv(p.M, 128) * cdiv(p.Cout, 128) >= target)
-            return launch_cfg<128, 128, 2, 2, MODE, POOL2, GATE>(p, s);
+            return launch_cfg<128, 128, 2, 2, BK, MODE, POOL2, GATE>(p, s);
         if ((long)cdiv(p.M, 128) * cdiv(p.Cout, 64) >= target)
-            return launch_cfg<128, 64, 2, 2, MODE, POOL2, GATE>(p, s);
-        return launch_cfg<64, 64, 2, 2, MODE, POOL2, GATE>(p, s);
+            return launch_cfg<128, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
+        return launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
     }
     if (p.Cout > 32) {
-        if ((long)cdiv(p.M, 128) >= target) return launch_cfg<128, 64, 2, 2, MODE, POOL2, GATE>(p, s);
-        return launch_cfg<64, 64, 2, 2, MODE, POOL2, GATE>(p, s);
+        if ((long)cdiv(p.M, 128) >= target) return launch_cfg<128, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
+        return launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
     }
-    return launch_cfg<128, 32, 4, 1, MODE, POOL2, GATE>(p, s);
+    return launch_cfg<128, 32, 4, 1, BK, MODE, POOL2, GATE>(p, s);
+}
+
+template <int MODE, bool POOL2, bool GATE>
+static int launch_bk(ConvParams& p, int bk, hipStream_t s) {
+    if (MODE == 1 || bk == 32) return launch_tiled<32, MODE, POOL2, GATE>(p, s);
+    if (MODE == 0 && bk == 16) return launch_tiled<16, 0, POOL2, GATE>(p, s);
+    return launch_tiled<8, 0, POOL2, GATE>(p, s);
 }
 
 int launch_conv(const ConvDesc& d, hipStream_t s) {
@@ -449,14 +485,15 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     } else {
         p.M = d.B * d.Ho * d.Wo;
     }
+    const int bk = choose_bk(d.Cin, d.x_nchw);
     if (d.x_nchw) {
-        return d.pool2 ? launch_tiled<1, true, false>(p, s) : launch_tiled<1, false, false>(p, s);
+        return d.pool2 ? launch_bk<1, true, false>(p, bk, s) : launch_bk<1, false, false>(p, bk, s);
     }
     if (d.gate) {
         ORBIT_REQUIRE(!d.pool2, "conv: gate + pool2 is not instantiated");
-        return launch_tiled<0, false, true>(p, s);
+        return launch_bk<0, false, true>(p, bk, s);
     }
-    return d.pool2 ? launch_tiled<0, true, false>(p, s) : launch_tiled<0, false, false>(p, s);
+    return d.pool2 ? launch_bk<0, true, false>(p, bk, s) : launch_bk<0, false, false>(p, bk, s);
 }
 
 }  // namespace orbit

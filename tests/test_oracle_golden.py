@@ -1,0 +1,167 @@
+"""Pin the oracle to the reference: every restatement in oracle/ is checked against the golden vectors that
+tests/golden/make_golden.py captured from the reference's own modules (imported in the build container)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import orbit_dataset_amd  # noqa: F401
+from oracle import blocks
+from oracle.recogniser import OracleRecogniser
+from orbit_dataset_amd import synthetic
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return {k: (torch.from_numpy(v) if v.dtype.kind in "fiu" and v.ndim > 0 else v)
+            for k, v in np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False).items()}
+
+
+HEAD_CASES = ["w5_d512", "w10_d96", "noncontig_d96", "oneshot_d64"]
+
+
+@pytest.mark.parametrize("case", HEAD_CASES)
+@pytest.mark.parametrize("dist", ["euclidean", "cosine"])
+@pytest.mark.parametrize("scale", [1, 32])
+def test_G1_head(case, dist, scale):
+    g = gold("G1_head")
+    feats, labels, q = g[case + "_feats"], g[case + "_labels"], g[case + "_q"]
+    ids, W, b = blocks.proto_configure(feats, labels, dist)
+    key = "%s_%s_s%d" % (case, dist, scale)
+    assert ids == sorted(set(labels.tolist()))
+    assert torch.allclose(W, g[key + "_W"], atol=1e-6)
+    if dist == "euclidean":
+        assert torch.allclose(b, g[key + "_b"], atol=1e-4, rtol=1e-6)
+    logits = blocks.proto_predict(q, W, b, float(scale), dist)
+    want = g[key + "_logits"]
+    assert (logits - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
+    assert torch.equal(logits.argmax(1), want.argmax(1))
+    if dist == "cosine":
+        assert torch.all(want[0] == 0) and torch.all(logits[0] == 0)  # zero query row
+    assert bool(g[case + "_support_grad_is_none"])  # reference quirk: head is detached from support features
+
+
+def test_G2_pooler():
+    g = gold("G2_pooler")
+    for T in (1, 3, 8):
+        assert torch.allclose(blocks.mean_pool(g["x"], T), g["T%d" % T], atol=1e-7)
+
+
+def test_G3_set_encoder():
+    g = gold("G3_set_encoder")
+    enc = blocks.SetEncoder().eval()
+    synthetic.init_parameters_(enc)
+    with torch.no_grad():
+        reps = enc(g["x"])
+        assert torch.allclose(reps, g["reps"], atol=2e-6)
+        assert torch.allclose(enc.aggregate([reps[:2], reps[2:]]), g["mean"], atol=2e-6)
+        assert torch.allclose(enc(g["x"][:, :, :, :32, :32]), g["reps32"], atol=2e-6)
+
+
+def test_G4_film_generator():
+    from oracle import extractors
+    g = gold("G4_film_generator")
+    ref = OracleRecogniser("efficientnet_b0", True, "proto", 1, 16)
+    synthetic.init_parameters_(ref.fe)
+    gen = ref.build_film_generator()
+    synthetic.init_parameters_(gen, prefix="film_generator.")
+    assert gen.film_parameter_names == [str(n) for n in g["names"]]
+    with torch.no_grad():
+        film = gen(g["z"])
+    for i, n in enumerate(gen.film_parameter_names):
+        assert torch.allclose(film[n], g["film_%03d" % i], atol=1e-6), n
+    assert abs(float(gen.regularization_term()) - float(g["l2_term"])) < 1e-6 * float(g["l2_term"]) + 1e-9
+
+
+def test_G7_utils():
+    g = gold("G7_utils")
+    assert torch.equal(blocks.attach_frame_history(g["frames"], 1), g["hist1"])
+    assert torch.equal(blocks.attach_frame_history(g["frames"], 3), g["hist3"])
+    assert [list(blocks.get_batch_indices(i, 10, 4)) for i in range(3)] == g["batch_10_4"].tolist()
+    assert [list(blocks.get_batch_indices(i, 257, 256)) for i in range(2)] == g["batch_257_256"].tolist()
+
+
+def oracle_recogniser(adapt, classifier, clip_length, batch_size, num_lite=16, scale=1.0):
+    ref = OracleRecogniser("resnet18", adapt, classifier, clip_length, batch_size, num_lite, scale)
+    synthetic.init_parameters_(ref.fe)
+    if adapt:
+        synthetic.init_parameters_(ref.set_encoder)
+        synthetic.init_parameters_(ref.build_film_generator(), prefix="film_generator.")
+    return ref
+
+
+@pytest.mark.parametrize("tag,adapt,classifier,scale", [("proto", False, "proto", 1.0),
+                                                        ("cosine", False, "proto_cosine", 32.0),
+                                                        ("film", True, "proto", 1.0)])
+def test_G5_recogniser(tag, adapt, classifier, scale):
+    g = gold("G5_recogniser")
+    ref = oracle_recogniser(adapt, classifier, 1, 4, scale=scale)
+    ref.personalise(g["context_clips"], g["context_labels"])
+    logits = ref.predict(g["target_clips"])
+    want = g[tag + "_logits"]
+    assert (logits - want).abs().max().item() < 2e-4
+    assert torch.equal(logits.argmax(1), want.argmax(1))
+    assert torch.allclose(ref.W, g[tag + "_W"], atol=1e-5)
+    if adapt:
+        assert torch.allclose(ref.film_dict["bn1.weight"], g["film_film_bn1_weight"], atol=1e-6)
+        assert abs(float(ref.film_generator.regularization_term()) - float(g["film_l2"])) < 1e-5 * float(g["film_l2"])
+
+
+def test_G5_clip_length_3_with_frame_history():
+    g = gold("G5_recogniser")
+    clips = blocks.attach_frame_history(g["T3_video"], 3)
+    assert torch.equal(clips, g["T3_clips"])
+    ref = oracle_recogniser(False, "proto", 3, 2)
+    ref.personalise(g["T3_context_clips"], g["T3_context_labels"])
+    logits = ref.predict(clips)
+    assert ref.class_ids == [3, 7, 9]
+    assert (logits - g["T3_logits"]).abs().max().item() < 2e-4
+
+
+def test_G6_lite_forward():
+    """LITE call order, permutation handling, caches, concat order and label reordering (forward values; the
+    recorded gradients are kept in the fixture for the training row)."""
+    import torch.nn.functional as F
+    g = gold("G6_lite")
+    nl, tpb, bs = int(g["num_lite_samples"]), int(g["tasks_per_batch"]), int(g["batch_size"])
+    ref = oracle_recogniser(True, "proto", 1, bs, num_lite=nl)
+    ref.clear_caches()
+    for b in range(2):
+        np.random.seed(500 + b)
+        assert np.array_equal(np.random.permutation(len(g["context_clips"])), g["perm_%d" % b].numpy())
+        np.random.seed(500 + b)
+        ref.personalise_with_lite(g["context_clips"], g["context_labels"])
+        tgt = g["target_clips"][b * bs:(b + 1) * bs]
+        logits = blocks.proto_predict(blocks.mean_pool(ref._features(tgt, ref.film_dict), 1), ref.W, ref.b)
+        want = g["logits_%d" % b]
+        assert (logits - want).abs().max().item() < 2e-4
+        loss = len(g["context_labels"]) / (nl * tpb) * F.cross_entropy(logits, g["target_labels"][b * bs:(b + 1) * bs])
+        loss = loss + 0.001 * ref.film_generator.regularization_term()
+        assert abs(float(loss) - float(g["loss_%d" % b])) < 1e-4
+        ref.reset()
+    assert not bool(g["extractor_has_grad"])
+
+
+def test_C_restatement_of_head_against_golden():
+    """oracle/proto_head.c (double accumulation) against the reference's golden logits."""
+    import ctypes
+    so = os.path.join(os.path.dirname(GOLD), "..", "oracle", "_build", "libproto_head_ref.so")
+    if not os.path.exists(so):
+        import subprocess
+        subprocess.run(["make", "-s", "-C", os.path.join(os.path.dirname(GOLD), "..", "oracle")], check=True)
+    lib = ctypes.CDLL(so)
+    g = gold("G1_head")
+    fp, ip = ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_int64)
+    for case in HEAD_CASES:
+        feats, labels, q = (g[case + k].contiguous() for k in ("_feats", "_labels", "_q"))
+        ids = torch.unique(labels).contiguous()
+        N, D, C, M = feats.shape[0], feats.shape[1], len(ids), q.shape[0]
+        for dist, cos in (("euclidean", 0), ("cosine", 1)):
+            W, b, out = torch.empty(C, D), torch.empty(C), torch.empty(M, C)
+            p = lambda t, ty: ctypes.cast(t.data_ptr(), ty)
+            assert lib.proto_configure_ref(p(feats, fp), p(labels, ip), p(ids, ip), N, D, C, cos, p(W, fp), p(b, fp)) == 0
+            lib.proto_predict_ref(p(q, fp), p(W, fp), p(b, fp), M, D, C, ctypes.c_float(32.0), cos, p(out, fp))
+            want = g["%s_%s_s32_logits" % (case, dist)]
+            assert (out - want).abs().max().item() < 1e-4 * max(1.0, want.abs().max().item())
