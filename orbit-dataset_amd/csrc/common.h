@@ -69,6 +69,14 @@ int launch_conv(const ConvDesc& d, hipStream_t s);
 int launch_dwconv(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                   int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho, int Wo,
                   int act, hipStream_t s);
+// depthwise + fused SE pooling partials [B][chunks][C] (pool_partial may be nullptr); chunks = dwconv_se_chunks(Ho)
+int dwconv_se_chunks(int Ho);
+int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
+                     float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
+                     int Wo, int act, hipStream_t s);
+int launch_se_gate2(const float* partial, int chunks, int HW, const float* w1, const float* b1, const float* w2t,
+                    const float* b2, float* gate, int B, int C, int R, hipStream_t s);
+int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
 // [C][1][K][K] -> [K][K][C]
 int dwconv_pack_weights(const float* w, float* w_khwc, int C, int K, hipStream_t s);
 int launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int K, int stride, int pad,

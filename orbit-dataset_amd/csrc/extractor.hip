@@ -51,6 +51,8 @@ struct Op {
     int weight = -1, bias = -1, bn = -1;  // param / BN indices
     size_t packed_off = 0;                // into the packed-weight pool
     int se_w1 = -1, se_b1 = -1, se_w2 = -1, se_b2 = -1, R = 0;
+    int se_chunks = 0, se_hw = 0;  // squeeze-excite pooling partials produced by the preceding depthwise conv
+    int pool_partial = 0;          // depthwise: also emit the pooling partials
     int pool_k = 0, pool_pad = 0;
 };
 
@@ -87,6 +89,7 @@ struct orbit_extractor {
     size_t pool_floats = 0, packed_floats = 0, fold_floats = 0;
     size_t buf_elems[3] = {0, 0, 0};  // per-frame element counts of the rotating activation buffers
     int max_se_c = 0;
+    size_t max_partial = 0;  // floats per frame of the SE pooling-partial buffer
     double macs = 0;
     float* d_pool = nullptr;
     float* d_packed = nullptr;
@@ -245,17 +248,20 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
         o.weight = fe->add_param(wkey, (size_t)C * K * K);
         o.packed_off = fe->packed_floats;
         fe->packed_floats += (size_t)(C * K * K + 3) / 4 * 4;
+        o.pool_partial = 1;
+        fe->max_partial = std::max(fe->max_partial, (size_t)dwconv_se_chunks(o.Ho) * C);
         ho = o.Ho, wo = o.Wo;
         fe->note_buf(out, (size_t)ho * wo * C);
         fe->macs += (double)ho * wo * C * K * K;
         fe->ops.push_back(o);
     };
     auto add_se = [&](const std::string& p, int buf, int C, int R, int hh, int ww) {
-        Op a;
-        a.kind = OP_AVGPOOL, a.in = buf, a.out = 101, a.H = hh, a.W = ww, a.Cin = C, a.Cout = C;
-        fe->ops.push_back(a);
+        (void)buf;  // the pooled sums come from the depthwise kernel's partials (buffer 101), not from a re-read
         Op s;
         s.kind = OP_SE, s.in = 101, s.out = 102, s.Cin = C, s.R = R;
+        s.se_chunks = dwconv_se_chunks(hh), s.se_hw = hh * ww;
+        s.packed_off = fe->packed_floats;  // W2 transposed to [R][C]
+        fe->packed_floats += (size_t)(C * R + 3) / 4 * 4;
         s.se_w1 = fe->add_param(p + ".conv_reduce.weight", (size_t)R * C);
         s.se_b1 = fe->add_param(p + ".conv_reduce.bias", R);
         s.se_w2 = fe->add_param(p + ".conv_expand.weight", (size_t)C * R);
@@ -349,7 +355,7 @@ static WsLayout ws_layout(const orbit_extractor* fe, int B) {
         off += align_up(fe->buf_elems[i] * (size_t)B * sizeof(float), 256);
     }
     L.pooled = off;
-    off += align_up((size_t)std::max(fe->max_se_c, 1) * B * sizeof(float), 256);
+    off += align_up(std::max<size_t>(std::max<size_t>(fe->max_partial, fe->max_se_c), 1) * B * sizeof(float), 256);
     L.gate = off;
     off += align_up((size_t)std::max(fe->max_se_c, 1) * B * sizeof(float), 256);
     L.fold = off;
@@ -432,6 +438,9 @@ int orbit_extractor_finalize(orbit_extractor_t* fe, orbit_stream_t stream) {
             int rc = dwconv_pack_weights(fe->d_pool + fe->params[o.weight].off, fe->d_packed + o.packed_off, o.Cin,
                                          o.KH, s);
             if (rc != ORBIT_OK) return rc;
+        } else if (o.kind == OP_SE) {
+            int rc = launch_transpose(fe->d_pool + fe->params[o.se_w2].off, fe->d_packed + o.packed_off, o.Cin, o.R, s);
+            if (rc != ORBIT_OK) return rc;
         }
     }
     dim3 grid((unsigned)fe->bns.size(), 2);
@@ -506,9 +515,10 @@ int orbit_extractor_forward(orbit_extractor_t* fe, const float* frames, int B, c
                 break;
             }
             case OP_DWCONV:
-                rc = launch_dwconv(buf(o.in), fe->d_packed + o.packed_off, buf(o.out),
-                                   scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off, B, o.H, o.W,
-                                   o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, o.act, s);
+                rc = launch_dwconv_se(buf(o.in), fe->d_packed + o.packed_off, buf(o.out),
+                                      scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off,
+                                      o.pool_partial ? buf(101) : nullptr, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t,
+                                      o.pad_l, o.Ho, o.Wo, o.act, s);
                 break;
             case OP_MAXPOOL:
                 rc = launch_maxpool(buf(o.in), buf(o.out), B, o.H, o.W, o.Cin, o.pool_k, o.stride, o.pool_pad, o.Ho,
@@ -518,9 +528,9 @@ int orbit_extractor_forward(orbit_extractor_t* fe, const float* frames, int B, c
                 rc = launch_avgpool(buf(o.in), buf(o.out), B, o.H * o.W, o.Cin, s);
                 break;
             case OP_SE:
-                rc = launch_se_gate(buf(101), fe->d_pool + fe->params[o.se_w1].off, fe->d_pool + fe->params[o.se_b1].off,
-                                    fe->d_pool + fe->params[o.se_w2].off, fe->d_pool + fe->params[o.se_b2].off,
-                                    buf(102), B, o.Cin, o.R, s);
+                rc = launch_se_gate2(buf(101), o.se_chunks, o.se_hw, fe->d_pool + fe->params[o.se_w1].off,
+                                     fe->d_pool + fe->params[o.se_b1].off, fe->d_packed + o.packed_off,
+                                     fe->d_pool + fe->params[o.se_b2].off, buf(102), B, o.Cin, o.R, s);
                 break;
         }
         if (rc != ORBIT_OK) return rc;

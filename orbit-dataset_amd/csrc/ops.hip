@@ -73,6 +73,149 @@ __global__ __launch_bounds__(256) void dw_pack_kernel(const float* __restrict__ 
     }
 }
 
+// ---- depthwise KxK + folded BN + activation + fused squeeze-excite pooling ---------------------------------
+// HBM-bound (reads the 6x-expanded tensor once, writes the depthwise output once). Thread = 4 channels (float4) x
+// 4 consecutive output columns of one output row: the (3*S + K) input columns a row of taps needs are loaded once
+// and reused by the 4 outputs (K=5,S=1: 10 loads per output float4 instead of 25). The block's weights (its
+// channel slice x K*K taps) sit in LDS. Every thread owns a FIXED channel quad, so its running sum of activated
+// outputs is the squeeze-excite pooling partial: reduced across the block's column lanes in a fixed order and
+// written to pool_partial[b][row_chunk][c] (deterministic; orbit se_gate sums the row chunks).
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                        float* __restrict__ y, const float* __restrict__ scale,
+                                                        const float* __restrict__ shift,
+                                                        float* __restrict__ pool_partial, int H, int W, int C,
+                                                        int pad_t, int pad_l, int Ho, int Wo, int act, int cb4,
+                                                        int rows_per_chunk) {
+    constexpr int NCOL = 3 * S + K;
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float4* wl = reinterpret_cast<float4*>(sm);             // [K*K][cb4]
+    float4* red = wl + K * K * cb4;                         // [WL][cb4]
+    const int b = blockIdx.z, chunk = blockIdx.y;
+    const int c4_0 = blockIdx.x * cb4;
+    const int WL = 256 / cb4;
+    const int tid = threadIdx.x;
+    const int lc = tid % cb4, lw = tid / cb4;
+    const bool active = lw < WL;
+    const int c = (c4_0 + lc) * 4;
+    for (int i = tid; i < K * K * cb4; i += 256) {
+        const int tap = i / cb4, cc = i % cb4;
+        wl[i] = *reinterpret_cast<const float4*>(w + (size_t)tap * C + (c4_0 + cc) * 4);
+    }
+    __syncthreads();
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) sc = *reinterpret_cast<const float4*>(scale + c);
+    if (shift) sh = *reinterpret_cast<const float4*>(shift + c);
+    float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float* xb = x + (size_t)b * H * W * C + c;
+    float* yb = y + (size_t)b * Ho * Wo * C + c;
+    const int ho_end = min(Ho, (chunk + 1) * rows_per_chunk);
+    const int WQ = (Wo + 3) >> 2;
+    if (active) {
+        for (int ho = chunk * rows_per_chunk; ho < ho_end; ++ho) {
+            for (int wq = lw; wq < WQ; wq += WL) {
+                float4 acc[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int wi0 = wq * 4 * S - pad_l;
+#pragma unroll
+                for (int kh = 0; kh < K; ++kh) {
+                    const int hi = ho * S - pad_t + kh;
+                    if ((unsigned)hi >= (unsigned)H) continue;  // uniform over the block's row
+                    const float* xr = xb + (size_t)hi * W * C;
+                    float4 col[NCOL];
+#pragma unroll
+                    for (int q = 0; q < NCOL; ++q) {
+                        const int wi = wi0 + q;
+                        col[q] = (unsigned)wi < (unsigned)W ? *reinterpret_cast<const float4*>(xr + (size_t)wi * C)
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw) {
+                        const float4 f = wl[(kh * K + kw) * cb4 + lc];
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float4 v = col[j * S + kw];
+                            acc[j].x = fmaf(v.x, f.x, acc[j].x);
+                            acc[j].y = fmaf(v.y, f.y, acc[j].y);
+                            acc[j].z = fmaf(v.z, f.z, acc[j].z);
+                            acc[j].w = fmaf(v.w, f.w, acc[j].w);
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int wo = wq * 4 + j;
+                    if (wo < Wo) {
+                        float4 o;
+                        o.x = act_fn(acc[j].x * sc.x + sh.x, act);
+                        o.y = act_fn(acc[j].y * sc.y + sh.y, act);
+                        o.z = act_fn(acc[j].z * sc.z + sh.z, act);
+                        o.w = act_fn(acc[j].w * sc.w + sh.w, act);
+                        *reinterpret_cast<float4*>(yb + ((size_t)ho * Wo + wo) * C) = o;
+                        psum.x += o.x, psum.y += o.y, psum.z += o.z, psum.w += o.w;
+                    }
+                }
+            }
+        }
+    }
+    if (pool_partial == nullptr) return;
+    if (active) red[lw * cb4 + lc] = psum;
+    __syncthreads();
+    if (tid < cb4) {
+        float4 t = red[tid];
+        for (int l = 1; l < WL; ++l) {
+            const float4 u = red[l * cb4 + tid];
+            t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
+        }
+        *reinterpret_cast<float4*>(pool_partial + ((size_t)b * gridDim.y + chunk) * C + (c4_0 + tid) * 4) = t;
+    }
+}
+
+// squeeze-excite gate from pooling partials: pooled[c] = (sum_chunks partial[b][chunk][c]) / HW, then
+// g = sigmoid(W2 silu(W1 pooled + b1) + b2). w2t is W2 transposed to [R][C] so the second layer reads coalesced.
+__global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__ partial, int chunks, float inv_hw,
+                                                       const float* __restrict__ w1, const float* __restrict__ b1,
+                                                       const float* __restrict__ w2t, const float* __restrict__ b2,
+                                                       float* __restrict__ gate, int C, int R) {
+    extern __shared__ float sm2[];  // [C] pooled, [R] hidden
+    float* sp = sm2;
+    float* hid = sm2 + C;
+    const int b = blockIdx.x;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = 0.f;
+        for (int k = 0; k < chunks; ++k) s += partial[((size_t)b * chunks + k) * C + c];
+        sp[c] = s * inv_hw;
+    }
+    __syncthreads();
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int r = wave; r < R; r += 4) {
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s = fmaf(w1[(size_t)r * C + c], sp[c], s);
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) {
+            s += b1[r];
+            hid[r] = s / (1.0f + expf(-s));
+        }
+    }
+    __syncthreads();
+    for (int c = threadIdx.x; c < C; c += 256) {
+        float s = b2[c];
+        for (int r = 0; r < R; ++r) s = fmaf(w2t[(size_t)r * C + c], hid[r], s);
+        gate[(size_t)b * C + c] = 1.0f / (1.0f + expf(-s));
+    }
+}
+
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int rows,
+                                                        int cols) {
+    const int total = rows * cols;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int r = i / cols, c = i % cols;
+        out[(size_t)c * rows + r] = in[i];
+    }
+}
+
 // ---- max-pool NHWC ------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                       int B, int H, int W, int C, int K, int stride, int pad,
@@ -188,6 +331,53 @@ int launch_dwconv(const float* x, const float* w_khwc, float* y, const float* sc
     return ORBIT_OK;
 }
 
+// channel quads per block: the largest divisor of C/4 that is <= 64 (keeps every thread on a fixed channel quad)
+static int dw_cb4(int C) {
+    const int c4 = C / 4;
+    for (int d = c4 < 64 ? c4 : 64; d >= 1; --d)
+        if (c4 % d == 0) return d;
+    return 1;
+}
+int dwconv_se_rows_per_chunk(int Ho) { return Ho >= 56 ? 8 : (Ho >= 14 ? 7 : Ho); }
+int dwconv_se_chunks(int Ho) { return cdiv(Ho, dwconv_se_rows_per_chunk(Ho)); }
+
+int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
+                     float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
+                     int Wo, int act, hipStream_t s) {
+    ORBIT_REQUIRE(x && w_khwc && y, "dwconv_se: null pointer");
+    ORBIT_REQUIRE(C % 4 == 0, "dwconv_se: C %% 4 != 0 (C=%d)", C);
+    ORBIT_REQUIRE((K == 3 || K == 5) && (stride == 1 || stride == 2), "dwconv_se: K=%d stride=%d not instantiated", K,
+                  stride);
+    const int cb4 = dw_cb4(C), rpc = dwconv_se_rows_per_chunk(Ho);
+    dim3 grid(C / 4 / cb4, cdiv(Ho, rpc), B);
+    const size_t lds = (size_t)(K * K * cb4 + (256 / cb4) * cb4) * sizeof(float4);
+#define ORBIT_DW(KK, SS)                                                                                         \
+    dwconv_se_kernel<KK, SS><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t, pad_l, \
+                                                    Ho, Wo, act, cb4, rpc)
+    if (K == 3 && stride == 1) ORBIT_DW(3, 1);
+    else if (K == 3) ORBIT_DW(3, 2);
+    else if (stride == 1) ORBIT_DW(5, 1);
+    else ORBIT_DW(5, 2);
+#undef ORBIT_DW
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int launch_se_gate2(const float* partial, int chunks, int HW, const float* w1, const float* b1, const float* w2t,
+                    const float* b2, float* gate, int B, int C, int R, hipStream_t s) {
+    ORBIT_REQUIRE(partial && w1 && b1 && w2t && b2 && gate, "se_gate2: null pointer");
+    se_gate2_kernel<<<B, 256, (size_t)(C + R) * sizeof(float), s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2,
+                                                                     gate, C, R);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s) {
+    transpose_kernel<<<grid_for((size_t)rows * cols), 256, 0, s>>>(in, out, rows, cols);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
 int dwconv_pack_weights(const float* w, float* w_khwc, int C, int K, hipStream_t s) {
     dw_pack_kernel<<<grid_for((size_t)C * K * K), 256, 0, s>>>(w, w_khwc, C, K);
     ORBIT_LAUNCH_CHECK();
@@ -242,7 +432,7 @@ int orbit_op_dwconv2d(const float* x, const float* w, float* y, const float* sca
     ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&wp), (size_t)C * K * K * sizeof(float), s));
     int rc = dwconv_pack_weights(w, wp, C, K, s);
     if (rc == ORBIT_OK)
-        rc = launch_dwconv(x, wp, y, scale, shift, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, act, s);
+        rc = launch_dwconv_se(x, wp, y, scale, shift, nullptr, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, act, s);
     (void)hipFreeAsync(wp, s);
     return rc;
 }

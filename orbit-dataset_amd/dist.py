@@ -1,0 +1,113 @@
+"""Multi-GPU forms of the episodic path: one process per GPU, torch.distributed (backend "nccl" = RCCL over xGMI
+on ROCm; "gloo" on CPU for the tests).
+
+The reference is single-process (no collectives anywhere). The path shards three ways:
+  1. task-parallel   tasks are independent units -> task i runs on rank i % world; NO data-path collective
+                     (frame-accuracy counts are reduced after the fact). This is bench.py's N>1 form (weak scaling).
+  2. support-sharded ONE task's support frames are split over ranks; each rank extracts features for its slice and
+                     produces per-class partial sums [C][D] + counts [C] (orbit_proto_configure's outputs, 25.6 KB at
+                     C=5, D=1280); one all-reduce(SUM) of that payload gives every rank identical prototypes.
+                     Exact for eval-mode BatchNorm only (test mode or frozen extractor). With FiLM adaptation the
+                     set-encoder embedding sums (64 floats + count) are reduced the same way.
+  3. query-sharded   query frames are independent given (W, b, FiLM) -> split, no collective (optional gather).
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun). Returns
+    (rank, world, local_rank). Single-process when WORLD_SIZE is unset or 1."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        kwargs = {}
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            kwargs["device_id"] = torch.device("cuda", local_rank)
+        dist.init_process_group(backend, rank=rank, world_size=world, **kwargs)
+    return rank, world, local_rank
+
+
+def tasks_for_rank(num_tasks, rank, world):
+    """Task-parallel assignment: task i -> rank i % world."""
+    return range(rank, num_tasks, world)
+
+
+def shard_bounds(n, rank, world):
+    """Contiguous balanced split of n items: the first n % world ranks get one extra item."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0)
+
+
+def allreduce_sum_(tensor, group=None):
+    """In-place all-reduce(SUM); a no-op without a process group. Used as PrototypicalClassifier.partial_reduce."""
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=group)
+    return tensor
+
+
+class SupportSharding:
+    """Attach to a SingleStepFewShotRecogniser to personalise ONE task with its support clips split over ranks."""
+
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+
+    def bounds(self, n):
+        return shard_bounds(n, self.rank, self.world)
+
+    def reduce_(self, tensor):
+        return allreduce_sum_(tensor, self.group)
+
+
+def personalise_support_sharded(model, context_clips, context_labels, sharding):
+    """personalise() with the support set sharded over ranks (form 2). Every rank passes the FULL label vector
+    (tiny) and either the full clip tensor or at least its own slice [lo:hi) of it; features are extracted only
+    for the local slice. After the call every rank holds identical classifier weights."""
+    model._set_batch_norm_state()
+    N = len(context_labels)
+    lo, hi = sharding.bounds(N)
+    class_ids = model.classifier.unique_labels(context_labels, model.device)  # global label set
+    local_clips = context_clips[lo:hi] if len(context_clips) == N else context_clips
+    local_labels = context_labels[lo:hi]
+    z = None
+    if model.adapt_features:
+        reps = model._get_task_embedding_in_batches(local_clips, aggregation="none")
+        # sum of the local embeddings, reduced over ranks, divided by the global frame count
+        total = torch.zeros(reps.shape[1] + 1, device=reps.device, dtype=torch.float32)
+        if reps.shape[0] > 0:
+            total[:-1] = model.set_encoder.aggregate(reps, "mean").reshape(-1) * reps.shape[0]
+            total[-1] = reps.shape[0]
+        sharding.reduce_(total)
+        z = (total[:-1] / total[-1]).reshape(1, -1)
+    model.film_dict = model._generate_film_params(z)
+    feats = model._get_features_in_batches(local_clips, model.film_dict)
+    T = local_clips.shape[1] if local_clips.dim() == 5 else 1
+    model.classifier.partial_reduce = sharding.reduce_
+    try:
+        model.classifier.configure(feats, local_labels, frames_per_clip=T, class_ids=class_ids)
+    finally:
+        model.classifier.partial_reduce = None
+
+
+def predict_query_sharded(model, target_clips, sharding, gather=True):
+    """predict() with the query clips split over ranks (form 3). Returns the full [M, C] logits on every rank when
+    `gather`, else (local logits, (lo, hi))."""
+    M = len(target_clips)
+    lo, hi = sharding.bounds(M)
+    local = model.predict(target_clips[lo:hi])
+    if not gather or sharding.world == 1:
+        return local if gather else (local, (lo, hi))
+    C = local.shape[1]
+    full = torch.zeros(M, C, device=local.device, dtype=local.dtype)
+    full[lo:hi] = local
+    sharding.reduce_(full)  # disjoint slices: a SUM all-reduce is an all-gather for ragged shards
+    return full

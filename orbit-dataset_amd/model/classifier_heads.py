@@ -70,9 +70,12 @@ class PrototypicalClassifier(nn.Module):
         payload = torch.empty(C * D + C, device=dev, dtype=torch.float32)
         sums, counts = payload[: C * D], payload[C * D:]
         lib, st = _lib.load(), _lib.stream_handle()
-        _lib.check(lib.orbit_proto_configure(_lib.dptr(feats, torch.float32), _lib.dptr(labels, torch.int64),
-                                             _lib.dptr(class_ids, torch.int64), 1, N, T, D, C,
-                                             _lib.dptr(sums), _lib.dptr(counts), st), "orbit_proto_configure")
+        if N > 0:
+            _lib.check(lib.orbit_proto_configure(_lib.dptr(feats, torch.float32), _lib.dptr(labels, torch.int64),
+                                                 _lib.dptr(class_ids, torch.int64), 1, N, T, D, C,
+                                                 _lib.dptr(sums), _lib.dptr(counts), st), "orbit_proto_configure")
+        else:  # an empty local shard contributes zeros to the all-reduce
+            payload.zero_()
         if self.partial_reduce is not None:
             self.partial_reduce(payload)
         weight = torch.empty(C, D, device=dev, dtype=torch.float32)

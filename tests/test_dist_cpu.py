@@ -1,0 +1,90 @@
+"""Multi-rank logic on CPU (gloo, world_size 2): sharding helpers, and the support-sharded prototype exchange —
+per-rank partial sums + counts, ONE all-reduce(SUM) of the [C*D + C] payload, identical prototypes on every rank,
+equal to the single-process result. The per-rank partials are produced by a numpy restatement of
+orbit_proto_configure's contract (the HIP kernel itself needs a GPU; its N>1 use is covered on-device)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import orbit_dataset_amd  # noqa: E402,F401
+from oracle import blocks  # noqa: E402
+from orbit_dataset_amd import dist as odist  # noqa: E402
+
+
+def test_sharding_helpers():
+    for n in (0, 1, 5, 200, 201, 207):
+        for world in (1, 2, 3, 8):
+            spans = [odist.shard_bounds(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert list(odist.tasks_for_rank(10, 1, 4)) == [1, 5, 9]
+    assert sorted(sum((list(odist.tasks_for_rank(64, r, 8)) for r in range(8)), [])) == list(range(64))
+
+
+def partial_payload(feats, labels, class_ids, T=1):
+    """numpy restatement of orbit_proto_configure: per-class sums of per-clip means + counts, ascending clip order."""
+    C, D = len(class_ids), feats.shape[1]
+    pooled = feats.reshape(-1, T, D).mean(1)
+    out = np.zeros(C * D + C, dtype=np.float32)
+    for c, cid in enumerate(class_ids):
+        rows = pooled[labels == cid]
+        out[c * D:(c + 1) * D] = rows.sum(0, dtype=np.float32) if len(rows) else 0
+        out[C * D + c] = len(rows)
+    return out
+
+
+def _worker(rank, world, port, feats, labels, q, result):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = odist.init_from_env("gloo")
+    sh = odist.SupportSharding(r, w)
+    lo, hi = sh.bounds(len(labels))
+    class_ids = np.unique(labels.numpy())
+    payload = torch.from_numpy(partial_payload(feats[lo:hi].numpy(), labels[lo:hi].numpy(), class_ids))
+    sh.reduce_(payload)  # the one exchange step
+    C, D = len(class_ids), feats.shape[1]
+    sums, counts = payload[:C * D].reshape(C, D), payload[C * D:]
+    W = 2 * sums / counts[:, None]
+    b = -((sums / counts[:, None]) ** 2).sum(1)
+    logits = q @ W.t() + b
+    # query-sharded gather through the same helper the GPU path uses
+    ql, qh = sh.bounds(len(q))
+    full = torch.zeros_like(logits)
+    full[ql:qh] = logits[ql:qh]
+    sh.reduce_(full)
+    result[rank] = (W.numpy(), b.numpy(), full.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("N,way", [(200, 5), (7, 3)])
+def test_support_sharded_prototypes_world2(N, way):
+    g = torch.Generator().manual_seed(N)
+    labels = torch.tensor([3, 7, 9, 11, 20][:way])[torch.randint(0, way, (N,), generator=g)]
+    labels[:way] = torch.tensor([3, 7, 9, 11, 20][:way])  # every class present at least once (rank 0 only, for N=7)
+    feats = torch.rand(N, 96, generator=g)
+    q = torch.rand(16, 96, generator=g)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_worker, args=(2, port, feats, labels, q, result), nprocs=2, join=True)
+    ids, W, b = blocks.proto_configure(feats, labels)
+    want = blocks.proto_predict(q, W, b)
+    for r in range(2):
+        Wr, br, lr = result[r]
+        assert np.allclose(Wr, W.numpy(), atol=1e-5) and np.allclose(br, b.numpy(), atol=1e-4)
+        assert np.allclose(lr, want.numpy(), atol=1e-3)
+    assert np.array_equal(result[0][0], result[1][0])  # bit-identical prototypes on both ranks
