@@ -271,7 +271,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         __syncthreads();
     }
 
-    // ---- epilogue: C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
+    // The tile goes through LDS (the pipeline buffers are free after the last barrier) so that HBM sees whole
+    // rows: every thread then moves 16 bytes, a wave instruction covers 256-1024 contiguous bytes per output row
+    // (the direct form issues 4-byte stores, 128 B per row fragment, and is store-issue-bound on the wide, short-K
+    // EfficientNet layers).
+    constexpr int CS = BN + 4;                    // LDS row stride (floats), keeps float4 rows 16-B aligned
+    constexpr int OROWS = POOL2 ? BM / 4 : BM;    // output rows of this tile
+    float* Cs = smem;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn + j * 32 + l31;
@@ -282,25 +289,40 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int rq = 0; rq < 4; ++rq) {
-                const int mrow = m0 + wm + i * 32 + 8 * rq + 4 * lh;  // first of 4 consecutive rows
-                if (POOL2) {
-                    // the 4 rows are one pooling window (window-major row order)
+                const int rowl = wm + i * 32 + 8 * rq + 4 * lh;  // first of 4 consecutive tile rows
+                if (POOL2) {  // the 4 rows are one pooling window (window-major row order)
                     float v = -INFINITY;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r)
-                        v = fmaxf(v, apply_act(acc[i][j][rq * 4 + r] * sc + sh, p.act));
-                    if (n_ok && mrow < p.M) p.y[(size_t)(mrow >> 2) * p.Cout + n] = v;
+                    for (int r = 0; r < 4; ++r) v = fmaxf(v, apply_act(acc[i][j][rq * 4 + r] * sc + sh, p.act));
+                    Cs[(rowl >> 2) * CS + wn + j * 32 + l31] = v;
                 } else {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const int m = mrow + r;
-                        if (n_ok && m < p.M) {
-                            float v = acc[i][j][rq * 4 + r] * sc + sh;
-                            if (p.residual) v += p.residual[(size_t)m * p.Cout + n];
-                            p.y[(size_t)m * p.Cout + n] = apply_act(v, p.act);
-                        }
-                    }
+                    for (int r = 0; r < 4; ++r)
+                        Cs[(rowl + r) * CS + wn + j * 32 + l31] = acc[i][j][rq * 4 + r] * sc + sh;
                 }
+            }
+        }
+    }
+    __syncthreads();
+    {
+        constexpr int TPO = BN / 4;      // threads per output row
+        constexpr int RPO = 256 / TPO;   // rows per pass
+        const int oc = (tid % TPO) * 4;
+        const int n = n0 + oc;
+        const int mo0 = POOL2 ? (m0 >> 2) : m0;
+        const int mout = POOL2 ? (p.M >> 2) : p.M;
+        if (n < p.Cout) {
+#pragma unroll 4
+            for (int r = tid / TPO; r < OROWS; r += RPO) {
+                const int m = mo0 + r;
+                if (m >= mout) break;
+                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS + oc);
+                if (!POOL2) {
+                    if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.Cout + n);
+                    v[0] = apply_act(v[0], p.act), v[1] = apply_act(v[1], p.act);
+                    v[2] = apply_act(v[2], p.act), v[3] = apply_act(v[3], p.act);
+                }
+                *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n) = v;
             }
         }
     }
@@ -403,7 +425,9 @@ template <int BM, int BN, int WGM, int WGN, int BK, int MODE, bool POOL2, bool G
 static int launch_cfg(ConvParams& p, hipStream_t s) {
     p.m_tiles = cdiv(p.M, BM);
     p.n_tiles = cdiv(p.Cout, BN);
-    const size_t lds = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+    const size_t lds_pipe = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
+    const size_t lds_epi = (size_t)(POOL2 ? BM / 4 : BM) * (BN + 4) * sizeof(float);
+    const size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
     auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, BK, MODE, POOL2, GATE>;
     static bool attr_set = false;  // >64 KiB dynamic LDS needs the opt-in once per kernel
     if (!attr_set && lds > 64 * 1024) {
@@ -442,6 +466,10 @@ static int launch_tiled(ConvParams& p, hipStream_t s) {
         if (!strcmp(force, "64x64")) return launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
         if (!strcmp(force, "128x32")) return launch_cfg<128, 32, 4, 1, BK, MODE, POOL2, GATE>(p, s);
     }
+    // short-K layers (EfficientNet's 1x1 convs, K <= 1152) are HBM/latency-bound, not MFMA-bound: many small
+    // blocks in flight beat large tiles (measured: 64x64 is fastest on every such layer with Cout > 32)
+    const int ktrue = p.KH * p.KW * p.Cin;
+    if (p.Cout > 32 && ktrue <= 1152 && p.KH == 1) return launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
     if (p.Cout > 64) {
         if ((long)cdiv(p.M, 128) * cdiv(p.Cout, 128) >= target)
             return launch_cfg<128, 128, 2, 2, BK, MODE, POOL2, GATE>(p, s);
@@ -470,6 +498,7 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     ORBIT_REQUIRE(d.x_nchw ? d.Cin <= 4 : (d.Cin % 4 == 0),
                   "conv: NHWC path needs Cin %% 4 == 0, NCHW stem path needs Cin <= 4 (Cin=%d)", d.Cin);
     ORBIT_REQUIRE(!(d.pool2 && d.residual), "conv: pool2 cannot be combined with a residual input");
+    ORBIT_REQUIRE(d.Cout % 4 == 0, "conv: Cout %% 4 != 0 (Cout=%d): the epilogue writes float4 rows", d.Cout);
     ORBIT_REQUIRE(!(d.gate && d.x_nchw), "conv: gate is only supported on the NHWC path");
     const ConvPackGeom g = conv_pack_geom(d.Cin, d.Cout, d.KH, d.KW, d.x_nchw);
     ConvParams p;

@@ -143,7 +143,7 @@ def test_conv_stem_nchw(lib, device, case):
 
 def test_conv_transpose_detecting(lib, device):
     """Asymmetric weights + one-hot input: catches row/col or (kh,kw) swaps that random data could hide."""
-    B, Cin, H, W, Cout = 1, 4, 5, 7, 3
+    B, Cin, H, W, Cout = 1, 4, 5, 7, 4
     x = torch.zeros(B, Cin, H, W)
     x[0, 2, 1, 4] = 1.0
     w = torch.arange(Cout * Cin * 9, dtype=torch.float32).reshape(Cout, Cin, 3, 3)
