@@ -142,16 +142,17 @@ def main():
             logits = run_task(model, task)
             correct[0] += (logits.argmax(1) == task["target_labels"]).sum()
             correct[1] += logits.shape[0]
+        issued = time.perf_counter() - t0  # host time to enqueue everything (diagnostic: host- vs device-bound)
         barrier()
-        return time.perf_counter() - t0, correct
+        return time.perf_counter() - t0, correct, issued
 
     for i in range(args.warmup):
         run_task(model, tasks[i % len(tasks)])
-    elapsed, correct = loop(args.steps)  # the timed region behind `value`
+    elapsed, correct, issued = loop(args.steps)  # the timed region behind `value`
     # roofline leg: the SAME K steps again with one HIP-event pair recorded per conv_igemm launch on its stream
     # (kept out of the timed region above: recording ~80 events per task costs host time and serialises the queue)
     lib.orbit_prof_enable(1)
-    elapsed_prof, _ = loop(args.steps)
+    elapsed_prof, _, _ = loop(args.steps)
     lib.orbit_prof_enable(0)
     if dist is not None:
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -191,6 +192,7 @@ def main():
                                    WAY * SHOTS * FRAMES_PER_SHOT, SHOTS, FRAMES_PER_SHOT, NUM_QUERY),
                    "tasks_per_step": 1, "parallelism": "task-parallel x%d (independent tasks per rank)" % world},
         "frame_accuracy": float(correct[0].item() / max(correct[1].item(), 1)),
+        "host_enqueue_ms_per_step": 1e3 * issued / args.steps,
         "extractor_gflop_per_task": 2 * macs * (WAY * SHOTS * FRAMES_PER_SHOT + NUM_QUERY) / 1e9,
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,

@@ -77,23 +77,22 @@ __global__ __launch_bounds__(256) void dw_pack_kernel(const float* __restrict__ 
 
 // ---- depthwise KxK + folded BN + activation + fused squeeze-excite pooling ---------------------------------
 // HBM-bound (reads the 6x-expanded tensor once, writes the depthwise output once). Thread = 4 channels (float4) x
-// NOUT consecutive output columns of one output row (4 for 3x3, 2 for 5x5): the input columns a row of taps needs
-// are loaded once and reused by those outputs (3x3,S=1: 4.5 loads per output float4 instead of 9). The block's weights (its
+// 4 consecutive output columns of one output row: the (3*S + K) input columns a row of taps needs are loaded once
+// and reused by the 4 outputs (K=5,S=1: 10 loads per output float4 instead of 25). The block's weights (its
 // channel slice x K*K taps) sit in LDS. Every thread owns a FIXED channel quad, so its running sum of activated
 // outputs is the squeeze-excite pooling partial: reduced across the block's column lanes in a fixed order and
 // written to pool_partial[b][row_chunk][c] (deterministic; orbit se_gate sums the row chunks).
 template <int K, int S>
-__global__ __launch_bounds__(256, 3) void dwconv_se_kernel(const float* __restrict__ x, const float* __restrict__ w,
+__global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         float* __restrict__ y, const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         float* __restrict__ pool_partial, int H, int W, int C,
                                                         int pad_t, int pad_l, int Ho, int Wo, int act, int cb4,
                                                         int rows_per_chunk) {
-    constexpr int NOUT = K == 3 ? 4 : 2;          // output columns per thread (register budget: 3 waves/SIMD)
-    constexpr int NCOL = (NOUT - 1) * S + K;      // input columns those outputs touch
+    constexpr int NCOL = 3 * S + K;
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    v4f* wl = reinterpret_cast<v4f*>(sm);                   // [K*K][cb4]
-    v4f* red = wl + K * K * cb4;                            // [WL][cb4]
+    float4* wl = reinterpret_cast<float4*>(sm);             // [K*K][cb4]
+    float4* red = wl + K * K * cb4;                         // [WL][cb4]
     const int b = blockIdx.z, chunk = blockIdx.y;
     const int c4_0 = blockIdx.x * cb4;
     const int WL = 256 / cb4;
@@ -103,66 +102,60 @@ __global__ __launch_bounds__(256, 3) void dwconv_se_kernel(const float* __restri
     const int c = (c4_0 + lc) * 4;
     for (int i = tid; i < K * K * cb4; i += 256) {
         const int tap = i / cb4, cc = i % cb4;
-        wl[i] = *reinterpret_cast<const v4f*>(w + (size_t)tap * C + (c4_0 + cc) * 4);
+        wl[i] = *reinterpret_cast<const float4*>(w + (size_t)tap * C + (c4_0 + cc) * 4);
     }
     __syncthreads();
-    v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f};
-    if (scale) sc = *reinterpret_cast<const v4f*>(scale + c);
-    if (shift) sh = *reinterpret_cast<const v4f*>(shift + c);
-    v4f psum = {0.f, 0.f, 0.f, 0.f};
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (scale) sc = *reinterpret_cast<const float4*>(scale + c);
+    if (shift) sh = *reinterpret_cast<const float4*>(shift + c);
+    float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* xb = x + (size_t)b * H * W * C + c;
     float* yb = y + (size_t)b * Ho * Wo * C + c;
     const int ho_end = min(Ho, (chunk + 1) * rows_per_chunk);
-    const int WQ = (Wo + NOUT - 1) / NOUT;
+    const int WQ = (Wo + 3) >> 2;
     if (active) {
         for (int ho = chunk * rows_per_chunk; ho < ho_end; ++ho) {
             for (int wq = lw; wq < WQ; wq += WL) {
-                v4f acc[NOUT];
+                float4 acc[4];
 #pragma unroll
-                for (int j = 0; j < NOUT; ++j) acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
-                const int wi0 = wq * NOUT * S - pad_l;
-                // the K*K weight quads are loop-invariant; left alone the compiler keeps all of them in registers
-                // (100 VGPRs at K=5 -> spills / 1 wave per SIMD). An opaque lane offset makes it re-read LDS instead.
-                int lco = lc;
-                asm volatile("" : "+v"(lco));
-                // rows are software-pipelined two deep: the taps of row kh+1 are in flight while row kh is consumed.
-                // Out-of-range taps read a clamped (valid, finite) address and are multiplied by 0: the loads stay
-                // unconditional, so they batch instead of turning into one branch per tap.
-                v4f col[2][NCOL];
-                auto load_row = [&](int kh, v4f* dst) {
+                for (int j = 0; j < 4; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+                const int wi0 = wq * 4 * S - pad_l;
+#pragma unroll
+                for (int kh = 0; kh < K; ++kh) {
                     const int hi = ho * S - pad_t + kh;
-                    const bool row_ok = (unsigned)hi < (unsigned)H;
-                    const float* xr = xb + (size_t)(row_ok ? hi : 0) * W * C;
+                    if ((unsigned)hi >= (unsigned)H) continue;  // uniform over the block's row
+                    const float* xr = xb + (size_t)hi * W * C;
+                    float4 col[NCOL];
 #pragma unroll
                     for (int q = 0; q < NCOL; ++q) {
                         const int wi = wi0 + q;
-                        const bool ok = row_ok && (unsigned)wi < (unsigned)W;
-                        const v4f v = *reinterpret_cast<const v4f*>(xr + (size_t)(ok ? wi : 0) * C);
-                        dst[q] = v * (ok ? 1.0f : 0.0f);
+                        col[q] = (unsigned)wi < (unsigned)W ? *reinterpret_cast<const float4*>(xr + (size_t)wi * C)
+                                                            : make_float4(0.f, 0.f, 0.f, 0.f);
                     }
-                };
-                load_row(0, col[0]);
-#pragma unroll
-                for (int kh = 0; kh < K; ++kh) {
-                    if (kh + 1 < K) load_row(kh + 1, col[(kh + 1) & 1]);
 #pragma unroll
                     for (int kw = 0; kw < K; ++kw) {
-                        int widx = (kh * K + kw) * cb4 + lco;
-                        asm volatile("" : "+v"(widx));  // pins this LDS read here (volatile asms keep their order)
-                        const v4f f = wl[widx];
+                        const float4 f = wl[(kh * K + kw) * cb4 + lc];
 #pragma unroll
-                        for (int j = 0; j < NOUT; ++j) acc[j] += col[kh & 1][j * S + kw] * f;
+                        for (int j = 0; j < 4; ++j) {
+                            const float4 v = col[j * S + kw];
+                            acc[j].x = fmaf(v.x, f.x, acc[j].x);
+                            acc[j].y = fmaf(v.y, f.y, acc[j].y);
+                            acc[j].z = fmaf(v.z, f.z, acc[j].z);
+                            acc[j].w = fmaf(v.w, f.w, acc[j].w);
+                        }
                     }
-                    __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int j = 0; j < NOUT; ++j) {
-                    const int wo = wq * NOUT + j;
+                for (int j = 0; j < 4; ++j) {
+                    const int wo = wq * 4 + j;
                     if (wo < Wo) {
-                        v4f o = acc[j] * sc + sh;
-                        o[0] = act_fn(o[0], act), o[1] = act_fn(o[1], act), o[2] = act_fn(o[2], act), o[3] = act_fn(o[3], act);
-                        *reinterpret_cast<v4f*>(yb + ((size_t)ho * Wo + wo) * C) = o;
-                        psum += o;
+                        float4 o;
+                        o.x = act_fn(acc[j].x * sc.x + sh.x, act);
+                        o.y = act_fn(acc[j].y * sc.y + sh.y, act);
+                        o.z = act_fn(acc[j].z * sc.z + sh.z, act);
+                        o.w = act_fn(acc[j].w * sc.w + sh.w, act);
+                        *reinterpret_cast<float4*>(yb + ((size_t)ho * Wo + wo) * C) = o;
+                        psum.x += o.x, psum.y += o.y, psum.z += o.z, psum.w += o.w;
                     }
                 }
             }
@@ -172,9 +165,12 @@ __global__ __launch_bounds__(256, 3) void dwconv_se_kernel(const float* __restri
     if (active) red[lw * cb4 + lc] = psum;
     __syncthreads();
     if (tid < cb4) {
-        v4f t = red[tid];
-        for (int l = 1; l < WL; ++l) t += red[l * cb4 + tid];
-        *reinterpret_cast<v4f*>(pool_partial + ((size_t)b * gridDim.y + chunk) * C + (c4_0 + tid) * 4) = t;
+        float4 t = red[tid];
+        for (int l = 1; l < WL; ++l) {
+            const float4 u = red[l * cb4 + tid];
+            t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
+        }
+        *reinterpret_cast<float4*>(pool_partial + ((size_t)b * gridDim.y + chunk) * C + (c4_0 + tid) * 4) = t;
     }
 }
 
