@@ -42,14 +42,27 @@ class PrototypicalClassifier(nn.Module):
     def _cosine(self):
         return 1 if self.distance_fn == "cosine" else 0
 
-    @staticmethod
-    def unique_labels(context_labels, device):
+    _unique_cache = {}  # (data_ptr, version, numel, device) -> class_ids; small, cleared when it grows
+
+    @classmethod
+    def unique_labels(cls, context_labels, device):
         """Ascending unique label values on `device` (column order of the logits, classifier_heads.py:246-248).
         Host-resident labels are reduced on the host (no device sync); device labels need one sync for the class
-        count, exactly like the reference's torch.unique(...).item() loop (:96-100)."""
+        count, exactly like the reference's torch.unique(...).item() loop (:96-100). The result is memoised per
+        label tensor (storage address + version counter): LITE re-personalises the same task once per query batch
+        (single-step-learner.py:220-222), and a resident task set is re-used across epochs."""
+        key = (context_labels.data_ptr(), context_labels._version, context_labels.numel(), str(context_labels.device))
+        hit = cls._unique_cache.get(key)
+        if hit is not None and hit[0] is context_labels:
+            return hit[1]
         if context_labels.is_cuda:
-            return torch.unique(context_labels.to(torch.int64))
-        return torch.unique(context_labels.to(torch.int64)).to(device, non_blocking=True)
+            ids = torch.unique(context_labels.to(torch.int64))
+        else:
+            ids = torch.unique(context_labels.to(torch.int64)).to(device, non_blocking=True)
+        if len(cls._unique_cache) > 256:
+            cls._unique_cache.clear()
+        cls._unique_cache[key] = (context_labels, ids)  # holding the tensor keeps its address from being re-used
+        return ids
 
     def configure(self, context_features, context_labels, ops_counter=None, frames_per_clip: int = 1,
                   class_ids=None):
