@@ -69,8 +69,8 @@ int launch_conv(const ConvDesc& d, hipStream_t s);
 int launch_dwconv(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                   int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho, int Wo,
                   int act, hipStream_t s);
-// depthwise + fused SE pooling partials [B][chunks][C] (pool_partial may be nullptr); chunks = tiles per frame
-int dwconv_se_chunks(int Ho, int Wo, int stride);
+// depthwise + fused SE pooling partials [B][chunks][C] (pool_partial may be nullptr); chunks = dwconv_se_chunks(Ho)
+int dwconv_se_chunks(int Ho);
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                      float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
                      int Wo, int act, hipStream_t s);

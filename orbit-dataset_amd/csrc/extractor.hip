@@ -249,17 +249,17 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
         o.packed_off = fe->packed_floats;
         fe->packed_floats += (size_t)(C * K * K + 3) / 4 * 4;
         o.pool_partial = 1;
-        fe->max_partial = std::max(fe->max_partial, (size_t)dwconv_se_chunks(o.Ho, o.Wo, stride) * C);
+        fe->max_partial = std::max(fe->max_partial, (size_t)dwconv_se_chunks(o.Ho) * C);
         ho = o.Ho, wo = o.Wo;
         fe->note_buf(out, (size_t)ho * wo * C);
         fe->macs += (double)ho * wo * C * K * K;
         fe->ops.push_back(o);
     };
-    auto add_se = [&](const std::string& p, int buf, int C, int R, int hh, int ww, int dw_stride) {
+    auto add_se = [&](const std::string& p, int buf, int C, int R, int hh, int ww) {
         (void)buf;  // the pooled sums come from the depthwise kernel's partials (buffer 101), not from a re-read
         Op s;
         s.kind = OP_SE, s.in = 101, s.out = 102, s.Cin = C, s.R = R;
-        s.se_chunks = dwconv_se_chunks(hh, ww, dw_stride), s.se_hw = hh * ww;
+        s.se_chunks = dwconv_se_chunks(hh), s.se_hw = hh * ww;
         s.packed_off = fe->packed_floats;  // W2 transposed to [R][C]
         fe->packed_floats += (size_t)(C * R + 3) / 4 * 4;
         s.se_w1 = fe->add_param(p + ".conv_reduce.weight", (size_t)R * C);
@@ -282,7 +282,7 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
         // conv_dw param is registered inside add_dw, bn1 after it: keep state_dict order cosmetic only
         const int bn1 = fe->add_bn(p + ".bn1", 32, eps, false);
         add_dw(p + ".conv_dw.weight", bn1, cur, t1, 32, 3, 1, h, w, ho, wo);
-        add_se(p + ".se", t1, 32, 8, ho, wo, 1);
+        add_se(p + ".se", t1, 32, 8, ho, wo);
         const int bn2 = fe->add_bn(p + ".bn2", 16, eps, false);
         fe->add_conv(p + ".conv_pw.weight", bn2, t1, t2, -1, ho, wo, 32, 16, 1, 1, 0, 0, ho, wo, ORBIT_ACT_NONE,
                      0, 0, 1);
@@ -304,7 +304,7 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
                          0, 0);
             const int bn2 = fe->add_bn(p + ".bn2", mid, eps, true);  // InvertedResidual.bn2 is FiLM-tagged
             add_dw(p + ".conv_dw.weight", bn2, t1, t2, mid, K, stride, h, w, ho, wo);
-            add_se(p + ".se", t2, mid, rd, ho, wo, stride);
+            add_se(p + ".se", t2, mid, rd, ho, wo);
             const int bn3 = fe->add_bn(p + ".bn3", cout, eps, false);
             // project: reads t2 (gated), residual from cur, writes t1 (free again)
             fe->add_conv(p + ".conv_pwl.weight", bn3, t2, t1, skip ? cur : -1, ho, wo, mid, cout, 1, 1, 0, 0, ho, wo,

@@ -174,93 +174,6 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
     }
 }
 
-// ---- LDS-tiled depthwise KxK (+BN +act +SE pooling partials) ---------------------------------------------------
-// Block = (64-channel slice, TH x TW output tile, frame). The input patch ((TH-1)S+K) x ((TW-1)S+K) x 64 channels is
-// staged ONCE in LDS (256 contiguous bytes per pixel), so HBM/L2 see each input element ~1.6-2.3x (tile halo) instead
-// of the K*K/S^2 .. K*NCOL/NOUT re-reads of a register-only kernel (which made the 5x5 layers L2-bandwidth-bound).
-// Thread = (channel quad, NOUT consecutive output columns): taps and weights come from LDS as conflict-free
-// ds_read_b128 (lanes of a 16-lane group read 16 consecutive quads). Pooling partials: one [64-channel] sum per tile,
-// reduced in fixed order -> pool_partial[b][tile][c].
-template <int K, int S, int TH, int TW>
-__global__ __launch_bounds__(256) void dwconv_tile_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                          float* __restrict__ y, const float* __restrict__ scale,
-                                                          const float* __restrict__ shift,
-                                                          float* __restrict__ pool_partial, int H, int W, int C,
-                                                          int pad_t, int pad_l, int Ho, int Wo, int act, int tiles_x) {
-    constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
-    constexpr int NOUT = TH * TW / 16;            // outputs per thread along W (16 segments x 16 channel quads)
-    constexpr int SEG_PER_ROW = TW / NOUT;
-    constexpr int NCOL = (NOUT - 1) * S + K;
-    static_assert(TH * TW % 16 == 0 && TW % NOUT == 0 && 16 / SEG_PER_ROW == TH, "tile/thread mapping");
-    extern __shared__ __attribute__((aligned(16))) float smt[];
-    v4f* tile = reinterpret_cast<v4f*>(smt);      // [IH*IW][16]
-    v4f* wl = tile + IH * IW * 16;                // [K*K][16]
-    v4f* red = wl + K * K * 16;                   // [16][16]
-    const int b = blockIdx.z, t_idx = blockIdx.y;
-    const int ty = t_idx / tiles_x, tx = t_idx - ty * tiles_x;
-    const int c4_0 = blockIdx.x * 16;
-    const int C4 = C >> 2;
-    const int nc4 = min(16, C4 - c4_0);
-    const int tid = threadIdx.x;
-    const int lc = tid & 15, seg = tid >> 4;
-    const bool lane_ok = lc < nc4;
-    const int cq = lane_ok ? c4_0 + lc : c4_0;    // clamped channel quad (idle lanes read valid memory)
-    const int hi0 = ty * TH * S - pad_t, wi0 = tx * TW * S - pad_l;
-    const float* xb = x + (size_t)b * H * W * C + (size_t)cq * 4;
-    const v4f zero = {0.f, 0.f, 0.f, 0.f};
-    for (int p = seg; p < IH * IW; p += 16) {
-        const int iy = p / IW, ix = p - iy * IW;
-        const int hi = hi0 + iy, wi = wi0 + ix;
-        v4f v = zero;
-        if (lane_ok && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
-            v = *reinterpret_cast<const v4f*>(xb + ((size_t)hi * W + wi) * C);
-        tile[p * 16 + lc] = v;
-    }
-    for (int tap = seg; tap < K * K; tap += 16)
-        wl[tap * 16 + lc] = *reinterpret_cast<const v4f*>(w + (size_t)tap * C + (size_t)cq * 4);
-    __syncthreads();
-    const int oy = seg / SEG_PER_ROW, ox0 = (seg % SEG_PER_ROW) * NOUT;
-    v4f acc[NOUT];
-#pragma unroll
-    for (int j = 0; j < NOUT; ++j) acc[j] = zero;
-#pragma unroll
-    for (int kh = 0; kh < K; ++kh) {
-        const v4f* trow = tile + ((oy * S + kh) * IW + ox0 * S) * 16 + lc;
-        v4f col[NCOL];
-#pragma unroll
-        for (int q = 0; q < NCOL; ++q) col[q] = trow[q * 16];
-#pragma unroll
-        for (int kw = 0; kw < K; ++kw) {
-            const v4f f = wl[(kh * K + kw) * 16 + lc];
-#pragma unroll
-            for (int j = 0; j < NOUT; ++j) acc[j] += col[j * S + kw] * f;
-        }
-    }
-    v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = zero, psum = zero;
-    if (scale) sc = *reinterpret_cast<const v4f*>(scale + (size_t)cq * 4);
-    if (shift) sh = *reinterpret_cast<const v4f*>(shift + (size_t)cq * 4);
-    const int ho = ty * TH + oy;
-#pragma unroll
-    for (int j = 0; j < NOUT; ++j) {
-        const int wo = tx * TW + ox0 + j;
-        if (lane_ok && ho < Ho && wo < Wo) {
-            v4f o = acc[j] * sc + sh;
-            o[0] = act_fn(o[0], act), o[1] = act_fn(o[1], act), o[2] = act_fn(o[2], act), o[3] = act_fn(o[3], act);
-            *reinterpret_cast<v4f*>(y + (((size_t)b * Ho + ho) * Wo + wo) * C + (size_t)cq * 4) = o;
-            psum += o;
-        }
-    }
-    if (pool_partial == nullptr) return;
-    red[seg * 16 + lc] = psum;
-    __syncthreads();
-    if (tid < nc4) {
-        v4f t = red[tid];
-#pragma unroll
-        for (int l = 1; l < 16; ++l) t += red[l * 16 + tid];
-        *reinterpret_cast<v4f*>(pool_partial + ((size_t)b * gridDim.y + t_idx) * C + (size_t)(c4_0 + tid) * 4) = t;
-    }
-}
-
 // squeeze-excite gate from pooling partials: pooled[c] = (sum_chunks partial[b][chunk][c]) / HW, then
 // g = sigmoid(W2 silu(W1 pooled + b1) + b2). w2t is W2 transposed to [R][C] so the second layer reads coalesced.
 __global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__ partial, int chunks, float inv_hw,
@@ -444,20 +357,14 @@ int launch_dwconv(const float* x, const float* w_khwc, float* y, const float* sc
 // channel quads per block: the largest divisor of C/4 that is <= 64 (keeps every thread on a fixed channel quad)
 static int dw_cb4(int C) {
     const int c4 = C / 4;
-    for (int d = c4 < 64 ? c4 : 64; d >= 1; --d)
+    static const char* env = getenv("ORBIT_DW_CB4");  // tuning experiments only
+    const int cap = env ? atoi(env) : 64;
+    for (int d = c4 < cap ? c4 : cap; d >= 1; --d)
         if (c4 % d == 0) return d;
     return 1;
 }
-// tile geometry of dwconv_tile_kernel: 8x8 outputs at stride 1, 4x8 at stride 2 (keeps the LDS patch <= ~53 KB)
-static void dw_tile_geom(int stride, int Ho, int Wo, int& th, int& tw, int& tiles_y, int& tiles_x) {
-    th = stride == 1 ? 8 : 4, tw = 8;
-    tiles_y = cdiv(Ho, th), tiles_x = cdiv(Wo, tw);
-}
-int dwconv_se_chunks(int Ho, int Wo, int stride) {
-    int th, tw, tyc, txc;
-    dw_tile_geom(stride, Ho, Wo, th, tw, tyc, txc);
-    return tyc * txc;
-}
+int dwconv_se_rows_per_chunk(int Ho) { return Ho >= 56 ? 8 : (Ho >= 14 ? 7 : Ho); }
+int dwconv_se_chunks(int Ho) { return cdiv(Ho, dwconv_se_rows_per_chunk(Ho)); }
 
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                      float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
@@ -466,19 +373,17 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     ORBIT_REQUIRE(C % 4 == 0, "dwconv_se: C %% 4 != 0 (C=%d)", C);
     ORBIT_REQUIRE((K == 3 || K == 5) && (stride == 1 || stride == 2), "dwconv_se: K=%d stride=%d not instantiated", K,
                   stride);
-    int th, tw, tiles_y, tiles_x;
-    dw_tile_geom(stride, Ho, Wo, th, tw, tiles_y, tiles_x);
-    dim3 grid(cdiv(C / 4, 16), tiles_y * tiles_x, B);
-    const int ih = (th - 1) * stride + K, iw = (tw - 1) * stride + K;
-    const size_t lds = (size_t)(ih * iw * 16 + K * K * 16 + 256) * 4 * sizeof(float);
-#define ORBIT_DWT(KK, SS, TH_, TW_)                                                                                  \
-    dwconv_tile_kernel<KK, SS, TH_, TW_><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t, \
-                                                               pad_l, Ho, Wo, act, tiles_x)
-    if (K == 3 && stride == 1) ORBIT_DWT(3, 1, 8, 8);
-    else if (K == 3) ORBIT_DWT(3, 2, 4, 8);
-    else if (stride == 1) ORBIT_DWT(5, 1, 8, 8);
-    else ORBIT_DWT(5, 2, 4, 8);
-#undef ORBIT_DWT
+    const int cb4 = dw_cb4(C), rpc = dwconv_se_rows_per_chunk(Ho);
+    dim3 grid(C / 4 / cb4, cdiv(Ho, rpc), B);
+    const size_t lds = (size_t)(K * K * cb4 + (256 / cb4) * cb4) * sizeof(float4);
+#define ORBIT_DW(KK, SS)                                                                                         \
+    dwconv_se_kernel<KK, SS><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t, pad_l, \
+                                                    Ho, Wo, act, cb4, rpc)
+    if (K == 3 && stride == 1) ORBIT_DW(3, 1);
+    else if (K == 3) ORBIT_DW(3, 2);
+    else if (stride == 1) ORBIT_DW(5, 1);
+    else ORBIT_DW(5, 2);
+#undef ORBIT_DW
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }

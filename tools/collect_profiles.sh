@@ -1,0 +1,36 @@
+#!/bin/bash
+# Run on the GPU box (through gpurun): rocprofv3 evidence for bench.py's numbers.
+#   tools/collect_profiles.sh <outdir> <round-tag>
+# Produces (CSV) kernel-trace stats of the default bench command and of the resnet18_84 workload, and the HBM
+# traffic counters of the dominant kernel in their own passes (FETCH_SIZE and WRITE_SIZE cannot share a pass; PMC is
+# never combined with other trace domains).
+set -u
+OUT=${1:-gpurun_out/profiles}; TAG=${2:-r01}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p "$R/$OUT"; O="$R/$OUT"
+cd /tmp && export TMPDIR=/tmp
+for W in efficientnet_b0_224 resnet18_84; do
+  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- \
+      python $R/bench.py --workload $W --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_$W.json 2> $O/${TAG}_bench_$W.err
+  cp $(ls $O/stats_$W/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_$W.csv
+done
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$C -- \
+      python $R/bench.py --workload efficientnet_b0_224 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/${TAG}_pmc_$C.err
+  F=$(ls $O/pmc_$C/*/*counter_collection.csv | head -1)
+  python - "$F" "$C" > $O/${TAG}_pmc_${C}_summary.txt <<'PY'
+import csv, sys, collections
+f, c = sys.argv[1], sys.argv[2]
+agg = collections.defaultdict(lambda: [0, 0.0])
+for r in csv.DictReader(open(f)):
+    if r.get("Counter_Name") != c:
+        continue
+    k = r["Kernel_Name"].split("(")[0][:90]
+    agg[k][0] += 1
+    agg[k][1] += float(r["Counter_Value"])
+print("# %s per kernel (sum over dispatches, and per launch); unit = KiB as reported by rocprofv3" % c)
+for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
+    print("%-92s launches %6d  total %14.0f  per_launch %12.1f" % (k, n, v, v / n))
+PY
+done
+ls -la $O | head -40
