@@ -38,9 +38,9 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 WAY, SHOTS, FRAMES_PER_SHOT, NUM_QUERY = 5, 5, 8, 200
 
 
-def build_model(workload, device):
+def build_model(workload, device, batch_size=256):
     fe_name, adapt, _ = WORKLOADS[workload]
-    model = SingleStepFewShotRecogniser(fe_name, adapt, "proto", 1, 256, False, 16, 1.0)
+    model = SingleStepFewShotRecogniser(fe_name, adapt, "proto", 1, batch_size, False, 16, 1.0)
     synthetic.init_parameters_(model)
     if adapt:
         from orbit_dataset_amd.model.film import get_film_parameters
@@ -104,6 +104,7 @@ def main():
     ap.add_argument("--workload", default="efficientnet_b0_224", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-tasks", type=int, default=4, help="tasks resident in HBM, cycled through")
+    ap.add_argument("--batch-size", type=int, default=256, help="clips per extractor call (reference --batch_size)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -121,7 +122,7 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     fe_name, adapt, size = WORKLOADS[args.workload]
-    model = build_model(args.workload, device)
+    model = build_model(args.workload, device, args.batch_size)
     # each rank owns its own tasks (task index = rank + world * i): weak scaling, independent units
     tasks = [synthetic.make_task_on_device(rank + world * i, WAY, SHOTS, FRAMES_PER_SHOT, NUM_QUERY, size, 1, device)
              for i in range(max(1, args.distinct_tasks))]
