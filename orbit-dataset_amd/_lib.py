@@ -49,6 +49,7 @@ _SIGNATURES = {
     "orbit_op_maxpool2d": (c_int, [P, P] + [c_int] * 9 + [P]),
     "orbit_op_avgpool": (c_int, [P, P, c_int, c_int, c_int, P]),
     "orbit_op_se_gate": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
+    "orbit_op_mbconv_front": (c_int, [P] * 9 + [c_int] * 11 + [P]),
     "orbit_prof_enable": (c_int, [c_int]),
     "orbit_prof_collect": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(ctypes.c_long)]),
     "orbit_prof_num_variants": (c_int, []),

@@ -77,6 +77,12 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
 int launch_se_gate2(const float* partial, int chunks, int HW, const float* w1, const float* b1, const float* w2t,
                     const float* b2, float* gate, int B, int C, int R, hipStream_t s);
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
+// fused expand(1x1, MFMA) + BN + SiLU + depthwise + BN + SiLU (+ SE pooling partials [B][tiles][mid]); csrc/mbconv.hip
+bool mbconv_front_supported(int Cin, int mid, int K, int stride);
+int mbconv_front_tiles(int Ho, int Wo, int stride);
+int launch_mbconv_front(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
+                        const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
+                        int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s);
 // [C][1][K][K] -> [K][K][C]
 int dwconv_pack_weights(const float* w, float* w_khwc, int C, int K, hipStream_t s);
 int launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int K, int stride, int pad,

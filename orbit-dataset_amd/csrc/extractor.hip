@@ -10,6 +10,7 @@
 // Activations are NHWC fp32 and live in caller-provided workspace (three rotating buffers); frames come
 // in as NCHW (the reference's clip layout) and are consumed directly by the stem convolution.
 #include <algorithm>
+#include <cstdlib>
 #include <map>
 #include <string>
 #include <vector>
@@ -41,7 +42,7 @@ struct BNDev {         // device descriptor for the fold kernel
     float eps;
 };
 
-enum OpKind { OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_AVGPOOL, OP_SE };
+enum OpKind { OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_AVGPOOL, OP_SE, OP_MBFRONT };
 
 struct Op {
     OpKind kind;
@@ -53,6 +54,7 @@ struct Op {
     int se_w1 = -1, se_b1 = -1, se_w2 = -1, se_b2 = -1, R = 0;
     int se_chunks = 0, se_hw = 0;  // squeeze-excite pooling partials produced by the preceding depthwise conv
     int pool_partial = 0;          // depthwise: also emit the pooling partials
+    int weight2 = -1, bn2 = -1;    // OP_MBFRONT: depthwise weight (packed at packed_off) and its BatchNorm
     int pool_k = 0, pool_pad = 0;
 };
 
@@ -231,6 +233,8 @@ static int build_resnet18(orbit_extractor* fe, int H, int W) {
 static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
     fe->out_size = 1280;
     const float eps = 1e-3f;
+    static const char* nofuse = getenv("ORBIT_NO_MBCONV_FUSION");  // A/B experiments
+    const bool fuse_front = nofuse == nullptr;
     int h, w, pt, pl;
     same_pad(H, 3, 2, h, pt);
     same_pad(W, 3, 2, w, pl);
@@ -255,11 +259,11 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
         fe->macs += (double)ho * wo * C * K * K;
         fe->ops.push_back(o);
     };
-    auto add_se = [&](const std::string& p, int buf, int C, int R, int hh, int ww) {
+    auto add_se = [&](const std::string& p, int buf, int C, int R, int hh, int ww, int chunks) {
         (void)buf;  // the pooled sums come from the depthwise kernel's partials (buffer 101), not from a re-read
         Op s;
         s.kind = OP_SE, s.in = 101, s.out = 102, s.Cin = C, s.R = R;
-        s.se_chunks = dwconv_se_chunks(hh), s.se_hw = hh * ww;
+        s.se_chunks = chunks, s.se_hw = hh * ww;
         s.packed_off = fe->packed_floats;  // W2 transposed to [R][C]
         fe->packed_floats += (size_t)(C * R + 3) / 4 * 4;
         s.se_w1 = fe->add_param(p + ".conv_reduce.weight", (size_t)R * C);
@@ -282,7 +286,7 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
         // conv_dw param is registered inside add_dw, bn1 after it: keep state_dict order cosmetic only
         const int bn1 = fe->add_bn(p + ".bn1", 32, eps, false);
         add_dw(p + ".conv_dw.weight", bn1, cur, t1, 32, 3, 1, h, w, ho, wo);
-        add_se(p + ".se", t1, 32, 8, ho, wo);
+        add_se(p + ".se", t1, 32, 8, ho, wo, dwconv_se_chunks(ho));
         const int bn2 = fe->add_bn(p + ".bn2", 16, eps, false);
         fe->add_conv(p + ".conv_pw.weight", bn2, t1, t2, -1, ho, wo, 32, 16, 1, 1, 0, 0, ho, wo, ORBIT_ACT_NONE,
                      0, 0, 1);
@@ -300,11 +304,33 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
             const bool skip = stride == 1 && cin == cout;
             int ho, wo;
             const int bn1 = fe->add_bn(p + ".bn1", mid, eps, false);
-            fe->add_conv(p + ".conv_pw.weight", bn1, cur, t1, -1, h, w, cin, mid, 1, 1, 0, 0, h, w, ORBIT_ACT_SILU, 0,
-                         0, 0);
-            const int bn2 = fe->add_bn(p + ".bn2", mid, eps, true);  // InvertedResidual.bn2 is FiLM-tagged
-            add_dw(p + ".conv_dw.weight", bn2, t1, t2, mid, K, stride, h, w, ho, wo);
-            add_se(p + ".se", t2, mid, rd, ho, wo);
+            int se_chunks;
+            if (fuse_front && mbconv_front_supported(cin, mid, K, stride)) {
+                // expand + depthwise in one kernel: the 6x-expanded tensor never leaves LDS (csrc/mbconv.hip)
+                Op o;
+                o.kind = OP_MBFRONT, o.in = cur, o.out = t2, o.H = h, o.W = w, o.Cin = cin, o.Cout = mid;
+                o.KH = o.KW = K, o.stride = stride, o.bn = bn1;
+                same_pad(h, K, stride, o.Ho, o.pad_t);
+                same_pad(w, K, stride, o.Wo, o.pad_l);
+                o.weight = fe->add_param(p + ".conv_pw.weight", (size_t)mid * cin);
+                o.bn2 = fe->add_bn(p + ".bn2", mid, eps, true);  // InvertedResidual.bn2 is FiLM-tagged
+                o.weight2 = fe->add_param(p + ".conv_dw.weight", (size_t)mid * K * K);
+                o.packed_off = fe->packed_floats;
+                fe->packed_floats += (size_t)(mid * K * K + 3) / 4 * 4;
+                ho = o.Ho, wo = o.Wo;
+                se_chunks = mbconv_front_tiles(ho, wo, stride);
+                fe->max_partial = std::max(fe->max_partial, (size_t)se_chunks * mid);
+                fe->note_buf(t2, (size_t)ho * wo * mid);
+                fe->macs += (double)h * w * cin * mid + (double)ho * wo * mid * K * K;
+                fe->ops.push_back(o);
+            } else {
+                fe->add_conv(p + ".conv_pw.weight", bn1, cur, t1, -1, h, w, cin, mid, 1, 1, 0, 0, h, w, ORBIT_ACT_SILU,
+                             0, 0, 0);
+                const int bn2 = fe->add_bn(p + ".bn2", mid, eps, true);  // InvertedResidual.bn2 is FiLM-tagged
+                add_dw(p + ".conv_dw.weight", bn2, t1, t2, mid, K, stride, h, w, ho, wo);
+                se_chunks = dwconv_se_chunks(ho);
+            }
+            add_se(p + ".se", t2, mid, rd, ho, wo, se_chunks);
             const int bn3 = fe->add_bn(p + ".bn3", cout, eps, false);
             // project: reads t2 (gated), residual from cur, writes t1 (free again)
             fe->add_conv(p + ".conv_pwl.weight", bn3, t2, t1, skip ? cur : -1, ho, wo, mid, cout, 1, 1, 0, 0, ho, wo,
@@ -438,6 +464,10 @@ int orbit_extractor_finalize(orbit_extractor_t* fe, orbit_stream_t stream) {
             int rc = dwconv_pack_weights(fe->d_pool + fe->params[o.weight].off, fe->d_packed + o.packed_off, o.Cin,
                                          o.KH, s);
             if (rc != ORBIT_OK) return rc;
+        } else if (o.kind == OP_MBFRONT) {
+            int rc = dwconv_pack_weights(fe->d_pool + fe->params[o.weight2].off, fe->d_packed + o.packed_off, o.Cout,
+                                         o.KH, s);
+            if (rc != ORBIT_OK) return rc;
         } else if (o.kind == OP_SE) {
             int rc = launch_transpose(fe->d_pool + fe->params[o.se_w2].off, fe->d_packed + o.packed_off, o.Cin, o.R, s);
             if (rc != ORBIT_OK) return rc;
@@ -519,6 +549,13 @@ int orbit_extractor_forward(orbit_extractor_t* fe, const float* frames, int B, c
                                       scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off,
                                       o.pool_partial ? buf(101) : nullptr, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t,
                                       o.pad_l, o.Ho, o.Wo, o.act, s);
+                break;
+            case OP_MBFRONT:
+                rc = launch_mbconv_front(buf(o.in), fe->d_pool + fe->params[o.weight].off,
+                                         scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off,
+                                         fe->d_packed + o.packed_off, scale + fe->bns[o.bn2].fold_off,
+                                         shift + fe->bns[o.bn2].fold_off, buf(o.out), buf(101), B, o.H, o.W, o.Cin, o.Cout,
+                                         o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
                 break;
             case OP_MAXPOOL:
                 rc = launch_maxpool(buf(o.in), buf(o.out), B, o.H, o.W, o.Cin, o.pool_k, o.stride, o.pool_pad, o.Ho,

@@ -1,0 +1,258 @@
+// Fused MBConv front half for gfx950: expand 1x1 conv (fp32 MFMA) -> BN1 -> SiLU -> depthwise KxK (TF-SAME) -> BN2
+// -> SiLU -> squeeze-excite pooling partials, in ONE kernel. The 6x-expanded tensor lives only in LDS.
+//
+// Replaces, for EfficientNet-B0's early InvertedResidual blocks (Cin <= 40: blocks.1.0 .. blocks.3.0, which carry 75 %
+// of the expanded-tensor bytes of the network), the reference's conv_pw -> bn1 -> act -> conv_dw -> bn2 -> act ->
+// se.mean sequence (timm InvertedResidual.forward, reached from model/feature_extractors.py:39-43). Unfused, the
+// expanded tensor costs one HBM write + one HBM read of up to 963 MB per 200 frames per block; fused, HBM sees only the
+// block input (Cin floats per pixel, + tile halo) and the depthwise output.
+//
+// Block = one TH x TW output tile of one frame, ALL expanded channels in chunks of 32:
+//   LDS  Xs [PR][Cin+4]   input patch ((TH-1)S+K) x ((TW-1)S+K) pixels, loaded once (PR = pixels rounded up to 32)
+//        Ws [32][Cin+4]   expand weights of the current channel chunk (torch [mid][Cin] layout, K contiguous)
+//        Es [P][36]       expanded patch of the chunk (BN1 + SiLU applied; ZERO outside the image: the depthwise
+//                         convolution zero-pads the EXPANDED tensor, not the input)
+//        Ds [K*K][8] quads depthwise weights of the chunk
+//   per chunk: MFMA phase (each wave owns patch row-tiles w, w+4: Cin/2 v_mfma_f32_32x32x2_f32 each) -> barrier ->
+//   depthwise phase (thread = channel quad x NOUT output columns, taps via conflict-free ds_read_b128) -> barrier.
+// Pooling partials: every thread keeps a fixed (chunk-relative) channel quad, sums its activated outputs, the block
+// reduces across its 32 column segments in fixed order and writes pool_partial[b][tile][c] (deterministic).
+#include "common.h"
+
+namespace orbit {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using v4f = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+
+struct MbParams {
+    const float* x;    // [B][H][W][Cin] NHWC
+    const float* w1;   // [mid][Cin]
+    const float* sc1;  // [mid] folded BN1
+    const float* sh1;
+    const float* wdw;  // [K][K][mid]
+    const float* sc2;  // [mid] folded BN2
+    const float* sh2;
+    float* y;          // [B][Ho][Wo][mid]
+    float* pool;       // [B][tiles][mid] or nullptr
+    int H, W, Cin, mid, pad_t, pad_l, Ho, Wo, tiles_x;
+};
+
+template <int K, int S, int TH, int TW>
+__global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
+    constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
+    constexpr int P = IH * IW;                      // patch pixels
+    constexpr int PT = (P + 31) / 32;               // 32-row MFMA tiles over the patch
+    constexpr int PR = PT * 32;
+    constexpr int NOUT = TH * TW / 32;              // outputs per thread along W (32 segments x 8 channel quads)
+    constexpr int SEG_PER_ROW = TW / NOUT;
+    constexpr int NCOL = (NOUT - 1) * S + K;
+    constexpr int ES = 36;                          // Es row stride (floats)
+    static_assert(NOUT >= 1 && TW % NOUT == 0 && 32 / SEG_PER_ROW == TH, "tile/thread mapping");
+    static_assert(PT <= 8, "each wave owns at most two patch row-tiles");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int XS = p.Cin + 4;                       // Xs / Ws row stride (floats)
+    float* Xs = smem;                               // [PR][XS]
+    float* Ws = Xs + PR * XS;                       // [32][XS]
+    float* Es = Ws + 32 * XS;                       // [PR][ES]
+    v4f* Ds = reinterpret_cast<v4f*>(Es + PR * ES); // [K*K][8]
+    v4f* red = Ds + K * K * 8;                      // [32][8]
+    unsigned char* valid = reinterpret_cast<unsigned char*>(red + 256);  // [PR] pixel-inside-image flags
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int b = blockIdx.y, t_idx = blockIdx.x;
+    const int ty = t_idx / p.tiles_x, tx = t_idx - ty * p.tiles_x;
+    const int hi0 = ty * TH * S - p.pad_t, wi0 = tx * TW * S - p.pad_l;
+    const int cin4 = p.Cin >> 2;
+
+    // ---- stage the input patch (zero outside the image / beyond P) and the pixel validity flags
+    const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
+    for (int i = tid; i < PR * cin4; i += 256) {
+        const int px = i / cin4, c4 = i - px * cin4;
+        v4f v = {0.f, 0.f, 0.f, 0.f};
+        if (px < P) {
+            const int iy = px / IW, ix = px - iy * IW;
+            const int hi = hi0 + iy, wi = wi0 + ix;
+            if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                v = *reinterpret_cast<const v4f*>(xb + ((size_t)hi * p.W + wi) * p.Cin + c4 * 4);
+        }
+        *reinterpret_cast<v4f*>(Xs + px * XS + c4 * 4) = v;
+    }
+    for (int px = tid; px < PR; px += 256) {
+        bool ok = false;
+        if (px < P) {
+            const int iy = px / IW, ix = px - iy * IW;
+            ok = (unsigned)(hi0 + iy) < (unsigned)p.H && (unsigned)(wi0 + ix) < (unsigned)p.W;
+        }
+        valid[px] = ok ? 1 : 0;
+    }
+
+    // depthwise thread mapping: channel quad lc (8 per chunk), column segment seg (32 per tile)
+    const int lc = tid & 7, seg = tid >> 3;
+    const int oy = seg / SEG_PER_ROW, ox0 = (seg % SEG_PER_ROW) * NOUT;
+    const int ho = ty * TH + oy;
+    const int ngrp = p.Cin >> 3;
+    const int tiles = gridDim.x;
+
+    for (int c0 = 0; c0 < p.mid; c0 += 32) {
+        // ---- chunk weights: expand rows c0..c0+31 (zero rows past mid), depthwise taps
+        for (int i = tid; i < 32 * cin4; i += 256) {
+            const int r = i / cin4, c4 = i - r * cin4;
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (c0 + r < p.mid) v = *reinterpret_cast<const v4f*>(p.w1 + (size_t)(c0 + r) * p.Cin + c4 * 4);
+            *reinterpret_cast<v4f*>(Ws + r * XS + c4 * 4) = v;
+        }
+        for (int i = tid; i < K * K * 8; i += 256) {
+            const int tap = i >> 3, q = i & 7;
+            v4f v = {0.f, 0.f, 0.f, 0.f};
+            if (c0 + q * 4 < p.mid) v = *reinterpret_cast<const v4f*>(p.wdw + (size_t)tap * p.mid + c0 + q * 4);
+            Ds[i] = v;
+        }
+        __syncthreads();  // Xs (first chunk), Ws, Ds visible; previous chunk's readers of Es are done
+
+        // ---- expand: E[patch rows][32 ch] = Xs . Ws^T on the fp32 matrix cores; BN1 + SiLU; zero outside the image
+        const int ch = c0 + l31;
+        const bool ch_ok = ch < p.mid;
+        const float s1 = ch_ok ? p.sc1[ch] : 0.f, h1 = ch_ok ? p.sh1[ch] : 0.f;
+        for (int t = wave; t < PT; t += 4) {
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+            const float* A = Xs + (t * 32 + l31) * XS + lh * 4;
+            const float* Bq = Ws + l31 * XS + lh * 4;
+            for (int g = 0; g < ngrp; ++g) {
+                const v4f af = *reinterpret_cast<const v4f*>(A + g * 8);
+                const v4f bf = *reinterpret_cast<const v4f*>(Bq + g * 8);
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf[kk], acc, 0, 0, 0);
+            }
+            // C/D layout: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (patch pixel)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int px = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float e = valid[px] ? silu_f(acc[r] * s1 + h1) : 0.f;
+                Es[px * ES + l31] = e;
+            }
+        }
+        __syncthreads();
+
+        // ---- depthwise from LDS + BN2 + SiLU -> HBM; pooling partial
+        const int cq = c0 + lc * 4;
+        const bool q_ok = cq < p.mid;
+        v4f acc2[NOUT];
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) acc2[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const float* erow = Es + ((oy * S + kh) * IW + ox0 * S) * ES + lc * 4;
+            v4f col[NCOL];
+#pragma unroll
+            for (int q = 0; q < NCOL; ++q) col[q] = *reinterpret_cast<const v4f*>(erow + q * ES);
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const v4f f = Ds[(kh * K + kw) * 8 + lc];
+#pragma unroll
+                for (int j = 0; j < NOUT; ++j) acc2[j] += col[j * S + kw] * f;
+            }
+        }
+        v4f psum = {0.f, 0.f, 0.f, 0.f};
+        if (q_ok) {
+            const v4f s2 = *reinterpret_cast<const v4f*>(p.sc2 + cq);
+            const v4f h2 = *reinterpret_cast<const v4f*>(p.sh2 + cq);
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) {
+                const int wo = tx * TW + ox0 + j;
+                if (ho < p.Ho && wo < p.Wo) {
+                    v4f o = acc2[j] * s2 + h2;
+                    o[0] = silu_f(o[0]), o[1] = silu_f(o[1]), o[2] = silu_f(o[2]), o[3] = silu_f(o[3]);
+                    *reinterpret_cast<v4f*>(p.y + (((size_t)b * p.Ho + ho) * p.Wo + wo) * p.mid + cq) = o;
+                    psum += o;
+                }
+            }
+        }
+        if (p.pool) red[seg * 8 + lc] = psum;
+        __syncthreads();  // all depthwise reads of Es/Ds done before the next chunk overwrites Ws/Ds (and red complete)
+        if (p.pool && tid < 8 && c0 + tid * 4 < p.mid) {
+            v4f t = red[tid];
+#pragma unroll
+            for (int l = 1; l < 32; ++l) t += red[l * 8 + tid];
+            *reinterpret_cast<v4f*>(p.pool + ((size_t)b * tiles + t_idx) * p.mid + c0 + tid * 4) = t;
+        }
+        // red is next written two barriers from here, Es after the barrier at the top of the next chunk
+    }
+}
+
+static void mb_tile_geom(int stride, int& th, int& tw) { th = stride == 1 ? 8 : 4, tw = 8; }
+
+int mbconv_front_tiles(int Ho, int Wo, int stride) {
+    int th, tw;
+    mb_tile_geom(stride, th, tw);
+    return cdiv(Ho, th) * cdiv(Wo, tw);
+}
+
+// can this (Cin, K, stride) be served by the fused kernel? (LDS budget: two blocks per CU)
+bool mbconv_front_supported(int Cin, int mid, int K, int stride) {
+    return Cin % 8 == 0 && Cin <= 40 && mid % 4 == 0 && (K == 3 || K == 5) && (stride == 1 || stride == 2);
+}
+
+int launch_mbconv_front(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
+                        const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
+                        int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s) {
+    ORBIT_REQUIRE(x && w1 && sc1 && sh1 && wdw && sc2 && sh2 && y, "mbconv_front: null pointer");
+    ORBIT_REQUIRE(mbconv_front_supported(Cin, mid, K, stride), "mbconv_front: unsupported shape (Cin=%d mid=%d K=%d s=%d)",
+                  Cin, mid, K, stride);
+    int th, tw;
+    mb_tile_geom(stride, th, tw);
+    MbParams p;
+    p.x = x, p.w1 = w1, p.sc1 = sc1, p.sh1 = sh1, p.wdw = wdw, p.sc2 = sc2, p.sh2 = sh2, p.y = y, p.pool = pool;
+    p.H = H, p.W = W, p.Cin = Cin, p.mid = mid, p.pad_t = pad_t, p.pad_l = pad_l, p.Ho = Ho, p.Wo = Wo;
+    p.tiles_x = cdiv(Wo, tw);
+    const int tiles = p.tiles_x * cdiv(Ho, th);
+    const int ih = (th - 1) * stride + K, iw = (tw - 1) * stride + K;
+    const int pr = (ih * iw + 31) / 32 * 32;
+    const size_t lds = ((size_t)pr * (Cin + 4) + 32 * (Cin + 4) + (size_t)pr * 36) * sizeof(float) +
+                       (size_t)(K * K * 8 + 256) * 16 + pr;
+    dim3 grid(tiles, B);
+#define ORBIT_MB(KK, SS, TH_, TW_)                                                                  \
+    do {                                                                                            \
+        auto kern = mbconv_front_kernel<KK, SS, TH_, TW_>;                                          \
+        static bool attr_set = false;                                                               \
+        if (!attr_set && lds > 64 * 1024) {                                                         \
+            ORBIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); \
+            attr_set = true;                                                                        \
+        }                                                                                           \
+        kern<<<grid, 256, lds, s>>>(p);                                                             \
+    } while (0)
+    if (K == 3 && stride == 1) ORBIT_MB(3, 1, 8, 8);
+    else if (K == 3) ORBIT_MB(3, 2, 4, 8);
+    else if (stride == 1) ORBIT_MB(5, 1, 8, 8);
+    else ORBIT_MB(5, 2, 4, 8);
+#undef ORBIT_MB
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+}  // namespace orbit
+
+using namespace orbit;
+
+// single-operator entry for the parity tests: w1 torch [mid][Cin][1][1], wdw torch [mid][1][K][K]
+extern "C" int orbit_op_mbconv_front(const float* x, const float* w1, const float* scale1, const float* shift1,
+                                     const float* wdw, const float* scale2, const float* shift2, float* y,
+                                     float* pool_partial, int B, int H, int W, int Cin, int mid, int K, int stride,
+                                     int pad_top, int pad_left, int Ho, int Wo, orbit_stream_t stream) {
+    ORBIT_REQUIRE(x && w1 && wdw && y, "op_mbconv_front: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    float* wp = nullptr;
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&wp), (size_t)mid * K * K * sizeof(float), s));
+    int rc = dwconv_pack_weights(wdw, wp, mid, K, s);
+    if (rc == ORBIT_OK)
+        rc = launch_mbconv_front(x, w1, scale1, shift1, wp, scale2, shift2, y, pool_partial, B, H, W, Cin, mid, K, stride,
+                                 pad_top, pad_left, Ho, Wo, s);
+    (void)hipFreeAsync(wp, s);
+    return rc;
+}

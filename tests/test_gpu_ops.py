@@ -226,3 +226,38 @@ def test_mean_pool_and_set_mean(lib, device):
     torch.cuda.synchronize()
     assert (out.cpu() - x.view(25, 8, 512).mean(1)).abs().max().item() < 1e-6
     assert (m.cpu() - x.mean(0)).abs().max().item() < 1e-6
+
+
+MB_CASES = [  # Cin, mid, K, stride, H, W
+    (16, 96, 3, 2, 38, 38), (24, 144, 3, 1, 28, 28), (24, 144, 5, 2, 30, 30), (40, 240, 5, 1, 28, 28),
+    (40, 240, 3, 2, 28, 28), (16, 96, 3, 2, 37, 21), (24, 144, 5, 1, 7, 11), (40, 100, 3, 1, 9, 9)]
+
+
+@pytest.mark.parametrize("Cin,mid,K,stride,H,W", MB_CASES)
+def test_mbconv_front_fused(lib, device, Cin, mid, K, stride, H, W):
+    """expand 1x1 (MFMA) + BN + SiLU + depthwise (TF-SAME) + BN + SiLU with the expanded tensor in LDS, and the SE
+    pooling partials, against the unfused PyTorch-CPU sequence (incl. image borders, partial tiles, partial chunks)."""
+    g = torch.Generator().manual_seed(Cin * 1000 + mid + K + stride)
+    B = 3
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w1 = torch.randn(mid, Cin, 1, 1, generator=g) / Cin ** 0.5
+    wd = torch.randn(mid, 1, K, K, generator=g) / K
+    s1, h1 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.3
+    s2, h2 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.1
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph, pw = max((Ho - 1) * stride + K - H, 0), max((Wo - 1) * stride + K - W, 0)
+    e = F.silu(F.conv2d(x, w1) * s1[None, :, None, None] + h1[None, :, None, None])
+    ep = F.pad(e, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])  # the EXPANDED tensor is zero-padded
+    want = F.silu(F.conv2d(ep, wd, None, stride, 0, 1, mid) * s2[None, :, None, None] + h2[None, :, None, None])
+    th = 8 if stride == 1 else 4
+    tiles = -(-Ho // th) * -(-Wo // 8)
+    y = torch.full((B, Ho, Wo, mid), float("nan"), device=device)
+    pool = torch.full((B, tiles, mid), float("nan"), device=device)
+    dev = [t.to(device).contiguous() for t in (nhwc(x), w1, s1, h1, wd, s2, h2)]
+    _lib.check(lib.orbit_op_mbconv_front(*[_lib.dptr(t) for t in dev], _lib.dptr(y), _lib.dptr(pool), B, H, W, Cin, mid, K,
+                                         stride, ph // 2, pw // 2, Ho, Wo, _st()), "mbconv_front")
+    torch.cuda.synchronize()
+    got = nchw(y.cpu())
+    assert not torch.isnan(got).any() and not torch.isnan(pool).any()
+    assert (got - want).abs().max().item() < 5e-5
+    assert (pool.cpu().sum(1) - want.sum((2, 3))).abs().max().item() < 2e-3 * max(1.0, want.sum((2, 3)).abs().max().item())
