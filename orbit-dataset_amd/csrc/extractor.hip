@@ -233,8 +233,10 @@ static int build_resnet18(orbit_extractor* fe, int H, int W) {
 static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
     fe->out_size = 1280;
     const float eps = 1e-3f;
-    static const char* nofuse = getenv("ORBIT_NO_MBCONV_FUSION");  // A/B experiments
-    const bool fuse_front = nofuse == nullptr;
+    // The fused expand+depthwise kernel (csrc/mbconv.hip) is parity-green but, as measured on MI355X, slower than the
+    // two tuned kernels it replaces (2.6 ms vs 1.7 ms per 200-frame forward over the five eligible blocks): opt-in.
+    static const char* fuse_env = getenv("ORBIT_MBCONV_FUSION");
+    const bool fuse_front = fuse_env != nullptr && fuse_env[0] == '1';
     int h, w, pt, pl;
     same_pad(H, 3, 2, h, pt);
     same_pad(W, 3, 2, w, pl);

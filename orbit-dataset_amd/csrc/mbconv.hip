@@ -24,7 +24,7 @@ namespace orbit {
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 using v4f = __attribute__((ext_vector_type(4))) float;
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + expf(-v)); }
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
 
 struct MbParams {
     const float* x;    // [B][H][W][Cin] NHWC

@@ -15,7 +15,7 @@ using v4f = __attribute__((ext_vector_type(4))) float;
 
 __device__ __forceinline__ float act_fn(float v, int act) {
     if (act == ORBIT_ACT_RELU) return fmaxf(v, 0.f);
-    if (act == ORBIT_ACT_SILU) return v / (1.0f + expf(-v));
+    if (act == ORBIT_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));  // v_exp_f32 + v_rcp_f32, ~1 ulp each
     return v;
 }
 
