@@ -59,6 +59,36 @@ def run_task(model, task):
     return logits
 
 
+def head_roofline(device, n_tasks=64, M=200, D=1280, C=5, reps=40):
+    """HBM roofline of the distance kernel (orbit_proto_predict) on the 64-task batched launch SURVEY §8(d) names:
+    algorithmic bytes 4*(M*D + C*D + C + M*C) per task = 67.4 MB per launch. Eight distinct query sets (540 MB) are
+    cycled so the 256 MB Infinity Cache cannot serve the stream; timed with HIP events on the launch stream."""
+    lib = _lib.load()
+    g = torch.Generator(device=device).manual_seed(7)
+    qs = [torch.rand(n_tasks, M, D, device=device, generator=g) for _ in range(8)]
+    W = torch.rand(n_tasks, C, D, device=device, generator=g)
+    b = torch.rand(n_tasks, C, device=device, generator=g)
+    out = torch.empty(n_tasks, M, C, device=device)
+
+    def run(i):
+        _lib.check(lib.orbit_proto_predict(_lib.dptr(qs[i % 8]), _lib.dptr(W), _lib.dptr(b), n_tasks, M, 1, D, C, 1.0, 0,
+                                           _lib.dptr(out), None, _lib.stream_handle()), "orbit_proto_predict")
+    for i in range(8):
+        run(i)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for i in range(reps):
+        run(i)
+    e1.record()
+    torch.cuda.synchronize()
+    us = 1e3 * e0.elapsed_time(e1) / reps
+    nbytes = 4.0 * (M * D + C * D + C + M * C) * n_tasks
+    gbs = nbytes / (us * 1e-6) / 1e9
+    return {"kernel": "orbit::proto_predict_kernel<5> (64 tasks x 200 queries x 1280, euclidean)", "bound": "hbm",
+            "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "avg_launch_us": us,
+            "bytes_per_launch": nbytes, "traffic": None}
+
+
 def cpu_baseline(workload, model):
     """The oracle (CPU restatement of the reference path) on ONE task of the same workload, all host cores."""
     from oracle.recogniser import OracleRecogniser
@@ -113,13 +143,20 @@ def main():
     if args.gpus != world and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     _lib.require_gpu()
-    torch.cuda.set_device(local_rank)
-    device = torch.device("cuda", local_rank)
+    # one rank per GPU; ORBIT_BENCH_BACKEND=gloo lets several ranks share a GPU (self-test of the N>1 path on a
+    # one-GPU box — RCCL refuses two ranks on one device)
+    backend = os.environ.get("ORBIT_BENCH_BACKEND", "nccl")
+    dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(dev_index)
+    device = torch.device("cuda", dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     fe_name, adapt, size = WORKLOADS[args.workload]
     model = build_model(args.workload, device, args.batch_size)
@@ -160,6 +197,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.all_reduce(correct)  # frame-accuracy counts: the only exchange of the task-parallel form
+        torch.cuda.synchronize()
 
     ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
     _lib.check(lib.orbit_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "orbit_prof_collect")
@@ -204,6 +242,7 @@ def main():
                                  "(instrumented repeat took %.1f ms/step)" % (args.steps, 1e3 * elapsed_prof / args.steps),
                      "variants": variants},
     }
+    out["head_roofline"] = head_roofline(device)
     if not args.no_cpu_baseline and world == 1:
         base, task, want = cpu_baseline(args.workload, model)
         got = run_task(model, {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in task.items()}).cpu()
