@@ -201,15 +201,21 @@ def main():
 
     ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
     _lib.check(lib.orbit_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "orbit_prof_collect")
-    variants = []
+    variants, total_bytes = [], 0.0
     for i in range(lib.orbit_prof_num_variants()):
         name = ctypes.create_string_buffer(48)
-        ln, vms, vfl = ctypes.c_long(), ctypes.c_double(), ctypes.c_double()
-        lib.orbit_prof_variant(i, name, ctypes.byref(ln), ctypes.byref(vms), ctypes.byref(vfl))
-        if ln.value:
+        ln, vms, vfl, vby = ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
+        lib.orbit_prof_variant(i, name, ctypes.byref(ln), ctypes.byref(vms), ctypes.byref(vfl), ctypes.byref(vby))
+        if ln.value and vms.value > 0:
+            sec = vms.value * 1e-3
+            tf, gbs = vfl.value / sec / 1e12, vby.value / sec / 1e9
+            total_bytes += vby.value
             variants.append({"kernel": name.value.decode(), "launches": ln.value,
-                             "avg_us": round(1e3 * vms.value / ln.value, 2),
-                             "tflops": round(vfl.value / (vms.value * 1e-3) / 1e12, 2) if vms.value > 0 else None})
+                             "avg_us": round(1e3 * vms.value / ln.value, 2), "tflops": round(tf, 2),
+                             "algorithmic_gbs": round(gbs, 1),
+                             # which roof the algorithmic work of this variant sits under (157.3 TFLOP/s vs 8 TB/s)
+                             "binding_roof": "mfma" if tf / PEAK_FP32_MFMA_TFLOPS >= gbs / 8000.0 else "hbm",
+                             "frac_of_binding_roof": round(max(tf / PEAK_FP32_MFMA_TFLOPS, gbs / 8000.0), 3)})
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -237,6 +243,7 @@ def main():
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
                      "kernel": "orbit::conv_igemm_kernel (all instantiations)",
                      "launches": n.value, "avg_launch_us": 1e3 * ms.value / max(n.value, 1),
+                     "algorithmic_hbm_gbs": total_bytes / (ms.value * 1e-3) / 1e9 if ms.value > 0 else None,
                      "kernel_time_share": ms.value / (1e3 * elapsed),
                      "measured": "per-launch HIP events on the launch stream over a repeat of the %d timed steps "
                                  "(instrumented repeat took %.1f ms/step)" % (args.steps, 1e3 * elapsed_prof / args.steps),

@@ -175,7 +175,8 @@ int orbit_prof_enable(int on);   /* on: reset and start recording an event pair 
 /* waits for the recorded launches, returns summed duration, summed ALGORITHMIC flops and launch count */
 int orbit_prof_collect(double* total_ms, double* total_flops, long* launches);
 int orbit_prof_num_variants(void);
-int orbit_prof_variant(int i, char* name48, long* launches, double* ms, double* flops);
+/* one row per kernel instantiation: launches, summed duration, summed algorithmic flops and algorithmic HBM bytes */
+int orbit_prof_variant(int i, char* name48, long* launches, double* ms, double* flops, double* bytes);
 
 /* ---- RCCL over xGMI (one process per GPU) ------------------------------------------------------- */
 /* The reference has no collectives; this is the exchange step of the support-sharded variant: the

@@ -54,7 +54,7 @@ _SIGNATURES = {
     "orbit_prof_collect": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(ctypes.c_long)]),
     "orbit_prof_num_variants": (c_int, []),
     "orbit_prof_variant": (c_int, [c_int, ctypes.c_char_p, POINTER(ctypes.c_long), POINTER(c_double),
-                                   POINTER(c_double)]),
+                                   POINTER(c_double), POINTER(c_double)]),
     "orbit_comm_unique_id": (c_int, [P]),
     "orbit_comm_init": (c_int, [c_int, c_int, P]),
     "orbit_comm_world": (c_int, []),
@@ -145,8 +145,13 @@ def require_gpu():
 
 
 def stream_handle():
+    """hipStream_t of torch's CURRENT stream on the current device, as an opaque pointer. Uses the raw accessor:
+    torch.cuda.current_stream() re-checks device availability on every call (~80 us each)."""
     import torch
-    return c_void_p(torch.cuda.current_stream().cuda_stream)
+    try:
+        return c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))
+    except AttributeError:  # private accessors moved: fall back to the public API
+        return c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
 def dptr(t, dtype=None):

@@ -389,12 +389,12 @@ int conv_pack_weights(const float* w_oihw, float* w_packed, int Cin, int Cout, i
 struct ProfRec {
     hipEvent_t start, stop;
     int variant;
-    double flops;
+    double flops, bytes;
 };
 struct ProfVariant {
     char name[48];
     long launches;
-    double ms, flops;
+    double ms, flops, bytes;
 };
 static bool g_prof_on = false;
 static std::vector<ProfRec> g_prof_recs;
@@ -443,6 +443,9 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
         r.start = prof_event(), r.stop = prof_event(), r.variant = prof_variant(name);
         const double pix = POOL2 ? (double)p.B * p.HoP * p.WoP * 4 : (double)p.B * p.Ho * p.Wo;
         r.flops = 2.0 * pix * p.Cout * p.KH * p.KW * p.Cin;  // algorithmic (unpadded) FLOPs of this launch
+        // algorithmic HBM bytes: input once, output once (pooled if fused), residual once, weights once
+        r.bytes = 4.0 * ((double)p.B * p.H * p.W * p.Cin + (POOL2 ? pix / 4 : pix) * p.Cout * (p.residual ? 2.0 : 1.0) +
+                         (double)p.Cout * p.KH * p.KW * p.Cin);
         (void)hipEventRecord(r.start, s);
         kern<<<p.m_tiles * p.n_tiles, 256, lds, s>>>(p);
         (void)hipEventRecord(r.stop, s);
@@ -551,7 +554,7 @@ int orbit_prof_collect(double* total_ms, double* total_flops, long* launches) {
         float t = 0.f;
         ORBIT_HIP_CHECK(hipEventElapsedTime(&t, r.start, r.stop));
         ProfVariant& v = g_prof_variants[r.variant];
-        v.launches += 1, v.ms += t, v.flops += r.flops;
+        v.launches += 1, v.ms += t, v.flops += r.flops, v.bytes += r.bytes;
         ms += t, fl += r.flops;
         g_prof_pool.push_back(r.start), g_prof_pool.push_back(r.stop);
     }
@@ -564,13 +567,14 @@ int orbit_prof_collect(double* total_ms, double* total_flops, long* launches) {
 
 int orbit_prof_num_variants(void) { return (int)g_prof_variants.size(); }
 
-int orbit_prof_variant(int i, char* name48, long* launches, double* ms, double* flops) {
+int orbit_prof_variant(int i, char* name48, long* launches, double* ms, double* flops, double* bytes) {
     ORBIT_REQUIRE(i >= 0 && i < (int)g_prof_variants.size(), "prof_variant: index out of range");
     const ProfVariant& v = g_prof_variants[i];
     if (name48) memcpy(name48, v.name, sizeof(v.name));
     if (launches) *launches = v.launches;
     if (ms) *ms = v.ms;
     if (flops) *flops = v.flops;
+    if (bytes) *bytes = v.bytes;
     return ORBIT_OK;
 }
 

@@ -46,7 +46,7 @@ def main():
         ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
         lib.orbit_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
         nm = ctypes.create_string_buffer(48)
-        lib.orbit_prof_variant(0, nm, None, None, None)
+        lib.orbit_prof_variant(0, nm, None, None, None, None)
         print("%-14s M=%7d N=%4d K=%5d  %-28s %8.1f us  %6.1f TFLOP/s" % (
             name, B * Ho * Ho, Cout, Cin * K * K, nm.value.decode(), 1e3 * ms.value / n.value, fl.value / ms.value / 1e9))
 
