@@ -86,81 +86,114 @@ __global__ __launch_bounds__(256) void proto_finalize_kernel(const float* __rest
 }
 
 // ---- predict -----------------------------------------------------------------------------------
-// One wave per query clip; lanes stride the feature dimension with float4 loads (1 KiB per wave
-// instruction), CT classes are accumulated at a time in registers; W comes from L1/L2.
-template <int CT>
+// One wave handles R consecutive query clips; lanes stride the feature dimension with float4 loads (1 KiB per wave
+// instruction). Each W quad is loaded once per step and used for all R rows, so the L2 traffic for W is 1/R of the
+// query stream instead of C x larger than it (the single-row form was L2-bound at ~2.3 TB/s). CT classes are
+// accumulated at a time in registers (R*CT accumulators); reductions are wave64 shuffles.
+template <int CT, int R>
 __global__ __launch_bounds__(256) void proto_predict_kernel(
     const float* __restrict__ Q, const float* __restrict__ W, const float* __restrict__ bias, int M,
     int T, int D, int C, float logit_scale, int cosine, float* __restrict__ logits,
     int32_t* __restrict__ argmax) {
     const int task = blockIdx.y;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int m = blockIdx.x * 4 + wave;
-    if (m >= M) return;
-    const float* q = Q + ((size_t)task * M + m) * T * D;
+    const int m0 = (blockIdx.x * 4 + wave) * R;
+    if (m0 >= M) return;
     const float* Wt = W + (size_t)task * C * D;
     const float invT = 1.0f / (float)T;
     const bool vec = (D & 3) == 0;
-    float best = -INFINITY;
-    int best_c = 0;
-    float qn2 = 0.f;
-    for (int c0 = 0; c0 < C; c0 += CT) {
-        float dot[CT], wn2[CT];
+    const float* q[R];
+    bool row_ok[R];
 #pragma unroll
-        for (int j = 0; j < CT; ++j) dot[j] = 0.f, wn2[j] = 0.f;
-        float qq = 0.f;
+    for (int r = 0; r < R; ++r) {
+        row_ok[r] = m0 + r < M;
+        q[r] = Q + ((size_t)task * M + (row_ok[r] ? m0 + r : m0)) * T * D;  // clamped: tail rows re-read row m0
+    }
+    float best[R], qn2[R];
+    int best_c[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) best[r] = -INFINITY, best_c[r] = 0, qn2[r] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += CT) {
+        float dot[R][CT], wn2[CT], qq[R];
+#pragma unroll
+        for (int j = 0; j < CT; ++j) wn2[j] = 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            qq[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < CT; ++j) dot[r][j] = 0.f;
+        }
         if (vec) {
             for (int d = lane * 4; d < D; d += 256) {
-                float4 x = *reinterpret_cast<const float4*>(q + d);
-                for (int t = 1; t < T; ++t) {
-                    const float4 y = *reinterpret_cast<const float4*>(q + (size_t)t * D + d);
-                    x.x += y.x, x.y += y.y, x.z += y.z, x.w += y.w;
+                float4 x[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    x[r] = *reinterpret_cast<const float4*>(q[r] + d);
+                    for (int t = 1; t < T; ++t) {
+                        const float4 y = *reinterpret_cast<const float4*>(q[r] + (size_t)t * D + d);
+                        x[r].x += y.x, x[r].y += y.y, x[r].z += y.z, x[r].w += y.w;
+                    }
+                    if (T > 1) x[r].x *= invT, x[r].y *= invT, x[r].z *= invT, x[r].w *= invT;
+                    qq[r] += x[r].x * x[r].x + x[r].y * x[r].y + x[r].z * x[r].z + x[r].w * x[r].w;
                 }
-                if (T > 1) x.x *= invT, x.y *= invT, x.z *= invT, x.w *= invT;
-                qq += x.x * x.x + x.y * x.y + x.z * x.z + x.w * x.w;
 #pragma unroll
                 for (int j = 0; j < CT; ++j) {
                     if (c0 + j < C) {
                         const float4 w = *reinterpret_cast<const float4*>(Wt + (size_t)(c0 + j) * D + d);
-                        dot[j] += x.x * w.x + x.y * w.y + x.z * w.z + x.w * w.w;
                         if (cosine) wn2[j] += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+#pragma unroll
+                        for (int r = 0; r < R; ++r)
+                            dot[r][j] += x[r].x * w.x + x[r].y * w.y + x[r].z * w.z + x[r].w * w.w;
                     }
                 }
             }
         } else {
             for (int d = lane; d < D; d += 64) {
-                float x = q[d];
-                for (int t = 1; t < T; ++t) x += q[(size_t)t * D + d];
-                if (T > 1) x *= invT;
-                qq += x * x;
+                float x[R];
+#pragma unroll
+                for (int r = 0; r < R; ++r) {
+                    x[r] = q[r][d];
+                    for (int t = 1; t < T; ++t) x[r] += q[r][(size_t)t * D + d];
+                    if (T > 1) x[r] *= invT;
+                    qq[r] += x[r] * x[r];
+                }
 #pragma unroll
                 for (int j = 0; j < CT; ++j) {
                     if (c0 + j < C) {
                         const float w = Wt[(size_t)(c0 + j) * D + d];
-                        dot[j] += x * w;
                         if (cosine) wn2[j] += w * w;
+#pragma unroll
+                        for (int r = 0; r < R; ++r) dot[r][j] += x[r] * w;
                     }
                 }
             }
         }
-        if (c0 == 0 && cosine) qn2 = wave_sum(qq);
+        if (c0 == 0 && cosine) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) qn2[r] = wave_sum(qq[r]);
+        }
 #pragma unroll
         for (int j = 0; j < CT; ++j) {
             if (c0 + j >= C) break;
-            float v = wave_sum(dot[j]);
-            if (cosine) {
-                const float wn = sqrtf(wave_sum(wn2[j]));
-                const float qn = sqrtf(qn2);
-                v = v / (fmaxf(qn, 1e-8f) * fmaxf(wn, 1e-8f));
-                v *= logit_scale;
-            } else {
-                v = logit_scale * (v + bias[(size_t)task * C + c0 + j]);
+            const float wn = cosine ? sqrtf(wave_sum(wn2[j])) : 0.f;
+            const float bj = cosine ? 0.f : bias[(size_t)task * C + c0 + j];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float v = wave_sum(dot[r][j]);
+                if (cosine)
+                    v = logit_scale * (v / (fmaxf(sqrtf(qn2[r]), 1e-8f) * fmaxf(wn, 1e-8f)));
+                else
+                    v = logit_scale * (v + bj);
+                if (lane == 0 && row_ok[r]) logits[((size_t)task * M + m0 + r) * C + c0 + j] = v;
+                if (v > best[r]) best[r] = v, best_c[r] = c0 + j;
             }
-            if (lane == 0) logits[((size_t)task * M + m) * C + c0 + j] = v;
-            if (v > best) best = v, best_c = c0 + j;
         }
     }
-    if (argmax != nullptr && lane == 0) argmax[(size_t)task * M + m] = best_c;
+    if (argmax != nullptr && lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (row_ok[r]) argmax[(size_t)task * M + m0 + r] = best_c[r];
+    }
 }
 
 // ---- MeanPooler --------------------------------------------------------------------------------
@@ -237,12 +270,24 @@ int orbit_proto_predict(const float* Q, const float* W, const float* b, int n_ta
     ORBIT_REQUIRE(Q && W && logits, "proto_predict: null pointer");
     ORBIT_REQUIRE(cosine || b, "proto_predict: weight and/or bias not set - is the model personalised?");
     ORBIT_REQUIRE(n_tasks > 0 && M > 0 && T > 0 && D > 0 && C > 0, "proto_predict: bad sizes");
-    dim3 grid(cdiv(M, 4), n_tasks);
     hipStream_t s = (hipStream_t)stream;
-    if (C <= 5)
-        proto_predict_kernel<5><<<grid, 256, 0, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine, logits, argmax);
-    else
-        proto_predict_kernel<10><<<grid, 256, 0, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine, logits, argmax);
+    // rows per wave: 4 while that still yields >= 2 blocks per CU, else 1 (single small task: latency-bound anyway)
+    const long blocks4 = (long)cdiv(M, 16) * n_tasks;
+    if (C <= 5) {
+        if (blocks4 >= 512)
+            proto_predict_kernel<5, 4><<<dim3(cdiv(M, 16), n_tasks), 256, 0, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine,
+                                                                            logits, argmax);
+        else
+            proto_predict_kernel<5, 1><<<dim3(cdiv(M, 4), n_tasks), 256, 0, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine,
+                                                                           logits, argmax);
+    } else {
+        if (blocks4 >= 512)
+            proto_predict_kernel<10, 2><<<dim3(cdiv(M, 8), n_tasks), 256, 0, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine,
+                                                                            logits, argmax);
+        else
+            proto_predict_kernel<10, 1><<<dim3(cdiv(M, 4), n_tasks), 256, 0, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine,
+                                                                            logits, argmax);
+    }
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
