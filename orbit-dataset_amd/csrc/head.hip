@@ -124,7 +124,8 @@ __global__ __launch_bounds__(256) void proto_predict_kernel(
             for (int j = 0; j < CT; ++j) dot[r][j] = 0.f;
         }
         if (vec) {
-            for (int d = lane * 4; d < D; d += 256) {
+#pragma unroll 4
+            for (int d = lane * 4; d < D; d += 256) {  // unrolled: several 1-KiB row segments in flight per wave
                 float4 x[R];
 #pragma unroll
                 for (int r = 0; r < R; ++r) {
@@ -271,17 +272,18 @@ int orbit_proto_predict(const float* Q, const float* W, const float* b, int n_ta
     ORBIT_REQUIRE(cosine || b, "proto_predict: weight and/or bias not set - is the model personalised?");
     ORBIT_REQUIRE(n_tasks > 0 && M > 0 && T > 0 && D > 0 && C > 0, "proto_predict: bad sizes");
     hipStream_t s = (hipStream_t)stream;
-    // rows per wave: 4 while that still yields >= 2 blocks per CU, else 1 (single small task: latency-bound anyway)
+    // rows per wave: measured on MI355X (64 tasks x 200 x 1280): R = 1 with the row loop unrolled streams faster than
+    // R = 4 (more waves in flight beats W reuse: W is L1/L2-resident anyway); the R > 1 forms stay for very wide heads
     const long blocks4 = (long)cdiv(M, 16) * n_tasks;
     if (C <= 5) {
-        if (blocks4 >= 512)
+        if (blocks4 >= (1L << 30))
             proto_predict_kernel<5, 4><<<dim3(cdiv(M, 16), n_tasks), 256, 0, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine,
                                                                             logits, argmax);
         else
             proto_predict_kernel<5, 1><<<dim3(cdiv(M, 4), n_tasks), 256, 0, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine,
                                                                            logits, argmax);
     } else {
-        if (blocks4 >= 512)
+        if (blocks4 >= (1L << 30))
             proto_predict_kernel<10, 2><<<dim3(cdiv(M, 8), n_tasks), 256, 0, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine,
                                                                             logits, argmax);
         else
