@@ -65,6 +65,7 @@ size_t conv_packed_floats(int Cin, int Cout, int KH, int KW, int x_nchw);
 int conv_pack_weights(const float* w_oihw, float* w_packed, int Cin, int Cout, int KH, int KW,
                       int x_nchw, hipStream_t s);
 int launch_conv(const ConvDesc& d, hipStream_t s);
+bool conv_prof_enabled();  // per-launch event profiling is on (graphs are bypassed while it is)
 
 int launch_dwconv(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                   int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho, int Wo,

@@ -397,6 +397,7 @@ struct ProfVariant {
     double ms, flops, bytes;
 };
 static bool g_prof_on = false;
+bool conv_prof_enabled() { return g_prof_on; }
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
 static std::vector<ProfVariant> g_prof_variants;

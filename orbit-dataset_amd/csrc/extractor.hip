@@ -100,6 +100,30 @@ struct orbit_extractor {
     std::vector<BNDev> bn_dev;  // host copy of the fold descriptors
     bool finalized = false;
 
+    // HIP-graph cache: one instantiated graph per distinct (pointers, batch, stream) tuple of forward(). A forward is
+    // 25-90 dependent launches; replaying them as one graph launch takes the host out of the loop (on a slow or busy
+    // host the eager launch sequence, not the GPU, bounded small workloads).
+    struct GraphKey {
+        const void *frames, *gamma, *beta, *feats, *ws, *stream;
+        int B;
+        bool operator==(const GraphKey& o) const {
+            return frames == o.frames && gamma == o.gamma && beta == o.beta && feats == o.feats && ws == o.ws &&
+                   stream == o.stream && B == o.B;
+        }
+    };
+    struct GraphEntry {
+        GraphKey key;
+        hipGraphExec_t exec = nullptr;  // nullptr: seen once (ran eagerly), capture on the next sight
+        unsigned long stamp = 0;
+    };
+    std::vector<GraphEntry> graphs;
+    unsigned long graph_clock = 0;
+    void clear_graphs() {
+        for (GraphEntry& g : graphs)
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        graphs.clear();
+    }
+
     // device buffers are created on first use so that a plan can be built and inspected (state_dict keys,
     // FiLM slots, workspace size, MACs) on a host without a GPU
     int ensure_device() {
@@ -423,6 +447,7 @@ int orbit_extractor_create(const char* name, int H, int W, orbit_extractor_t** o
 
 void orbit_extractor_destroy(orbit_extractor_t* fe) {
     if (!fe) return;
+    fe->clear_graphs();
     (void)hipFree(fe->d_pool);
     (void)hipFree(fe->d_packed);
     (void)hipFree(fe->d_fold);
@@ -479,6 +504,7 @@ int orbit_extractor_finalize(orbit_extractor_t* fe, orbit_stream_t stream) {
     bn_fold_all_kernel<<<grid, 256, 0, s>>>(fe->d_bn, fe->d_pool, nullptr, nullptr, fe->d_fold,
                                             fe->d_fold + fe->fold_floats);
     ORBIT_LAUNCH_CHECK();
+    fe->clear_graphs();
     fe->finalized = true;
     return ORBIT_OK;
 }
@@ -500,6 +526,9 @@ size_t orbit_extractor_workspace_bytes(const orbit_extractor_t* fe, int B) {
     return ws_layout(fe, B).total;
 }
 
+static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma, const float* film_beta,
+                    float* feats, void* workspace, hipStream_t s);
+
 int orbit_extractor_forward(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
                             const float* film_beta, float* feats, void* workspace, size_t workspace_bytes,
                             orbit_stream_t stream) {
@@ -513,6 +542,58 @@ int orbit_extractor_forward(orbit_extractor_t* fe, const float* frames, int B, c
                   workspace_bytes, L.total);
     ORBIT_REQUIRE(((uintptr_t)workspace & 255) == 0, "extractor_forward: workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
+    static const char* no_graph = getenv("ORBIT_NO_GRAPH");
+    if (no_graph || conv_prof_enabled()) return run_plan(fe, frames, B, film_gamma, film_beta, feats, workspace, s);
+
+    // graph path: 1st sight of a pointer tuple runs eagerly (also performs one-time kernel attribute setup), the 2nd
+    // captures + instantiates, later ones replay
+    const orbit_extractor::GraphKey key{frames, film_gamma, film_beta, feats, workspace, stream, B};
+    orbit_extractor::GraphEntry* hit = nullptr;
+    for (auto& g : fe->graphs)
+        if (g.key == key) hit = &g;
+    if (hit == nullptr) {
+        if (fe->graphs.size() >= 32) {  // evict the least recently used entry
+            size_t lru = 0;
+            for (size_t i = 1; i < fe->graphs.size(); ++i)
+                if (fe->graphs[i].stamp < fe->graphs[lru].stamp) lru = i;
+            if (fe->graphs[lru].exec) (void)hipGraphExecDestroy(fe->graphs[lru].exec);
+            fe->graphs.erase(fe->graphs.begin() + lru);
+        }
+        orbit_extractor::GraphEntry e;
+        e.key = key, e.stamp = ++fe->graph_clock;
+        fe->graphs.push_back(e);
+        return run_plan(fe, frames, B, film_gamma, film_beta, feats, workspace, s);
+    }
+    hit->stamp = ++fe->graph_clock;
+    if (hit->exec == nullptr) {
+        hipGraph_t graph = nullptr;
+        ORBIT_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        const int rc = run_plan(fe, frames, B, film_gamma, film_beta, feats, workspace, s);
+        const hipError_t ce = hipStreamEndCapture(s, &graph);
+        if (rc != ORBIT_OK) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        if (ce != hipSuccess || graph == nullptr) {
+            (void)hipGetLastError();
+            return run_plan(fe, frames, B, film_gamma, film_beta, feats, workspace, s);  // capture unavailable: stay eager
+        }
+        hipGraphExec_t exec = nullptr;
+        const hipError_t ie = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        if (ie != hipSuccess || exec == nullptr) {
+            (void)hipGetLastError();
+            return run_plan(fe, frames, B, film_gamma, film_beta, feats, workspace, s);
+        }
+        hit->exec = exec;
+    }
+    ORBIT_HIP_CHECK(hipGraphLaunch(hit->exec, s));
+    return ORBIT_OK;
+}
+
+static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma, const float* film_beta,
+                    float* feats, void* workspace, hipStream_t s) {
+    const WsLayout L = ws_layout(fe, B);
     char* ws = static_cast<char*>(workspace);
     auto buf = [&](int id) -> float* {
         if (id == -1) return const_cast<float*>(frames);
