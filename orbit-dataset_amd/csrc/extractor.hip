@@ -118,6 +118,8 @@ struct orbit_extractor {
     };
     std::vector<GraphEntry> graphs;
     unsigned long graph_clock = 0;
+    hipStream_t cap_stream = nullptr;  // private non-default stream used only to CAPTURE (the legacy default stream,
+                                       // torch's default, cannot be captured); graphs are launched on the caller's
     void clear_graphs() {
         for (GraphEntry& g : graphs)
             if (g.exec) (void)hipGraphExecDestroy(g.exec);
@@ -448,6 +450,7 @@ int orbit_extractor_create(const char* name, int H, int W, orbit_extractor_t** o
 void orbit_extractor_destroy(orbit_extractor_t* fe) {
     if (!fe) return;
     fe->clear_graphs();
+    if (fe->cap_stream) (void)hipStreamDestroy(fe->cap_stream);
     (void)hipFree(fe->d_pool);
     (void)hipFree(fe->d_packed);
     (void)hipFree(fe->d_fold);
@@ -547,7 +550,7 @@ int orbit_extractor_forward(orbit_extractor_t* fe, const float* frames, int B, c
 
     // graph path: 1st sight of a pointer tuple runs eagerly (also performs one-time kernel attribute setup), the 2nd
     // captures + instantiates, later ones replay
-    const orbit_extractor::GraphKey key{frames, film_gamma, film_beta, feats, workspace, stream, B};
+    const orbit_extractor::GraphKey key{frames, film_gamma, film_beta, feats, workspace, nullptr, B};
     orbit_extractor::GraphEntry* hit = nullptr;
     for (auto& g : fe->graphs)
         if (g.key == key) hit = &g;
@@ -567,9 +570,14 @@ int orbit_extractor_forward(orbit_extractor_t* fe, const float* frames, int B, c
     hit->stamp = ++fe->graph_clock;
     if (hit->exec == nullptr) {
         hipGraph_t graph = nullptr;
-        ORBIT_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        const int rc = run_plan(fe, frames, B, film_gamma, film_beta, feats, workspace, s);
-        const hipError_t ce = hipStreamEndCapture(s, &graph);
+        if (fe->cap_stream == nullptr)
+            ORBIT_HIP_CHECK(hipStreamCreateWithFlags(&fe->cap_stream, hipStreamNonBlocking));
+        if (hipStreamBeginCapture(fe->cap_stream, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            (void)hipGetLastError();
+            return run_plan(fe, frames, B, film_gamma, film_beta, feats, workspace, s);  // capture unavailable: stay eager
+        }
+        const int rc = run_plan(fe, frames, B, film_gamma, film_beta, feats, workspace, fe->cap_stream);
+        const hipError_t ce = hipStreamEndCapture(fe->cap_stream, &graph);
         if (rc != ORBIT_OK) {
             if (graph) (void)hipGraphDestroy(graph);
             return rc;
