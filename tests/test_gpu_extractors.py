@@ -111,3 +111,29 @@ def test_film_generator_matches_oracle(device):
         assert (got[k].cpu() - want[k]).abs().max().item() < 1e-5, k
     assert abs(float(gen.regularization_term()) - float(ref.regularization_term())) < 1e-4 * float(ref.l2_term)
     assert sum(v.numel() for v in got.values()) == 20480
+
+
+def test_graph_replay_matches_eager(device):
+    """ORBIT_GRAPH=1: the captured-and-replayed forward must equal the eager launch sequence bit for bit (run in a
+    subprocess because the switch is read once per process)."""
+    import os
+    import subprocess
+    import sys
+    code = (
+        "import sys, torch; sys.path.insert(0, %r)\n"
+        "import orbit_dataset_amd\n"
+        "from orbit_dataset_amd import synthetic\n"
+        "from orbit_dataset_amd.model.feature_extractors import create_feature_extractor\n"
+        "fe,_ = create_feature_extractor('resnet18', True, False, False); synthetic.init_parameters_(fe); fe = fe.cuda()\n"
+        "x = torch.randn(6, 3, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()\n"
+        "out = torch.empty(6, 512, device='cuda')\n"
+        "outs = [fe(x, out=out).clone() for _ in range(4)]  # eager, capture, replay, replay\n"
+        "torch.cuda.synchronize(); print(all(torch.equal(outs[0], o) for o in outs), float(outs[0].abs().sum()))\n"
+    ) % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for flag in ("0", "1"):
+        env = dict(os.environ, ORBIT_GRAPH=flag)
+        r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=240)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[flag] = r.stdout.strip().splitlines()[-1]
+    assert res["0"].startswith("True") and res["0"] == res["1"], res
