@@ -67,9 +67,6 @@ int conv_pack_weights(const float* w_oihw, float* w_packed, int Cin, int Cout, i
 int launch_conv(const ConvDesc& d, hipStream_t s);
 bool conv_prof_enabled();  // per-launch event profiling is on (graphs are bypassed while it is)
 
-int launch_dwconv(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
-                  int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho, int Wo,
-                  int act, hipStream_t s);
 // depthwise + fused SE pooling partials [B][chunks][C] (pool_partial may be nullptr); chunks = dwconv_se_chunks(Ho)
 int dwconv_se_chunks(int Ho);
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
@@ -91,8 +88,5 @@ int launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int K, 
 int launch_avgpool(const float* x, float* y, int B, int HW, int C, hipStream_t s);
 int launch_se_gate(const float* pooled, const float* w1, const float* b1, const float* w2,
                    const float* b2, float* gate, int B, int C, int R, hipStream_t s);
-// scale = g / sqrt(var + eps); shift = b + (conv_bias - mean) * scale   (conv_bias may be nullptr)
-int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
-                   const float* conv_bias, float eps, int C, float* scale, float* shift, hipStream_t s);
 
 }  // namespace orbit

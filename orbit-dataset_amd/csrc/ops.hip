@@ -1,6 +1,6 @@
 // HBM-bound layer kernels of the extractors (NHWC activations, channels innermost so every wave
-// instruction moves 1 KiB of contiguous data): depthwise convolution, max/avg pooling, squeeze-excite
-// gate, BatchNorm folding.
+// instruction moves 1 KiB of contiguous data): depthwise convolution (+ fused squeeze-excite pooling),
+// max/avg pooling, squeeze-excite gate.
 //
 // Reference sites these stand in for (all run through ATen in the reference):
 //   depthwise / SE / SiLU        timm tf_efficientnet_b0 blocks used by model/feature_extractors.py:39-43
@@ -17,53 +17,6 @@ __device__ __forceinline__ float act_fn(float v, int act) {
     if (act == ORBIT_ACT_RELU) return fmaxf(v, 0.f);
     if (act == ORBIT_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));  // v_exp_f32 + v_rcp_f32, ~1 ulp each
     return v;
-}
-
-// ---- depthwise KxK, NHWC, float4 over channels --------------------------------------------------
-template <int K>
-__global__ __launch_bounds__(256) void dwconv_kernel(const float* __restrict__ x,
-                                                     const float* __restrict__ w,  // [K][K][C]
-                                                     float* __restrict__ y, const float* __restrict__ scale,
-                                                     const float* __restrict__ shift, int B, int H, int W,
-                                                     int C, int stride, int pad_t, int pad_l, int Ho, int Wo,
-                                                     int act) {
-    const int C4 = C >> 2;
-    const size_t total = (size_t)B * Ho * Wo * C4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % C4) * 4;
-        size_t r = i / C4;
-        const int wo = (int)(r % Wo);
-        r /= Wo;
-        const int ho = (int)(r % Ho);
-        const int b = (int)(r / Ho);
-        const float* xb = x + (size_t)b * H * W * C + c;
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int kh = 0; kh < K; ++kh) {
-            const int hi = ho * stride - pad_t + kh;
-            if ((unsigned)hi >= (unsigned)H) continue;
-#pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-                const int wi = wo * stride - pad_l + kw;
-                if ((unsigned)wi >= (unsigned)W) continue;
-                const float4 v = *reinterpret_cast<const float4*>(xb + ((size_t)hi * W + wi) * C);
-                const float4 f = *reinterpret_cast<const float4*>(w + (size_t)(kh * K + kw) * C + c);
-                acc.x = fmaf(v.x, f.x, acc.x);
-                acc.y = fmaf(v.y, f.y, acc.y);
-                acc.z = fmaf(v.z, f.z, acc.z);
-                acc.w = fmaf(v.w, f.w, acc.w);
-            }
-        }
-        float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (scale) sc = *reinterpret_cast<const float4*>(scale + c);
-        if (shift) sh = *reinterpret_cast<const float4*>(shift + c);
-        float4 o;
-        o.x = act_fn(acc.x * sc.x + sh.x, act);
-        o.y = act_fn(acc.y * sc.y + sh.y, act);
-        o.z = act_fn(acc.z * sc.z + sh.z, act);
-        o.w = act_fn(acc.w * sc.w + sh.w, act);
-        *reinterpret_cast<float4*>(y + (((size_t)b * Ho + ho) * Wo + wo) * C + c) = o;
-    }
 }
 
 __global__ __launch_bounds__(256) void dw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp,
@@ -318,40 +271,9 @@ __global__ __launch_bounds__(256) void se_gate_kernel(const float* __restrict__ 
     }
 }
 
-// ---- BatchNorm (eval) folding -------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_fold_kernel(const float* __restrict__ gamma,
-                                                      const float* __restrict__ beta,
-                                                      const float* __restrict__ mean, const float* __restrict__ var,
-                                                      const float* __restrict__ conv_bias, float eps, int C,
-                                                      float* __restrict__ scale, float* __restrict__ shift) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    const float sc = gamma[c] / sqrtf(var[c] + eps);
-    const float cb = conv_bias ? conv_bias[c] : 0.f;
-    scale[c] = sc;
-    shift[c] = beta[c] + (cb - mean[c]) * sc;
-}
-
 static int grid_for(size_t total) {
     size_t b = (total + 255) / 256;
     return (int)(b > 8192 ? 8192 : (b == 0 ? 1 : b));
-}
-
-int launch_dwconv(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
-                  int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho, int Wo,
-                  int act, hipStream_t s) {
-    ORBIT_REQUIRE(x && w_khwc && y, "dwconv: null pointer");
-    ORBIT_REQUIRE(C % 4 == 0, "dwconv: C %% 4 != 0 (C=%d)", C);
-    ORBIT_REQUIRE(K == 3 || K == 5, "dwconv: only 3x3 and 5x5 kernels are instantiated (K=%d)", K);
-    const size_t total = (size_t)B * Ho * Wo * (C / 4);
-    if (K == 3)
-        dwconv_kernel<3><<<grid_for(total), 256, 0, s>>>(x, w_khwc, y, scale, shift, B, H, W, C, stride, pad_t,
-                                                         pad_l, Ho, Wo, act);
-    else
-        dwconv_kernel<5><<<grid_for(total), 256, 0, s>>>(x, w_khwc, y, scale, shift, B, H, W, C, stride, pad_t,
-                                                         pad_l, Ho, Wo, act);
-    ORBIT_LAUNCH_CHECK();
-    return ORBIT_OK;
 }
 
 // channel quads per block: the largest divisor of C/4 that is <= 64 (keeps every thread on a fixed channel quad)
@@ -431,13 +353,6 @@ int launch_se_gate(const float* pooled, const float* w1, const float* b1, const 
                    float* gate, int B, int C, int R, hipStream_t s) {
     ORBIT_REQUIRE(pooled && w1 && b1 && w2 && b2 && gate, "se_gate: null pointer");
     se_gate_kernel<<<B, 256, (size_t)(C + R) * sizeof(float), s>>>(pooled, w1, b1, w2, b2, gate, C, R);
-    ORBIT_LAUNCH_CHECK();
-    return ORBIT_OK;
-}
-
-int launch_bn_fold(const float* gamma, const float* beta, const float* mean, const float* var,
-                   const float* conv_bias, float eps, int C, float* scale, float* shift, hipStream_t s) {
-    bn_fold_kernel<<<cdiv(C, 256), 256, 0, s>>>(gamma, beta, mean, var, conv_bias, eps, C, scale, shift);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
