@@ -131,3 +131,19 @@ def test_errors_match_reference(device):
     model, _ = build_pair("resnet18", False, "proto", 1, 8)
     with pytest.raises(AttributeError):  # predict before personalise (classifier_heads.py:210-211)
         model.predict(torch.zeros(2, 1, 3, 32, 32, device=device))
+
+
+def test_learner_test_mode_end_to_end(device, tmp_path):
+    """single-step-learner counterpart, --mode test: personalise -> per video {attach_frame_history -> predict} ->
+    _reset, with clip_length 2, on three synthetic tasks."""
+    from orbit_dataset_amd.learner import main
+    out = tmp_path / "results.json"
+    stats = main(["--mode", "test", "--feature_extractor", "resnet18", "--classifier", "proto", "--frame_size", "64",
+                  "--clip_length", "2", "--batch_size", "16", "--way", "3", "--shots", "2", "--frames_per_shot", "4",
+                  "--num_query_videos", "2", "--frames_per_video", "6", "--num_test_tasks", "3",
+                  "--results_path", str(out)])
+    assert stats["num_tasks"] == 3 and 0.0 <= stats["frame_acc"][0] <= 1.0
+    assert stats["personalise_ms"][0] > 0 and stats["inference_ms_per_frame"][0] > 0
+    assert out.exists()
+    with pytest.raises(NotImplementedError):
+        main(["--mode", "train", "--learn_extractor", "--feature_extractor", "resnet18", "--frame_size", "64"])

@@ -97,3 +97,20 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), os.path.join(dirpath, f)
                 assert "oracle/" not in src or f in ("synthetic.py",), os.path.join(dirpath, f)
+
+
+def test_learner_cli_flags_match_reference_names():
+    """The counterpart CLI accepts the reference's hot-path flag names (utils/args.py) and its training guard."""
+    from orbit_dataset_amd.learner import build_parser, mean_ci, verify_args
+    p = build_parser()
+    a = p.parse_args(["--mode", "test", "--feature_extractor", "resnet18", "--classifier", "proto_cosine",
+                      "--logit_scale", "32", "--clip_length", "8", "--frame_size", "84", "--batch_size", "64",
+                      "--tasks_per_batch", "16", "--with_lite", "--num_lite_samples", "16", "--gpu", "0", "--seed", "7",
+                      "--adapt_features", "--model_path", "x.pt"])
+    assert (a.feature_extractor, a.classifier, a.logit_scale, a.clip_length, a.frame_size) == (
+        "resnet18", "proto_cosine", 32.0, 8, 84)
+    assert a.with_lite and a.adapt_features and not a.learn_extractor
+    with pytest.raises(SystemExit):  # args.py:209-211: training needs something learnable
+        verify_args(p.parse_args(["--mode", "train"]))
+    m, ci = mean_ci([0.5, 0.7])
+    assert abs(m - 0.6) < 1e-12 and abs(ci - 1.96 * 0.1 / 2 ** 0.5) < 1e-12
