@@ -222,6 +222,15 @@ def main():
         return
 
     achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
+    # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process; the value is
+    # the one tools/collect_profiles.sh measured with rocprofv3 on this same command (committed under profiles/)
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
+    if os.path.exists(tpath):
+        with open(tpath) as f:
+            tj = json.load(f)
+        if tj.get("workload") == args.workload:
+            traffic = tj.get("traffic_bytes_per_launch")
     macs = model.feature_extractor.macs_per_frame(size, size)
     out = {
         "metric": "query frames/sec per task (224x224, 5-way ProtoNet) + frame accuracy vs ref",
@@ -240,7 +249,8 @@ def main():
         "host_enqueue_ms_per_step": 1e3 * issued / args.steps,
         "extractor_gflop_per_task": 2 * macs * (WAY * SHOTS * FRAMES_PER_SHOT + NUM_QUERY) / 1e9,
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                     "algorithmic_bytes_per_launch": total_bytes / max(n.value, 1),
                      "kernel": "orbit::conv_igemm_kernel (all instantiations)",
                      "launches": n.value, "avg_launch_us": 1e3 * ms.value / max(n.value, 1),
                      "algorithmic_hbm_gbs": total_bytes / (ms.value * 1e-3) / 1e9 if ms.value > 0 else None,

@@ -147,3 +147,49 @@ def test_learner_test_mode_end_to_end(device, tmp_path):
     assert out.exists()
     with pytest.raises(NotImplementedError):
         main(["--mode", "train", "--learn_extractor", "--feature_extractor", "resnet18", "--frame_size", "64"])
+
+
+def test_sharded_forms_on_device_world1(device):
+    """dist.personalise_support_sharded / predict_query_sharded executed on the GPU (world 1: the all-reduce is the
+    identity) must reproduce personalise()/predict() exactly, including with FiLM adaptation — the partial-sum payload,
+    global label set and embedding-sum exchange are the code the N>1 run uses."""
+    from orbit_dataset_amd import dist as odist
+    for adapt in (False, True):
+        model, _ = build_pair("resnet18", adapt, "proto", 1, 8)
+        task = synthetic.make_task(9, way=4, shots=1, frames_per_shot=5, num_query=11, frame_size=64,
+                                   label_values=(2, 5, 6, 9))
+        ctx, lab, tgt = task["context_clips"].cuda(), task["context_labels"].cuda(), task["target_clips"].cuda()
+        model.personalise(ctx, lab)
+        want_W, want = model.classifier.weight.clone(), model.predict(tgt)
+        model._reset()
+        sh = odist.SupportSharding(0, 1)
+        odist.personalise_support_sharded(model, ctx, lab, sh)
+        assert torch.allclose(model.classifier.weight, want_W, atol=1e-6)
+        got = odist.predict_query_sharded(model, tgt, sh)
+        assert torch.allclose(got, want, atol=1e-5)
+        # emulate rank 1 of 2 locally: its slice alone must give partial sums that add up with rank 0's
+        payloads = []
+        for r in range(2):
+            s2 = odist.SupportSharding(r, 2)
+            s2.reduce_ = lambda t: payloads.append(t.clone()) or t  # capture instead of all-reduce
+            odist.personalise_support_sharded(model, ctx, lab, s2)
+            model._reset()
+        if not adapt:
+            C, D = 4, 512
+            total = payloads[0] + payloads[1]
+            W = 2 * total[:C * D].reshape(C, D) / total[C * D:, None]
+            assert torch.allclose(W, want_W, atol=1e-5)
+
+
+def test_edge_empty_query_and_ragged_batches(device):
+    """empty query set -> [0, C] logits; support/query counts that leave a ragged last mini-batch; single clip class."""
+    model, ref = build_pair("resnet18", False, "proto", 1, 7)  # batch_size 7: 20 support clips -> 7 + 7 + 6
+    task = synthetic.make_task(12, way=5, shots=1, frames_per_shot=4, num_query=15, frame_size=64)
+    check_task(model, ref, task, to_device=True)
+    model.personalise(task["context_clips"].cuda(), task["context_labels"].cuda())
+    empty = model.predict(task["target_clips"][:0].cuda())
+    assert tuple(empty.shape) == (0, 5)
+    model._reset()
+    one = synthetic.make_task(13, way=1, shots=1, frames_per_shot=3, num_query=4, frame_size=64)
+    model.personalise(one["context_clips"].cuda(), one["context_labels"].cuda())
+    assert tuple(model.predict(one["target_clips"].cuda()).shape) == (4, 1)
