@@ -58,6 +58,10 @@ int orbit_version(void);
 const char* orbit_last_error(void);
 /* number of visible HIP devices (<=0: no usable GPU); does not create a context on failure */
 int orbit_device_count(void);
+/* tuning switches, all default 0 (initial value from the environment ORBIT_DW_WINDOW / ORBIT_MBCONV_FUSION /
+ * ORBIT_GRAPH): "dw_window" register-window depthwise kernel, "mbconv_fusion" fused expand+depthwise kernel (takes
+ * effect for extractors created afterwards), "graph" HIP-graph replay of extractor forwards. */
+int orbit_set_option(const char* name, int value);
 
 /* ---- prototype head ---------------------------------------------------------------------------- */
 /* Per-class sums of per-clip mean-pooled support features.

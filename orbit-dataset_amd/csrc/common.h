@@ -12,6 +12,8 @@ namespace orbit {
 // thread-local error message returned by orbit_last_error()
 char* err_buf();
 int set_err(int code, const char* fmt, ...);
+// tuning switches (orbit_set_option / ORBIT_* environment): "dw_window", "mbconv_fusion", "graph"
+int get_option(const char* name);
 
 #define ORBIT_HIP_CHECK(expr)                                                                  \
     do {                                                                                       \

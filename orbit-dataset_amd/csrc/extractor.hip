@@ -261,8 +261,7 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
     const float eps = 1e-3f;
     // The fused expand+depthwise kernel (csrc/mbconv.hip) is parity-green but, as measured on MI355X, slower than the
     // two tuned kernels it replaces (2.6 ms vs 1.7 ms per 200-frame forward over the five eligible blocks): opt-in.
-    static const char* fuse_env = getenv("ORBIT_MBCONV_FUSION");
-    const bool fuse_front = fuse_env != nullptr && fuse_env[0] == '1';
+    const bool fuse_front = get_option("mbconv_fusion") != 0;
     int h, w, pt, pl;
     same_pad(H, 3, 2, h, pt);
     same_pad(W, 3, 2, w, pl);
@@ -548,8 +547,7 @@ int orbit_extractor_forward(orbit_extractor_t* fe, const float* frames, int B, c
     // Opt-in (ORBIT_GRAPH=1): measured on MI355X with a fast host, replaying the 21-node resnet18 graph costs MORE than
     // the eager launch sequence (5.3 vs 4.5 ms per task, host enqueue 2.3 vs 1.6 ms), so eager is the default; the
     // graph path is kept for hosts whose launch path is the bottleneck.
-    static const char* use_graph = getenv("ORBIT_GRAPH");
-    if (use_graph == nullptr || use_graph[0] != '1' || conv_prof_enabled())
+    if (!get_option("graph") || conv_prof_enabled())
         return run_plan(fe, frames, B, film_gamma, film_beta, feats, workspace, s);
 
     // graph path: 1st sight of a pointer tuple runs eagerly (also performs one-time kernel attribute setup), the 2nd

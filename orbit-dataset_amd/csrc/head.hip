@@ -8,6 +8,7 @@
 //
 // All three kernels are HBM-bound (AI ~ 2.4 FLOP/B): rows are streamed once with 16-byte loads, the
 // class matrix W (C*D*4 B ~ 25 KB) stays in L1/L2, reductions are wave64 DPP/shuffle reductions.
+#include <cstdlib>
 #include "common.h"
 
 namespace orbit {
@@ -20,6 +21,33 @@ int set_err(int code, const char* fmt, ...) {
     vsnprintf(g_err, sizeof(g_err), fmt, ap);
     va_end(ap);
     return code;
+}
+
+// ---- library options (tuning switches): name -> int; initial value from the environment ORBIT_<NAME upper-cased>
+struct Option {
+    const char* name;
+    const char* env;
+    int value;
+    bool init;
+};
+static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 0, false},
+                             {"mbconv_fusion", "ORBIT_MBCONV_FUSION", 0, false},
+                             {"graph", "ORBIT_GRAPH", 0, false}};
+static Option* find_option(const char* name) {
+    for (Option& o : g_options)
+        if (strcmp(o.name, name) == 0) {
+            if (!o.init) {
+                const char* e = getenv(o.env);
+                if (e) o.value = atoi(e);
+                o.init = true;
+            }
+            return &o;
+        }
+    return nullptr;
+}
+int get_option(const char* name) {
+    Option* o = find_option(name);
+    return o ? o->value : 0;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {
@@ -228,6 +256,14 @@ using namespace orbit;
 extern "C" {
 
 int orbit_version(void) { return 100; }
+
+int orbit_set_option(const char* name, int value) {
+    ORBIT_REQUIRE(name, "set_option: null name");
+    Option* o = find_option(name);
+    ORBIT_REQUIRE(o != nullptr, "set_option: unknown option '%s'", name);
+    o->value = value;
+    return ORBIT_OK;
+}
 const char* orbit_last_error(void) { return err_buf(); }
 
 int orbit_device_count(void) {

@@ -127,6 +127,111 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
     }
 }
 
+// ---- depthwise with a vertical sliding window in registers ---------------------------------------------------------
+// Same mapping and outputs as dwconv_se_kernel, but a thread walks DOWN its column strip keeping the last K input rows
+// (K x NCOL quads) in registers: every output row loads only the S new input rows instead of all K, i.e. 3-5x fewer
+// L1/L2 requests (the plain kernel re-reads each input ~K*NCOL/NOUT times and is L2-bandwidth-bound on the 5x5 layers).
+// The ring slot of an input row is static: the row loop is unrolled over one ring period (K steps).
+template <int K, int S, int NOUT>
+__global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         float* __restrict__ pool_partial, int H, int W, int C,
+                                                         int pad_t, int pad_l, int Ho, int Wo, int act, int cb4,
+                                                         int rows_per_chunk) {
+    constexpr int NCOL = (NOUT - 1) * S + K;
+    extern __shared__ __attribute__((aligned(16))) float smw[];
+    v4f* wl = reinterpret_cast<v4f*>(smw);  // [K*K][cb4]
+    v4f* red = wl + K * K * cb4;            // [WL][cb4]
+    const int b = blockIdx.z, chunk = blockIdx.y;
+    const int c4_0 = blockIdx.x * cb4;
+    const int WL = 256 / cb4;
+    const int tid = threadIdx.x;
+    const int lc = tid % cb4, lw = tid / cb4;
+    const bool active = lw < WL;
+    const int c = (c4_0 + lc) * 4;
+    for (int i = tid; i < K * K * cb4; i += 256) {
+        const int tap = i / cb4, cc = i % cb4;
+        wl[i] = *reinterpret_cast<const v4f*>(w + (size_t)tap * C + (c4_0 + cc) * 4);
+    }
+    __syncthreads();
+    v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, psum = {0.f, 0.f, 0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const v4f*>(scale + c);
+    if (shift) sh = *reinterpret_cast<const v4f*>(shift + c);
+    const float* xb = x + (size_t)b * H * W * C + c;
+    float* yb = y + (size_t)b * Ho * Wo * C + c;
+    const int ho0 = chunk * rows_per_chunk;
+    const int ho_end = min(Ho, ho0 + rows_per_chunk);
+    const int WQ = (Wo + NOUT - 1) / NOUT;
+    if (active) {
+        for (int wq = lw; wq < WQ; wq += WL) {
+            const int wi0 = wq * NOUT * S - pad_l;
+            int coff[NCOL];
+            float cmask[NCOL];
+#pragma unroll
+            for (int q = 0; q < NCOL; ++q) {
+                const bool ok = (unsigned)(wi0 + q) < (unsigned)W;
+                coff[q] = ok ? (wi0 + q) * C : 0;
+                cmask[q] = ok ? 1.f : 0.f;
+            }
+            v4f win[K][NCOL];
+            auto load_row = [&](int hi, v4f* dst) {
+                const bool row_ok = (unsigned)hi < (unsigned)H;
+                const float* xr = xb + (size_t)(row_ok ? hi : 0) * W * C;
+                const float rm = row_ok ? 1.f : 0.f;
+#pragma unroll
+                for (int q = 0; q < NCOL; ++q) dst[q] = *reinterpret_cast<const v4f*>(xr + coff[q]) * (rm * cmask[q]);
+            };
+            const int hi_base = ho0 * S - pad_t;  // input row of ring position 0
+#pragma unroll
+            for (int r = 0; r < K - S; ++r) load_row(hi_base + r, win[r]);
+            for (int hob = ho0; hob < ho_end; hob += K) {
+                const int rel = (hob - ho0) * S;  // multiple of K: ring slots below are static
+#pragma unroll
+                for (int ph = 0; ph < K; ++ph) {
+                    const int ho = hob + ph;
+                    if (ho < ho_end) {
+#pragma unroll
+                        for (int s2 = 0; s2 < S; ++s2)
+                            load_row(hi_base + rel + ph * S + K - S + s2, win[(ph * S + K - S + s2) % K]);
+                        v4f acc[NOUT];
+#pragma unroll
+                        for (int j = 0; j < NOUT; ++j) acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                        for (int kh = 0; kh < K; ++kh) {
+#pragma unroll
+                            for (int kw = 0; kw < K; ++kw) {
+                                const v4f f = wl[(kh * K + kw) * cb4 + lc];
+#pragma unroll
+                                for (int j = 0; j < NOUT; ++j) acc[j] += win[(ph * S + kh) % K][j * S + kw] * f;
+                            }
+                        }
+#pragma unroll
+                        for (int j = 0; j < NOUT; ++j) {
+                            const int wo = wq * NOUT + j;
+                            if (wo < Wo) {
+                                v4f o = acc[j] * sc + sh;
+                                o[0] = act_fn(o[0], act), o[1] = act_fn(o[1], act), o[2] = act_fn(o[2], act),
+                                o[3] = act_fn(o[3], act);
+                                *reinterpret_cast<v4f*>(yb + ((size_t)ho * Wo + wo) * C) = o;
+                                psum += o;
+                            }
+                        }
+                    }
+                }
+            }
+        }
+    }
+    if (pool_partial == nullptr) return;
+    if (active) red[lw * cb4 + lc] = psum;
+    __syncthreads();
+    if (tid < cb4) {
+        v4f t = red[tid];
+        for (int l = 1; l < WL; ++l) t += red[l * cb4 + tid];
+        *reinterpret_cast<v4f*>(pool_partial + ((size_t)b * gridDim.y + chunk) * C + (c4_0 + tid) * 4) = t;
+    }
+}
+
 // squeeze-excite gate from pooling partials: pooled[c] = (sum_chunks partial[b][chunk][c]) / HW, then
 // g = sigmoid(W2 silu(W1 pooled + b1) + b2). w2t is W2 transposed to [R][C] so the second layer reads coalesced.
 __global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__ partial, int chunks, float inv_hw,
@@ -298,6 +403,18 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     const int cb4 = dw_cb4(C), rpc = dwconv_se_rows_per_chunk(Ho);
     dim3 grid(C / 4 / cb4, cdiv(Ho, rpc), B);
     const size_t lds = (size_t)(K * K * cb4 + (256 / cb4) * cb4) * sizeof(float4);
+    if (get_option("dw_window")) {
+#define ORBIT_DWW(KK, SS, NO)                                                                                    \
+    dwconv_win_kernel<KK, SS, NO><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t, \
+                                                         pad_l, Ho, Wo, act, cb4, rpc)
+        if (K == 3 && stride == 1) ORBIT_DWW(3, 1, 4);
+        else if (K == 3) ORBIT_DWW(3, 2, 4);
+        else if (stride == 1) ORBIT_DWW(5, 1, 2);
+        else ORBIT_DWW(5, 2, 1);
+#undef ORBIT_DWW
+        ORBIT_LAUNCH_CHECK();
+        return ORBIT_OK;
+    }
 #define ORBIT_DW(KK, SS)                                                                                         \
     dwconv_se_kernel<KK, SS><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t, pad_l, \
                                                     Ho, Wo, act, cb4, rpc)

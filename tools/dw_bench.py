@@ -12,8 +12,11 @@ SHAPES = [("b0 k3s1 112x32", 112, 32, 3, 1), ("b1.0 k3s2 112x96", 112, 96, 3, 2)
 lib = _lib.load()
 dev = torch.device("cuda", 0)
 B = 200
-tot = 0
+tot = {0: 0.0, 1: 0.0}
 for name, H, C, K, S in SHAPES:
+  line = "%-20s" % name
+  for opt in (0, 1, 0, 1):  # in-process A/B of the register-window kernel (interleaved to cancel drift)
+    lib.orbit_set_option(b"dw_window", opt)
     Ho = -(-H // S)
     pad = max((Ho - 1) * S + K - H, 0) // 2
     x = torch.randn(B, H, H, C, device=dev); w = torch.randn(C, 1, K, K, device=dev)
@@ -28,6 +31,7 @@ for name, H, C, K, S in SHAPES:
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 100
     gb = 4.0 * B * C * (H * H + Ho * Ho) / 1e9
-    tot += us
-    print("%-20s %8.1f us  %6.2f GB  %6.2f TB/s" % (name, us, gb, gb / us * 1e3 / 1e3 * 1e3 / 1e3 if False else gb / (us * 1e-6) / 1e3))
-print("sum of one instance each: %.1f us" % tot)
+    tot[opt] += us / 2
+    line += "  %s %7.1f us %5.2f TB/s" % ("win" if opt else "std", us, gb / (us * 1e-6) / 1e3)
+  print(line)
+print("sum of one instance each: std %.1f us, window %.1f us" % (tot[0], tot[1]))
