@@ -58,9 +58,11 @@ int orbit_version(void);
 const char* orbit_last_error(void);
 /* number of visible HIP devices (<=0: no usable GPU); does not create a context on failure */
 int orbit_device_count(void);
-/* tuning switches, all default 0 (initial value from the environment ORBIT_DW_WINDOW / ORBIT_MBCONV_FUSION /
- * ORBIT_GRAPH): "dw_window" register-window depthwise kernel, "mbconv_fusion" fused expand+depthwise kernel (takes
- * effect for extractors created afterwards), "graph" HIP-graph replay of extractor forwards. */
+/* tuning switches (initial value from the environment ORBIT_DW_WINDOW / ORBIT_MBCONV_FUSION / ORBIT_GRAPH):
+ *   "dw_window"     register-window depthwise kernel: 1 = where it wins (3x3, stride 1, >= 14 rows; default), 0 = never,
+ *                   2 = always
+ *   "mbconv_fusion" fused expand+depthwise kernel, default 0 (takes effect for extractors created afterwards)
+ *   "graph"         HIP-graph replay of extractor forwards, default 0 */
 int orbit_set_option(const char* name, int value);
 
 /* ---- prototype head ---------------------------------------------------------------------------- */

@@ -30,7 +30,7 @@ struct Option {
     int value;
     bool init;
 };
-static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 0, false},
+static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"mbconv_fusion", "ORBIT_MBCONV_FUSION", 0, false},
                              {"graph", "ORBIT_GRAPH", 0, false}};
 static Option* find_option(const char* name) {

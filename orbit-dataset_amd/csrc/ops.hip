@@ -403,7 +403,11 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     const int cb4 = dw_cb4(C), rpc = dwconv_se_rows_per_chunk(Ho);
     dim3 grid(C / 4 / cb4, cdiv(Ho, rpc), B);
     const size_t lds = (size_t)(K * K * cb4 + (256 / cb4) * cb4) * sizeof(float4);
-    if (get_option("dw_window")) {
+    // register-window kernel: measured in-process on MI355X against the plain streaming kernel (tools/dw_bench.py):
+    // +30..45 % on 3x3 / stride 1 with >= 14 rows (112x32, 56x144, 14x480), slower on 5x5 (K x NCOL window -> 256
+    // VGPRs, 1 wave/SIMD) and on stride 2. dw_window: 1 = auto (default), 0 = never, 2 = always.
+    const int win_opt = get_option("dw_window");
+    if (win_opt == 2 || (win_opt == 1 && K == 3 && stride == 1 && Ho >= 14)) {
 #define ORBIT_DWW(KK, SS, NO)                                                                                    \
     dwconv_win_kernel<KK, SS, NO><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t, \
                                                          pad_l, Ho, Wo, act, cb4, rpc)
