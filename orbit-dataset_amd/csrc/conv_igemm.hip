@@ -460,32 +460,22 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
 
 template <int BK, int MODE, bool POOL2, bool GATE>
 static int launch_tiled(ConvParams& p, hipStream_t s) {
-    // Tile choice: the widest N tile the layer fills, the tallest M tile that still yields >= ~2 blocks
-    // per CU (256 CUs); small-M late layers fall back to 64-row tiles to keep the chip occupied.
-    const long target = 512;
-    static const char* force = getenv("ORBIT_CONV_TILE");  // tuning experiments only: 128x128|128x64|64x64|128x32
-    if (force) {
-        if (!strcmp(force, "128x128")) return launch_cfg<128, 128, 2, 2, BK, MODE, POOL2, GATE>(p, s);
-        if (!strcmp(force, "128x64")) return launch_cfg<128, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
-        if (!strcmp(force, "64x64")) return launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
-        if (!strcmp(force, "128x32")) return launch_cfg<128, 32, 4, 1, BK, MODE, POOL2, GATE>(p, s);
+    switch (get_option("conv_tile")) {  // tuning sweeps (tools/conv_bench.py): 0 = heuristic below
+        case 1: return launch_cfg<128, 128, 2, 2, BK, MODE, POOL2, GATE>(p, s);
+        case 2: return launch_cfg<128, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
+        case 3: return launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
+        case 4: return launch_cfg<128, 32, 4, 1, BK, MODE, POOL2, GATE>(p, s);
+        default: break;
     }
-    // short-K layers (EfficientNet's 1x1 convs, K <= 1152) are HBM/latency-bound, not MFMA-bound: many small
-    // blocks in flight beat large tiles (measured: 64x64 is fastest on every such layer with Cout > 32)
-    const int ktrue = p.KH * p.KW * p.Cin;
-    if (p.Cout > 32 && ktrue <= 1152 && p.KH == 1) return launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
-    if (p.Cout > 64) {
-        if ((long)cdiv(p.M, 128) * cdiv(p.Cout, 128) >= target)
-            return launch_cfg<128, 128, 2, 2, BK, MODE, POOL2, GATE>(p, s);
-        if ((long)cdiv(p.M, 128) * cdiv(p.Cout, 64) >= target)
-            return launch_cfg<128, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
-        return launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
-    }
-    if (p.Cout > 32) {
-        if ((long)cdiv(p.M, 128) >= target) return launch_cfg<128, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
-        return launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
-    }
-    return launch_cfg<128, 32, 4, 1, BK, MODE, POOL2, GATE>(p, s);
+    // Measured sweep on MI355X (tools/conv_bench.py <net> sweep, in-process A/B over every layer shape of resnet18 @84
+    // and @224, efficientnet_b0 @224 and the set encoder): the 64x64 tile (36 KB LDS -> 4 blocks = 4 waves per SIMD) is
+    // the fastest on EVERY layer, including the large MFMA-bound ones (+10..24 % over 128x128 / 128x64, whose 2 blocks
+    // per CU cover the per-K-tile bubble worse). 128x32 wins only where the last 64-wide column tile would be mostly
+    // padding (Cout <= 32, or e.g. Cout = 80, 96, 144).
+    const double waste64 = (double)(cdiv(p.Cout, 64) * 64 - p.Cout) / p.Cout;
+    const double waste32 = (double)(cdiv(p.Cout, 32) * 32 - p.Cout) / p.Cout;
+    if (p.Cout <= 32 || waste64 - waste32 >= 0.15) return launch_cfg<128, 32, 4, 1, BK, MODE, POOL2, GATE>(p, s);
+    return launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
 }
 
 template <int MODE, bool POOL2, bool GATE>

@@ -18,37 +18,60 @@ SHAPES = {
         ("stem3x3", 200, 224, 3, 32, 3, 2, 0, 1), ("pw16_96", 200, 112, 16, 96, 1, 1, 0, 0), ("pwl96_24", 200, 56, 96, 24, 1, 1, 0, 0),
         ("pw24_144", 200, 56, 24, 144, 1, 1, 0, 0), ("pw40_240", 200, 28, 40, 240, 1, 1, 0, 0), ("pw80_480", 200, 14, 80, 480, 1, 1, 0, 0),
         ("pwl480_112", 200, 14, 480, 112, 1, 1, 0, 0), ("pw112_672", 200, 14, 112, 672, 1, 1, 0, 0), ("pw192_1152", 200, 7, 192, 1152, 1, 1, 0, 0),
-        ("pwl1152_320", 200, 7, 1152, 320, 1, 1, 0, 0), ("head320_1280", 200, 7, 320, 1280, 1, 1, 0, 0)],
+        ("pwl1152_320", 200, 7, 1152, 320, 1, 1, 0, 0), ("head320_1280", 200, 7, 320, 1280, 1, 1, 0, 0),
+        ("pwl32_16", 200, 112, 32, 16, 1, 1, 0, 0), ("pwl144_24", 200, 56, 144, 24, 1, 1, 0, 0),
+        ("pwl144_40", 200, 28, 144, 40, 1, 1, 0, 0), ("pwl240_40", 200, 28, 240, 40, 1, 1, 0, 0),
+        ("pwl240_80", 200, 14, 240, 80, 1, 1, 0, 0), ("pwl480_80", 200, 14, 480, 80, 1, 1, 0, 0),
+        ("pwl672_112", 200, 14, 672, 112, 1, 1, 0, 0), ("pwl672_192", 200, 7, 672, 192, 1, 1, 0, 0),
+        ("pwl1152_192", 200, 7, 1152, 192, 1, 1, 0, 0)],
+    "setenc_224": [
+        ("se_l1", 200, 224, 3, 64, 3, 1, 1, 1), ("se_l2", 200, 112, 64, 64, 3, 1, 1, 0), ("se_l3", 200, 56, 64, 64, 3, 1, 1, 0),
+        ("se_l4", 200, 28, 64, 64, 3, 1, 1, 0), ("se_l5", 200, 14, 64, 64, 3, 1, 1, 0)],
 }
+TILES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32"}
 
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "resnet18_84"
+    sweep = len(sys.argv) > 2 and sys.argv[2] == "sweep"
     lib = _lib.load()
     dev = torch.device("cuda", 0)
+    import ctypes
     for name, B, H, Cin, Cout, K, stride, pad, nchw in SHAPES[which]:
         Ho = -(-H // stride) if (which.startswith("effnet") and nchw) else (H + 2 * pad - K) // stride + 1
         x = torch.randn(B, Cin, H, H, device=dev) if nchw else torch.randn(B, H, H, Cin, device=dev)
         w = torch.randn(Cout, Cin, K, K, device=dev)
         y = torch.empty(B, Ho, Ho, Cout, device=dev)
         sc, sh = torch.rand(Cout, device=dev), torch.rand(Cout, device=dev)
+
         def run():
             _lib.check(lib.orbit_op_conv2d(_lib.dptr(x), nchw, _lib.dptr(w), _lib.dptr(y), _lib.dptr(sc), _lib.dptr(sh), None, None,
                                            B, H, H, Cin, Cout, K, K, stride, pad, pad, Ho, Ho, 1, 0, _lib.stream_handle()))
-        for _ in range(3):
-            run()
-        lib.orbit_prof_enable(1)
-        for _ in range(10):
-            run()
-        torch.cuda.synchronize()
-        lib.orbit_prof_enable(0)
-        import ctypes
-        ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
-        lib.orbit_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
-        nm = ctypes.create_string_buffer(48)
-        lib.orbit_prof_variant(0, nm, None, None, None, None)
-        print("%-14s M=%7d N=%4d K=%5d  %-28s %8.1f us  %6.1f TFLOP/s" % (
-            name, B * Ho * Ho, Cout, Cin * K * K, nm.value.decode(), 1e3 * ms.value / n.value, fl.value / ms.value / 1e9))
+
+        def measure(tile):
+            lib.orbit_set_option(b"conv_tile", tile)
+            for _ in range(2):
+                run()
+            lib.orbit_prof_enable(1)
+            for _ in range(8):
+                run()
+            torch.cuda.synchronize()
+            lib.orbit_prof_enable(0)
+            ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+            lib.orbit_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
+            nm = ctypes.create_string_buffer(48)
+            lib.orbit_prof_variant(0, nm, None, None, None, None)
+            return 1e3 * ms.value / n.value, fl.value / ms.value / 1e9, nm.value.decode()
+
+        us, tf, nm = measure(0)
+        line = "%-14s M=%7d N=%4d K=%5d  %-26s %8.1f us %6.1f TF" % (name, B * Ho * Ho, Cout, Cin * K * K, nm, us, tf)
+        if sweep:
+            res = {t: measure(t)[0] for t in (1, 2, 3, 4) if not (t == 4 and Cout > 32 and False)}
+            best = min(res, key=res.get)
+            line += "  | " + "  ".join("%s %.1f" % (TILES[t], res[t]) for t in res) + "  -> best %s (%.0f%% vs auto)" % (
+                TILES[best], 100 * (us / res[best] - 1))
+        lib.orbit_set_option(b"conv_tile", 0)
+        print(line)
 
 
 if __name__ == "__main__":
