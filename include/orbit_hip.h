@@ -64,7 +64,9 @@ int orbit_device_count(void);
  *   "mbconv_fusion" fused expand+depthwise kernel, default 0 (takes effect for extractors created afterwards)
  *   "graph"         HIP-graph replay of extractor forwards, default 0
  *   "conv_tile"     force the implicit-GEMM block tile: 0 = heuristic (default), 1 = 128x128, 2 = 128x64, 3 = 64x64,
- *                   4 = 128x32 (tuning sweeps only) */
+ *                   4 = 128x32 (tuning sweeps only)
+ *   "conv_bk"       cap the K-tile width: 0 = widest of 32/16/8 dividing Cin (default), 8, 16, 32 (tuning sweeps only;
+ *                   read when weights are packed AND at launch, so set it before creating/finalizing an extractor) */
 int orbit_set_option(const char* name, int value);
 
 /* ---- prototype head ---------------------------------------------------------------------------- */

@@ -349,8 +349,10 @@ __global__ __launch_bounds__(256) void conv_pack_kernel(const float* __restrict_
 
 // K-tile width for a layer: the widest of 32/16/8 that divides Cin (stems: 32)
 static int choose_bk(int Cin, int x_nchw) {
-    if (x_nchw || Cin % 32 == 0) return 32;
-    if (Cin % 16 == 0) return 16;
+    if (x_nchw) return 32;
+    const int cap = get_option("conv_bk");  // tuning sweeps: 0 = widest that divides Cin (default), else 8 / 16 / 32
+    if (Cin % 32 == 0 && (cap == 0 || cap >= 32)) return 32;
+    if (Cin % 16 == 0 && (cap == 0 || cap >= 16)) return 16;
     return 8;
 }
 

@@ -65,6 +65,13 @@ def main():
 
         us, tf, nm = measure(0)
         line = "%-14s M=%7d N=%4d K=%5d  %-26s %8.1f us %6.1f TF" % (name, B * Ho * Ho, Cout, Cin * K * K, nm, us, tf)
+        if len(sys.argv) > 2 and sys.argv[2] == "bk":
+            res = {}
+            for bk in (32, 16, 8):
+                lib.orbit_set_option(b"conv_bk", bk)
+                res[bk] = measure(0)
+            lib.orbit_set_option(b"conv_bk", 0)
+            line += "  | " + "  ".join("BK<=%d %.1f us (%s)" % (bk, r[0], r[2].split("<")[1][:9]) for bk, r in res.items())
         if sweep:
             res = {t: measure(t)[0] for t in (1, 2, 3, 4) if not (t == 4 and Cout > 32 and False)}
             best = min(res, key=res.get)
