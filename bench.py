@@ -247,6 +247,7 @@ def main():
                    "tasks_per_step": 1, "parallelism": "task-parallel x%d (independent tasks per rank)" % world},
         "frame_accuracy": float(correct[0].item() / max(correct[1].item(), 1)),
         "host_enqueue_ms_per_step": 1e3 * issued / args.steps,
+        "graph_option": os.environ.get("ORBIT_GRAPH", "2 (adaptive)"),
         "extractor_gflop_per_task": 2 * macs * (WAY * SHOTS * FRAMES_PER_SHOT + NUM_QUERY) / 1e9,
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,

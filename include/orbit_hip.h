@@ -62,7 +62,8 @@ int orbit_device_count(void);
  *   "dw_window"     register-window depthwise kernel: 1 = where it wins (3x3, stride 1, >= 14 rows; default), 0 = never,
  *                   2 = always
  *   "mbconv_fusion" fused expand+depthwise kernel, default 0 (takes effect for extractors created afterwards)
- *   "graph"         HIP-graph replay of extractor forwards, default 0
+ *   "graph"         HIP-graph replay of extractor forwards: 0 = never, 1 = always, 2 = adaptive (default: only while an
+ *                   eager kernel launch costs > ~12 us of host time on this host)
  *   "conv_tile"     force the implicit-GEMM block tile: 0 = heuristic (default), 1 = 128x128, 2 = 128x64, 3 = 64x64,
  *                   4 = 128x32 (tuning sweeps only)
  *   "conv_bk"       cap the K-tile width: 0 = widest of 32/16/8 dividing Cin (default), 8, 16, 32 (tuning sweeps only;

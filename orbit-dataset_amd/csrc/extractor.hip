@@ -10,6 +10,7 @@
 // Activations are NHWC fp32 and live in caller-provided workspace (three rotating buffers); frames come
 // in as NCHW (the reference's clip layout) and are consumed directly by the stem convolution.
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <map>
 #include <string>
@@ -118,6 +119,8 @@ struct orbit_extractor {
     };
     std::vector<GraphEntry> graphs;
     unsigned long graph_clock = 0;
+    double eager_us_per_launch = 0.0;  // running average of the HOST cost of one eager kernel launch (option graph=2)
+    int eager_samples = 0;
     hipStream_t cap_stream = nullptr;  // private non-default stream used only to CAPTURE (the legacy default stream,
                                        // torch's default, cannot be captured); graphs are launched on the caller's
     void clear_graphs() {
@@ -544,11 +547,23 @@ int orbit_extractor_forward(orbit_extractor_t* fe, const float* frames, int B, c
                   workspace_bytes, L.total);
     ORBIT_REQUIRE(((uintptr_t)workspace & 255) == 0, "extractor_forward: workspace must be 256-byte aligned");
     hipStream_t s = (hipStream_t)stream;
-    // Opt-in (ORBIT_GRAPH=1): measured on MI355X with a fast host, replaying the 21-node resnet18 graph costs MORE than
-    // the eager launch sequence (5.3 vs 4.5 ms per task, host enqueue 2.3 vs 1.6 ms), so eager is the default; the
-    // graph path is kept for hosts whose launch path is the bottleneck.
-    if (!get_option("graph") || conv_prof_enabled())
-        return run_plan(fe, frames, B, film_gamma, film_beta, feats, workspace, s);
+    // graph = 0 never, 1 always, 2 (default) adaptive. Measured on MI355X: with a fast host, replaying the graph of a
+    // forward is SLOWER than the eager launch sequence (resnet18@84: 5.3 vs 4.5 ms per task), but pool hosts differ 4x
+    // in launch cost and on the slow ones the eager sequence (~170 launches per efficientnet task) makes the default
+    // workload host-bound. Adaptive: time the host side of the eager sequence; replay graphs only while a launch costs
+    // more than ~12 us of host time on average.
+    const int graph_opt = get_option("graph");
+    bool want_graph = graph_opt == 1;
+    if (graph_opt == 2 && fe->eager_samples >= 3 && fe->eager_us_per_launch > 12.0) want_graph = true;
+    if (!want_graph || conv_prof_enabled()) {
+        const auto t0 = std::chrono::steady_clock::now();
+        const int rc = run_plan(fe, frames, B, film_gamma, film_beta, feats, workspace, s);
+        const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count() /
+                          (double)(fe->ops.size() + 1);
+        fe->eager_us_per_launch = fe->eager_samples == 0 ? us : 0.7 * fe->eager_us_per_launch + 0.3 * us;
+        fe->eager_samples++;
+        return rc;
+    }
 
     // graph path: 1st sight of a pointer tuple runs eagerly (also performs one-time kernel attribute setup), the 2nd
     // captures + instantiates, later ones replay
