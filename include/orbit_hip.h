@@ -181,6 +181,77 @@ int orbit_op_mbconv_front(const float* x, const float* w1, const float* scale1, 
                           int B, int H, int W, int Cin, int mid, int K, int stride, int pad_top, int pad_left,
                           int Ho, int Wo, orbit_stream_t stream);
 
+/* ---- training (LITE meta-training step) -----------------------------------------------------
+ * What `loss.backward()` runs in the reference (single-step-learner.py:234) for the graph recorded by
+ * model/few_shot_recognisers.py:99-122 (_get_features, grad enabled), :345-356 (_get_task_embedding on the LITE
+ * subset) and model/classifier_heads.py:202-230 (head). BatchNorm mode follows few_shot_recognisers.py:176-183.
+ * Available for the resnet18 and set_encoder plans (orbit_extractor_supports_training). */
+int orbit_extractor_supports_training(const orbit_extractor_t* fe);
+size_t orbit_extractor_tape_bytes(const orbit_extractor_t* fe, int B);
+size_t orbit_extractor_backward_workspace_bytes(const orbit_extractor_t* fe, int B);
+size_t orbit_extractor_grad_floats(const orbit_extractor_t* fe);          /* length of the flat gradient buffer */
+size_t orbit_extractor_param_offset(const orbit_extractor_t* fe, int i);  /* offset of parameter i inside it */
+size_t orbit_extractor_bn_stat_floats(const orbit_extractor_t* fe);
+/* dst[0][.] running means, dst[1][.] running variances of every BatchNorm (in parameter order, each padded to a
+ * multiple of 4 channels; row length = orbit_extractor_bn_stat_floats): how the caller's state_dict buffers follow the
+ * running-stat updates of train-mode forwards */
+int orbit_extractor_export_bn_stats(orbit_extractor_t* fe, float* dst, orbit_stream_t stream);
+/* Forward that records the tape (raw convolution outputs, activations, pooling argmax; caller-owned, 256-B aligned).
+ * bn_train != 0: batch statistics + running-stat update with `momentum` (nn.BatchNorm2d semantics);
+ * bn_train == 0: running statistics. film_gamma/film_beta as in orbit_extractor_forward. */
+int orbit_extractor_train_forward(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
+                                  const float* film_beta, int bn_train, float momentum, float* feats, void* tape,
+                                  size_t tape_bytes, orbit_stream_t stream);
+/* Reverse pass for the tape of one train_forward (same frames / B / film / bn_train).
+ *   dfeats [B][D]: gradient w.r.t. the features.
+ *   param_grads: NULL (frozen extractor) or orbit_extractor_grad_floats() floats; the gradient of parameter i is
+ *     WRITTEN at orbit_extractor_param_offset(i) in the parameter's torch layout (OIHW filters). Slots of buffers
+ *     (running statistics) and of BatchNorm weight/bias replaced by FiLM vectors are left untouched.
+ *   dfilm_gamma / dfilm_beta: NULL or film_size floats each, written.
+ * Deterministic: fixed reduction order, no atomics. */
+int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
+                             const float* film_beta, int bn_train, const float* dfeats, const void* tape,
+                             size_t tape_bytes, float* param_grads, float* dfilm_gamma, float* dfilm_beta,
+                             void* workspace, size_t workspace_bytes, orbit_stream_t stream);
+/* Backward of orbit_filmgen_forward: given d(film_gamma), d(film_beta) (film_size floats each) and d(l2) ([1], NULL = 0)
+ * writes the gradients of every generator parameter into `grads` (orbit_filmgen_grad_floats floats; tensor t of
+ * generator i at orbit_filmgen_param_offset(g, i, t), same tensor names as orbit_filmgen_load except "init") and
+ * d(z) [z_dim] (NULL to skip). Reference: autograd through model/feature_adapters.py:66-78, model/mlps.py:52-63. */
+size_t orbit_filmgen_grad_floats(const orbit_filmgen_t* g);
+size_t orbit_filmgen_param_offset(const orbit_filmgen_t* g, int gen, const char* tensor);
+int orbit_filmgen_backward(orbit_filmgen_t* g, const float* z, const float* dfilm_gamma, const float* dfilm_beta,
+                           const float* dl2, float* grads, float* dz, orbit_stream_t stream);
+/* d(features) of orbit_proto_predict for ONE task: features [M*T][D] (frame features, pooled over T inside),
+ * weight [C][D] (treated as a constant: the reference wraps it in nn.Parameter, classifier_heads.py:261-263),
+ * dlogits [M][C] -> dfeatures [M*T][D]. C <= 64. */
+int orbit_proto_predict_backward(const float* dlogits, const float* features, const float* weight, int M, int T, int D,
+                                 int C, float logit_scale, int cosine, float* dfeatures, orbit_stream_t stream);
+
+/* single training operators (NHWC, [M][C] = [B*H*W][C]), exposed for parity tests against torch autograd */
+/* out = act(BN_train(y) + residual): batch mean / biased variance, saves mean and 1/sqrt(var+eps), updates the running
+ * statistics in place when given (unbiased variance, momentum). gamma/beta NULL = 1/0. act: NONE or RELU. */
+int orbit_op_bn_train_forward(const float* y, int M, int C, const float* gamma, const float* beta, float eps,
+                              float momentum, float* running_mean, float* running_var, const float* residual, int act,
+                              float* out, float* save_mean, float* save_invstd, orbit_stream_t stream);
+/* backward of out = act(BN(y) + residual): dy, dres (= dout * act', NULL to skip), dgamma, dbeta.
+ * train != 0: batch-statistics form; train == 0: mean/invstd are running statistics (constants). */
+int orbit_op_bn_backward(const float* dout, const float* out, const float* y, int M, int C, const float* gamma,
+                         const float* mean, const float* invstd, int train, int act, float* dy, float* dres,
+                         float* dgamma, float* dbeta, orbit_stream_t stream);
+/* dx of a convolution: dy NHWC [B][Ho][Wo][Cout], w OIHW, dx NHWC [B][H][W][Cin] (= accumulate + grad if given) */
+int orbit_op_conv2d_dgrad(const float* dy, const float* w, const float* accumulate, float* dx, int B, int H, int W,
+                          int Cin, int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                          orbit_stream_t stream);
+/* dw (OIHW) of a convolution; x NHWC (or NCHW when x_nchw, Cin <= 4) */
+int orbit_op_conv2d_wgrad(const float* x, int x_nchw, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                          int KH, int KW, int stride, int pad_top, int pad_left, int Ho, int Wo, orbit_stream_t stream);
+/* max-pool that records the argmax (position inside the window, first maximum in scan order) and its backward */
+int orbit_op_maxpool2d_train(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, int K, int stride,
+                             int pad, int Ho, int Wo, orbit_stream_t stream);
+int orbit_op_maxpool2d_backward(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, int K,
+                                int stride, int pad, int Ho, int Wo, orbit_stream_t stream);
+int orbit_op_avgpool_backward(const float* dy, float* dx, int B, int HW, int C, orbit_stream_t stream);
+
 /* ---- measurement: per-launch HIP-event timing of the dominant kernel (conv_igemm, all variants) ---- */
 int orbit_prof_enable(int on);   /* on: reset and start recording an event pair per launch on its stream */
 /* waits for the recorded launches, returns summed duration, summed ALGORITHMIC flops and launch count */

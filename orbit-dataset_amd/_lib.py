@@ -51,6 +51,26 @@ _SIGNATURES = {
     "orbit_op_avgpool": (c_int, [P, P, c_int, c_int, c_int, P]),
     "orbit_op_se_gate": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "orbit_op_mbconv_front": (c_int, [P] * 9 + [c_int] * 11 + [P]),
+    "orbit_extractor_supports_training": (c_int, [P]),
+    "orbit_extractor_tape_bytes": (c_size_t, [P, c_int]),
+    "orbit_extractor_backward_workspace_bytes": (c_size_t, [P, c_int]),
+    "orbit_extractor_grad_floats": (c_size_t, [P]),
+    "orbit_extractor_param_offset": (c_size_t, [P, c_int]),
+    "orbit_extractor_bn_stat_floats": (c_size_t, [P]),
+    "orbit_extractor_export_bn_stats": (c_int, [P, P, P]),
+    "orbit_extractor_train_forward": (c_int, [P, P, c_int, P, P, c_int, c_float, P, P, c_size_t, P]),
+    "orbit_extractor_backward": (c_int, [P, P, c_int, P, P, c_int, P, P, c_size_t, P, P, P, P, c_size_t, P]),
+    "orbit_filmgen_grad_floats": (c_size_t, [P]),
+    "orbit_filmgen_param_offset": (c_size_t, [P, c_int, c_char_p]),
+    "orbit_filmgen_backward": (c_int, [P, P, P, P, P, P, P, P]),
+    "orbit_proto_predict_backward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P, P]),
+    "orbit_op_bn_train_forward": (c_int, [P, c_int, c_int, P, P, c_float, c_float, P, P, P, c_int, P, P, P, P]),
+    "orbit_op_bn_backward": (c_int, [P, P, P, c_int, c_int, P, P, P, c_int, c_int, P, P, P, P, P]),
+    "orbit_op_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 12 + [P]),
+    "orbit_op_conv2d_wgrad": (c_int, [P, c_int, P, P] + [c_int] * 12 + [P]),
+    "orbit_op_maxpool2d_train": (c_int, [P, P, P] + [c_int] * 9 + [P]),
+    "orbit_op_maxpool2d_backward": (c_int, [P, P, P] + [c_int] * 9 + [P]),
+    "orbit_op_avgpool_backward": (c_int, [P, P, c_int, c_int, c_int, P]),
     "orbit_prof_enable": (c_int, [c_int]),
     "orbit_prof_collect": (c_int, [POINTER(c_double), POINTER(c_double), POINTER(ctypes.c_long)]),
     "orbit_prof_num_variants": (c_int, []),

@@ -91,4 +91,34 @@ int launch_avgpool(const float* x, float* y, int B, int HW, int C, hipStream_t s
 int launch_se_gate(const float* pooled, const float* w1, const float* b1, const float* w2,
                    const float* b2, float* gate, int B, int C, int R, hipStream_t s);
 
+
+// ---- training-side launchers (train_ops.hip, conv_wgrad.hip) ------------------------------------------------------
+int bn_reduce_blocks(int M, int C);  // rows of the [blocks][2][C] partial buffer the BatchNorm reductions need
+// batch statistics of y[M][C] -> mean, invstd, folded scale/shift (gamma/beta nullable = 1/0), running-stat update
+int launch_bn_stats(const float* y, int M, int C, float eps, float momentum, const float* gamma, const float* beta,
+                    const float* conv_bias, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                    float* running_var, float* partial, hipStream_t s);
+int launch_scale_shift_act(const float* y, const float* scale, const float* shift, const float* residual, int act,
+                           size_t M, int C, float* out, hipStream_t s);
+// coef: 3*C floats of scratch; dy nullable (reductions only); dres nullable (gradient of the residual input)
+int launch_bn_backward(const float* dout, const float* out, const float* y, const float* mean, const float* invstd,
+                       const float* gamma, int train, int act, int M, int C, float* dy, float* dres, int dres_accumulate,
+                       float* dgamma, float* dbeta, float* dbias, float* partial, float* coef, hipStream_t s);
+int launch_maxpool_idx(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, int K, int stride, int pad,
+                       int Ho, int Wo, hipStream_t s);
+int launch_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, int K, int stride,
+                       int pad, int Ho, int Wo, hipStream_t s);
+int launch_avgpool_bwd(const float* dy, float* dx, int B, int HW, int C, hipStream_t s);
+int launch_upsample_zero(const float* src, float* dst, int B, int H, int W, int C, int stride, int Hs, int Ws,
+                         hipStream_t s);
+int launch_add_inplace(float* dst, const float* src, size_t n, hipStream_t s);
+size_t conv_wgrad_scratch_floats(int B, int Cin, int Cout, int KH, int KW, int Ho, int Wo);
+int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
+                      int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float* scratch, hipStream_t s);
+size_t conv_dgrad_packed_floats(int Cin, int Cout, int KH, int KW);
+int conv_pack_dgrad_weights(const float* w_oihw, float* w_packed, int Cin, int Cout, int KH, int KW, hipStream_t s);
+int launch_conv_dgrad(const float* dy, const float* w_dgrad_packed, const float* accumulate, float* dx, float* up, int B,
+                      int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                      hipStream_t s);
+
 }  // namespace orbit

@@ -1,0 +1,319 @@
+// Convolution weight gradient and the weight repack of the data gradient, on the fp32 matrix cores.
+//
+// Reference: the autograd backward of every nn.Conv2d of the extractor / set encoder when the LITE step calls
+// loss.backward() (single-step-learner.py:234; model/few_shot_recognisers.py:99-122 builds the graph).
+//
+//   wgrad   dW[co][(kh,kw,ci)] = sum_m dY[m][co] * Xg[m][(kh,kw,ci)]          m = (b, ho, wo)
+//           GEMM with the LONG dimension (M = B*Ho*Wo, up to ~3e6) as the reduction: the output is tiny (Cout x K),
+//           so the work is split along m over `splits` blocks per output tile; each block accumulates its rows with
+//           v_mfma_f32_32x32x2_f32 and writes a partial tile, and a second kernel adds the partials in a fixed order
+//           (deterministic, no atomics) while transposing to the OIHW layout of the parameter.
+//           Both operands are "k-major" in memory (row m holds the contiguous channels), which is exactly the MFMA
+//           operand order: LDS tiles are [m][64] and a lane fetches A[k = 2j + lane/32][i = lane%32] with a
+//           conflict-free ds_read_b32 (32 consecutive floats per lane group).
+//   dgrad   is the forward implicit-GEMM kernel (conv_igemm.hip) run on dY with the filter rotated by 180 degrees and
+//           its in/out channels swapped; strided layers first spread dY over the input grid (zero insertion,
+//           train_ops.hip). conv_pack_dgrad_weights builds that filter directly in the packed layout.
+#include "common.h"
+
+namespace orbit {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+struct WgradParams {
+    const float* x;
+    const float* dy;
+    float* partial;  // [splits][Cout][NC]
+    int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo;
+    int M, NC;
+    int co_tiles, n_tiles, splits, steps_per_split;
+};
+
+constexpr int WG_BKM = 32;  // rows of m per K-step
+
+// MODE 0: x NHWC, columns ordered (kh, kw, ci), Cin % 4 == 0.   MODE 1: x NCHW (stems), columns ordered (ci, kh, kw).
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
+    __shared__ __attribute__((aligned(16))) float As[2][WG_BKM][64];  // dY tile  [m][co]
+    __shared__ __attribute__((aligned(16))) float Bs[2][WG_BKM][64];  // X  tile  [m][col]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = (wave >> 1) * 32, wn = (wave & 1) * 32;
+
+    int bid = blockIdx.x;
+    const int n_tile = bid % p.n_tiles;
+    bid /= p.n_tiles;
+    const int co_tile = bid % p.co_tiles;
+    const int split = bid / p.co_tiles;
+    const int co0 = co_tile * 64, n0 = n_tile * 64;
+    const int m_begin = split * p.steps_per_split * WG_BKM;
+    const int m_end = min(p.M, m_begin + p.steps_per_split * WG_BKM);
+    const int nsteps = m_end > m_begin ? (m_end - m_begin + WG_BKM - 1) / WG_BKM : 0;
+    const int HoWo = p.Ho * p.Wo;
+
+    // ---- staging bookkeeping -------------------------------------------------------------------------------
+    // dY (and x in MODE 0): thread owns float4 column c4 of rows (tid >> 4) and (tid >> 4) + 16
+    const int c4 = tid & 15, lrow = tid >> 4;
+    const bool a_col_ok = co0 + c4 * 4 < p.Cout;
+    // MODE 0 column decode (fixed for the whole loop)
+    int kh0 = 0, kw0 = 0, ci0 = 0;
+    bool b_col_ok = false;
+    // MODE 1: thread owns scalar column (tid & 63) of rows (tid >> 6) + 4 i
+    int kh1 = 0, kw1 = 0, ci1 = 0;
+    bool b1_col_ok = false;
+    if (MODE == 0) {
+        const int n = n0 + c4 * 4;
+        b_col_ok = n < p.NC;
+        const int tap = b_col_ok ? n / p.Cin : 0;
+        ci0 = n - tap * p.Cin;
+        kh0 = tap / p.KW, kw0 = tap - kh0 * p.KW;
+    } else {
+        const int n = n0 + (tid & 63);
+        b1_col_ok = n < p.NC;
+        const int kk = p.KH * p.KW;
+        ci1 = b1_col_ok ? n / kk : 0;
+        const int r = n - ci1 * kk;
+        kh1 = r / p.KW, kw1 = r - kh1 * p.KW;
+    }
+
+    f32x4 a_stage[2];
+    f32x4 b_stage[2];  // MODE 1 reuses these as 8 scalars
+
+    auto load_step = [&](int step) {
+        const int mb = m_begin + step * WG_BKM;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int m = mb + lrow + 16 * i;
+            f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            if (m < m_end) {
+                if (a_col_ok) va = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + co0 + c4 * 4);
+                if (MODE == 0 && b_col_ok) {
+                    const int b = m / HoWo;
+                    const int r = m - b * HoWo;
+                    const int ho = r / p.Wo, wo = r - ho * p.Wo;
+                    const int hi = ho * p.stride - p.pad_t + kh0, wi = wo * p.stride - p.pad_l + kw0;
+                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                        vb = *reinterpret_cast<const f32x4*>(p.x + (((size_t)b * p.H + hi) * p.W + wi) * p.Cin + ci0);
+                }
+            }
+            a_stage[i] = va;
+            if (MODE == 0) b_stage[i] = vb;
+        }
+        if (MODE == 1) {
+            const size_t plane = (size_t)p.H * p.W;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int m = mb + (tid >> 6) + 4 * i;
+                float v = 0.f;
+                if (m < m_end && b1_col_ok) {
+                    const int b = m / HoWo;
+                    const int r = m - b * HoWo;
+                    const int ho = r / p.Wo, wo = r - ho * p.Wo;
+                    const int hi = ho * p.stride - p.pad_t + kh1, wi = wo * p.stride - p.pad_l + kw1;
+                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                        v = p.x[((size_t)b * p.Cin + ci1) * plane + (size_t)hi * p.W + wi];
+                }
+                b_stage[i >> 2][i & 3] = v;
+            }
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<f32x4*>(&As[buf][lrow + 16 * i][c4 * 4]) = a_stage[i];
+            if (MODE == 0) *reinterpret_cast<f32x4*>(&Bs[buf][lrow + 16 * i][c4 * 4]) = b_stage[i];
+        }
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) Bs[buf][(tid >> 6) + 4 * i][tid & 63] = b_stage[i >> 2][i & 3];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    if (nsteps > 0) {
+        load_step(0);
+        store_step(0);
+    }
+    __syncthreads();
+    for (int st = 0; st < nsteps; ++st) {
+        const int cur = st & 1;
+        if (st + 1 < nsteps) load_step(st + 1);
+#pragma unroll
+        for (int j = 0; j < WG_BKM / 2; ++j) {
+            const float a = As[cur][2 * j + lh][wm + l31];
+            const float b = Bs[cur][2 * j + lh][wn + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (st + 1 < nsteps) store_step(cur ^ 1);
+        __syncthreads();
+    }
+
+    // C/D layout: col (n) = lane & 31, row (co) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    const int n = n0 + wn + l31;
+    if (n < p.NC) {
+        float* out = p.partial + (size_t)split * p.Cout * p.NC;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wm + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            if (co < p.Cout) out[(size_t)co * p.NC + n] = acc[r];
+        }
+    }
+}
+
+// dw (OIHW) = sum over splits, in ascending split order; MODE 0 columns (kh,kw,ci) -> (ci,kh,kw)
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int Cout,
+                                                                int NC, int Cin, int KH, int KW, int mode,
+                                                                float* __restrict__ dw) {
+    const size_t total = (size_t)Cout * NC;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        float s = 0.f;
+        for (int k = 0; k < splits; ++k) s += partial[(size_t)k * total + i];
+        if (mode == 1) {
+            dw[i] = s;
+        } else {
+            const int co = (int)(i / NC), n = (int)(i % NC);
+            const int tap = n / Cin, ci = n - tap * Cin;
+            dw[((size_t)co * Cin + ci) * KH * KW + tap] = s;
+        }
+    }
+}
+
+// number of m-splits for a layer: enough blocks to fill the chip, at least 8 K-steps per block
+static void wgrad_geometry(int M, int Cout, int NC, int& co_tiles, int& n_tiles, int& splits, int& steps_per_split) {
+    co_tiles = cdiv(Cout, 64), n_tiles = cdiv(NC, 64);
+    const int tiles = co_tiles * n_tiles;
+    const int total_steps = cdiv(M, WG_BKM);
+    splits = cdiv(2048, tiles);
+    const int max_splits = total_steps >= 8 ? total_steps / 8 : 1;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    steps_per_split = cdiv(total_steps, splits);
+    splits = cdiv(total_steps, steps_per_split);
+}
+
+size_t conv_wgrad_scratch_floats(int B, int Cin, int Cout, int KH, int KW, int Ho, int Wo) {
+    int ct, nt, sp, sps;
+    const int NC = KH * KW * Cin;
+    wgrad_geometry(B * Ho * Wo, Cout, NC, ct, nt, sp, sps);
+    return (size_t)sp * Cout * NC;
+}
+
+int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
+                      int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float* scratch, hipStream_t s) {
+    ORBIT_REQUIRE(x && dy && dw_oihw && scratch, "conv_wgrad: null pointer");
+    ORBIT_REQUIRE(Cout % 4 == 0, "conv_wgrad: Cout %% 4 != 0");
+    ORBIT_REQUIRE(x_nchw || Cin % 4 == 0, "conv_wgrad: NHWC path needs Cin %% 4 == 0");
+    WgradParams p;
+    p.x = x, p.dy = dy, p.partial = scratch;
+    p.B = B, p.H = H, p.W = W, p.Cin = Cin, p.Cout = Cout, p.KH = KH, p.KW = KW, p.stride = stride;
+    p.pad_t = pad_t, p.pad_l = pad_l, p.Ho = Ho, p.Wo = Wo;
+    p.M = B * Ho * Wo, p.NC = KH * KW * Cin;
+    wgrad_geometry(p.M, Cout, p.NC, p.co_tiles, p.n_tiles, p.splits, p.steps_per_split);
+    const int grid = p.co_tiles * p.n_tiles * p.splits;
+    if (x_nchw) conv_wgrad_kernel<1><<<grid, 256, 0, s>>>(p);
+    else conv_wgrad_kernel<0><<<grid, 256, 0, s>>>(p);
+    ORBIT_LAUNCH_CHECK();
+    const size_t total = (size_t)Cout * p.NC;
+    int rblocks = (int)((total + 255) / 256);
+    if (rblocks > 4096) rblocks = 4096;
+    conv_wgrad_reduce_kernel<<<rblocks, 256, 0, s>>>(scratch, p.splits, Cout, p.NC, Cin, KH, KW, x_nchw ? 1 : 0, dw_oihw);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+// ---- dgrad filter: packed [n = ci][k = (kh', kw', co)] with value W[co][ci][KH-1-kh'][KW-1-kw'], in the geometry the
+// forward kernel expects for a convolution with Cin' = Cout, Cout' = Cin ------------------------------------------
+__global__ __launch_bounds__(256) void conv_pack_dgrad_kernel(const float* __restrict__ w, float* __restrict__ wp,
+                                                              int Cin, int Cout, int KH, int KW, int cin_pad, int KT,
+                                                              int cout_pad) {
+    const size_t total = (size_t)cout_pad * KT;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int n = (int)(i / KT), k = (int)(i % KT);  // n = ci (output channel of the dgrad conv)
+        const int tap = k / cin_pad, co = k % cin_pad;  // co = input channel of the dgrad conv
+        float v = 0.f;
+        if (n < Cin && tap < KH * KW && co < Cout) {
+            const int kh = KH - 1 - tap / KW, kw = KW - 1 - tap % KW;
+            v = w[(((size_t)co * Cin + n) * KH + kh) * KW + kw];
+        }
+        wp[i] = v;
+    }
+}
+
+size_t conv_dgrad_packed_floats(int Cin, int Cout, int KH, int KW) { return conv_packed_floats(Cout, Cin, KH, KW, 0); }
+
+int conv_pack_dgrad_weights(const float* w_oihw, float* w_packed, int Cin, int Cout, int KH, int KW, hipStream_t s) {
+    const ConvPackGeom g = conv_pack_geom(Cout, Cin, KH, KW, 0);
+    const size_t total = (size_t)g.cout_pad * g.kt;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    conv_pack_dgrad_kernel<<<blocks, 256, 0, s>>>(w_oihw, w_packed, Cin, Cout, KH, KW, g.cin_pad, g.kt, g.cout_pad);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+// dX (+= accumulate) of a convolution. `up` is scratch of B*H*W*Cout floats, only touched when stride > 1.
+int launch_conv_dgrad(const float* dy, const float* w_dgrad_packed, const float* accumulate, float* dx, float* up, int B,
+                      int H, int W, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo,
+                      hipStream_t s) {
+    ORBIT_REQUIRE(dy && w_dgrad_packed && dx, "conv_dgrad: null pointer");
+    ORBIT_REQUIRE(pad_t <= KH - 1 && pad_l <= KW - 1, "conv_dgrad: padding larger than the filter");
+    const float* src = dy;
+    int Hs = Ho, Ws = Wo;
+    if (stride > 1) {
+        ORBIT_REQUIRE(up, "conv_dgrad: strided layers need the upsampling scratch");
+        if (int rc = launch_upsample_zero(dy, up, B, H, W, Cout, stride, Ho, Wo, s)) return rc;
+        src = up, Hs = H, Ws = W;
+    }
+    ConvDesc d;
+    d.x = src, d.w_packed = w_dgrad_packed, d.y = dx, d.scale = nullptr, d.shift = nullptr;
+    d.residual = accumulate, d.gate = nullptr;
+    d.B = B, d.H = Hs, d.W = Ws, d.Cin = Cout, d.Cout = Cin, d.KH = KH, d.KW = KW, d.stride = 1;
+    d.pad_t = KH - 1 - pad_t, d.pad_l = KW - 1 - pad_l, d.Ho = H, d.Wo = W;
+    d.act = ORBIT_ACT_NONE, d.pool2 = 0, d.x_nchw = 0;
+    return launch_conv(d, s);
+}
+
+}  // namespace orbit
+
+using namespace orbit;
+
+extern "C" {
+
+int orbit_op_conv2d_wgrad(const float* x, int x_nchw, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
+                          int KH, int KW, int stride, int pad_top, int pad_left, int Ho, int Wo, orbit_stream_t stream) {
+    ORBIT_REQUIRE(x && dy && dw, "op_conv2d_wgrad: null pointer");
+    ORBIT_REQUIRE(B > 0 && KH > 0 && KW > 0 && stride > 0 && Ho > 0 && Wo > 0, "op_conv2d_wgrad: bad geometry");
+    hipStream_t s = (hipStream_t)stream;
+    float* scratch = nullptr;
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&scratch),
+                                   conv_wgrad_scratch_floats(B, Cin, Cout, KH, KW, Ho, Wo) * sizeof(float), s));
+    const int rc = launch_conv_wgrad(x, x_nchw, dy, dw, B, H, W, Cin, Cout, KH, KW, stride, pad_top, pad_left, Ho, Wo,
+                                     scratch, s);
+    (void)hipFreeAsync(scratch, s);
+    return rc;
+}
+
+int orbit_op_conv2d_dgrad(const float* dy, const float* w, const float* accumulate, float* dx, int B, int H, int W,
+                          int Cin, int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                          orbit_stream_t stream) {
+    ORBIT_REQUIRE(dy && w && dx, "op_conv2d_dgrad: null pointer");
+    ORBIT_REQUIRE(B > 0 && KH > 0 && KW > 0 && stride > 0 && Ho > 0 && Wo > 0, "op_conv2d_dgrad: bad geometry");
+    ORBIT_REQUIRE(Cin % 4 == 0 && Cout % 4 == 0, "op_conv2d_dgrad: Cin and Cout must be multiples of 4");
+    hipStream_t s = (hipStream_t)stream;
+    float* tmp = nullptr;
+    const size_t npack = conv_dgrad_packed_floats(Cin, Cout, KH, KW);
+    const size_t nup = stride > 1 ? (size_t)B * H * W * Cout : 0;
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), (npack + nup) * sizeof(float), s));
+    int rc = conv_pack_dgrad_weights(w, tmp, Cin, Cout, KH, KW, s);
+    if (rc == ORBIT_OK)
+        rc = launch_conv_dgrad(dy, tmp, accumulate, dx, stride > 1 ? tmp + npack : nullptr, B, H, W, Cin, Cout, KH, KW,
+                               stride, pad_top, pad_left, Ho, Wo, s);
+    (void)hipFreeAsync(tmp, s);
+    return rc;
+}
+
+}  // extern "C"

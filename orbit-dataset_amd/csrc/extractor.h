@@ -1,0 +1,201 @@
+// Plan / parameter structures of the network runtime, shared by the forward runtime (extractor.hip) and the
+// training runtime (extractor_train.hip).
+#pragma once
+#include <algorithm>
+#include <map>
+#include <string>
+#include <vector>
+#include "common.h"
+
+namespace orbit {
+
+struct Param {
+    std::string key;
+    size_t numel = 0, off = 0;  // offset (floats) into the parameter pool
+    bool loaded = false;
+};
+
+struct BNDesc {        // host side
+    int gamma, beta, mean, var;  // param indices
+    int conv_bias;               // param index or -1
+    int C;
+    float eps;
+    int film_slot;               // -1 if not FiLM-modulated
+    int film_off;                // offset inside film_gamma / film_beta
+    size_t fold_off;             // offset of this layer's scale/shift in the fold arrays
+    std::string name;
+};
+
+struct BNDev {         // device descriptor for the fold kernel
+    size_t gamma, beta, mean, var, conv_bias;  // pool offsets (conv_bias = SIZE_MAX if none)
+    size_t fold_off;
+    int C, film_off;                           // film_off < 0: not modulated
+    float eps;
+};
+
+enum OpKind { OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_AVGPOOL, OP_SE, OP_MBFRONT };
+
+struct Op {
+    OpKind kind;
+    int in = -1, out = -1, res = -1;  // buffer ids: -1 frames, 0..2 activations, 100 feats, 101 pooled, 102 gate
+    int H = 0, W = 0, Cin = 0, Cout = 0, KH = 1, KW = 1, stride = 1, pad_t = 0, pad_l = 0, Ho = 0, Wo = 0;
+    int act = ORBIT_ACT_NONE, pool2 = 0, x_nchw = 0, use_gate = 0;
+    int weight = -1, bias = -1, bn = -1;  // param / BN indices
+    size_t packed_off = 0;                // into the packed-weight pool
+    int se_w1 = -1, se_b1 = -1, se_w2 = -1, se_b2 = -1, R = 0;
+    int se_chunks = 0, se_hw = 0;  // squeeze-excite pooling partials produced by the preceding depthwise conv
+    int pool_partial = 0;          // depthwise: also emit the pooling partials
+    int weight2 = -1, bn2 = -1;    // OP_MBFRONT: depthwise weight (packed at packed_off) and its BatchNorm
+    int pool_k = 0, pool_pad = 0;
+};
+
+// folds eval-mode BatchNorm (+ per-task FiLM gamma/beta, + the bias of the preceding convolution) into scale/shift;
+// static: each runtime translation unit launches its own copy (no relocatable device code needed)
+static __global__ __launch_bounds__(256) void bn_fold_all_kernel(const BNDev* __restrict__ descs,
+                                                          const float* __restrict__ pool,
+                                                          const float* __restrict__ film_gamma,
+                                                          const float* __restrict__ film_beta,
+                                                          float* __restrict__ scale, float* __restrict__ shift) {
+    const BNDev d = descs[blockIdx.x];
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < d.C; c += gridDim.y * 256) {
+        const bool film = film_gamma != nullptr && d.film_off >= 0;
+        const float g = film ? film_gamma[d.film_off + c] : pool[d.gamma + c];
+        const float b = film ? film_beta[d.film_off + c] : pool[d.beta + c];
+        const float sc = g / sqrtf(pool[d.var + c] + d.eps);
+        const float cb = d.conv_bias != (size_t)-1 ? pool[d.conv_bias + c] : 0.f;
+        scale[d.fold_off + c] = sc;
+        shift[d.fold_off + c] = b + (cb - pool[d.mean + c]) * sc;
+    }
+}
+
+
+}  // namespace orbit
+
+struct orbit_extractor;
+namespace orbit {
+void extractor_train_invalidate(const orbit_extractor* fe);  // parameters changed: training-side repacks are stale
+void extractor_train_release(const orbit_extractor* fe);     // plan is being destroyed
+}  // namespace orbit
+
+using namespace orbit;  // internal header: only included by the two runtime translation units
+
+struct orbit_extractor {
+    std::string name;
+    int H = 0, W = 0, out_size = 0;
+    std::vector<Param> params;
+    std::map<std::string, int> index;
+    std::vector<BNDesc> bns;
+    std::vector<Op> ops;
+    std::vector<int> film_slots;  // BN indices in module-traversal order
+    int film_size = 0;
+    size_t pool_floats = 0, packed_floats = 0, fold_floats = 0;
+    size_t buf_elems[3] = {0, 0, 0};  // per-frame element counts of the rotating activation buffers
+    int max_se_c = 0;
+    size_t max_partial = 0;  // floats per frame of the SE pooling-partial buffer
+    double macs = 0;
+    float* d_pool = nullptr;
+    float* d_packed = nullptr;
+    float* d_fold = nullptr;  // static (non-FiLM) scale | shift
+    BNDev* d_bn = nullptr;
+    std::vector<BNDev> bn_dev;  // host copy of the fold descriptors
+    bool finalized = false;
+
+    // HIP-graph cache: one instantiated graph per distinct (pointers, batch, stream) tuple of forward(). A forward is
+    // 25-90 dependent launches; replaying them as one graph launch takes the host out of the loop (on a slow or busy
+    // host the eager launch sequence, not the GPU, bounded small workloads).
+    struct GraphKey {
+        const void *frames, *gamma, *beta, *feats, *ws, *stream;
+        int B;
+        bool operator==(const GraphKey& o) const {
+            return frames == o.frames && gamma == o.gamma && beta == o.beta && feats == o.feats && ws == o.ws &&
+                   stream == o.stream && B == o.B;
+        }
+    };
+    struct GraphEntry {
+        GraphKey key;
+        hipGraphExec_t exec = nullptr;  // nullptr: seen once (ran eagerly), capture on the next sight
+        unsigned long stamp = 0;
+    };
+    std::vector<GraphEntry> graphs;
+    unsigned long graph_clock = 0;
+    double eager_us_per_launch = 0.0;  // running average of the HOST cost of one eager kernel launch (option graph=2)
+    int eager_samples = 0;
+    hipStream_t cap_stream = nullptr;  // private non-default stream used only to CAPTURE (the legacy default stream,
+                                       // torch's default, cannot be captured); graphs are launched on the caller's
+    void clear_graphs() {
+        for (GraphEntry& g : graphs)
+            if (g.exec) (void)hipGraphExecDestroy(g.exec);
+        graphs.clear();
+    }
+
+    // device buffers are created on first use so that a plan can be built and inspected (state_dict keys,
+    // FiLM slots, workspace size, MACs) on a host without a GPU
+    int ensure_device() {
+        if (d_pool) return ORBIT_OK;
+        hipError_t e = hipMalloc(reinterpret_cast<void**>(&d_pool), pool_floats * sizeof(float));
+        if (e == hipSuccess) e = hipMemset(d_pool, 0, pool_floats * sizeof(float));
+        if (e == hipSuccess)
+            e = hipMalloc(reinterpret_cast<void**>(&d_packed), std::max<size_t>(packed_floats, 4) * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_fold), 2 * fold_floats * sizeof(float));
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&d_bn), bn_dev.size() * sizeof(BNDev));
+        if (e == hipSuccess)
+            e = hipMemcpy(d_bn, bn_dev.data(), bn_dev.size() * sizeof(BNDev), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {
+            (void)hipFree(d_pool), (void)hipFree(d_packed), (void)hipFree(d_fold), (void)hipFree(d_bn);
+            d_pool = d_packed = d_fold = nullptr, d_bn = nullptr;
+            (void)hipGetLastError();
+            return set_err(ORBIT_ERR_HIP, "extractor: device allocation failed: %s", hipGetErrorString(e));
+        }
+        return ORBIT_OK;
+    }
+
+    int add_param(const std::string& key, size_t numel) {
+        Param p;
+        p.key = key, p.numel = numel, p.off = pool_floats;
+        pool_floats += (numel + 3) / 4 * 4;
+        params.push_back(p);
+        index[key] = (int)params.size() - 1;
+        return (int)params.size() - 1;
+    }
+    int add_bn(const std::string& prefix, int C, float eps, bool film, int conv_bias = -1) {
+        BNDesc b;
+        b.name = prefix;
+        b.gamma = add_param(prefix + ".weight", C);
+        b.beta = add_param(prefix + ".bias", C);
+        b.mean = add_param(prefix + ".running_mean", C);
+        b.var = add_param(prefix + ".running_var", C);
+        b.conv_bias = conv_bias, b.C = C, b.eps = eps;
+        b.film_slot = -1, b.film_off = -1;
+        b.fold_off = fold_floats;
+        fold_floats += (size_t)(C + 3) / 4 * 4;
+        if (film) {
+            b.film_slot = (int)film_slots.size();
+            b.film_off = film_size;
+            film_size += C;
+            film_slots.push_back((int)bns.size());
+        }
+        bns.push_back(b);
+        return (int)bns.size() - 1;
+    }
+    void note_buf(int id, size_t elems) {
+        if (id >= 0 && id < 3) buf_elems[id] = std::max(buf_elems[id], elems);
+    }
+    // dense conv + BN (+act) (+residual) (+gate) (+pool2); returns output dims through Ho/Wo
+    void add_conv(const std::string& wkey, int bn, int in, int out, int res, int H_, int W_, int Cin, int Cout,
+                  int K, int stride, int pad_t, int pad_l, int Ho, int Wo, int act, int pool2, int x_nchw,
+                  int use_gate, int bias = -1) {
+        Op o;
+        o.kind = OP_CONV, o.in = in, o.out = out, o.res = res;
+        o.H = H_, o.W = W_, o.Cin = Cin, o.Cout = Cout, o.KH = K, o.KW = K, o.stride = stride;
+        o.pad_t = pad_t, o.pad_l = pad_l, o.Ho = Ho, o.Wo = Wo, o.act = act, o.pool2 = pool2;
+        o.x_nchw = x_nchw, o.use_gate = use_gate, o.bn = bn, o.bias = bias;
+        o.weight = index.count(wkey) ? index[wkey] : add_param(wkey, (size_t)Cout * Cin * K * K);
+        o.packed_off = packed_floats;
+        packed_floats += conv_packed_floats(Cin, Cout, K, K, x_nchw);
+        const int oh = pool2 ? Ho / 2 : Ho, ow = pool2 ? Wo / 2 : Wo;
+        note_buf(out, (size_t)oh * ow * Cout);
+        macs += (double)(pool2 ? oh * 2 : Ho) * (pool2 ? ow * 2 : Wo) * Cout * Cin * K * K;
+        ops.push_back(o);
+    }
+};
+

@@ -1,0 +1,471 @@
+// Training runtime of the network plans: forward with a tape (raw convolution outputs + activations + pooling
+// argmax), train- or eval-mode BatchNorm, and the reverse pass producing parameter gradients (flat, in the layout of
+// the parameter pool), FiLM gamma/beta gradients and nothing else (frames need no gradient).
+//
+// Reference: the graph autograd records for model/few_shot_recognisers.py:99-122 (_get_features with grad enabled),
+// :345-356 (_get_task_embedding on the LITE subset) and walks in single-step-learner.py:234 (loss.backward()).
+// BatchNorm mode follows :176-183: batch statistics (and running-stat updates, also on the no-grad LITE cache
+// passes) iff the extractor is being learned; the set encoder always normalises with running statistics.
+//
+// Generic over the plans made of OP_CONV (+BN, ReLU, residual, fused 2x2 pool) / OP_MAXPOOL / OP_AVGPOOL, i.e.
+// resnet18 and the set encoder. efficientnet_b0 (depthwise / squeeze-excite backward) is the next widening step.
+#include "extractor.h"
+
+namespace orbit {
+
+__global__ __launch_bounds__(256) void bn_eval_stats_kernel(const BNDev* __restrict__ descs,
+                                                            const float* __restrict__ pool, float* __restrict__ mean,
+                                                            float* __restrict__ invstd) {
+    const BNDev d = descs[blockIdx.x];
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < d.C; c += gridDim.y * 256) {
+        const float cb = d.conv_bias != (size_t)-1 ? pool[d.conv_bias + c] : 0.f;
+        mean[d.fold_off + c] = pool[d.mean + c] - cb;  // xhat = (y_conv - mean') * invstd
+        invstd[d.fold_off + c] = 1.0f / sqrtf(pool[d.var + c] + d.eps);
+    }
+}
+
+// dst[0][fold_off + c] = running_mean, dst[1][fold_off + c] = running_var
+__global__ __launch_bounds__(256) void bn_export_kernel(const BNDev* __restrict__ descs, const float* __restrict__ pool,
+                                                        float* __restrict__ dst, size_t fold_floats) {
+    const BNDev d = descs[blockIdx.x];
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < d.C; c += gridDim.y * 256) {
+        dst[d.fold_off + c] = pool[d.mean + c];
+        dst[fold_floats + d.fold_off + c] = pool[d.var + c];
+    }
+}
+
+struct TapeLayout {
+    std::vector<size_t> y, a, p, idx;  // byte offsets per op ((size_t)-1: none)
+    size_t mean = 0, invstd = 0, scale = 0, shift = 0, partial = 0, total = 0;
+};
+
+static const size_t NONE = (size_t)-1;
+
+static bool plan_trainable(const orbit_extractor* fe) {
+    for (const Op& o : fe->ops)
+        if (o.kind != OP_CONV && o.kind != OP_MAXPOOL && o.kind != OP_AVGPOOL) return false;
+    for (const Op& o : fe->ops)
+        if (o.kind == OP_CONV && (o.bn < 0 || o.use_gate || (o.act != ORBIT_ACT_NONE && o.act != ORBIT_ACT_RELU)))
+            return false;
+    return true;
+}
+
+static size_t max_bn_partial_floats(const orbit_extractor* fe, int B) {
+    size_t m = 4;
+    for (const Op& o : fe->ops)
+        if (o.kind == OP_CONV)
+            m = std::max(m, (size_t)bn_reduce_blocks(B * o.Ho * o.Wo, o.Cout) * 2 * o.Cout + 3 * (size_t)o.Cout);
+    return m;
+}
+
+static TapeLayout tape_layout(const orbit_extractor* fe, int B) {
+    TapeLayout L;
+    const size_t n = fe->ops.size();
+    L.y.assign(n, NONE), L.a.assign(n, NONE), L.p.assign(n, NONE), L.idx.assign(n, NONE);
+    size_t off = 0;
+    auto take = [&](size_t bytes) {
+        const size_t o = off;
+        off += align_up(bytes, 256);
+        return o;
+    };
+    for (size_t i = 0; i < n; ++i) {
+        const Op& o = fe->ops[i];
+        if (o.kind == OP_CONV) {
+            const size_t e = (size_t)B * o.Ho * o.Wo * o.Cout;
+            L.y[i] = take(e * 4), L.a[i] = take(e * 4);
+            if (o.pool2) {
+                const size_t pe = (size_t)B * (o.Ho / 2) * (o.Wo / 2) * o.Cout;
+                L.p[i] = take(pe * 4), L.idx[i] = take(pe);
+            }
+        } else if (o.kind == OP_MAXPOOL) {
+            const size_t pe = (size_t)B * o.Ho * o.Wo * o.Cout;
+            L.p[i] = take(pe * 4), L.idx[i] = take(pe);
+        }
+    }
+    L.mean = take(fe->fold_floats * 4), L.invstd = take(fe->fold_floats * 4);
+    L.scale = take(fe->fold_floats * 4), L.shift = take(fe->fold_floats * 4);
+    L.partial = take(max_bn_partial_floats(fe, B) * 4);
+    L.total = off;
+    return L;
+}
+
+// which op produced the tensor an op reads (index into ops, -1 = the frames)
+struct Producers {
+    std::vector<int> in, res;
+};
+static Producers producers(const orbit_extractor* fe) {
+    Producers P;
+    std::map<int, int> last;  // buffer id -> op index
+    for (size_t i = 0; i < fe->ops.size(); ++i) {
+        const Op& o = fe->ops[i];
+        P.in.push_back(o.in >= 0 && last.count(o.in) ? last[o.in] : -1);
+        P.res.push_back(o.res >= 0 && last.count(o.res) ? last[o.res] : -1);
+        last[o.out] = (int)i;
+    }
+    return P;
+}
+
+struct BwdLayout {
+    static const int NSLOTS = 8;
+    size_t slot_bytes = 0, slots = 0, up = 0, wgrad = 0, partial = 0, total = 0;
+};
+static BwdLayout bwd_layout(const orbit_extractor* fe, int B) {
+    BwdLayout L;
+    size_t slot = 4, up = 4, wg = 4;
+    for (const Op& o : fe->ops) {
+        if (o.kind == OP_CONV) {
+            slot = std::max(slot, (size_t)B * o.Ho * o.Wo * o.Cout);
+            if (!o.x_nchw) slot = std::max(slot, (size_t)B * o.H * o.W * o.Cin);
+            if (o.stride > 1 && !o.x_nchw) up = std::max(up, (size_t)B * o.H * o.W * o.Cout);
+            wg = std::max(wg, conv_wgrad_scratch_floats(B, o.Cin, o.Cout, o.KH, o.KW, o.Ho, o.Wo));
+        } else if (o.kind == OP_MAXPOOL || o.kind == OP_AVGPOOL) {
+            slot = std::max(slot, (size_t)B * o.H * o.W * o.Cin);
+        }
+    }
+    size_t off = 0;
+    L.slot_bytes = align_up(slot * 4, 256);
+    L.slots = off, off += L.slot_bytes * BwdLayout::NSLOTS;
+    L.up = off, off += align_up(up * 4, 256);
+    L.wgrad = off, off += align_up(wg * 4, 256);
+    L.partial = off, off += align_up(max_bn_partial_floats(fe, B) * 4, 256);
+    L.total = off;
+    return L;
+}
+
+}  // namespace orbit
+
+using namespace orbit;
+
+// lazily built training-side device state of a plan
+struct orbit_train_state {
+    float* d_dgrad = nullptr;  // dgrad-packed filters
+    std::vector<size_t> dgrad_off;
+    size_t dgrad_floats = 0;
+    bool packed = false;
+};
+
+static std::map<const orbit_extractor*, orbit_train_state>& train_states() {
+    static std::map<const orbit_extractor*, orbit_train_state> m;
+    return m;
+}
+
+namespace orbit {
+void extractor_train_invalidate(const orbit_extractor* fe) {  // parameters changed: repack on next use
+    auto it = train_states().find(fe);
+    if (it != train_states().end()) it->second.packed = false;
+}
+void extractor_train_release(const orbit_extractor* fe) {
+    auto it = train_states().find(fe);
+    if (it == train_states().end()) return;
+    (void)hipFree(it->second.d_dgrad);
+    train_states().erase(it);
+}
+}  // namespace orbit
+
+static int ensure_dgrad_filters(orbit_extractor* fe, orbit_train_state** out, hipStream_t s) {
+    orbit_train_state& st = train_states()[fe];
+    if (st.dgrad_off.empty()) {
+        st.dgrad_off.assign(fe->ops.size(), NONE);
+        size_t off = 0;
+        for (size_t i = 0; i < fe->ops.size(); ++i) {
+            const Op& o = fe->ops[i];
+            if (o.kind != OP_CONV || o.x_nchw) continue;
+            st.dgrad_off[i] = off;
+            off += conv_dgrad_packed_floats(o.Cin, o.Cout, o.KH, o.KW);
+        }
+        st.dgrad_floats = std::max<size_t>(off, 4);
+        ORBIT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.d_dgrad), st.dgrad_floats * sizeof(float)));
+    }
+    if (!st.packed) {
+        for (size_t i = 0; i < fe->ops.size(); ++i) {
+            const Op& o = fe->ops[i];
+            if (st.dgrad_off[i] == NONE) continue;
+            if (int rc = conv_pack_dgrad_weights(fe->d_pool + fe->params[o.weight].off, st.d_dgrad + st.dgrad_off[i],
+                                                 o.Cin, o.Cout, o.KH, o.KW, s))
+                return rc;
+        }
+        st.packed = true;
+    }
+    *out = &st;
+    return ORBIT_OK;
+}
+
+extern "C" {
+
+int orbit_extractor_supports_training(const orbit_extractor_t* fe) { return fe && plan_trainable(fe) ? 1 : 0; }
+
+size_t orbit_extractor_tape_bytes(const orbit_extractor_t* fe, int B) {
+    if (!fe || B <= 0 || !plan_trainable(fe)) return 0;
+    return tape_layout(fe, B).total;
+}
+
+size_t orbit_extractor_backward_workspace_bytes(const orbit_extractor_t* fe, int B) {
+    if (!fe || B <= 0 || !plan_trainable(fe)) return 0;
+    return bwd_layout(fe, B).total;
+}
+
+size_t orbit_extractor_grad_floats(const orbit_extractor_t* fe) { return fe ? fe->pool_floats : 0; }
+size_t orbit_extractor_param_offset(const orbit_extractor_t* fe, int i) {
+    return (fe && i >= 0 && i < (int)fe->params.size()) ? fe->params[i].off : 0;
+}
+size_t orbit_extractor_bn_stat_floats(const orbit_extractor_t* fe) { return fe ? fe->fold_floats : 0; }
+
+int orbit_extractor_export_bn_stats(orbit_extractor_t* fe, float* dst, orbit_stream_t stream) {
+    ORBIT_REQUIRE(fe && dst, "extractor_export_bn_stats: null pointer");
+    if (!fe->finalized) return set_err(ORBIT_ERR_STATE, "extractor_export_bn_stats: plan is not finalized");
+    bn_export_kernel<<<dim3((unsigned)fe->bns.size(), 2), 256, 0, (hipStream_t)stream>>>(fe->d_bn, fe->d_pool, dst,
+                                                                                        fe->fold_floats);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int orbit_extractor_train_forward(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
+                                  const float* film_beta, int bn_train, float momentum, float* feats, void* tape,
+                                  size_t tape_bytes, orbit_stream_t stream) {
+    ORBIT_REQUIRE(fe && frames && feats && tape, "extractor_train_forward: null pointer");
+    ORBIT_REQUIRE(B > 0, "extractor_train_forward: empty batch");
+    if (!fe->finalized) return set_err(ORBIT_ERR_STATE, "extractor_train_forward: call orbit_extractor_finalize first");
+    if (!plan_trainable(fe))
+        return set_err(ORBIT_ERR_STATE, "extractor_train_forward: the %s plan has no training path yet", fe->name.c_str());
+    ORBIT_REQUIRE((film_gamma == nullptr) == (film_beta == nullptr),
+                  "extractor_train_forward: film_gamma and film_beta must be given together");
+    const TapeLayout L = tape_layout(fe, B);
+    ORBIT_REQUIRE(tape_bytes >= L.total, "extractor_train_forward: tape too small (%zu < %zu bytes)", tape_bytes, L.total);
+    ORBIT_REQUIRE(((uintptr_t)tape & 255) == 0, "extractor_train_forward: tape must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    char* tp = static_cast<char*>(tape);
+    auto fl = [&](size_t off) { return reinterpret_cast<float*>(tp + off); };
+    float *mean = fl(L.mean), *invstd = fl(L.invstd), *scale = fl(L.scale), *shift = fl(L.shift);
+    const bool film = film_gamma && fe->film_size > 0;
+    if (!bn_train) {
+        dim3 grid((unsigned)fe->bns.size(), 2);
+        bn_fold_all_kernel<<<grid, 256, 0, s>>>(fe->d_bn, fe->d_pool, film ? film_gamma : nullptr,
+                                                film ? film_beta : nullptr, scale, shift);
+        ORBIT_LAUNCH_CHECK();
+        bn_eval_stats_kernel<<<grid, 256, 0, s>>>(fe->d_bn, fe->d_pool, mean, invstd);
+        ORBIT_LAUNCH_CHECK();
+    }
+    std::map<int, const float*> cur;  // buffer id -> tensor currently held
+    cur[-1] = frames;
+    for (size_t i = 0; i < fe->ops.size(); ++i) {
+        const Op& o = fe->ops[i];
+        int rc = ORBIT_OK;
+        if (o.kind == OP_CONV) {
+            const BNDesc& bn = fe->bns[o.bn];
+            ConvDesc d;
+            d.x = cur[o.in], d.w_packed = fe->d_packed + o.packed_off, d.y = fl(L.y[i]);
+            d.scale = d.shift = d.residual = d.gate = nullptr;
+            d.B = B, d.H = o.H, d.W = o.W, d.Cin = o.Cin, d.Cout = o.Cout, d.KH = o.KH, d.KW = o.KW;
+            d.stride = o.stride, d.pad_t = o.pad_t, d.pad_l = o.pad_l, d.Ho = o.Ho, d.Wo = o.Wo;
+            d.act = ORBIT_ACT_NONE, d.pool2 = 0, d.x_nchw = o.x_nchw;
+            rc = launch_conv(d, s);
+            if (rc != ORBIT_OK) return rc;
+            const int M = B * o.Ho * o.Wo;
+            if (bn_train) {
+                const bool fm = film && bn.film_off >= 0;
+                rc = launch_bn_stats(d.y, M, o.Cout, bn.eps, momentum,
+                                     fm ? film_gamma + bn.film_off : fe->d_pool + fe->params[bn.gamma].off,
+                                     fm ? film_beta + bn.film_off : fe->d_pool + fe->params[bn.beta].off,
+                                     bn.conv_bias >= 0 ? fe->d_pool + fe->params[bn.conv_bias].off : nullptr,
+                                     mean + bn.fold_off, invstd + bn.fold_off, scale + bn.fold_off, shift + bn.fold_off,
+                                     fe->d_pool + fe->params[bn.mean].off, fe->d_pool + fe->params[bn.var].off,
+                                     fl(L.partial), s);
+                if (rc != ORBIT_OK) return rc;
+            }
+            rc = launch_scale_shift_act(d.y, scale + bn.fold_off, shift + bn.fold_off,
+                                        o.res >= 0 ? cur[o.res] : nullptr, o.act, (size_t)M, o.Cout, fl(L.a[i]), s);
+            if (rc != ORBIT_OK) return rc;
+            if (o.pool2) {
+                rc = launch_maxpool_idx(fl(L.a[i]), fl(L.p[i]), reinterpret_cast<uint8_t*>(tp + L.idx[i]), B, o.Ho, o.Wo,
+                                        o.Cout, 2, 2, 0, o.Ho / 2, o.Wo / 2, s);
+                cur[o.out] = fl(L.p[i]);
+            } else {
+                cur[o.out] = fl(L.a[i]);
+            }
+        } else if (o.kind == OP_MAXPOOL) {
+            rc = launch_maxpool_idx(cur[o.in], fl(L.p[i]), reinterpret_cast<uint8_t*>(tp + L.idx[i]), B, o.H, o.W, o.Cin,
+                                    o.pool_k, o.stride, o.pool_pad, o.Ho, o.Wo, s);
+            cur[o.out] = fl(L.p[i]);
+        } else {  // OP_AVGPOOL
+            rc = launch_avgpool(cur[o.in], feats, B, o.H * o.W, o.Cin, s);
+        }
+        if (rc != ORBIT_OK) return rc;
+    }
+    if (bn_train) {
+        // the forward plans fold the running statistics at finalize time: refresh the static fold and drop graphs
+        dim3 grid((unsigned)fe->bns.size(), 2);
+        bn_fold_all_kernel<<<grid, 256, 0, s>>>(fe->d_bn, fe->d_pool, nullptr, nullptr, fe->d_fold,
+                                                fe->d_fold + fe->fold_floats);
+        ORBIT_LAUNCH_CHECK();
+    }
+    return ORBIT_OK;
+}
+
+int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
+                             const float* film_beta, int bn_train, const float* dfeats, const void* tape,
+                             size_t tape_bytes, float* param_grads, float* dfilm_gamma, float* dfilm_beta,
+                             void* workspace, size_t workspace_bytes, orbit_stream_t stream) {
+    ORBIT_REQUIRE(fe && frames && dfeats && tape && workspace, "extractor_backward: null pointer");
+    ORBIT_REQUIRE(B > 0, "extractor_backward: empty batch");
+    if (!fe->finalized) return set_err(ORBIT_ERR_STATE, "extractor_backward: call orbit_extractor_finalize first");
+    if (!plan_trainable(fe))
+        return set_err(ORBIT_ERR_STATE, "extractor_backward: the %s plan has no training path yet", fe->name.c_str());
+    ORBIT_REQUIRE((dfilm_gamma == nullptr) == (dfilm_beta == nullptr),
+                  "extractor_backward: dfilm_gamma and dfilm_beta must be given together");
+    const bool film = film_gamma && film_beta && fe->film_size > 0;
+    ORBIT_REQUIRE(!dfilm_gamma || film, "extractor_backward: FiLM gradients requested without FiLM inputs");
+    if (!param_grads && !dfilm_gamma) return ORBIT_OK;  // nothing to compute
+    const TapeLayout L = tape_layout(fe, B);
+    const BwdLayout W = bwd_layout(fe, B);
+    ORBIT_REQUIRE(tape_bytes >= L.total, "extractor_backward: tape too small");
+    ORBIT_REQUIRE(workspace_bytes >= W.total, "extractor_backward: workspace too small (%zu < %zu bytes)", workspace_bytes,
+                  W.total);
+    ORBIT_REQUIRE(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)tape & 255) == 0,
+                  "extractor_backward: tape and workspace must be 256-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    orbit_train_state* st = nullptr;
+    if (int rc = ensure_dgrad_filters(fe, &st, s)) return rc;
+
+    const char* tp = static_cast<const char*>(tape);
+    auto tf = [&](size_t off) { return reinterpret_cast<const float*>(tp + off); };
+    char* ws = static_cast<char*>(workspace);
+    float* up = reinterpret_cast<float*>(ws + W.up);
+    float* wgrad_scratch = reinterpret_cast<float*>(ws + W.wgrad);
+    float* partial = reinterpret_cast<float*>(ws + W.partial);
+    const float *mean = tf(L.mean), *invstd = tf(L.invstd);
+
+    const Producers P = producers(fe);
+    const int n = (int)fe->ops.size();
+    // the earliest op whose backward yields something that was asked for
+    int first_needed = n;
+    for (int i = 0; i < n && first_needed == n; ++i) {
+        const Op& o = fe->ops[i];
+        if (o.kind != OP_CONV) continue;
+        if (param_grads || (dfilm_gamma && fe->bns[o.bn].film_off >= 0)) first_needed = i;
+    }
+
+    bool used[BwdLayout::NSLOTS] = {false};
+    std::vector<int> grad_slot(n, -1);  // gradient w.r.t. the OUTPUT tensor of op i
+    auto slot_ptr = [&](int k) { return reinterpret_cast<float*>(ws + W.slots + (size_t)k * W.slot_bytes); };
+    auto alloc = [&]() {
+        for (int k = 0; k < BwdLayout::NSLOTS; ++k)
+            if (!used[k]) {
+                used[k] = true;
+                return k;
+            }
+        return -1;
+    };
+    auto release = [&](int k) {
+        if (k >= 0) used[k] = false;
+    };
+    auto out_tensor = [&](int i) -> const float* {  // forward output of op i
+        if (i < 0) return frames;
+        const Op& o = fe->ops[i];
+        if (o.kind == OP_CONV) return o.pool2 ? tf(L.p[i]) : tf(L.a[i]);
+        return tf(L.p[i]);
+    };
+#define SLOT_OR_FAIL(var)                                                                      \
+    const int var = alloc();                                                                   \
+    if (var < 0) return set_err(ORBIT_ERR_STATE, "extractor_backward: gradient slots exhausted")
+
+    for (int i = n - 1; i >= first_needed; --i) {
+        const Op& o = fe->ops[i];
+        int rc = ORBIT_OK;
+        if (o.kind == OP_AVGPOOL) {
+            const int src = P.in[i];
+            if (src < first_needed) continue;
+            ORBIT_REQUIRE(grad_slot[src] < 0, "extractor_backward: unexpected fan-out into the global pool");
+            SLOT_OR_FAIL(k);
+            rc = launch_avgpool_bwd(dfeats, slot_ptr(k), B, o.H * o.W, o.Cin, s);
+            grad_slot[src] = k;
+        } else if (o.kind == OP_MAXPOOL) {
+            const int src = P.in[i];
+            const int g = grad_slot[i];
+            if (g < 0) continue;
+            if (src >= first_needed) {
+                ORBIT_REQUIRE(grad_slot[src] < 0, "extractor_backward: unexpected fan-out into a max-pool");
+                SLOT_OR_FAIL(k);
+                rc = launch_maxpool_bwd(slot_ptr(g), reinterpret_cast<const uint8_t*>(tp + L.idx[i]), slot_ptr(k), B, o.H,
+                                        o.W, o.Cin, o.pool_k, o.stride, o.pool_pad, o.Ho, o.Wo, s);
+                grad_slot[src] = k;
+            }
+            release(g), grad_slot[i] = -1;
+        } else {  // OP_CONV
+            int g = grad_slot[i];
+            if (g < 0) continue;  // no gradient reaches this op
+            const BNDesc& bn = fe->bns[o.bn];
+            const int M = B * o.Ho * o.Wo;
+            if (o.pool2) {
+                SLOT_OR_FAIL(k);
+                rc = launch_maxpool_bwd(slot_ptr(g), reinterpret_cast<const uint8_t*>(tp + L.idx[i]), slot_ptr(k), B, o.Ho,
+                                        o.Wo, o.Cout, 2, 2, 0, o.Ho / 2, o.Wo / 2, s);
+                if (rc != ORBIT_OK) return rc;
+                release(g), g = k;
+            }
+            // BatchNorm (+ReLU, + residual fan-out)
+            const bool fm = film && bn.film_off >= 0;
+            const float* gamma = fm ? film_gamma + bn.film_off : fe->d_pool + fe->params[bn.gamma].off;
+            float *dgam = nullptr, *dbet = nullptr, *dbias = nullptr;
+            if (fm) {
+                if (dfilm_gamma) dgam = dfilm_gamma + bn.film_off, dbet = dfilm_beta + bn.film_off;
+            } else if (param_grads) {
+                dgam = param_grads + fe->params[bn.gamma].off, dbet = param_grads + fe->params[bn.beta].off;
+            }
+            if (param_grads && bn.conv_bias >= 0) dbias = param_grads + fe->params[bn.conv_bias].off;
+            float* dres = nullptr;
+            int dres_acc = 0;
+            const int rsrc = o.res >= 0 ? P.res[i] : -1;
+            if (rsrc >= first_needed) {
+                if (grad_slot[rsrc] >= 0) {
+                    dres = slot_ptr(grad_slot[rsrc]), dres_acc = 1;
+                } else {
+                    SLOT_OR_FAIL(k);
+                    grad_slot[rsrc] = k, dres = slot_ptr(k);
+                }
+            }
+            const int src = P.in[i];
+            const bool need_dx = src >= first_needed;
+            const bool need_dy = need_dx || param_grads != nullptr;
+            int kdy = -1;
+            if (need_dy) {
+                kdy = alloc();
+                if (kdy < 0) return set_err(ORBIT_ERR_STATE, "extractor_backward: gradient slots exhausted");
+            }
+            // partial holds [blocks][2][C] followed by the 3*C apply coefficients
+            float* coef = partial + (size_t)bn_reduce_blocks(M, o.Cout) * 2 * o.Cout;
+            rc = launch_bn_backward(slot_ptr(g), tf(L.a[i]), tf(L.y[i]), mean + bn.fold_off, invstd + bn.fold_off, gamma,
+                                    bn_train, o.act, M, o.Cout, need_dy ? slot_ptr(kdy) : nullptr, dres, dres_acc, dgam,
+                                    dbet, dbias, partial, coef, s);
+            if (rc != ORBIT_OK) return rc;
+            if (!need_dy && dres) {
+                // reductions only, but the residual branch still needs g: rerun the apply pass is not available
+                // without dy, so materialise it through a scratch slot
+                return set_err(ORBIT_ERR_STATE, "extractor_backward: residual fan-out without a data gradient");
+            }
+            release(g), grad_slot[i] = -1;
+            if (param_grads) {
+                rc = launch_conv_wgrad(out_tensor(src), o.x_nchw, slot_ptr(kdy), param_grads + fe->params[o.weight].off, B,
+                                       o.H, o.W, o.Cin, o.Cout, o.KH, o.KW, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo,
+                                       wgrad_scratch, s);
+                if (rc != ORBIT_OK) return rc;
+            }
+            if (need_dx) {
+                const float* acc = nullptr;
+                if (grad_slot[src] < 0) {
+                    SLOT_OR_FAIL(k);
+                    grad_slot[src] = k;
+                } else {
+                    acc = slot_ptr(grad_slot[src]);
+                }
+                rc = launch_conv_dgrad(slot_ptr(kdy), st->d_dgrad + st->dgrad_off[i], acc, slot_ptr(grad_slot[src]), up, B,
+                                       o.H, o.W, o.Cin, o.Cout, o.KH, o.KW, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+            }
+            release(kdy);
+        }
+        if (rc != ORBIT_OK) return rc;
+    }
+#undef SLOT_OR_FAIL
+    return ORBIT_OK;
+}
+
+}  // extern "C"

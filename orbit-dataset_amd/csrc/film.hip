@@ -92,6 +92,105 @@ __global__ __launch_bounds__(256) void film_l2_kernel(const GenDesc* __restrict_
     if (threadIdx.x == 0) l2[0] = part[0];
 }
 
+// Backward of filmgen_kernel + film_l2_kernel for one generator per block. Recomputes the hidden activations (4 K
+// MACs) instead of taping them. grads has the layout of the parameter pool (w1 b1 ln_w ln_b w2 b2 reg; the `init`
+// slot is not a parameter and is left untouched); dz_partial[gen][z_dim] is summed by filmgen_dz_kernel in generator
+// order. Reference: autograd through model/feature_adapters.py:66-78 and model/mlps.py:52-63.
+__global__ __launch_bounds__(256) void filmgen_bwd_kernel(const GenDesc* __restrict__ gens,
+                                                          const float* __restrict__ pool, const float* __restrict__ z,
+                                                          int z_dim, int hid, const float* __restrict__ dgamma,
+                                                          const float* __restrict__ dbeta,
+                                                          const float* __restrict__ dl2, float* __restrict__ grads,
+                                                          float* __restrict__ dz_partial) {
+    extern __shared__ float ds[];  // [max_out] gradient w.r.t. the second Linear's outputs
+    __shared__ float zs[FILM_MAX_HID], xh[FILM_MAX_HID], hr[FILM_MAX_HID], dxh[FILM_MAX_HID], dhs[FILM_MAX_HID];
+    __shared__ float red[2];
+    const GenDesc g = gens[blockIdx.x];
+    const int t = threadIdx.x;
+    if (t < z_dim) zs[t] = z[t];
+    __syncthreads();
+    float h = 0.f;
+    if (t < hid) {
+        const float* w = pool + g.w1 + (size_t)t * z_dim;
+        for (int k = 0; k < z_dim; ++k) h = fmaf(w[k], zs[k], h);
+        h += pool[g.b1 + t];
+        xh[t] = h;
+    }
+    __syncthreads();
+    if (t == 0) {
+        float m = 0.f;
+        for (int k = 0; k < hid; ++k) m += xh[k];
+        m /= (float)hid;
+        float v = 0.f;
+        for (int k = 0; k < hid; ++k) v += (xh[k] - m) * (xh[k] - m);
+        v /= (float)hid;
+        red[0] = m;
+        red[1] = 1.0f / sqrtf(v + 1e-5f);
+    }
+    __syncthreads();
+    const float rstd = red[1];
+    float xhat = 0.f;
+    if (t < hid) {
+        xhat = (h - red[0]) * rstd;
+        hr[t] = fmaxf(xhat * pool[g.ln_w + t] + pool[g.ln_b + t], 0.f);
+    }
+    __syncthreads();
+    if (t < hid) xh[t] = xhat;
+    const float l2g = dl2 ? 2.0f * dl2[0] : 0.f;
+    for (int o = t; o < g.out; o += 256) {
+        const float* w = pool + g.w2 + (size_t)o * hid;
+        float s = 0.f;
+        for (int k = 0; k < hid; ++k) s = fmaf(w[k], hr[k], s);
+        s += pool[g.b2 + o];
+        const float r = pool[g.reg + o], init = pool[g.init + o];
+        const float dout = g.kind == 0 ? dgamma[g.dst + o] * init : dbeta[g.dst + o];
+        const float dso = dout * r;
+        grads[g.reg + o] = dout * s + l2g * r;
+        grads[g.b2 + o] = dso;
+        ds[o] = dso;
+        float* gw = grads + g.w2 + (size_t)o * hid;
+        for (int k = 0; k < hid; ++k) gw[k] = dso * hr[k];
+    }
+    __syncthreads();
+    if (t < hid) {
+        float dhr = 0.f;
+        for (int o = 0; o < g.out; ++o) dhr = fmaf(ds[o], pool[g.w2 + (size_t)o * hid + t], dhr);
+        const float dn = hr[t] > 0.f ? dhr : 0.f;
+        grads[g.ln_w + t] = dn * xh[t];
+        grads[g.ln_b + t] = dn;
+        dxh[t] = dn * pool[g.ln_w + t];
+    }
+    __syncthreads();
+    if (t == 0) {
+        float m1 = 0.f, m2 = 0.f;
+        for (int k = 0; k < hid; ++k) m1 += dxh[k], m2 += dxh[k] * xh[k];
+        red[0] = m1 / (float)hid, red[1] = m2 / (float)hid;
+    }
+    __syncthreads();
+    if (t < hid) {
+        const float dh = rstd * (dxh[t] - red[0] - xh[t] * red[1]);
+        grads[g.b1 + t] = dh;
+        dhs[t] = dh;
+        float* gw = grads + g.w1 + (size_t)t * z_dim;
+        for (int k = 0; k < z_dim; ++k) gw[k] = dh * zs[k];
+    }
+    __syncthreads();
+    if (t < z_dim) {
+        float s = 0.f;
+        for (int j = 0; j < hid; ++j) s = fmaf(dhs[j], pool[g.w1 + (size_t)j * z_dim + t], s);
+        dz_partial[(size_t)blockIdx.x * z_dim + t] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void filmgen_dz_kernel(const float* __restrict__ dz_partial, int n_gen, int z_dim,
+                                                         float* __restrict__ dz) {
+    const int k = threadIdx.x;
+    if (k >= z_dim) return;
+    float s = 0.f;
+    for (int i = 0; i < n_gen; ++i) s += dz_partial[(size_t)i * z_dim + k];
+    dz[k] = s;
+}
+
 }  // namespace orbit
 
 using namespace orbit;
@@ -181,6 +280,40 @@ int orbit_filmgen_forward(orbit_filmgen_t* g, const float* z, float* film_gamma,
         film_l2_kernel<<<1, 256, 0, s>>>(g->d_gens, g->n_gen, g->d_pool, l2);
         ORBIT_LAUNCH_CHECK();
     }
+    return ORBIT_OK;
+}
+
+size_t orbit_filmgen_grad_floats(const orbit_filmgen_t* g) { return g ? g->pool_floats : 0; }
+
+size_t orbit_filmgen_param_offset(const orbit_filmgen_t* g, int gen, const char* tensor) {
+    if (!g || !tensor || gen < 0 || gen >= g->n_gen) return (size_t)-1;
+    const GenDesc& d = g->gens[gen];
+    const std::string t(tensor);
+    if (t == "w1") return d.w1;
+    if (t == "b1") return d.b1;
+    if (t == "ln_w") return d.ln_w;
+    if (t == "ln_b") return d.ln_b;
+    if (t == "w2") return d.w2;
+    if (t == "b2") return d.b2;
+    if (t == "reg") return d.reg;
+    return (size_t)-1;
+}
+
+int orbit_filmgen_backward(orbit_filmgen_t* g, const float* z, const float* dfilm_gamma, const float* dfilm_beta,
+                           const float* dl2, float* grads, float* dz, orbit_stream_t stream) {
+    ORBIT_REQUIRE(g && z && dfilm_gamma && dfilm_beta && grads, "filmgen_backward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    float* dzp = nullptr;
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&dzp), (size_t)g->n_gen * g->z_dim * sizeof(float), s));
+    filmgen_bwd_kernel<<<g->n_gen, 256, (size_t)g->max_out * sizeof(float), s>>>(g->d_gens, g->d_pool, z, g->z_dim, g->hid,
+                                                                                dfilm_gamma, dfilm_beta, dl2, grads, dzp);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess && dz) {
+        filmgen_dz_kernel<<<1, 256, 0, s>>>(dzp, g->n_gen, g->z_dim, dz);
+        e = hipGetLastError();
+    }
+    (void)hipFreeAsync(dzp, s);
+    if (e != hipSuccess) return set_err(ORBIT_ERR_HIP, "filmgen_backward: %s", hipGetErrorString(e));
     return ORBIT_OK;
 }
 

@@ -1,0 +1,545 @@
+// Training-side elementwise / reduction kernels of the LITE meta-training step:
+//   train-mode BatchNorm forward (batch statistics, running-stat update) and BatchNorm backward (train + eval form),
+//   max-pool with recorded argmax + its backward, average-pool backward, zero-insertion upsampling (input of the
+//   strided-convolution data gradient), prototype-head backward.
+// Reference call sites: model/few_shot_recognisers.py:176-183 (_set_batch_norm_state: the extractor runs BatchNorm in
+// train() mode while meta-training an unfrozen extractor), :328-437 (LITE forward), single-step-learner.py:212-243
+// (loss.backward() through predict_a_batch -> extractor), model/classifier_heads.py:202-230 (head forward whose
+// gradient w.r.t. the query features is orbit_proto_predict_backward).
+// All tensors are NHWC fp32 viewed as [M][C] matrices (M = B*H*W); every kernel is HBM-bound: one pass, float4 per
+// thread, fixed reduction order (no atomics) so that gradients are run-to-run deterministic.
+#include "common.h"
+
+namespace orbit {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// column layout shared by the per-channel reductions: G threads cover G float4 channel-quads, R = 256 / G row lanes
+struct ColLayout {
+    int Q, G, R, ygroups;
+};
+static ColLayout col_layout(int C) {
+    ColLayout L;
+    L.Q = C / 4;
+    L.G = L.Q < 256 ? L.Q : 256;
+    L.R = 256 / L.G;
+    L.ygroups = cdiv(L.Q, L.G);
+    return L;
+}
+
+int bn_reduce_blocks(int M, int C) {
+    const ColLayout L = col_layout(C);
+    // enough blocks to fill the chip, at least 4 rows per row lane
+    int rows_per_block = cdiv(M, 1024);
+    if (rows_per_block < 4 * L.R) rows_per_block = 4 * L.R;
+    return cdiv(M, rows_per_block);
+}
+static int bn_rows_per_block(int M, int C) { return cdiv(M, bn_reduce_blocks(M, C)); }
+
+// partial[blk][0][c] = sum_m y, partial[blk][1][c] = sum_m y^2 over the block's rows
+__global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __restrict__ y, int M, int C,
+                                                               int rows_per_block, int G, int R,
+                                                               float* __restrict__ partial) {
+    __shared__ f32x4 red[2][256];
+    const int tid = threadIdx.x;
+    const int rl = tid / G, qi = tid - rl * G, q = blockIdx.y * G + qi;
+    const bool active = rl < R && q < (C >> 2);
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        for (int r = r0 + rl; r < r1; r += R) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(y + (size_t)r * C + q * 4);
+            s += v;
+            ss += v * v;
+        }
+    }
+    red[0][tid] = s, red[1][tid] = ss;
+    __syncthreads();
+    if (rl == 0 && q < (C >> 2)) {
+        for (int j = 1; j < R; ++j) s += red[0][j * G + qi], ss += red[1][j * G + qi];
+        *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 0) * C + q * 4) = s;
+        *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 1) * C + q * 4) = ss;
+    }
+}
+
+// mean / biased variance -> invstd, folded scale/shift, running statistics (momentum update with the unbiased
+// variance, torch.nn.BatchNorm2d semantics). gamma/beta point at the layer's own or the per-task FiLM vectors.
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblk, int M,
+                                                                int C, float eps, float momentum,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                const float* __restrict__ conv_bias,
+                                                                float* __restrict__ mean_out,
+                                                                float* __restrict__ invstd_out,
+                                                                float* __restrict__ scale, float* __restrict__ shift,
+                                                                float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, ss = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += (double)partial[((size_t)b * 2 + 0) * C + c];
+        ss += (double)partial[((size_t)b * 2 + 1) * C + c];
+    }
+    const double mean = s / M;
+    double var = ss / M - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float invstd = (float)(1.0 / sqrt(var + (double)eps));
+    mean_out[c] = (float)mean;
+    invstd_out[c] = invstd;
+    const float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    if (scale) {
+        const float sc = g * invstd;
+        scale[c] = sc;
+        shift[c] = b - (float)mean * sc;
+    }
+    if (running_mean) {
+        // y holds the convolution WITHOUT its bias; the module's input to BatchNorm includes it
+        const float cb = conv_bias ? conv_bias[c] : 0.f;
+        const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * ((float)mean + cb);
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+// a = act(y * scale + shift + residual)
+__global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __restrict__ y,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift,
+                                                              const float* __restrict__ residual, int act,
+                                                              size_t total4, int C4, float* __restrict__ out) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
+        if (scale) v = v * reinterpret_cast<const f32x4*>(scale)[q] + reinterpret_cast<const f32x4*>(shift)[q];
+        if (residual) v += reinterpret_cast<const f32x4*>(residual)[i];
+        if (act == ORBIT_ACT_RELU) {
+            v[0] = fmaxf(v[0], 0.f), v[1] = fmaxf(v[1], 0.f), v[2] = fmaxf(v[2], 0.f), v[3] = fmaxf(v[3], 0.f);
+        } else if (act == ORBIT_ACT_SILU) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) v[k] = v[k] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[k]));
+        }
+        reinterpret_cast<f32x4*>(out)[i] = v;
+    }
+}
+
+__device__ __forceinline__ f32x4 relu_mask(f32x4 g, f32x4 a) {
+    g[0] = a[0] > 0.f ? g[0] : 0.f, g[1] = a[1] > 0.f ? g[1] : 0.f;
+    g[2] = a[2] > 0.f ? g[2] : 0.f, g[3] = a[3] > 0.f ? g[3] : 0.f;
+    return g;
+}
+
+// partial[blk][0][c] = sum_m g, partial[blk][1][c] = sum_m g * xhat, with g = dout * act'(.) and
+// xhat = (y - mean) * invstd
+__global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dout,
+                                                             const float* __restrict__ out,
+                                                             const float* __restrict__ y,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ invstd, int act, int M, int C,
+                                                             int rows_per_block, int G, int R,
+                                                             float* __restrict__ partial) {
+    __shared__ f32x4 red[2][256];
+    const int tid = threadIdx.x;
+    const int rl = tid / G, qi = tid - rl * G, q = blockIdx.y * G + qi;
+    const bool active = rl < R && q < (C >> 2);
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(M, r0 + rows_per_block);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, sx = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
+        const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
+        for (int r = r0 + rl; r < r1; r += R) {
+            const size_t o = (size_t)r * C + q * 4;
+            f32x4 g = *reinterpret_cast<const f32x4*>(dout + o);
+            if (act == ORBIT_ACT_RELU) g = relu_mask(g, *reinterpret_cast<const f32x4*>(out + o));
+            const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + o) - mu) * is;
+            s += g;
+            sx += g * xh;
+        }
+    }
+    red[0][tid] = s, red[1][tid] = sx;
+    __syncthreads();
+    if (rl == 0 && q < (C >> 2)) {
+        for (int j = 1; j < R; ++j) s += red[0][j * G + qi], sx += red[1][j * G + qi];
+        *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 0) * C + q * 4) = s;
+        *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * 2 + 1) * C + q * 4) = sx;
+    }
+}
+
+// dbeta = sum g, dgamma = sum g*xhat; coefficients of the apply pass: dy = k1 * (g - k2 - xhat * k3)
+//   train: k1 = gamma*invstd, k2 = dbeta/M, k3 = dgamma/M         eval: k2 = k3 = 0
+// dbias (bias of the convolution in front of an eval-mode BatchNorm) = sum dy = k1 * dbeta
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int nblk, int M,
+                                                              int C, int train, const float* __restrict__ gamma,
+                                                              const float* __restrict__ invstd,
+                                                              float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                              float* __restrict__ dbias, float* __restrict__ coef) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    double s = 0.0, sx = 0.0;
+    for (int b = 0; b < nblk; ++b) {
+        s += (double)partial[((size_t)b * 2 + 0) * C + c];
+        sx += (double)partial[((size_t)b * 2 + 1) * C + c];
+    }
+    if (dgamma) dgamma[c] = (float)sx;
+    if (dbeta) dbeta[c] = (float)s;
+    const float k1 = (gamma ? gamma[c] : 1.f) * invstd[c];
+    coef[c] = k1;
+    coef[C + c] = train ? (float)(s / M) : 0.f;
+    coef[2 * C + c] = train ? (float)(sx / M) : 0.f;
+    if (dbias) dbias[c] = train ? 0.f : k1 * (float)s;
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dout,
+                                                           const float* __restrict__ out,
+                                                           const float* __restrict__ y,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd,
+                                                           const float* __restrict__ coef, int act, size_t total4,
+                                                           int C4, float* __restrict__ dy, float* __restrict__ dres,
+                                                           int dres_accumulate) {
+    const int C = C4 * 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        f32x4 g = reinterpret_cast<const f32x4*>(dout)[i];
+        if (act == ORBIT_ACT_RELU) g = relu_mask(g, reinterpret_cast<const f32x4*>(out)[i]);
+        const f32x4 xh = (reinterpret_cast<const f32x4*>(y)[i] - reinterpret_cast<const f32x4*>(mean)[q]) *
+                         reinterpret_cast<const f32x4*>(invstd)[q];
+        const f32x4 k1 = reinterpret_cast<const f32x4*>(coef)[q];
+        const f32x4 k2 = reinterpret_cast<const f32x4*>(coef + C)[q];
+        const f32x4 k3 = reinterpret_cast<const f32x4*>(coef + 2 * C)[q];
+        reinterpret_cast<f32x4*>(dy)[i] = k1 * (g - k2 - xh * k3);
+        if (dres) {
+            if (dres_accumulate) g += reinterpret_cast<const f32x4*>(dres)[i];
+            reinterpret_cast<f32x4*>(dres)[i] = g;
+        }
+    }
+}
+
+// ---- max-pool with recorded argmax (first maximum in (kh, kw) scan order, the rule of torch's CPU/GPU kernels) ----
+__global__ __launch_bounds__(256) void maxpool_idx_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                          uint8_t* __restrict__ idx, int B, int H, int W, int C4,
+                                                          int K, int stride, int pad, int Ho, int Wo) {
+    const size_t total = (size_t)B * Ho * Wo * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        size_t r = i / C4;
+        const int wo = (int)(r % Wo);
+        r /= Wo;
+        const int ho = (int)(r % Ho);
+        const int b = (int)(r / Ho);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int bi[4] = {-1, -1, -1, -1};
+        for (int kh = 0; kh < K; ++kh) {
+            const int hi = ho * stride - pad + kh;
+            if ((unsigned)hi >= (unsigned)H) continue;
+            for (int kw = 0; kw < K; ++kw) {
+                const int wi = wo * stride - pad + kw;
+                if ((unsigned)wi >= (unsigned)W) continue;
+                const f32x4 v = reinterpret_cast<const f32x4*>(x)[(((size_t)b * H + hi) * W + wi) * C4 + q];
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (bi[k] < 0 || v[k] > best[k]) best[k] = v[k], bi[k] = kh * K + kw;
+            }
+        }
+        reinterpret_cast<f32x4*>(y)[i] = best;
+        reinterpret_cast<uchar4*>(idx)[i] = make_uchar4((uint8_t)bi[0], (uint8_t)bi[1], (uint8_t)bi[2], (uint8_t)bi[3]);
+    }
+}
+
+// gather form: every input element sums the gradients of the windows whose recorded argmax is that element
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ dy,
+                                                          const uint8_t* __restrict__ idx, float* __restrict__ dx,
+                                                          int B, int H, int W, int C4, int K, int stride, int pad,
+                                                          int Ho, int Wo) {
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        size_t r = i / C4;
+        const int w = (int)(r % W);
+        r /= W;
+        const int h = (int)(r % H);
+        const int b = (int)(r / H);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < K; ++kh) {
+            const int t = h + pad - kh;
+            if (t < 0 || t % stride) continue;
+            const int ho = t / stride;
+            if (ho >= Ho) continue;
+            for (int kw = 0; kw < K; ++kw) {
+                const int u = w + pad - kw;
+                if (u < 0 || u % stride) continue;
+                const int wo = u / stride;
+                if (wo >= Wo) continue;
+                const size_t o = (((size_t)b * Ho + ho) * Wo + wo) * C4 + q;
+                const uchar4 id = reinterpret_cast<const uchar4*>(idx)[o];
+                const f32x4 d = reinterpret_cast<const f32x4*>(dy)[o];
+                const int me = kh * K + kw;
+                if (id.x == me) g[0] += d[0];
+                if (id.y == me) g[1] += d[1];
+                if (id.z == me) g[2] += d[2];
+                if (id.w == me) g[3] += d[3];
+            }
+        }
+        reinterpret_cast<f32x4*>(dx)[i] = g;
+    }
+}
+
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int B,
+                                                          int HW, int C4) {
+    const size_t total = (size_t)B * HW * C4;
+    const float inv = 1.0f / (float)HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        const int b = (int)(i / ((size_t)HW * C4));
+        reinterpret_cast<f32x4*>(dx)[i] = reinterpret_cast<const f32x4*>(dy)[(size_t)b * C4 + q] * inv;
+    }
+}
+
+// dst[b][h][w][:] = src[b][h/s][w/s][:] where h, w are multiples of s inside the source grid, else 0
+__global__ __launch_bounds__(256) void upsample_zero_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                            int B, int H, int W, int C4, int s, int Hs, int Ws) {
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        size_t r = i / C4;
+        const int w = (int)(r % W);
+        r /= W;
+        const int h = (int)(r % H);
+        const int b = (int)(r / H);
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (h % s == 0 && w % s == 0 && h / s < Hs && w / s < Ws)
+            v = reinterpret_cast<const f32x4*>(src)[(((size_t)b * Hs + h / s) * Ws + w / s) * C4 + q];
+        reinterpret_cast<f32x4*>(dst)[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void add_inplace_kernel(float* __restrict__ dst, const float* __restrict__ src,
+                                                          size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256)
+        reinterpret_cast<f32x4*>(dst)[i] += reinterpret_cast<const f32x4*>(src)[i];
+}
+
+static int grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (int)(b > 8192 ? 8192 : (b ? b : 1));
+}
+
+// ---- launchers (declared in common.h) -----------------------------------------------------------------------------
+int launch_bn_stats(const float* y, int M, int C, float eps, float momentum, const float* gamma, const float* beta,
+                    const float* conv_bias, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
+                    float* running_var, float* partial, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0 && M > 0, "bn_stats: C %% 4 != 0 or empty batch");
+    const ColLayout L = col_layout(C);
+    const int nblk = bn_reduce_blocks(M, C);
+    bn_stats_partial_kernel<<<dim3(nblk, L.ygroups), 256, 0, s>>>(y, M, C, bn_rows_per_block(M, C), L.G, L.R, partial);
+    ORBIT_LAUNCH_CHECK();
+    bn_stats_finalize_kernel<<<cdiv(C, 256), 256, 0, s>>>(partial, nblk, M, C, eps, momentum, gamma, beta, conv_bias, mean,
+                                                          invstd, scale, shift, running_mean, running_var);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int launch_scale_shift_act(const float* y, const float* scale, const float* shift, const float* residual, int act,
+                           size_t M, int C, float* out, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0, "scale_shift_act: C %% 4 != 0");
+    const size_t total4 = M * (size_t)(C / 4);
+    scale_shift_act_kernel<<<grid_for(total4), 256, 0, s>>>(y, scale, shift, residual, act, total4, C / 4, out);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int launch_bn_backward(const float* dout, const float* out, const float* y, const float* mean, const float* invstd,
+                       const float* gamma, int train, int act, int M, int C, float* dy, float* dres, int dres_accumulate,
+                       float* dgamma, float* dbeta, float* dbias, float* partial, float* coef, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0 && M > 0, "bn_backward: C %% 4 != 0 or empty batch");
+    ORBIT_REQUIRE(act == ORBIT_ACT_NONE || act == ORBIT_ACT_RELU, "bn_backward: only identity / ReLU activations");
+    const ColLayout L = col_layout(C);
+    const int nblk = bn_reduce_blocks(M, C);
+    bn_bwd_partial_kernel<<<dim3(nblk, L.ygroups), 256, 0, s>>>(dout, out, y, mean, invstd, act, M, C,
+                                                                bn_rows_per_block(M, C), L.G, L.R, partial);
+    ORBIT_LAUNCH_CHECK();
+    bn_bwd_finalize_kernel<<<cdiv(C, 256), 256, 0, s>>>(partial, nblk, M, C, train, gamma, invstd, dgamma, dbeta, dbias,
+                                                        coef);
+    ORBIT_LAUNCH_CHECK();
+    if (dy) {
+        const size_t total4 = (size_t)M * (C / 4);
+        bn_bwd_apply_kernel<<<grid_for(total4), 256, 0, s>>>(dout, out, y, mean, invstd, coef, act, total4, C / 4, dy,
+                                                             dres, dres_accumulate);
+        ORBIT_LAUNCH_CHECK();
+    }
+    return ORBIT_OK;
+}
+
+int launch_maxpool_idx(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, int K, int stride, int pad,
+                       int Ho, int Wo, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0 && K * K <= 255, "maxpool: C %% 4 != 0 or window too large");
+    maxpool_idx_kernel<<<grid_for((size_t)B * Ho * Wo * (C / 4)), 256, 0, s>>>(x, y, idx, B, H, W, C / 4, K, stride, pad,
+                                                                               Ho, Wo);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int launch_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, int K, int stride,
+                       int pad, int Ho, int Wo, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0, "maxpool_backward: C %% 4 != 0");
+    maxpool_bwd_kernel<<<grid_for((size_t)B * H * W * (C / 4)), 256, 0, s>>>(dy, idx, dx, B, H, W, C / 4, K, stride, pad,
+                                                                             Ho, Wo);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int launch_avgpool_bwd(const float* dy, float* dx, int B, int HW, int C, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0, "avgpool_backward: C %% 4 != 0");
+    avgpool_bwd_kernel<<<grid_for((size_t)B * HW * (C / 4)), 256, 0, s>>>(dy, dx, B, HW, C / 4);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int launch_upsample_zero(const float* src, float* dst, int B, int H, int W, int C, int stride, int Hs, int Ws,
+                         hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0 && stride >= 1, "upsample_zero: C %% 4 != 0");
+    upsample_zero_kernel<<<grid_for((size_t)B * H * W * (C / 4)), 256, 0, s>>>(src, dst, B, H, W, C / 4, stride, Hs, Ws);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int launch_add_inplace(float* dst, const float* src, size_t n, hipStream_t s) {
+    ORBIT_REQUIRE(n % 4 == 0, "add_inplace: length %% 4 != 0");
+    add_inplace_kernel<<<grid_for(n / 4), 256, 0, s>>>(dst, src, n / 4);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+// ---- prototype head backward: d(features) of logits = s*(q.W^T + b) or s*cos(q, w_c); q = mean of T frame rows -----
+__device__ __forceinline__ float wave_sum_f(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// one wave per query row; C <= 64 (dlogits of the row live in lane registers)
+__global__ __launch_bounds__(256) void proto_predict_bwd_kernel(const float* __restrict__ dlogits,
+                                                                const float* __restrict__ Q,
+                                                                const float* __restrict__ Wt, int M, int T, int D,
+                                                                int C, float logit_scale, int cosine,
+                                                                float* __restrict__ dQ) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int m = blockIdx.x * 4 + wave;
+    if (m >= M) return;
+    const float invT = 1.0f / (float)T;
+    const float* q = Q + (size_t)m * T * D;
+    float* dq = dQ + (size_t)m * T * D;
+    const float my_dl = lane < C ? dlogits[(size_t)m * C + lane] * logit_scale : 0.f;
+    if (!cosine) {
+        for (int d = lane; d < D; d += 64) {
+            float g = 0.f;
+            for (int c = 0; c < C; ++c) g += __shfl(my_dl, c, 64) * Wt[(size_t)c * D + d];
+            g *= invT;
+            for (int t = 0; t < T; ++t) dq[(size_t)t * D + d] = g;
+        }
+        return;
+    }
+    // cosine: cos_c = q.w_c / (max(|q|, eps) max(|w_c|, eps))
+    float qq = 0.f;
+    for (int d = lane; d < D; d += 64) {
+        float x = 0.f;
+        for (int t = 0; t < T; ++t) x += q[(size_t)t * D + d];
+        x *= invT;
+        qq += x * x;
+    }
+    const float nq = sqrtf(wave_sum_f(qq)), nqc = fmaxf(nq, 1e-8f);
+    float a_c = 0.f, b_sum = 0.f;  // lane c keeps dl_c / (nq' nw'_c); b_sum = sum_c dl_c dot_c / (nq'^2 nw'_c nq)
+    for (int c = 0; c < C; ++c) {
+        float dot = 0.f, ww = 0.f;
+        for (int d = lane; d < D; d += 64) {
+            float x = 0.f;
+            for (int t = 0; t < T; ++t) x += q[(size_t)t * D + d];
+            x *= invT;
+            const float w = Wt[(size_t)c * D + d];
+            dot += x * w, ww += w * w;
+        }
+        dot = wave_sum_f(dot);
+        const float nwc = fmaxf(sqrtf(wave_sum_f(ww)), 1e-8f);
+        const float dl = __shfl(my_dl, c, 64);
+        if (lane == c) a_c = dl / (nqc * nwc);
+        if (nq > 1e-8f) b_sum += dl * dot / (nqc * nqc * nwc * nq);
+    }
+    for (int d = lane; d < D; d += 64) {
+        float x = 0.f;
+        for (int t = 0; t < T; ++t) x += q[(size_t)t * D + d];
+        x *= invT;
+        float g = -b_sum * x;
+        for (int c = 0; c < C; ++c) g += __shfl(a_c, c, 64) * Wt[(size_t)c * D + d];
+        g *= invT;
+        for (int t = 0; t < T; ++t) dq[(size_t)t * D + d] = g;
+    }
+}
+
+}  // namespace orbit
+
+using namespace orbit;
+
+extern "C" {
+
+int orbit_op_bn_train_forward(const float* y, int M, int C, const float* gamma, const float* beta, float eps,
+                              float momentum, float* running_mean, float* running_var, const float* residual, int act,
+                              float* out, float* save_mean, float* save_invstd, orbit_stream_t stream) {
+    ORBIT_REQUIRE(y && out && save_mean && save_invstd, "op_bn_train_forward: null pointer");
+    ORBIT_REQUIRE((running_mean == nullptr) == (running_var == nullptr), "op_bn_train_forward: running stats come in pairs");
+    hipStream_t s = (hipStream_t)stream;
+    float* tmp = nullptr;
+    const size_t nfl = (size_t)bn_reduce_blocks(M, C) * 2 * C + 2 * (size_t)C;
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), nfl * sizeof(float), s));
+    float* scale = tmp + (size_t)bn_reduce_blocks(M, C) * 2 * C;
+    int rc = launch_bn_stats(y, M, C, eps, momentum, gamma, beta, nullptr, save_mean, save_invstd, scale, scale + C,
+                             running_mean, running_var, tmp, s);
+    if (rc == ORBIT_OK) rc = launch_scale_shift_act(y, scale, scale + C, residual, act, (size_t)M, C, out, s);
+    (void)hipFreeAsync(tmp, s);
+    return rc;
+}
+
+int orbit_op_bn_backward(const float* dout, const float* out, const float* y, int M, int C, const float* gamma,
+                         const float* mean, const float* invstd, int train, int act, float* dy, float* dres,
+                         float* dgamma, float* dbeta, orbit_stream_t stream) {
+    ORBIT_REQUIRE(dout && y && mean && invstd && dy, "op_bn_backward: null pointer");
+    ORBIT_REQUIRE(act == ORBIT_ACT_NONE || out, "op_bn_backward: the activation output is needed for the ReLU mask");
+    hipStream_t s = (hipStream_t)stream;
+    float* tmp = nullptr;
+    const size_t npart = (size_t)bn_reduce_blocks(M, C) * 2 * C;
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), (npart + 3 * (size_t)C) * sizeof(float), s));
+    const int rc = launch_bn_backward(dout, out, y, mean, invstd, gamma, train, act, M, C, dy, dres, 0, dgamma, dbeta,
+                                      nullptr, tmp, tmp + npart, s);
+    (void)hipFreeAsync(tmp, s);
+    return rc;
+}
+
+int orbit_op_maxpool2d_train(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, int K, int stride,
+                             int pad, int Ho, int Wo, orbit_stream_t stream) {
+    ORBIT_REQUIRE(x && y && idx, "op_maxpool2d_train: null pointer");
+    return launch_maxpool_idx(x, y, idx, B, H, W, C, K, stride, pad, Ho, Wo, (hipStream_t)stream);
+}
+
+int orbit_op_maxpool2d_backward(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, int K,
+                                int stride, int pad, int Ho, int Wo, orbit_stream_t stream) {
+    ORBIT_REQUIRE(dy && idx && dx, "op_maxpool2d_backward: null pointer");
+    return launch_maxpool_bwd(dy, idx, dx, B, H, W, C, K, stride, pad, Ho, Wo, (hipStream_t)stream);
+}
+
+int orbit_op_avgpool_backward(const float* dy, float* dx, int B, int HW, int C, orbit_stream_t stream) {
+    ORBIT_REQUIRE(dy && dx, "op_avgpool_backward: null pointer");
+    return launch_avgpool_bwd(dy, dx, B, HW, C, (hipStream_t)stream);
+}
+
+int orbit_proto_predict_backward(const float* dlogits, const float* features, const float* weight, int M, int T, int D,
+                                 int C, float logit_scale, int cosine, float* dfeatures, orbit_stream_t stream) {
+    ORBIT_REQUIRE(dlogits && features && weight && dfeatures, "proto_predict_backward: null pointer");
+    ORBIT_REQUIRE(M > 0 && T > 0 && D > 0 && C > 0 && C <= 64, "proto_predict_backward: bad sizes (C must be <= 64)");
+    proto_predict_bwd_kernel<<<cdiv(M, 4), 256, 0, (hipStream_t)stream>>>(dlogits, features, weight, M, T, D, C,
+                                                                          logit_scale, cosine, dfeatures);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+}  // extern "C"

@@ -105,6 +105,11 @@ class PrototypicalClassifier(nn.Module):
             raise AttributeError("Weight and/or bias not set - is model personalised?")
         _lib.require_gpu()
         T = int(frames_per_clip)
+        if features.requires_grad and torch.is_grad_enabled() and not return_argmax:
+            # meta-training: the gradient flows into the query features only (weight/bias are constants, :261-263)
+            from .autograd import ProtoPredictFunction
+            return ProtoPredictFunction.apply(features, self.weight, None if self._cosine else self.bias, T,
+                                              float(self.logit_scale), self._cosine)
         q = features.detach().contiguous().float()
         MT, D = q.shape
         M = MT // T

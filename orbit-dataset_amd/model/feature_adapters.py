@@ -88,9 +88,11 @@ class FilmParameterGenerator(nn.Module):
     def forward(self, x):
         _lib.require_gpu()
         self._sync()
-        z = x.detach().reshape(-1).contiguous().float()
-        if z.numel() != self.pooled_size:
+        if x.numel() != self.pooled_size:
             raise ValueError("task embedding must have %d elements" % self.pooled_size)
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self._forward_with_grad(x)
+        z = x.detach().reshape(-1).contiguous().float()
         gamma = torch.empty(self.film_size, device=z.device, dtype=torch.float32)
         beta = torch.empty(self.film_size, device=z.device, dtype=torch.float32)
         l2 = torch.empty(1, device=z.device, dtype=torch.float32)
@@ -99,10 +101,29 @@ class FilmParameterGenerator(nn.Module):
                    "orbit_filmgen_forward")
         self.l2_term = l2[0]
         self.last_film = (gamma, beta)
+        return self._film_dict(gamma, beta)
+
+    def _film_dict(self, gamma, beta):
         film_dict = {}
         for name, size, kind, dst in zip(self.film_parameter_names, self._sizes, self._kinds, self._dsts):
             film_dict[name] = (gamma if kind == 0 else beta)[dst:dst + size]
         return film_dict
+
+    def _forward_with_grad(self, x):
+        """Meta-training form: one autograd node whose backward is orbit_filmgen_backward."""
+        from .autograd import FilmGeneratorFunction
+        lib = _lib.load()
+        params, index = [], []
+        for i in range(len(self.film_parameter_names)):
+            for tname, t in self._tensors(i):
+                if tname == "init":
+                    continue
+                params.append(t)
+                index.append((lib.orbit_filmgen_param_offset(self._handle, i, tname.encode()), tuple(t.shape)))
+        gamma, beta, l2 = FilmGeneratorFunction.apply(self, x, tuple(index), *params)
+        self.l2_term = l2[0]
+        self.last_film = (gamma, beta)
+        return self._film_dict(gamma, beta)
 
     def __del__(self):
         try:

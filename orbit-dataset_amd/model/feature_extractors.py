@@ -17,6 +17,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
+from .autograd import ExtractorFunction
 
 _EXTRACTOR_OUTPUT = {"resnet18": 512, "efficientnet_b0": 1280}
 _BN_EPS = {"resnet18": 1e-5, "efficientnet_b0": 1e-3, "set_encoder": 1e-5}
@@ -192,6 +193,85 @@ class HipNetwork(nn.Module):
         betas = [m._parameters["bias"].detach().reshape(-1) for _, m in slots]
         return torch.cat(gammas).float().contiguous(), torch.cat(betas).float().contiguous()
 
+    # ---- training path (tape + autograd) -------------------------------------------------------------
+    bn_momentum = 0.1  # nn.BatchNorm2d default (torchvision resnet18, SimplePrePoolNet)
+
+    def wants_grad(self, film=None):
+        """True when a forward issued now has to record a tape: autograd is on and either one of the network's own
+        parameters or the FiLM vectors require a gradient."""
+        if not torch.is_grad_enabled():
+            return False
+        if film is not None and (film[0].requires_grad or film[1].requires_grad):
+            return True
+        return any(own is not None and own.requires_grad for _, _, _, own in self._leaves)
+
+    def _param_index(self, plan):
+        """[(flat-gradient offset, torch shape, is a FiLM-replaceable BatchNorm weight/bias)] per own Parameter."""
+        cached = self.__dict__.get("_param_index_cache")
+        if cached is None:
+            lib = _lib.load()
+            film_keys = set()
+            for name in self._film_slot_names:
+                film_keys.add(name + ".weight"), film_keys.add(name + ".bias")
+            cached = []
+            for i, (node, attr, key, own) in enumerate(self._leaves):
+                if own is not None:
+                    cached.append((own, (lib.orbit_extractor_param_offset(plan.handle, i), tuple(own.shape),
+                                         key in film_keys)))
+            self.__dict__["_param_index_cache"] = cached
+        return cached
+
+    def _pull_running_stats(self, plan):
+        """Copy the running statistics a train-mode forward updated inside the plan back into the module's buffers
+        (state_dict parity with nn.BatchNorm2d in train()), and bump num_batches_tracked."""
+        lib = _lib.load()
+        n = lib.orbit_extractor_bn_stat_floats(plan.handle)
+        dev = None
+        dst, src, counters = [], [], []
+        off = 0
+        for node, attr, key, own in self._leaves:
+            if attr != "running_mean":
+                continue
+            rm, rv = node._buffers["running_mean"], node._buffers["running_var"]
+            if dev is None:
+                dev = rm.device
+                flat = torch.empty(2, n, device=dev, dtype=torch.float32)
+                _lib.check(lib.orbit_extractor_export_bn_stats(plan.handle, _lib.dptr(flat), _lib.stream_handle()),
+                           "orbit_extractor_export_bn_stats")
+            C = rm.numel()
+            dst += [rm, rv]
+            src += [flat[0, off:off + C], flat[1, off:off + C]]
+            counters.append(node._buffers["num_batches_tracked"])
+            off += (C + 3) // 4 * 4
+        torch._foreach_copy_(dst, src)
+        torch._foreach_add_(counters, 1)
+        plan.stamp = self._stamp()  # the plan already holds these values
+
+    def _forward_train(self, plan, x, film, use_tape, bn_train, out):
+        lib = _lib.load()
+        if not lib.orbit_extractor_supports_training(plan.handle):
+            raise NotImplementedError(
+                "%s has no native training path yet (train-mode BatchNorm / backward are built for resnet18 and the "
+                "set encoder); use set_test_mode(True) or a frozen extractor without FiLM gradients" % self.native_name)
+        B = x.shape[0]
+        gamma, beta = film if film is not None else (None, None)
+        if use_tape:
+            if out is not None:
+                raise ValueError("`out=` cannot be combined with autograd")
+            entries = [(own, meta) for own, meta in self._param_index(plan) if own.requires_grad]
+            feats = ExtractorFunction.apply(self, plan, x, gamma, beta, bn_train, self.bn_momentum,
+                                            tuple(meta for _, meta in entries), *[own for own, _ in entries])
+        else:
+            feats = out if out is not None else torch.empty(B, self.output_size, device=x.device, dtype=torch.float32)
+            tape = torch.empty(lib.orbit_extractor_tape_bytes(plan.handle, B), dtype=torch.uint8, device=x.device)
+            _lib.check(lib.orbit_extractor_train_forward(
+                plan.handle, _lib.dptr(x, torch.float32), B, _lib.dptr(gamma), _lib.dptr(beta), int(bn_train),
+                float(self.bn_momentum), _lib.dptr(feats, torch.float32), ctypes.c_void_p(tape.data_ptr()), tape.numel(),
+                _lib.stream_handle()), "orbit_extractor_train_forward")
+        if bn_train:
+            self._pull_running_stats(plan)
+        return feats
+
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, x, film=None, out=None, check_sync=True):
         _lib.require_gpu()
@@ -208,15 +288,19 @@ class HipNetwork(nn.Module):
             film = self._gather_swapped_film()
         if check_sync or plan.stamp is None:
             self.sync(plan)
+        if film is not None:
+            if film[0].numel() != self.film_size or film[1].numel() != self.film_size:
+                raise ValueError("film vectors must have %d elements" % self.film_size)
+            film = (film[0].contiguous().float(), film[1].contiguous().float())
+        use_tape = B > 0 and self.wants_grad(film)
+        if B > 0 and (use_tape or self.training):
+            # batch-statistics BatchNorm and/or a recorded tape: the training runtime (csrc/extractor_train.hip)
+            return self._forward_train(plan, x, film, use_tape, self.training, out)
         feats = out if out is not None else torch.empty(B, self.output_size, device=x.device, dtype=torch.float32)
         if B == 0:
             return feats
         ws = self._workspace(plan, B, x.device)
-        gamma = beta = None
-        if film is not None:
-            gamma, beta = film
-            if gamma.numel() != self.film_size or beta.numel() != self.film_size:
-                raise ValueError("film vectors must have %d elements" % self.film_size)
+        gamma, beta = film if film is not None else (None, None)
         _lib.check(_lib.load().orbit_extractor_forward(
             plan.handle, _lib.dptr(x, torch.float32), B, _lib.dptr(gamma), _lib.dptr(beta),
             _lib.dptr(feats, torch.float32), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_handle()),

@@ -10,9 +10,10 @@ LITE caches) and errors. What differs is where the arithmetic runs: every frame 
 launch, the head is the wavefront-reduction prototype kernel. Frames may arrive on the host (they are moved
 per mini-batch, as in the reference) or already resident in HBM.
 
-Scope notes: the native path is the inference/forward form. Train-mode BatchNorm and
-autograd through the extractor (`learn_extractor=True` outside test mode) are the "next" row and raise
-NotImplementedError instead of silently falling back to another backend.
+Meta-training: with autograd enabled the same calls record native tapes and
+`loss.backward()` runs the native backward kernels (model/autograd.py) — train-mode BatchNorm, conv dgrad/wgrad,
+FiLM-generator and set-encoder gradients — for the resnet18 extractor. efficientnet_b0 has no training path yet and
+raises NotImplementedError outside test mode instead of silently falling back to another backend.
 """
 import numpy as np
 import torch
@@ -87,9 +88,19 @@ class FewShotRecogniser(nn.Module):
         num_clips = len(clips)
         frames_per_clip = clips.shape[1] if clips.dim() == 5 else 1
         D = self.feature_extractor.output_size
-        features = torch.empty(num_clips * frames_per_clip, D, device=self.device, dtype=torch.float32)
         film = self._film_vectors(film_dict)
         num_batches = int(np.ceil(float(num_clips) / float(self.batch_size)))
+        if self.feature_extractor.wants_grad(film):  # meta-training: autograd nodes per batch, concatenated
+            parts = []
+            for batch in range(num_batches):
+                lo, hi = get_batch_indices(batch, num_clips, self.batch_size)
+                batch_clips = clips[lo:hi]
+                if batch_clips.dim() == 5:
+                    batch_clips = batch_clips.flatten(end_dim=1)
+                parts.append(self.feature_extractor(batch_clips.to(self.device, non_blocking=True), film=film,
+                                                    check_sync=(batch == 0)))
+            return torch.cat(parts, dim=0)
+        features = torch.empty(num_clips * frames_per_clip, D, device=self.device, dtype=torch.float32)
         for batch in range(num_batches):
             lo, hi = get_batch_indices(batch, num_clips, self.batch_size)
             batch_clips = clips[lo:hi]
@@ -108,14 +119,13 @@ class FewShotRecogniser(nn.Module):
         self.test_mode = test_mode
 
     def _set_batch_norm_state(self):
-        """eval() everywhere; the reference switches the extractor to train() when meta-training an unfrozen
-        extractor (:176-183). Batch-statistics BatchNorm is not part of the native forward (next row)."""
-        if self.training or self.feature_extractor.training:
+        """eval() everywhere, but the extractor in train() (batch-statistics BatchNorm, running-stat updates) when
+        meta-training an unfrozen extractor (reference :176-183)."""
+        want_train = bool(self.learn_extractor and not self.test_mode)
+        if self.training or (self.feature_extractor.training and not want_train):
             self.eval()
-        if self.learn_extractor and not self.test_mode:
-            raise NotImplementedError(
-                "train-mode BatchNorm (learn_extractor=True outside test mode) is not implemented by the native "
-                "forward path; call set_test_mode(True) or construct with learn_extractor=False")
+        if want_train and not self.feature_extractor.training:
+            self.feature_extractor.train()
 
 
 class SingleStepFewShotRecogniser(FewShotRecogniser):
@@ -192,9 +202,16 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
             return None
         num_clips = len(context_clips)
         frames_per_clip = context_clips.shape[1] if context_clips.dim() == 5 else 1
+        num_batches = int(np.ceil(float(num_clips) / float(self.batch_size)))
+        if self.set_encoder.wants_grad():  # meta-training without LITE: autograd nodes per batch
+            parts = []
+            for batch in range(num_batches):
+                lo, hi = get_batch_indices(batch, num_clips, self.batch_size)
+                parts.append(self.set_encoder(context_clips[lo:hi].to(self.device, non_blocking=True),
+                                              check_sync=(batch == 0)))
+            return self.set_encoder.aggregate(parts, aggregation=aggregation)
         reps = torch.empty(num_clips * frames_per_clip, self.set_encoder.output_size, device=self.device,
                            dtype=torch.float32)
-        num_batches = int(np.ceil(float(num_clips) / float(self.batch_size)))
         for batch in range(num_batches):
             lo, hi = get_batch_indices(batch, num_clips, self.batch_size)
             batch_clips = context_clips[lo:hi].to(self.device, non_blocking=True)
@@ -209,7 +226,8 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
             return None
         self._set_batch_norm_state()
         if self.reps_cache is None:
-            self.reps_cache = self._get_task_embedding_in_batches(context_clips, aggregation="none")
+            with torch.no_grad():
+                self.reps_cache = self._get_task_embedding_in_batches(context_clips, aggregation="none")
         reps_with_grads = self._get_task_embedding(context_clips[grad_idxs], aggregation="none")
         reps_without_grads = self.reps_cache[torch.as_tensor(no_grad_idxs, device=self.reps_cache.device)]
         # mean over the concatenation (reference :413 returns a [64] vector here, not [1,64])
@@ -218,7 +236,8 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
     def _get_features_with_split_batch(self, context_clips, film_dict, grad_idxs, no_grad_idxs):
         self._set_batch_norm_state()
         if self.features_cache is None:
-            self.features_cache = self._get_features_in_batches(context_clips, film_dict)
+            with torch.no_grad():
+                self.features_cache = self._get_features_in_batches(context_clips, film_dict)
         features_with_grads = self._get_features(context_clips[grad_idxs], film_dict)
         if context_clips.dim() == 5 and context_clips.shape[1] > 1:
             # the cache holds frame features [N*T, D]; the reference indexes it with clip indices (:434),

@@ -16,6 +16,9 @@ class MeanPooler(nn.Module):
         if self.T == 1:
             return x.view(-1, feat_dim)
         _lib.require_gpu()
+        if x.requires_grad and torch.is_grad_enabled():
+            from .autograd import MeanPoolFunction
+            return MeanPoolFunction.apply(x, self.T)
         x = x.contiguous().float()
         n = x.numel() // (self.T * feat_dim)
         out = torch.empty(n, feat_dim, device=x.device, dtype=torch.float32)

@@ -32,6 +32,9 @@ class SetEncoder(HipNetwork):
             x = torch.cat(x, dim=0)
         if aggregation == "mean":
             _lib.require_gpu()
+            if x.requires_grad and torch.is_grad_enabled():
+                from .autograd import SetMeanFunction
+                return SetMeanFunction.apply(x)
             x = x.contiguous().float()
             out = torch.empty(1, x.shape[1], device=x.device, dtype=torch.float32)
             _lib.check(_lib.load().orbit_set_mean(_lib.dptr(x, torch.float32), x.shape[0], x.shape[1],

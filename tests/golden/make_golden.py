@@ -142,7 +142,7 @@ def g4_film_generator():
 
 
 def make_reference_recogniser(fsr, fe_name, adapt, classifier, clip_length, batch_size, num_lite, logit_scale=1.0,
-                              film_strength=0.1):
+                              film_strength=0.1, learn_extractor=False):
     def factory(feature_extractor_name, pretrained, with_film=False, learn_extractor=True):
         fe = oracle_extractors.create(feature_extractor_name)
         synthetic.init_parameters_(fe)
@@ -159,8 +159,8 @@ def make_reference_recogniser(fsr, fe_name, adapt, classifier, clip_length, batc
         return fe, names
 
     fsr.create_feature_extractor = factory
-    model = fsr.SingleStepFewShotRecogniser(fe_name, adapt, classifier, clip_length, batch_size, False, num_lite,
-                                            logit_scale)
+    model = fsr.SingleStepFewShotRecogniser(fe_name, adapt, classifier, clip_length, batch_size, learn_extractor,
+                                            num_lite, logit_scale)
     sd = synthetic.synthetic_state_dict(model, film_strength=film_strength)
     model.load_state_dict(sd)
     if adapt:  # the reference snapshots gamma0/beta0 at construction (film.py:81-87): they already hold the
@@ -237,6 +237,57 @@ def g6_lite(fsr):
     save("G6_lite", **out)
 
 
+def g8_lite_learn_extractor(fsr):
+    """LITE meta-training steps with an UNFROZEN extractor (the README's `--learn_extractor --with_lite` recipe):
+    the extractor runs BatchNorm in train() mode (few_shot_recognisers.py:176-183) on every pass, including the
+    no-grad cache passes, and loss.backward() fills the extractor's .grad. Variant a: ProtoNets; variant b: + FiLM."""
+    import torch.nn.functional as F
+    task = synthetic.make_task(41, way=4, shots=1, frames_per_shot=4, num_query=16, frame_size=64)
+    ctx, lab, tgt, tlab = task["context_clips"], task["context_labels"], task["target_clips"], task["target_labels"]
+    num_lite, tasks_per_batch, batch_size = 4, 2, 8
+    out = {"context_clips": ctx, "context_labels": lab, "target_clips": tgt, "target_labels": tlab,
+           "num_lite_samples": num_lite, "tasks_per_batch": tasks_per_batch, "batch_size": batch_size}
+    watched = ("feature_extractor.conv1.weight", "feature_extractor.bn1.weight", "feature_extractor.bn1.bias",
+               "feature_extractor.layer1.0.conv1.weight", "feature_extractor.layer1.1.bn2.weight",
+               "feature_extractor.layer2.0.conv1.weight", "feature_extractor.layer2.0.downsample.0.weight",
+               "feature_extractor.layer2.0.downsample.1.bias", "feature_extractor.layer3.1.conv2.weight",
+               "feature_extractor.layer4.0.conv2.weight", "feature_extractor.layer4.1.bn2.bias",
+               "set_encoder.encoder.layer1.0.weight", "film_generator.regularizers.0",
+               "film_generator.generators.3.block.0.weight")
+    stats = ("feature_extractor.bn1.running_mean", "feature_extractor.bn1.running_var",
+             "feature_extractor.layer2.0.downsample.1.running_mean", "feature_extractor.layer4.1.bn2.running_var",
+             "feature_extractor.layer4.1.bn2.num_batches_tracked")
+    for tag, adapt in (("a", False), ("b", True)):
+        model = make_reference_recogniser(fsr, "resnet18", adapt, "proto", 1, batch_size, num_lite,
+                                          learn_extractor=True)
+        model.set_test_mode(False)
+        model._clear_caches()
+        model.zero_grad()
+        for b in range(2):
+            np.random.seed(800 + b)
+            model.personalise_with_lite(ctx, lab)
+            logits = model.predict_a_batch(tgt[b * batch_size:(b + 1) * batch_size])
+            scaling = len(lab) / (num_lite * tasks_per_batch)
+            loss = scaling * F.cross_entropy(logits, tlab[b * batch_size:(b + 1) * batch_size])
+            loss = loss + 0.001 * model.film_generator.regularization_term()
+            loss.backward()
+            out["%s_logits_%d" % (tag, b)], out["%s_loss_%d" % (tag, b)] = logits, loss
+            model._reset()
+        params = dict(model.named_parameters())
+        for name in watched:
+            if name in params and params[name].grad is not None:
+                # large filters are stored as a strided sample (<= 4096 values) plus the L2 norm of the whole gradient
+                flat = params[name].grad.flatten()
+                out["%s_grad__%s" % (tag, name)] = flat[::max(1, flat.numel() // 4096)][:4096].clone()
+                out["%s_gnorm__%s" % (tag, name)] = flat.double().norm().float()
+        sd = model.state_dict()
+        for name in stats:
+            out["%s_stat__%s" % (tag, name)] = sd[name].float()
+        # film-replaced BatchNorm weights receive no gradient under functional_call
+        out["%s_bn1_weight_has_grad" % tag] = np.array(params["feature_extractor.bn1.weight"].grad is not None)
+    save("G8_lite_learn_extractor", **out)
+
+
 def g7_utils():
     from data.utils import attach_frame_history, get_batch_indices
     frames = torch.arange(6 * 3 * 2 * 2, dtype=torch.float32).reshape(6, 3, 2, 2)
@@ -257,6 +308,7 @@ def main():
     import model.few_shot_recognisers as fsr
     g5_recogniser(fsr)
     g6_lite(fsr)
+    g8_lite_learn_extractor(fsr)
 
 
 if __name__ == "__main__":

@@ -1,0 +1,226 @@
+"""Meta-training on the HIP path: native tapes + backward kernels behind torch.autograd.
+
+* G6 / G8 golden fixtures: gradients, losses, logits and BatchNorm running statistics recorded from the REFERENCE's
+  own `personalise_with_lite` / `predict_a_batch` / `loss.backward()` (tests/golden/make_golden.py) — frozen
+  extractor + FiLM (G6), unfrozen extractor with train-mode BatchNorm (G8a), both (G8b).
+* extractor / set-encoder level: orbit_extractor_train_forward + orbit_extractor_backward against torch autograd on
+  the CPU oracle modules at other sizes and batch shapes.
+
+Tolerances: fp32 everywhere. Gradients pass through up to 20 batch-statistics BatchNorms whose backward
+re-normalises by 1/sigma, so rounding differences between the CPU and GPU summation orders are amplified: gradient
+checks are relative to the largest reference magnitude of the tensor (5e-3), logits keep the 1e-3 absolute bar.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import orbit_dataset_amd  # noqa: E402,F401
+from oracle import blocks as oracle_blocks  # noqa: E402
+from oracle import extractors as oracle_extractors  # noqa: E402
+from orbit_dataset_amd import synthetic  # noqa: E402
+from orbit_dataset_amd.model.feature_extractors import create_feature_extractor  # noqa: E402
+from orbit_dataset_amd.model.few_shot_recognisers import SingleStepFewShotRecogniser  # noqa: E402
+from orbit_dataset_amd.model.film import get_film_parameters  # noqa: E402
+from orbit_dataset_amd.model.set_encoders import SetEncoder  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def gold(name):
+    return {k: (torch.from_numpy(v) if v.dtype.kind in "fiu" and v.ndim > 0 else v)
+            for k, v in np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False).items()}
+
+
+def native(adapt, batch_size, num_lite, learn_extractor):
+    m = SingleStepFewShotRecogniser("resnet18", adapt, "proto", 1, batch_size, learn_extractor, num_lite, 1.0)
+    synthetic.init_parameters_(m)
+    if adapt:
+        m.film_generator.initial_film_parameters = get_film_parameters(m.film_parameter_names, m.feature_extractor)
+    m._set_device("cuda:0")
+    m._send_to_device()
+    return m
+
+
+def rel(got, ref):
+    ref = ref.double()
+    return float((got.double().cpu() - ref).abs().max() / max(float(ref.abs().max()), 1e-30))
+
+
+def lite_steps(m, g, seed0, prefix=""):
+    """Learner.train_task_with_lite's loop (single-step-learner.py:212-243) over the two query batches."""
+    nl, tpb, bs = int(g["num_lite_samples"]), int(g["tasks_per_batch"]), int(g["batch_size"])
+    dev = torch.device("cuda:0")
+    ctx, lab = g["context_clips"].to(dev), g["context_labels"].to(dev)
+    m.set_test_mode(False)
+    m._clear_caches()
+    m.zero_grad()
+    for b in range(2):
+        np.random.seed(seed0 + b)
+        m.personalise_with_lite(ctx, lab)
+        logits = m.predict_a_batch(g["target_clips"][b * bs:(b + 1) * bs].to(dev))
+        want = g[prefix + "logits_%d" % b]
+        assert (logits.detach().cpu() - want).abs().max().item() < 1e-3, "logits of batch %d" % b
+        loss = len(lab) / (nl * tpb) * F.cross_entropy(logits, g["target_labels"][b * bs:(b + 1) * bs].to(dev))
+        loss = loss + 0.001 * m.film_generator.regularization_term()
+        assert abs(float(loss) - float(g[prefix + "loss_%d" % b])) < 1e-3
+        loss.backward()
+        m._reset()
+
+
+def test_G6_lite_backward_frozen_extractor(device):
+    g = gold("G6_lite")
+    m = native(True, int(g["batch_size"]), int(g["num_lite_samples"]), False)
+    lite_steps(m, g, 500)
+    params = dict(m.named_parameters())
+    for key in g:
+        if not key.startswith("grad__"):
+            continue
+        name = key[len("grad__"):]
+        assert params[name].grad is not None, name
+        assert rel(params[name].grad, g[key]) < 2e-3, (name, rel(params[name].grad, g[key]))
+    assert not bool(g["extractor_has_grad"])
+    assert all(p.grad is None for p in m.feature_extractor.parameters())
+
+
+@pytest.mark.parametrize("tag,adapt", [("a", False), ("b", True)])
+def test_G8_lite_unfrozen_extractor(device, tag, adapt):
+    g = gold("G8_lite_learn_extractor")
+    m = native(adapt, int(g["batch_size"]), int(g["num_lite_samples"]), True)
+    lite_steps(m, g, 800, prefix=tag + "_")
+    params = dict(m.named_parameters())
+    checked = 0
+    for key in g:
+        if not key.startswith(tag + "_grad__"):
+            continue
+        name = key[len(tag + "_grad__"):]
+        grad = params[name].grad
+        assert grad is not None, name
+        flat = grad.flatten()
+        sample = flat[::max(1, flat.numel() // 4096)][:4096]
+        assert rel(sample, g[key]) < 5e-3, (name, rel(sample, g[key]))
+        gn = float(g[tag + "_gnorm__" + name])
+        assert abs(float(flat.double().norm()) - gn) < 5e-3 * gn, name
+        checked += 1
+    assert checked >= 6
+    sd = m.state_dict()
+    for key in g:
+        if key.startswith(tag + "_stat__"):
+            name = key[len(tag + "_stat__"):]
+            want = g[key] if isinstance(g[key], torch.Tensor) else torch.tensor(float(g[key]))
+            assert rel(sd[name].float(), want) < 1e-4, name
+    has = params["feature_extractor.bn1.weight"].grad is not None
+    assert has == bool(g[tag + "_bn1_weight_has_grad"])
+
+
+# ---- extractor level, against torch autograd on the oracle modules ---------------------------------------------------
+def _oracle_and_native(name, device, requires_grad=True):
+    if name == "set_encoder":
+        ref, nat = oracle_blocks.SetEncoder(), SetEncoder()
+    else:
+        ref = oracle_extractors.create(name)
+        nat, _ = create_feature_extractor(name, with_film=True, learn_extractor=requires_grad)
+    synthetic.init_parameters_(ref)
+    synthetic.init_parameters_(nat)
+    return ref, nat.to(device)
+
+
+@pytest.mark.parametrize("bn_train", [True, False])
+@pytest.mark.parametrize("size,B", [(64, 6), (84, 3), (33, 4)])
+def test_resnet18_backward_matches_autograd(device, bn_train, size, B):
+    ref, nat = _oracle_and_native("resnet18", device)
+    ref.train(bn_train), nat.train(bn_train)
+    x = torch.randn(B, 3, size, size, generator=torch.Generator().manual_seed(size + B))
+    dfeat = torch.randn(B, 512, generator=torch.Generator().manual_seed(1))
+    out_ref = ref(x)
+    out_ref.backward(dfeat)
+    out = nat(x.to(device))
+    assert rel(out.detach(), out_ref.detach()) < 2e-4
+    out.backward(dfeat.to(device))
+    ref_grads = dict(ref.named_parameters())
+    worst = ("", 0.0)
+    for name, p in nat.named_parameters():
+        r = rel(p.grad, ref_grads[name].grad)
+        if r > worst[1]:
+            worst = (name, r)
+    assert worst[1] < 5e-3, worst
+    if bn_train:
+        ref_sd = ref.state_dict()
+        for name, buf in nat.state_dict().items():
+            if "running" in name:
+                assert rel(buf, ref_sd[name]) < 1e-4, name
+            elif "num_batches_tracked" in name:
+                assert int(buf) == int(ref_sd[name]) == 1
+
+
+def test_resnet18_film_gradients_frozen_extractor(device):
+    """CNAPs-style: frozen extractor in eval mode, gradients only w.r.t. the per-task FiLM vectors."""
+    from torch.func import functional_call
+    ref, nat = _oracle_and_native("resnet18", device, requires_grad=False)
+    ref.eval(), nat.eval()
+    for p in ref.parameters():
+        p.requires_grad = False
+    slots = [n for n, _ in nat.film_slot_modules()]
+    gen = torch.Generator().manual_seed(11)
+    film_ref, gam, bet = {}, [], []
+    params = dict(ref.named_parameters())
+    for n in slots:
+        gvec = (params[n + ".weight"].detach() * (1 + 0.1 * torch.randn(params[n + ".weight"].shape, generator=gen)))
+        bvec = (params[n + ".bias"].detach() + 0.1 * torch.randn(params[n + ".bias"].shape, generator=gen))
+        film_ref[n + ".weight"], film_ref[n + ".bias"] = gvec.requires_grad_(True), bvec.requires_grad_(True)
+        gam.append(gvec.detach()), bet.append(bvec.detach())
+    x = torch.randn(5, 3, 64, 64, generator=gen)
+    dfeat = torch.randn(5, 512, generator=gen)
+    functional_call(ref, film_ref, (x,)).backward(dfeat)
+    gamma = torch.cat(gam).to(device).requires_grad_(True)
+    beta = torch.cat(bet).to(device).requires_grad_(True)
+    out = nat(x.to(device), film=(gamma, beta))
+    out.backward(dfeat.to(device))
+    dg_ref = torch.cat([film_ref[n + ".weight"].grad for n in slots])
+    db_ref = torch.cat([film_ref[n + ".bias"].grad for n in slots])
+    assert rel(gamma.grad, dg_ref) < 2e-3
+    assert rel(beta.grad, db_ref) < 2e-3
+    assert all(p.grad is None for p in nat.parameters())
+
+
+@pytest.mark.parametrize("size,B", [(32, 3), (84, 5), (50, 2)])
+def test_set_encoder_backward_matches_autograd(device, size, B):
+    ref, nat = _oracle_and_native("set_encoder", device)
+    ref.eval(), nat.eval()  # the set encoder always normalises with running statistics (few_shot_recognisers.py:176-183)
+    x = torch.randn(B, 3, size, size, generator=torch.Generator().manual_seed(size))
+    dfeat = torch.randn(B, 64, generator=torch.Generator().manual_seed(2))
+    out_ref = ref(x)
+    out_ref.backward(dfeat)
+    out = nat(x.to(device))
+    assert rel(out.detach(), out_ref.detach()) < 2e-4
+    out.backward(dfeat.to(device))
+    ref_grads = dict(ref.named_parameters())
+    for name, p in nat.named_parameters():
+        assert rel(p.grad, ref_grads[name].grad) < 2e-3, (name, rel(p.grad, ref_grads[name].grad))
+
+
+def test_backward_is_deterministic(device):
+    _, nat = _oracle_and_native("resnet18", device)
+    nat.train()
+    x = torch.randn(8, 3, 64, 64, generator=torch.Generator().manual_seed(4)).to(device)
+    dfeat = torch.randn(8, 512, generator=torch.Generator().manual_seed(5)).to(device)
+    sd0 = {k: v.clone() for k, v in nat.state_dict().items()}
+    grads = []
+    for _ in range(2):
+        nat.load_state_dict(sd0)
+        nat.zero_grad()
+        nat(x).backward(dfeat)
+        grads.append(torch.cat([p.grad.flatten() for p in nat.parameters()]).cpu())
+    assert torch.equal(grads[0], grads[1])
+
+
+def test_efficientnet_training_raises(device):
+    nat, _ = create_feature_extractor("efficientnet_b0", learn_extractor=True)
+    synthetic.init_parameters_(nat)
+    nat = nat.to(device).train()
+    with pytest.raises(NotImplementedError):
+        nat(torch.randn(2, 3, 64, 64, device=device))

@@ -1,0 +1,263 @@
+"""GPU parity of the training operators (orbit_op_bn_*, conv2d_dgrad / wgrad, maxpool / avgpool backward,
+orbit_proto_predict_backward) against torch autograd on the CPU in fp32 (fp64 where the comparison itself would
+otherwise be the larger error). Every call goes through liborbit_hip.so via ctypes.
+
+Tolerances: gradients are sums of up to ~1e5 fp32 products; the checks are relative to the largest reference
+magnitude (2e-4) unless stated otherwise.
+"""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import orbit_dataset_amd  # noqa: E402,F401
+from orbit_dataset_amd import _lib  # noqa: E402
+
+
+def _st():
+    return _lib.stream_handle()
+
+
+def nhwc(x):
+    return x.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x):
+    return x.permute(0, 3, 1, 2).contiguous()
+
+
+def rel_err(got, ref):
+    return float((got.double() - ref.double()).abs().max() / max(float(ref.double().abs().max()), 1e-12))
+
+
+def _dev(t, device):
+    return None if t is None else t.to(device).contiguous()
+
+
+# ---- BatchNorm train forward ----------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,C,H,W,act,res", [(8, 64, 14, 14, 1, True), (3, 128, 7, 5, 0, False), (5, 512, 3, 3, 1, True),
+                                             (2, 24, 9, 9, 0, False), (4, 1280, 2, 2, 1, False), (64, 64, 28, 28, 1, True)])
+def test_bn_train_forward(device, B, C, H, W, act, res):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 131 + C)
+    y = torch.randn(B, C, H, W, generator=g) * 1.7 + 0.6
+    gamma, beta = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.2
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    residual = torch.randn(B, C, H, W, generator=g) if res else None
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.batch_norm(y, rm_ref, rv_ref, gamma, beta, True, 0.1, 1e-5)
+    if res:
+        ref = ref + residual
+    if act:
+        ref = F.relu(ref)
+    M = B * H * W
+    yd = nhwc(y).to(device)
+    out = torch.empty_like(yd)
+    sm, si = torch.empty(C, device=device), torch.empty(C, device=device)
+    rmd, rvd = rm.to(device), rv.to(device)
+    keep = [_dev(gamma, device), _dev(beta, device), _dev(None if residual is None else nhwc(residual), device)]
+    _lib.check(lib.orbit_op_bn_train_forward(_lib.dptr(yd), M, C, _lib.dptr(keep[0]), _lib.dptr(keep[1]), 1e-5, 0.1,
+                                             _lib.dptr(rmd), _lib.dptr(rvd), _lib.dptr(keep[2]), act, _lib.dptr(out),
+                                             _lib.dptr(sm), _lib.dptr(si), _st()), "bn_train_forward")
+    torch.cuda.synchronize()
+    assert (nchw(out.cpu()) - ref).abs().max() < 2e-5 * max(1.0, float(ref.abs().max()))
+    assert (rmd.cpu() - rm_ref).abs().max() < 1e-6
+    assert (rvd.cpu() - rv_ref).abs().max() < 1e-5
+    mean = y.double().mean(dim=(0, 2, 3))
+    var = y.double().var(dim=(0, 2, 3), unbiased=False)
+    assert (sm.cpu().double() - mean).abs().max() < 1e-6
+    assert ((si.cpu().double() - 1.0 / (var + 1e-5).sqrt()).abs() * (var + 1e-5).sqrt()).max() < 1e-5
+
+
+# ---- BatchNorm backward -----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("train", [1, 0])
+@pytest.mark.parametrize("B,C,H,W,act,res", [(8, 64, 14, 14, 1, True), (3, 128, 7, 5, 0, False), (5, 512, 3, 3, 1, True),
+                                             (32, 64, 28, 28, 1, False)])
+def test_bn_backward(device, train, B, C, H, W, act, res):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * 17 + C + train)
+    y = (torch.randn(B, C, H, W, generator=g) * 1.3 + 0.4).requires_grad_(True)
+    gamma = (torch.rand(C, generator=g) + 0.5).requires_grad_(True)
+    beta = (torch.randn(C, generator=g) * 0.2).requires_grad_(True)
+    residual = torch.randn(B, C, H, W, generator=g).requires_grad_(True) if res else None
+    rm, rv = torch.randn(C, generator=g) * 0.1, torch.rand(C, generator=g) + 0.5
+    out = F.batch_norm(y, rm.clone(), rv.clone(), gamma, beta, bool(train), 0.1, 1e-5)
+    if res:
+        out = out + residual
+    if act:
+        out = F.relu(out)
+    dout = torch.randn(B, C, H, W, generator=g)
+    out.backward(dout)
+    if train:
+        mean = y.detach().mean(dim=(0, 2, 3))
+        invstd = 1.0 / (y.detach().var(dim=(0, 2, 3), unbiased=False) + 1e-5).sqrt()
+    else:
+        mean, invstd = rm, 1.0 / (rv + 1e-5).sqrt()
+    M = B * H * W
+    d = lambda t: _dev(t, device)
+    t_dout, t_out, t_y = d(nhwc(dout)), d(nhwc(out.detach())), d(nhwc(y.detach()))
+    t_gamma, t_mean, t_invstd = d(gamma.detach()), d(mean), d(invstd)
+    dy = torch.empty_like(t_y)
+    dres = torch.empty_like(t_y) if res else None
+    dgamma, dbeta = torch.empty(C, device=device), torch.empty(C, device=device)
+    _lib.check(lib.orbit_op_bn_backward(_lib.dptr(t_dout), _lib.dptr(t_out), _lib.dptr(t_y), M, C, _lib.dptr(t_gamma),
+                                        _lib.dptr(t_mean), _lib.dptr(t_invstd), train, act, _lib.dptr(dy),
+                                        _lib.dptr(dres), _lib.dptr(dgamma), _lib.dptr(dbeta), _st()), "bn_backward")
+    torch.cuda.synchronize()
+    assert rel_err(nchw(dy.cpu()), y.grad) < 2e-4
+    assert rel_err(dgamma.cpu(), gamma.grad) < 2e-4
+    assert rel_err(dbeta.cpu(), beta.grad) < 2e-4
+    if res:
+        assert rel_err(nchw(dres.cpu()), residual.grad) < 1e-6
+
+
+# ---- convolution gradients -----------------------------------------------------------------------------------------------
+CONV_CASES = [
+    # B, Cin, H, W, Cout, K, stride, pad
+    (4, 64, 21, 21, 64, 3, 1, 1),
+    (3, 64, 21, 21, 128, 3, 2, 1),
+    (3, 64, 22, 20, 128, 3, 2, 1),
+    (3, 64, 21, 21, 128, 1, 2, 0),
+    (2, 128, 11, 11, 256, 3, 1, 1),
+    (2, 256, 6, 6, 512, 3, 2, 1),
+    (2, 512, 3, 3, 512, 3, 1, 1),
+    (5, 64, 9, 9, 64, 3, 1, 1),
+    (2, 24, 10, 10, 40, 1, 1, 0),
+    (16, 64, 28, 28, 64, 3, 1, 1),
+]
+
+
+def _conv_ref(B, Cin, H, W, Cout, K, stride, pad, seed, x_scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(B, Cin, H, W, generator=g) * x_scale).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride, pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    return x, w, y, dy
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_conv_dgrad(device, case, accumulate):
+    lib = _lib.load()
+    B, Cin, H, W, Cout, K, stride, pad = case
+    x, w, y, dy = _conv_ref(*case, seed=sum(case))
+    Ho, Wo = y.shape[2:]
+    t_dy, t_w = nhwc(dy).to(device), w.detach().to(device).contiguous()
+    acc_cpu = torch.randn(B, Cin, H, W, generator=torch.Generator().manual_seed(5)) if accumulate else None
+    t_acc = None if acc_cpu is None else nhwc(acc_cpu).to(device)
+    dx = torch.full((B, H, W, Cin), float("nan"), device=device)
+    _lib.check(lib.orbit_op_conv2d_dgrad(_lib.dptr(t_dy), _lib.dptr(t_w), _lib.dptr(t_acc), _lib.dptr(dx), B, H, W, Cin,
+                                         Cout, K, K, stride, pad, pad, Ho, Wo, _st()), "conv2d_dgrad")
+    torch.cuda.synchronize()
+    ref = x.grad + (acc_cpu if accumulate else 0)
+    assert rel_err(nchw(dx.cpu()), ref) < 2e-4
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv_wgrad(device, case):
+    lib = _lib.load()
+    B, Cin, H, W, Cout, K, stride, pad = case
+    x, w, y, dy = _conv_ref(*case, seed=sum(case) + 1)
+    Ho, Wo = y.shape[2:]
+    t_x, t_dy = nhwc(x.detach()).to(device), nhwc(dy).to(device)
+    dw = torch.full((Cout, Cin, K, K), float("nan"), device=device)
+    _lib.check(lib.orbit_op_conv2d_wgrad(_lib.dptr(t_x), 0, _lib.dptr(t_dy), _lib.dptr(dw), B, H, W, Cin, Cout, K, K,
+                                         stride, pad, pad, Ho, Wo, _st()), "conv2d_wgrad")
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), w.grad) < 2e-4
+
+
+@pytest.mark.parametrize("B,H,W,Cout,K,stride,pad", [(3, 32, 32, 64, 7, 2, 3), (2, 33, 29, 32, 3, 2, 1),
+                                                     (4, 20, 20, 64, 3, 1, 1)])
+def test_conv_wgrad_stem_nchw(device, B, H, W, Cout, K, stride, pad):
+    lib = _lib.load()
+    x, w, y, dy = _conv_ref(B, 3, H, W, Cout, K, stride, pad, seed=B + H + K)
+    Ho, Wo = y.shape[2:]
+    t_x, t_dy = x.detach().to(device).contiguous(), nhwc(dy).to(device)
+    dw = torch.full((Cout, 3, K, K), float("nan"), device=device)
+    _lib.check(lib.orbit_op_conv2d_wgrad(_lib.dptr(t_x), 1, _lib.dptr(t_dy), _lib.dptr(dw), B, H, W, 3, Cout, K, K,
+                                         stride, pad, pad, Ho, Wo, _st()), "conv2d_wgrad(nchw)")
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), w.grad) < 2e-4
+
+
+def test_conv_wgrad_is_deterministic(device):
+    lib = _lib.load()
+    case = (16, 64, 28, 28, 64, 3, 1, 1)
+    B, Cin, H, W, Cout, K, stride, pad = case
+    x, w, y, dy = _conv_ref(*case, seed=3)
+    t_x, t_dy = nhwc(x.detach()).to(device), nhwc(dy).to(device)
+    outs = []
+    for _ in range(2):
+        dw = torch.empty(Cout, Cin, K, K, device=device)
+        _lib.check(lib.orbit_op_conv2d_wgrad(_lib.dptr(t_x), 0, _lib.dptr(t_dy), _lib.dptr(dw), B, H, W, Cin, Cout, K, K,
+                                             stride, pad, pad, H, W, _st()), "conv2d_wgrad")
+        outs.append(dw.cpu())
+    assert torch.equal(outs[0], outs[1])
+
+
+# ---- pooling ------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,C,H,W,K,stride,pad,relu", [(3, 64, 21, 21, 3, 2, 1, True), (2, 64, 16, 16, 2, 2, 0, True),
+                                                       (2, 32, 15, 17, 2, 2, 0, False), (2, 64, 42, 42, 3, 2, 1, True)])
+def test_maxpool_train_and_backward(device, B, C, H, W, K, stride, pad, relu):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(H * W + K)
+    x = torch.randn(B, C, H, W, generator=g)
+    if relu:
+        x = F.relu(x)  # many exact ties at 0: exercises the first-maximum rule
+    x.requires_grad_(True)
+    y = F.max_pool2d(x, K, stride, pad)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    Ho, Wo = y.shape[2:]
+    t_x = nhwc(x.detach()).to(device)
+    t_y = torch.empty(B, Ho, Wo, C, device=device)
+    idx = torch.empty(B, Ho, Wo, C, dtype=torch.uint8, device=device)
+    _lib.check(lib.orbit_op_maxpool2d_train(_lib.dptr(t_x), _lib.dptr(t_y), _lib.dptr(idx, torch.uint8), B, H, W, C, K,
+                                            stride, pad, Ho, Wo, _st()), "maxpool2d_train")
+    t_dy = nhwc(dy).to(device)
+    dx = torch.full((B, H, W, C), float("nan"), device=device)
+    _lib.check(lib.orbit_op_maxpool2d_backward(_lib.dptr(t_dy), _lib.dptr(idx, torch.uint8), _lib.dptr(dx), B, H, W, C, K,
+                                               stride, pad, Ho, Wo, _st()), "maxpool2d_backward")
+    torch.cuda.synchronize()
+    assert torch.equal(nchw(t_y.cpu()), y.detach())
+    assert (nchw(dx.cpu()) - x.grad).abs().max() < 1e-6
+
+
+def test_avgpool_backward(device):
+    lib = _lib.load()
+    B, HW, C = 5, 49, 512
+    dy = torch.randn(B, C)
+    dx = torch.empty(B, HW, C, device=device)
+    t = dy.to(device)
+    _lib.check(lib.orbit_op_avgpool_backward(_lib.dptr(t), _lib.dptr(dx), B, HW, C, _st()), "avgpool_backward")
+    torch.cuda.synchronize()
+    assert (dx.cpu() - (dy / HW)[:, None, :]).abs().max() < 1e-7
+
+
+# ---- head backward ------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cosine", [0, 1])
+@pytest.mark.parametrize("M,T,D,C,scale", [(200, 1, 1280, 5, 1.0), (37, 1, 512, 10, 32.0), (12, 4, 512, 5, 1.0),
+                                           (9, 3, 130, 7, 2.0)])
+def test_proto_predict_backward(device, cosine, M, T, D, C, scale):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(M + D + C)
+    feats = torch.randn(M * T, D, generator=g).requires_grad_(True)
+    Wt = torch.randn(C, D, generator=g)
+    q = feats.view(M, T, D).mean(dim=1)
+    if cosine:
+        logits = scale * F.cosine_similarity(q[:, :, None], Wt.t()[None, :, :], dim=1)
+    else:
+        b = -(Wt / 2).pow(2).sum(dim=1)
+        logits = scale * (q @ Wt.t() + b)
+    dl = torch.randn(M, C, generator=g)
+    logits.backward(dl)
+    t_dl, t_f, t_w = dl.to(device), feats.detach().to(device), Wt.to(device)
+    df = torch.full((M * T, D), float("nan"), device=device)
+    _lib.check(lib.orbit_proto_predict_backward(_lib.dptr(t_dl), _lib.dptr(t_f), _lib.dptr(t_w), M, T, D, C, scale, cosine,
+                                                _lib.dptr(df), _st()), "proto_predict_backward")
+    torch.cuda.synchronize()
+    assert rel_err(df.cpu(), feats.grad) < 1e-4

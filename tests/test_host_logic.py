@@ -85,8 +85,17 @@ def test_recogniser_wiring_and_state_dict_names():
         SingleStepFewShotRecogniser("resnet18", False, "mahalanobis", 1, 4, False, 16)
     m3 = SingleStepFewShotRecogniser("resnet18", False, "proto", 1, 4, True, 16)
     m3.set_test_mode(False)
-    with pytest.raises(NotImplementedError):  # train-mode BatchNorm is a declared gap, not a silent fallback
-        m3._set_batch_norm_state()
+    # BatchNorm policy of the reference (few_shot_recognisers.py:176-183): everything eval(), the extractor train()
+    # iff it is being learned and the model is not in test mode
+    m3._set_batch_norm_state()
+    assert m3.feature_extractor.training and not m3.classifier.training and not m3.training
+    m3.set_test_mode(True)
+    m3._set_batch_norm_state()
+    assert not m3.feature_extractor.training
+    m4 = SingleStepFewShotRecogniser("resnet18", True, "proto", 1, 4, False, 16)
+    m4.set_test_mode(False)
+    m4._set_batch_norm_state()
+    assert not m4.feature_extractor.training and not m4.set_encoder.training
 
 
 def test_product_never_imports_oracle():
