@@ -432,12 +432,14 @@ __global__ __launch_bounds__(256) void proto_predict_bwd_kernel(const float* __r
     const float* q = Q + (size_t)m * T * D;
     float* dq = dQ + (size_t)m * T * D;
     const float my_dl = lane < C ? dlogits[(size_t)m * C + lane] * logit_scale : 0.f;
+    const int Dceil = (D + 63) & ~63;  // every lane runs every iteration: the shuffles below need the whole wave
     if (!cosine) {
-        for (int d = lane; d < D; d += 64) {
+        for (int d = lane; d < Dceil; d += 64) {
             float g = 0.f;
-            for (int c = 0; c < C; ++c) g += __shfl(my_dl, c, 64) * Wt[(size_t)c * D + d];
+            for (int c = 0; c < C; ++c) g += __shfl(my_dl, c, 64) * (d < D ? Wt[(size_t)c * D + d] : 0.f);
             g *= invT;
-            for (int t = 0; t < T; ++t) dq[(size_t)t * D + d] = g;
+            if (d < D)
+                for (int t = 0; t < T; ++t) dq[(size_t)t * D + d] = g;
         }
         return;
     }
@@ -466,14 +468,17 @@ __global__ __launch_bounds__(256) void proto_predict_bwd_kernel(const float* __r
         if (lane == c) a_c = dl / (nqc * nwc);
         if (nq > 1e-8f) b_sum += dl * dot / (nqc * nqc * nwc * nq);
     }
-    for (int d = lane; d < D; d += 64) {
+    for (int d = lane; d < Dceil; d += 64) {
         float x = 0.f;
-        for (int t = 0; t < T; ++t) x += q[(size_t)t * D + d];
-        x *= invT;
+        if (d < D) {
+            for (int t = 0; t < T; ++t) x += q[(size_t)t * D + d];
+            x *= invT;
+        }
         float g = -b_sum * x;
-        for (int c = 0; c < C; ++c) g += __shfl(a_c, c, 64) * Wt[(size_t)c * D + d];
+        for (int c = 0; c < C; ++c) g += __shfl(a_c, c, 64) * (d < D ? Wt[(size_t)c * D + d] : 0.f);
         g *= invT;
-        for (int t = 0; t < T; ++t) dq[(size_t)t * D + d] = g;
+        if (d < D)
+            for (int t = 0; t < T; ++t) dq[(size_t)t * D + d] = g;
     }
 }
 

@@ -2,8 +2,9 @@
 orbit_proto_predict_backward) against torch autograd on the CPU in fp32 (fp64 where the comparison itself would
 otherwise be the larger error). Every call goes through liborbit_hip.so via ctypes.
 
-Tolerances: gradients are sums of up to ~1e5 fp32 products; the checks are relative to the largest reference
-magnitude (2e-4) unless stated otherwise.
+Tolerances: the kernels accumulate in fp32 with fixed summation orders; measured against fp64 they are within
+~2e-6 of the largest reference magnitude (tools/train_diag2.py), the checks allow 2e-5 (the fp32 CPU reference carries
+its own ~1e-6).
 """
 import pytest
 import torch
@@ -105,9 +106,9 @@ def test_bn_backward(device, train, B, C, H, W, act, res):
                                         _lib.dptr(t_mean), _lib.dptr(t_invstd), train, act, _lib.dptr(dy),
                                         _lib.dptr(dres), _lib.dptr(dgamma), _lib.dptr(dbeta), _st()), "bn_backward")
     torch.cuda.synchronize()
-    assert rel_err(nchw(dy.cpu()), y.grad) < 2e-4
-    assert rel_err(dgamma.cpu(), gamma.grad) < 2e-4
-    assert rel_err(dbeta.cpu(), beta.grad) < 2e-4
+    assert rel_err(nchw(dy.cpu()), y.grad) < 2e-5
+    assert rel_err(dgamma.cpu(), gamma.grad) < 2e-5
+    assert rel_err(dbeta.cpu(), beta.grad) < 2e-5
     if res:
         assert rel_err(nchw(dres.cpu()), residual.grad) < 1e-6
 
@@ -153,7 +154,7 @@ def test_conv_dgrad(device, case, accumulate):
                                          Cout, K, K, stride, pad, pad, Ho, Wo, _st()), "conv2d_dgrad")
     torch.cuda.synchronize()
     ref = x.grad + (acc_cpu if accumulate else 0)
-    assert rel_err(nchw(dx.cpu()), ref) < 2e-4
+    assert rel_err(nchw(dx.cpu()), ref) < 2e-5
 
 
 @pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
@@ -167,7 +168,7 @@ def test_conv_wgrad(device, case):
     _lib.check(lib.orbit_op_conv2d_wgrad(_lib.dptr(t_x), 0, _lib.dptr(t_dy), _lib.dptr(dw), B, H, W, Cin, Cout, K, K,
                                          stride, pad, pad, Ho, Wo, _st()), "conv2d_wgrad")
     torch.cuda.synchronize()
-    assert rel_err(dw.cpu(), w.grad) < 2e-4
+    assert rel_err(dw.cpu(), w.grad) < 2e-5
 
 
 @pytest.mark.parametrize("B,H,W,Cout,K,stride,pad", [(3, 32, 32, 64, 7, 2, 3), (2, 33, 29, 32, 3, 2, 1),
@@ -181,7 +182,7 @@ def test_conv_wgrad_stem_nchw(device, B, H, W, Cout, K, stride, pad):
     _lib.check(lib.orbit_op_conv2d_wgrad(_lib.dptr(t_x), 1, _lib.dptr(t_dy), _lib.dptr(dw), B, H, W, 3, Cout, K, K,
                                          stride, pad, pad, Ho, Wo, _st()), "conv2d_wgrad(nchw)")
     torch.cuda.synchronize()
-    assert rel_err(dw.cpu(), w.grad) < 2e-4
+    assert rel_err(dw.cpu(), w.grad) < 2e-5
 
 
 def test_conv_wgrad_is_deterministic(device):
@@ -260,4 +261,4 @@ def test_proto_predict_backward(device, cosine, M, T, D, C, scale):
     _lib.check(lib.orbit_proto_predict_backward(_lib.dptr(t_dl), _lib.dptr(t_f), _lib.dptr(t_w), M, T, D, C, scale, cosine,
                                                 _lib.dptr(df), _st()), "proto_predict_backward")
     torch.cuda.synchronize()
-    assert rel_err(df.cpu(), feats.grad) < 1e-4
+    assert rel_err(df.cpu(), feats.grad) < 2e-5
