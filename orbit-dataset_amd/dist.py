@@ -111,3 +111,20 @@ def predict_query_sharded(model, target_clips, sharding, gather=True):
     full[lo:hi] = local
     sharding.reduce_(full)  # disjoint slices: a SUM all-reduce is an all-gather for ragged shards
     return full
+
+
+def allreduce_tensors(tensors, average=False):
+    """All-reduce a list of tensors as ONE flat bucket (a ring all-reduce over xGMI is per-link bound: one large
+    message beats many small ones). In place; no-op without an initialised process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1 or not tensors:
+        return
+    flat = torch.cat([t.reshape(-1) for t in tensors])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    if average:
+        flat /= dist.get_world_size()
+    off = 0
+    for t in tensors:
+        n = t.numel()
+        t.copy_(flat[off:off + n].view_as(t))
+        off += n

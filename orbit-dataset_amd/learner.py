@@ -1,4 +1,4 @@
-"""Counterpart of the reference's single-step-learner.py for the native path (test mode on synthetic tasks).
+"""Counterpart of the reference's single-step-learner.py for the native path (train / test on synthetic tasks).
 
 Keeps the reference CLI's flag names for everything that touches the hot path (reference utils/args.py:12-192:
 --feature_extractor --learn_extractor --adapt_features --classifier --logit_scale --clip_length --frame_size
@@ -9,8 +9,17 @@ loop's call order (reference single-step-learner.py:298-375): per task personali
 offline, so tasks come from `synthetic.make_task` in the task_dict layout of reference data/datasets.py:584-597;
 `--feature_extractor` additionally accepts resnet18 and `--frame_size` any size (BASELINE.json configs).
 
-Multi-GPU: launched under torchrun, tasks are dealt round-robin to ranks (task i -> rank i % world) and the
-per-task statistics are all-gathered at the end; no data-path collective.
+Training (reference single-step-learner.py:128-243): per task `train_task` or `train_task_with_lite` (per query
+batch {personalise_with_lite -> predict_a_batch -> N/(H*tasks_per_batch) * CE + 0.001 * l2 -> backward -> _reset}),
+optimizer.step()/zero_grad() every `tasks_per_batch` tasks, optimizer groups as utils/optim.py:11-33 (extractor
+parameters in their own group with `extractor_lr_scale`). All gradients come from the native backward kernels
+(model/autograd.py); the optimizer is torch.optim on the device-resident parameters. LR schedulers, validation and
+checkpoint rotation of the reference loop are not part of the hot path and are left out.
+
+Multi-GPU: launched under torchrun, tasks are dealt round-robin to ranks (task i -> rank i % world). Test mode has no
+data-path collective (per-task statistics are all-gathered at the end). Training all-reduces (SUM, RCCL) one flat
+gradient bucket per optimizer step: every task's loss already carries 1/tasks_per_batch, so the sum over ranks
+reproduces single-GPU accumulation; BatchNorm running statistics are averaged over ranks at the same point.
 """
 import argparse
 import json
@@ -52,6 +61,16 @@ def build_parser():
     p.add_argument("--num_query_videos", type=int, default=4)
     p.add_argument("--frames_per_video", type=int, default=50)
     p.add_argument("--num_test_tasks", type=int, default=8)
+    p.add_argument("--num_train_tasks", type=int, default=16)
+    p.add_argument("--epochs", "-e", type=int, default=1)
+    p.add_argument("--learning_rate", "-lr", type=float, default=5e-6)
+    p.add_argument("--extractor_lr_scale", type=float, default=1.0)
+    p.add_argument("--optimizer", default="adam", choices=["adam", "sgd"])
+    p.add_argument("--weight_decay", type=float, default=0.2)
+    p.add_argument("--epsilon", type=float, default=1e-6)
+    p.add_argument("--betas", type=float, nargs=2, default=(0.9, 0.98))
+    p.add_argument("--momentum", type=float, default=0.0)
+    p.add_argument("--print_by_step", action="store_true")
     p.add_argument("--results_path", default=None)
     return p
 
@@ -73,6 +92,32 @@ def mean_ci(values):
     """mean and 95 % confidence half-width, as the reference's evaluators report (utils/eval_metrics.py:24-25)."""
     v = np.asarray(values, dtype=np.float64)
     return float(v.mean()), float(1.96 * v.std() / math.sqrt(len(v))) if len(v) > 1 else 0.0
+
+
+def cross_entropy(test_logits, test_labels, reduction="mean"):
+    """reference utils/optim.py:8-9"""
+    return torch.nn.functional.cross_entropy(test_logits, test_labels, reduction=reduction)
+
+
+def init_optimizer(model, lr, optimizer_type, args=None, extractor_lr_scale=0.1):
+    """Parameter groups of reference utils/optim.py:11-33: everything but the extractor / the extractor. The reference
+    tags the second group with `lr_scale` for timm's scheduler; without a scheduler the scale is applied directly."""
+    extractor_ids = set(map(id, model.feature_extractor.parameters()))
+    base_params = [p for p in model.parameters() if id(p) not in extractor_ids]
+    groups = [{"params": base_params},
+              {"params": list(model.feature_extractor.parameters()), "lr": lr * extractor_lr_scale,
+               "lr_scale": extractor_lr_scale}]
+    if optimizer_type == "adam":
+        opt = torch.optim.Adam(groups, lr=lr, eps=getattr(args, "epsilon", 1e-8),
+                               weight_decay=getattr(args, "weight_decay", 0.0),
+                               betas=tuple(getattr(args, "betas", (0.9, 0.999))))
+    elif optimizer_type == "sgd":
+        opt = torch.optim.SGD(groups, lr=lr, momentum=getattr(args, "momentum", 0.0),
+                              weight_decay=getattr(args, "weight_decay", 0.0))
+    else:
+        raise ValueError("optimizer %s not valid" % optimizer_type)
+    opt.zero_grad()
+    return opt
 
 
 class Learner:
@@ -120,10 +165,106 @@ class Learner:
         return task["context_clips"], task["context_labels"], videos
 
     def run(self):
+        stats = {}
         if "train" in self.args.mode:
-            raise NotImplementedError("meta-training (backward through the native extractor) is the next scope row; "
-                                      "run with --mode test")
-        return self.test()
+            stats["train"] = self.train()
+        if "test" in self.args.mode:
+            stats["test"] = self.test()
+        return stats
+
+    # ---- meta-training (reference single-step-learner.py:128-243) ----------------------------------------------------
+    def make_train_task(self, index):
+        a = self.args
+        per_class = a.shots * a.frames_per_shot
+        per_class -= per_class % a.clip_length
+        return synthetic.make_task(10_000 + index, a.way, 1, per_class, a.num_query_videos * a.frames_per_video,
+                                   a.frame_size, clip_length=a.clip_length, seed=a.seed)
+
+    def train_task(self, task):
+        a = self.args
+        self.model.personalise(task["context_clips"], task["context_labels"].to(self.device))
+        target_logits = self.model.predict(task["target_clips"])
+        task_loss = cross_entropy(target_logits, task["target_labels"].to(self.device)) / a.tasks_per_batch
+        task_loss = task_loss + 0.001 * self.model.film_generator.regularization_term()
+        task_loss.backward()
+        self.model._reset()
+        return task_loss.detach(), target_logits.detach()
+
+    def train_task_with_lite(self, task):
+        a = self.args
+        context_clips, context_labels = task["context_clips"], task["context_labels"].to(self.device)
+        target_clips, target_labels = task["target_clips"], task["target_labels"]
+        self.model._clear_caches()
+        task_loss, target_logits = 0, []
+        num_clips = len(target_clips)
+        num_batches = int(np.ceil(float(num_clips) / float(a.batch_size)))
+        for batch in range(num_batches):
+            self.model.personalise_with_lite(context_clips, context_labels)
+            lo, hi = batch * a.batch_size, min((batch + 1) * a.batch_size, num_clips)
+            batch_target_logits = self.model.predict_a_batch(target_clips[lo:hi])
+            target_logits.append(batch_target_logits.detach())
+            loss_scaling = len(context_labels) / (a.num_lite_samples * a.tasks_per_batch)
+            batch_loss = loss_scaling * cross_entropy(batch_target_logits, target_labels[lo:hi].to(self.device))
+            batch_loss = batch_loss + 0.001 * self.model.film_generator.regularization_term()
+            batch_loss.backward()
+            task_loss += batch_loss.detach()
+            self.model._reset()
+        return task_loss, torch.cat(target_logits)
+
+    def _sync_gradients(self):
+        """X3 of SURVEY.md §8e: one all-reduce(SUM) of the flat gradient bucket per optimizer step (+ the running
+        statistics, averaged)."""
+        if self.world == 1:
+            return
+        import torch.distributed as dist
+        params = [p for p in self.model.parameters() if p.requires_grad]
+        for p in params:
+            if p.grad is None:
+                p.grad = torch.zeros_like(p)
+        odist.allreduce_tensors([p.grad for p in params], average=False)
+        stats = [b for n, b in self.model.named_buffers() if n.endswith("running_mean") or n.endswith("running_var")]
+        if stats and self.model.learn_extractor:
+            odist.allreduce_tensors(stats, average=True)
+        del dist
+
+    def train(self):
+        a = self.args
+        self.optimizer = init_optimizer(self.model, a.learning_rate, a.optimizer, a, a.extractor_lr_scale)
+        train_task_fn = self.train_task_with_lite if a.with_lite else self.train_task
+        losses, accs, times = [], [], []
+        prev = torch.is_grad_enabled()
+        torch.set_grad_enabled(True)
+        try:
+            self.model.set_test_mode(False)
+            for epoch in range(a.epochs):
+                total_steps = a.num_train_tasks
+                for step in range(total_steps):
+                    if step % self.world == self.rank:
+                        task = self.make_train_task(epoch * total_steps + step)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        task_loss, logits = train_task_fn(task)
+                        torch.cuda.synchronize()
+                        times.append(1e3 * (time.perf_counter() - t0))
+                        losses.append(float(task_loss))
+                        accs.append(frame_accuracy(logits.cpu(), task["target_labels"]))
+                        if a.print_by_step:
+                            print("epoch [%d/%d][%d/%d] rank %d train loss %.7f frame_acc %.3f  %.1f ms/task"
+                                  % (epoch + 1, a.epochs, step + 1, total_steps, self.rank, losses[-1], accs[-1], times[-1]))
+                    if (step + 1) % a.tasks_per_batch == 0 or step == total_steps - 1:
+                        self._sync_gradients()
+                        self.optimizer.step()
+                        self.optimizer.zero_grad()
+        finally:
+            torch.set_grad_enabled(prev)
+        stats = {"loss": mean_ci(losses) if losses else (0.0, 0.0), "frame_acc": mean_ci(accs) if accs else (0.0, 0.0),
+                 "ms_per_task": mean_ci(times) if times else (0.0, 0.0), "num_tasks": len(losses),
+                 "world_size": self.world}
+        if self.rank == 0:
+            print("train: loss %.5f | frame_acc %.2f %% | %.1f ms/task | %d tasks on this rank, %d GPU(s)"
+                  % (stats["loss"][0], 100 * stats["frame_acc"][0], stats["ms_per_task"][0], stats["num_tasks"],
+                     self.world))
+        return stats
 
     def test(self):
         a = self.args

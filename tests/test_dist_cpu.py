@@ -88,3 +88,50 @@ def test_support_sharded_prototypes_world2(N, way):
         assert np.allclose(Wr, W.numpy(), atol=1e-5) and np.allclose(br, b.numpy(), atol=1e-4)
         assert np.allclose(lr, want.numpy(), atol=1e-3)
     assert np.array_equal(result[0][0], result[1][0])  # bit-identical prototypes on both ranks
+
+
+# ---- X3: gradient all-reduce of the task-parallel LITE training step ------------------------------------------------
+def _lite_grads(task_ids, tasks_per_batch):
+    """Accumulated gradients of the oracle's LITE step over `task_ids` (oracle/training.py, pinned by G6/G8)."""
+    from oracle.recogniser import OracleRecogniser
+    from oracle.training import LiteTrainer
+    from orbit_dataset_amd import synthetic
+    ref = OracleRecogniser("resnet18", False, "proto", 1, 4, num_lite_samples=2)
+    synthetic.init_parameters_(ref.fe)
+    tr = LiteTrainer(ref, True, tasks_per_batch)
+    for t in task_ids:
+        task = synthetic.make_task(300 + t, way=3, shots=1, frames_per_shot=2, num_query=4, frame_size=32)
+        tr.train_task_with_lite(task["context_clips"], task["context_labels"], task["target_clips"],
+                                task["target_labels"], seeds=(900 + t,))
+    return [p.grad for _, p in sorted(ref.fe.named_parameters()) if p.grad is not None]
+
+
+def _train_worker(rank, world, port, result):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    r, w, _ = odist.init_from_env("gloo")
+    grads = _lite_grads(list(odist.tasks_for_rank(2, r, w)), tasks_per_batch=2)
+    odist.allreduce_tensors(grads, average=False)  # the one exchange step per optimizer step
+    result[rank] = [g.numpy() for g in grads[:4]] + [grads[-1].numpy()]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_matches_single_process_accumulation():
+    """Two ranks, one task each, SUM all-reduce of one flat bucket == one process accumulating both tasks (the loss
+    already carries 1/tasks_per_batch, single-step-learner.py:231)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_train_worker, args=(2, port, result), nprocs=2, join=True)
+    torch.set_num_threads(2)
+    want = _lite_grads([0, 1], tasks_per_batch=2)
+    want = [g.numpy() for g in want[:4]] + [want[-1].numpy()]
+    for r in range(2):
+        for got, ref in zip(result[r], want):
+            assert np.abs(got - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-12)
+    for a, b in zip(result[0], result[1]):
+        assert np.array_equal(a, b)  # identical gradients on both ranks -> identical optimizer steps

@@ -144,6 +144,68 @@ def test_G6_lite_forward():
     assert not bool(g["extractor_has_grad"])
 
 
+def _lite_trainer(adapt, learn_extractor, bs, nl, tpb):
+    from oracle.training import LiteTrainer
+    ref = oracle_recogniser(adapt, "proto", 1, bs, num_lite=nl)
+    return LiteTrainer(ref, learn_extractor, tpb)
+
+
+def _rel(got, want):
+    return float((got.double() - want.double()).abs().max() / max(float(want.double().abs().max()), 1e-30))
+
+
+def test_G6_lite_gradients_frozen_extractor():
+    """oracle/training.py against the gradients the reference recorded for the frozen-extractor + FiLM LITE step."""
+    g = gold("G6_lite")
+    nl, tpb, bs = int(g["num_lite_samples"]), int(g["tasks_per_batch"]), int(g["batch_size"])
+    tr = _lite_trainer(True, False, bs, nl, tpb)
+    out = tr.train_task_with_lite(g["context_clips"], g["context_labels"], g["target_clips"][:2 * bs],
+                                  g["target_labels"][:2 * bs], seeds=(500, 501))
+    for b, (logits, loss) in enumerate(out):
+        assert (logits - g["logits_%d" % b]).abs().max().item() < 2e-4
+        assert abs(float(loss) - float(g["loss_%d" % b])) < 1e-4
+    grads = {("set_encoder." if m is tr.r.set_encoder else "film_generator.") + n: p.grad
+             for m in (tr.r.set_encoder, tr.r.film_generator) for n, p in m.named_parameters()}
+    for key in g:
+        if key.startswith("grad__"):
+            assert _rel(grads[key[len("grad__"):]], g[key]) < 1e-3, key
+    assert all(p.grad is None for p in tr.r.fe.parameters())
+
+
+@pytest.mark.parametrize("tag,adapt", [("a", False), ("b", True)])
+def test_G8_lite_gradients_unfrozen_extractor(tag, adapt):
+    """... and for the unfrozen extractor: train-mode BatchNorm on every pass, gradients through the query batch only,
+    running statistics after the two steps."""
+    g = gold("G8_lite_learn_extractor")
+    nl, tpb, bs = int(g["num_lite_samples"]), int(g["tasks_per_batch"]), int(g["batch_size"])
+    tr = _lite_trainer(adapt, True, bs, nl, tpb)
+    out = tr.train_task_with_lite(g["context_clips"], g["context_labels"], g["target_clips"], g["target_labels"],
+                                  seeds=(800, 801))
+    for b, (logits, loss) in enumerate(out):
+        assert (logits - g["%s_logits_%d" % (tag, b)]).abs().max().item() < 2e-4
+        assert abs(float(loss) - float(g["%s_loss_%d" % (tag, b)])) < 1e-4
+    named = {"feature_extractor." + n: p for n, p in tr.r.fe.named_parameters()}
+    if adapt:
+        named.update({"set_encoder." + n: p for n, p in tr.r.set_encoder.named_parameters()})
+        named.update({"film_generator." + n: p for n, p in tr.r.film_generator.named_parameters()})
+    checked = 0
+    for key in g:
+        if not key.startswith(tag + "_grad__"):
+            continue
+        name = key[len(tag + "_grad__"):]
+        flat = named[name].grad.flatten()
+        sample = flat[::max(1, flat.numel() // 4096)][:4096]
+        assert _rel(sample, g[key]) < 1e-3, name
+        assert abs(float(flat.double().norm()) - float(g[tag + "_gnorm__" + name])) < 1e-3 * float(g[tag + "_gnorm__" + name])
+        checked += 1
+    assert checked >= 6
+    sd = {"feature_extractor." + k: v for k, v in tr.r.fe.state_dict().items()}
+    for key in g:
+        if key.startswith(tag + "_stat__"):
+            assert _rel(sd[key[len(tag + "_stat__"):]].float(), torch.as_tensor(g[key]).float()) < 1e-5, key
+    assert (named["feature_extractor.bn1.weight"].grad is not None) == bool(g[tag + "_bn1_weight_has_grad"])
+
+
 def test_C_restatement_of_head_against_golden():
     """oracle/proto_head.c (double accumulation) against the reference's golden logits."""
     import ctypes
