@@ -10,6 +10,12 @@ whole-job rate over all ranks (tasks are independent units: rank r runs its own 
 "scaling": "weak"). Rank 0 prints ONE JSON line carrying `roofline` (dominant kernel = the fp32-MFMA
 implicit-GEMM convolution, per-launch HIP events on its stream) and `cpu_baseline` (the PyTorch-CPU oracle of
 the same path timed on this box's host cores, N=1 only, bounded sample).
+
+`--mode lite_train` (resnet18 workloads) times the LITE meta-training step instead: one step = one task through
+Learner.train_task_with_lite (per query batch: personalise_with_lite -> predict_a_batch -> scaled CE -> backward)
+plus the optimizer step; with N > 1 every step all-reduces (RCCL) one flat gradient bucket. Same metric / unit /
+JSON contract; the roofline aggregates the forward + data-gradient (conv_igemm) and weight-gradient (conv_wgrad)
+kernels.
 """
 import argparse
 import ctypes
@@ -38,9 +44,15 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, de
 WAY, SHOTS, FRAMES_PER_SHOT, NUM_QUERY = 5, 5, 8, 200
 
 
-def build_model(workload, device, batch_size=256):
+NUM_LITE = 16
+
+
+def build_model(workload, device, batch_size=256, train=False):
     fe_name, adapt, _ = WORKLOADS[workload]
-    model = SingleStepFewShotRecogniser(fe_name, adapt, "proto", 1, batch_size, False, 16, 1.0)
+    # meta-training recipes of the reference README: ProtoNets learn the extractor; CNAPs keep it frozen and learn the
+    # set encoder + FiLM generator
+    learn_extractor = bool(train and not adapt)
+    model = SingleStepFewShotRecogniser(fe_name, adapt, "proto", 1, batch_size, learn_extractor, NUM_LITE, 1.0)
     synthetic.init_parameters_(model)
     if adapt:
         from orbit_dataset_amd.model.film import get_film_parameters
@@ -48,8 +60,42 @@ def build_model(workload, device, batch_size=256):
                                                                            model.feature_extractor)
     model._set_device(device)
     model._send_to_device()
-    model.set_test_mode(True)
+    model.set_test_mode(not train)
     return model
+
+
+class LiteTrainStep:
+    """One optimizer step of Learner.train_task_with_lite (reference single-step-learner.py:212-243) with
+    tasks_per_batch = 1 per rank; N > 1 ranks form a batch of N tasks whose gradients are summed by ONE all-reduce."""
+
+    def __init__(self, model, world, batch_size):
+        from orbit_dataset_amd.learner import init_optimizer
+        self.model, self.world, self.batch_size = model, world, batch_size
+        self.optimizer = init_optimizer(model, 5e-6, "adam", None, 1.0)
+        import numpy as np
+        np.random.seed(1991)
+
+    def __call__(self, model, task):
+        import torch.nn.functional as F
+        from orbit_dataset_amd import dist as odist
+        ctx, lab, tgt, tlab = task["context_clips"], task["context_labels"], task["target_clips"], task["target_labels"]
+        model._clear_caches()
+        out = []
+        with torch.enable_grad():
+            for lo in range(0, len(tgt), self.batch_size):
+                model.personalise_with_lite(ctx, lab)
+                logits = model.predict_a_batch(tgt[lo:lo + self.batch_size])
+                loss = len(lab) / (NUM_LITE * self.world) * F.cross_entropy(logits, tlab[lo:lo + self.batch_size])
+                loss = loss + 0.001 * model.film_generator.regularization_term()
+                loss.backward()
+                out.append(logits.detach())
+                model._reset()
+        if self.world > 1:
+            grads = [p.grad for p in model.parameters() if p.grad is not None]
+            odist.allreduce_tensors(grads, average=False)
+        self.optimizer.step()
+        self.optimizer.zero_grad()
+        return torch.cat(out)
 
 
 def run_task(model, task):
@@ -89,11 +135,11 @@ def head_roofline(device, n_tasks=64, M=200, D=1280, C=5, reps=40):
             "bytes_per_launch": nbytes, "traffic": None}
 
 
-def cpu_baseline(workload, model):
+def cpu_baseline(workload, model, train=False):
     """The oracle (CPU restatement of the reference path) on ONE task of the same workload, all host cores."""
     from oracle.recogniser import OracleRecogniser
     fe_name, adapt, size = WORKLOADS[workload]
-    ref = OracleRecogniser(fe_name, adapt, "proto", 1, 256)
+    ref = OracleRecogniser(fe_name, adapt, "proto", 1, 256, num_lite_samples=NUM_LITE)
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
     ref.fe.load_state_dict({k[len("feature_extractor."):]: v for k, v in sd.items() if k.startswith("feature_extractor.")})
     if adapt:
@@ -115,14 +161,28 @@ def cpu_baseline(workload, model):
         if best is None or dt < best:
             best, cores = dt, nt
     torch.set_num_threads(cores)
-    t0 = time.perf_counter()
-    ref.personalise(task["context_clips"], task["context_labels"])
-    logits = ref.predict(task["target_clips"])
-    dt = time.perf_counter() - t0
+    if train:
+        import numpy as np
+        from oracle.training import LiteTrainer
+        trainer = LiteTrainer(ref, not adapt, 1)
+        np.random.seed(1991)
+        t0 = time.perf_counter()
+        with torch.enable_grad():
+            (logits, _), = trainer.train_task_with_lite(task["context_clips"], task["context_labels"],
+                                                        task["target_clips"], task["target_labels"])
+        dt = time.perf_counter() - t0
+        what = "1 LITE training task (200 support + 200 query frames, H=%d, forward + backward)" % NUM_LITE
+    else:
+        t0 = time.perf_counter()
+        ref.personalise(task["context_clips"], task["context_labels"])
+        logits = ref.predict(task["target_clips"])
+        dt = time.perf_counter() - t0
+        what = "1 task (200 support + 200 query frames"
+        what += ")"
     return {"value": NUM_QUERY / dt, "unit": "query frames/s", "cores": cores, "kind": "port",
             "host_cpus": os.cpu_count(),
-            "sample": "1 task (200 support + 200 query frames, %dx%d), PyTorch-CPU oracle, %d threads (fastest of "
-                      "8/16/32/64/128 on a 32-frame probe), %.1f s" % (size, size, cores, dt)
+            "sample": "%s, %dx%d, PyTorch-CPU oracle, %d threads (fastest of 8/16/32/64/128 on a 32-frame probe), "
+                      "%.1f s" % (what, size, size, cores, dt)
             }, task, logits
 
 
@@ -132,6 +192,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="efficientnet_b0_224", choices=sorted(WORKLOADS))
+    ap.add_argument("--mode", default="inference", choices=["inference", "lite_train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-tasks", type=int, default=4, help="tasks resident in HBM, cycled through")
     ap.add_argument("--batch-size", type=int, default=256, help="clips per extractor call (reference --batch_size)")
@@ -159,7 +220,9 @@ def main():
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     fe_name, adapt, size = WORKLOADS[args.workload]
-    model = build_model(args.workload, device, args.batch_size)
+    train = args.mode == "lite_train"
+    model = build_model(args.workload, device, args.batch_size, train=train)
+    run_step = LiteTrainStep(model, world, args.batch_size) if train else run_task
     # each rank owns its own tasks (task index = rank + world * i): weak scaling, independent units
     tasks = [synthetic.make_task_on_device(rank + world * i, WAY, SHOTS, FRAMES_PER_SHOT, NUM_QUERY, size, 1, device)
              for i in range(max(1, args.distinct_tasks))]
@@ -177,7 +240,7 @@ def main():
         correct = torch.zeros(2, device=device)
         for i in range(steps):
             task = tasks[i % len(tasks)]
-            logits = run_task(model, task)
+            logits = run_step(model, task)
             correct[0] += (logits.argmax(1) == task["target_labels"]).sum()
             correct[1] += logits.shape[0]
         issued = time.perf_counter() - t0  # host time to enqueue everything (diagnostic: host- vs device-bound)
@@ -185,7 +248,7 @@ def main():
         return time.perf_counter() - t0, correct, issued
 
     for i in range(args.warmup):
-        run_task(model, tasks[i % len(tasks)])
+        run_step(model, tasks[i % len(tasks)])
     elapsed, correct, issued = loop(args.steps)  # the timed region behind `value`
     # roofline leg: the SAME K steps again with one HIP-event pair recorded per conv_igemm launch on its stream
     # (kept out of the timed region above: recording ~80 events per task costs host time and serialises the queue)
@@ -240,9 +303,12 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "%s: ProtoNet + %s%s, %dx%d, %d-way, %d support frames (%d shots x %d), %d query "
+        "config": {"workload": "%s%s: ProtoNet + %s%s, %dx%d, %d-way, %d support frames (%d shots x %d), %d query "
                                "frames, clip_length 1, batch_size 256, inputs resident in HBM" % (
-                                   args.workload, fe_name, " + CNAPs FiLM adaptation" if adapt else "", size, size, WAY,
+                                   args.workload,
+                                   " LITE meta-training step (H=%d, fwd+bwd+Adam%s)" % (
+                                       NUM_LITE, ", gradient all-reduce" if world > 1 else "") if train else "",
+                                   fe_name, " + CNAPs FiLM adaptation" if adapt else "", size, size, WAY,
                                    WAY * SHOTS * FRAMES_PER_SHOT, SHOTS, FRAMES_PER_SHOT, NUM_QUERY),
                    "tasks_per_step": 1, "parallelism": "task-parallel x%d (independent tasks per rank)" % world},
         "frame_accuracy": float(correct[0].item() / max(correct[1].item(), 1)),
@@ -252,7 +318,7 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                      "algorithmic_bytes_per_launch": total_bytes / max(n.value, 1),
-                     "kernel": "orbit::conv_igemm_kernel (all instantiations)",
+                     "kernel": "orbit::conv_igemm_kernel (all instantiations)" + (" + orbit::conv_wgrad_kernel" if train else ""),
                      "launches": n.value, "avg_launch_us": 1e3 * ms.value / max(n.value, 1),
                      "algorithmic_hbm_gbs": total_bytes / (ms.value * 1e-3) / 1e9 if ms.value > 0 else None,
                      "kernel_time_share": ms.value / (1e3 * elapsed),
@@ -262,8 +328,13 @@ def main():
     }
     out["head_roofline"] = head_roofline(device)
     if not args.no_cpu_baseline and world == 1:
-        base, task, want = cpu_baseline(args.workload, model)
-        got = run_task(model, {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in task.items()}).cpu()
+        sd_before = {k: v.clone() for k, v in model.state_dict().items()} if train else None
+        base, task, want = cpu_baseline(args.workload, model, train=train)
+        if train:  # the same LITE step on the same weights and permutation
+            import numpy as np
+            model.load_state_dict(sd_before)
+            np.random.seed(1991)
+        got = run_step(model, {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in task.items()}).cpu()
         base["max_abs_dlogit_vs_gpu"] = float((got - want).abs().max().item())
         base["argmax_identical"] = bool(torch.equal(got.argmax(1), want.argmax(1)))
         out["cpu_baseline"] = base

@@ -53,6 +53,7 @@ struct ConvDesc {
     int act;     // ORBIT_ACT_*
     int pool2;   // fused 2x2/2 max-pool of the activated output
     int x_nchw;  // stem gather from NCHW frames
+    float prof_flop_scale = 1.f;  // algorithmic / executed flops (strided dgrad runs on the zero-inserted grid)
 };
 
 // geometry of the packed weight matrix for a conv (shared by pack + launch)
@@ -67,7 +68,10 @@ size_t conv_packed_floats(int Cin, int Cout, int KH, int KW, int x_nchw);
 int conv_pack_weights(const float* w_oihw, float* w_packed, int Cin, int Cout, int KH, int KW,
                       int x_nchw, hipStream_t s);
 int launch_conv(const ConvDesc& d, hipStream_t s);
-bool conv_prof_enabled();  // per-launch event profiling is on (graphs are bypassed while it is)
+bool conv_prof_enabled();
+// per-launch HIP-event records of orbit_prof_* (no-ops returning -1 while profiling is off)
+int prof_start(const char* name, double flops, double bytes, hipStream_t s);
+void prof_stop(int idx, hipStream_t s);  // per-launch event profiling is on (graphs are bypassed while it is)
 
 // depthwise + fused SE pooling partials [B][chunks][C] (pool_partial may be nullptr); chunks = dwconv_se_chunks(Ho)
 int dwconv_se_chunks(int Ho);

@@ -52,6 +52,7 @@ struct ConvParams {
     int cin_pad;    // per-tap padded Cin (vector mode)
     int act;
     int m_tiles, n_tiles;
+    float prof_flop_scale;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -424,6 +425,20 @@ static int prof_variant(const char* name) {
     return (int)g_prof_variants.size() - 1;
 }
 
+// shared with the other MFMA kernels (conv_wgrad.hip): returns a record index or -1 when profiling is off
+int prof_start(const char* name, double flops, double bytes, hipStream_t s) {
+    if (!g_prof_on) return -1;
+    ProfRec r;
+    r.start = prof_event(), r.stop = prof_event(), r.variant = prof_variant(name);
+    r.flops = flops, r.bytes = bytes;
+    (void)hipEventRecord(r.start, s);
+    g_prof_recs.push_back(r);
+    return (int)g_prof_recs.size() - 1;
+}
+void prof_stop(int idx, hipStream_t s) {
+    if (idx >= 0 && idx < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx].stop, s);
+}
+
 template <int BM, int BN, int WGM, int WGN, int BK, int MODE, bool POOL2, bool GATE>
 static int launch_cfg(ConvParams& p, hipStream_t s) {
     p.m_tiles = cdiv(p.M, BM);
@@ -445,7 +460,7 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
         ProfRec r;
         r.start = prof_event(), r.stop = prof_event(), r.variant = prof_variant(name);
         const double pix = POOL2 ? (double)p.B * p.HoP * p.WoP * 4 : (double)p.B * p.Ho * p.Wo;
-        r.flops = 2.0 * pix * p.Cout * p.KH * p.KW * p.Cin;  // algorithmic (unpadded) FLOPs of this launch
+        r.flops = 2.0 * pix * p.Cout * p.KH * p.KW * p.Cin * p.prof_flop_scale;  // algorithmic (unpadded) FLOPs
         // algorithmic HBM bytes: input once, output once (pooled if fused), residual once, weights once
         r.bytes = 4.0 * ((double)p.B * p.H * p.W * p.Cin + (POOL2 ? pix / 4 : pix) * p.Cout * (p.residual ? 2.0 : 1.0) +
                          (double)p.Cout * p.KH * p.KW * p.Cin);
@@ -504,6 +519,7 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     p.stride = d.stride, p.pad_t = d.pad_t, p.pad_l = d.pad_l, p.Ho = d.Ho, p.Wo = d.Wo;
     p.HoP = d.Ho / 2, p.WoP = d.Wo / 2;
     p.KT = g.kt, p.cin_pad = g.cin_pad, p.act = d.act;
+    p.prof_flop_scale = d.prof_flop_scale;
     if (d.pool2) {
         ORBIT_REQUIRE(p.HoP > 0 && p.WoP > 0, "conv: pool2 needs Ho, Wo >= 2");
         p.M = d.B * p.HoP * p.WoP * 4;

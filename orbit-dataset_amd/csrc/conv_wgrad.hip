@@ -214,8 +214,12 @@ int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oih
     p.M = B * Ho * Wo, p.NC = KH * KW * Cin;
     wgrad_geometry(p.M, Cout, p.NC, p.co_tiles, p.n_tiles, p.splits, p.steps_per_split);
     const int grid = p.co_tiles * p.n_tiles * p.splits;
+    // algorithmic work: 2*M*Cout*K flops; bytes = input + output gradient once, filter gradient once
+    const int rec = prof_start(x_nchw ? "conv_wgrad<nchw>" : "conv_wgrad<nhwc>", 2.0 * p.M * Cout * p.NC,
+                               4.0 * ((double)B * H * W * Cin + (double)p.M * Cout + (double)Cout * p.NC), s);
     if (x_nchw) conv_wgrad_kernel<1><<<grid, 256, 0, s>>>(p);
     else conv_wgrad_kernel<0><<<grid, 256, 0, s>>>(p);
+    prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();
     const size_t total = (size_t)Cout * p.NC;
     int rblocks = (int)((total + 255) / 256);
@@ -274,6 +278,7 @@ int launch_conv_dgrad(const float* dy, const float* w_dgrad_packed, const float*
     d.B = B, d.H = Hs, d.W = Ws, d.Cin = Cout, d.Cout = Cin, d.KH = KH, d.KW = KW, d.stride = 1;
     d.pad_t = KH - 1 - pad_t, d.pad_l = KW - 1 - pad_l, d.Ho = H, d.Wo = W;
     d.act = ORBIT_ACT_NONE, d.pool2 = 0, d.x_nchw = 0;
+    d.prof_flop_scale = 1.0f / (float)(stride * stride);
     return launch_conv(d, s);
 }
 

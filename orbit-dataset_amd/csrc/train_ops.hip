@@ -63,6 +63,30 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
+// Sum of the [nblk][2][C] partials for 16 channels per block: 16 lanes per channel take every 16th partial (double
+// accumulation, fixed order), then a 16-way LDS reduction. (A one-thread-per-channel loop over ~1000 partials is a
+// 200 us latency chain; this form is ~10 us.)
+__device__ __forceinline__ bool reduce_partials(const float* __restrict__ partial, int nblk, int C, double& s0,
+                                                double& s1, int& c_out) {
+    __shared__ double sh[2][16][16];
+    const int cl = threadIdx.x & 15, ln = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    double a0 = 0.0, a1 = 0.0;
+    if (c < C) {
+#pragma unroll 4
+        for (int b = ln; b < nblk; b += 16) {
+            a0 += (double)partial[((size_t)b * 2 + 0) * C + c];
+            a1 += (double)partial[((size_t)b * 2 + 1) * C + c];
+        }
+    }
+    sh[0][ln][cl] = a0, sh[1][ln][cl] = a1;
+    __syncthreads();
+    if (ln != 0 || c >= C) return false;
+    for (int j = 1; j < 16; ++j) a0 += sh[0][j][cl], a1 += sh[1][j][cl];
+    s0 = a0, s1 = a1, c_out = c;
+    return true;
+}
+
 // mean / biased variance -> invstd, folded scale/shift, running statistics (momentum update with the unbiased
 // variance, torch.nn.BatchNorm2d semantics). gamma/beta point at the layer's own or the per-task FiLM vectors.
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblk, int M,
@@ -75,13 +99,9 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
                                                                 float* __restrict__ scale, float* __restrict__ shift,
                                                                 float* __restrict__ running_mean,
                                                                 float* __restrict__ running_var) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, ss = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += (double)partial[((size_t)b * 2 + 0) * C + c];
-        ss += (double)partial[((size_t)b * 2 + 1) * C + c];
-    }
+    double s, ss;
+    int c;
+    if (!reduce_partials(partial, nblk, C, s, ss, c)) return;
     const double mean = s / M;
     double var = ss / M - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -175,13 +195,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
                                                               const float* __restrict__ invstd,
                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
                                                               float* __restrict__ dbias, float* __restrict__ coef) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
-    double s = 0.0, sx = 0.0;
-    for (int b = 0; b < nblk; ++b) {
-        s += (double)partial[((size_t)b * 2 + 0) * C + c];
-        sx += (double)partial[((size_t)b * 2 + 1) * C + c];
-    }
+    double s, sx;
+    int c;
+    if (!reduce_partials(partial, nblk, C, s, sx, c)) return;
     if (dgamma) dgamma[c] = (float)sx;
     if (dbeta) dbeta[c] = (float)s;
     const float k1 = (gamma ? gamma[c] : 1.f) * invstd[c];
@@ -335,7 +351,7 @@ int launch_bn_stats(const float* y, int M, int C, float eps, float momentum, con
     const int nblk = bn_reduce_blocks(M, C);
     bn_stats_partial_kernel<<<dim3(nblk, L.ygroups), 256, 0, s>>>(y, M, C, bn_rows_per_block(M, C), L.G, L.R, partial);
     ORBIT_LAUNCH_CHECK();
-    bn_stats_finalize_kernel<<<cdiv(C, 256), 256, 0, s>>>(partial, nblk, M, C, eps, momentum, gamma, beta, conv_bias, mean,
+    bn_stats_finalize_kernel<<<cdiv(C, 16), 256, 0, s>>>(partial, nblk, M, C, eps, momentum, gamma, beta, conv_bias, mean,
                                                           invstd, scale, shift, running_mean, running_var);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
@@ -360,7 +376,7 @@ int launch_bn_backward(const float* dout, const float* out, const float* y, cons
     bn_bwd_partial_kernel<<<dim3(nblk, L.ygroups), 256, 0, s>>>(dout, out, y, mean, invstd, act, M, C,
                                                                 bn_rows_per_block(M, C), L.G, L.R, partial);
     ORBIT_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<cdiv(C, 256), 256, 0, s>>>(partial, nblk, M, C, train, gamma, invstd, dgamma, dbeta, dbias,
+    bn_bwd_finalize_kernel<<<cdiv(C, 16), 256, 0, s>>>(partial, nblk, M, C, train, gamma, invstd, dgamma, dbeta, dbias,
                                                         coef);
     ORBIT_LAUNCH_CHECK();
     if (dy) {

@@ -238,9 +238,17 @@ class Learner:
             self.model.set_test_mode(False)
             for epoch in range(a.epochs):
                 total_steps = a.num_train_tasks
+                # this rank's tasks of the epoch are generated up front (the reference prefetches with DataLoader
+                # workers): generating them between steps leaves the intra-op CPU threads spinning against the thread
+                # that enqueues kernels, which showed up as random 50-80 ms stalls per task
+                mine = [s_ for s_ in range(total_steps) if s_ % self.world == self.rank]
+                task_bytes = 4.0 * 3 * a.frame_size ** 2 * a.way * (a.shots * a.frames_per_shot
+                                                                   + a.num_query_videos * a.frames_per_video)
+                pregen = {s_: self.make_train_task(epoch * total_steps + s_) for s_ in mine} \
+                    if task_bytes * len(mine) < 16e9 else {}
                 for step in range(total_steps):
                     if step % self.world == self.rank:
-                        task = self.make_train_task(epoch * total_steps + step)
+                        task = pregen.pop(step, None) or self.make_train_task(epoch * total_steps + step)
                         torch.cuda.synchronize()
                         t0 = time.perf_counter()
                         task_loss, logits = train_task_fn(task)
