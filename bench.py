@@ -99,8 +99,9 @@ class LiteTrainStep:
 
 
 def run_task(model, task):
-    model.personalise(task["context_clips"], task["context_labels"])
-    logits = model.predict(task["target_clips"])
+    with torch.no_grad():  # as every test-time caller of the reference does (single-step-learner.py:311)
+        model.personalise(task["context_clips"], task["context_labels"])
+        logits = model.predict(task["target_clips"])
     model._reset()
     return logits
 

@@ -68,6 +68,7 @@ class SupportSharding:
         return allreduce_sum_(tensor, self.group)
 
 
+@torch.no_grad()
 def personalise_support_sharded(model, context_clips, context_labels, sharding):
     """personalise() with the support set sharded over ranks (form 2). Every rank passes the FULL label vector
     (tiny) and either the full clip tensor or at least its own slice [lo:hi) of it; features are extracted only
@@ -98,6 +99,7 @@ def personalise_support_sharded(model, context_clips, context_labels, sharding):
         model.classifier.partial_reduce = None
 
 
+@torch.no_grad()
 def predict_query_sharded(model, target_clips, sharding, gather=True):
     """predict() with the query clips split over ranks (form 3). Returns the full [M, C] logits on every rank when
     `gather`, else (local logits, (lo, hi))."""

@@ -67,6 +67,11 @@ class HipNetwork(nn.Module):
     (fast path). When the module is instead run under `torch.func.functional_call` with a FiLM dict (the
     reference's mechanism, few_shot_recognisers.py:114-115), the swapped-in BatchNorm tensors are detected and
     gathered automatically.
+
+    Like any nn.Module the network follows `self.training`: in eval() BatchNorm uses running statistics (the
+    inference runtime, fused kernels); in train() it uses batch statistics and updates the running statistics
+    (the training runtime). With autograd enabled and a parameter / FiLM vector requiring a gradient, the forward
+    records a tape and `backward()` runs the native gradient kernels (model/autograd.py).
     """
 
     def __init__(self, native_name):
@@ -252,7 +257,8 @@ class HipNetwork(nn.Module):
         if not lib.orbit_extractor_supports_training(plan.handle):
             raise NotImplementedError(
                 "%s has no native training path yet (train-mode BatchNorm / backward are built for resnet18 and the "
-                "set encoder); use set_test_mode(True) or a frozen extractor without FiLM gradients" % self.native_name)
+                "set encoder); for inference call it in eval() under torch.no_grad(), as the reference's test loops do"
+                % self.native_name)
         B = x.shape[0]
         gamma, beta = film if film is not None else (None, None)
         if use_tape:

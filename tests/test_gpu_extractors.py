@@ -31,7 +31,7 @@ def _pair(name, with_film=False):
     synthetic.init_parameters_(ref)
     fe, film_names = create_feature_extractor(name, True, with_film, False)
     fe.load_state_dict(ref.state_dict())
-    return ref, fe.cuda(), film_names
+    return ref, fe.cuda().eval(), film_names  # like ref: running-statistics BatchNorm (nn.Module defaults to train())
 
 
 @pytest.mark.parametrize("name,size,n", [("resnet18", 84, 12), ("resnet18", 32, 5), ("resnet18", 224, 3),
@@ -83,7 +83,7 @@ def test_set_encoder_matches_oracle(device, size, n):
     synthetic.init_parameters_(ref)
     enc = SetEncoder()
     enc.load_state_dict(ref.state_dict())
-    enc = enc.cuda()
+    enc = enc.cuda().eval()
     x = _frames(n, size)
     with torch.no_grad():
         want = ref(x)
@@ -124,7 +124,7 @@ def test_graph_replay_matches_eager(device):
         "import orbit_dataset_amd\n"
         "from orbit_dataset_amd import synthetic\n"
         "from orbit_dataset_amd.model.feature_extractors import create_feature_extractor\n"
-        "fe,_ = create_feature_extractor('resnet18', True, False, False); synthetic.init_parameters_(fe); fe = fe.cuda()\n"
+        "fe,_ = create_feature_extractor('resnet18', True, False, False); synthetic.init_parameters_(fe); fe = fe.cuda().eval()\n"
         "x = torch.randn(6, 3, 64, 64, generator=torch.Generator().manual_seed(1)).cuda()\n"
         "out = torch.empty(6, 512, device='cuda')\n"
         "outs = [fe(x, out=out).clone() for _ in range(4)]  # eager, capture, replay, replay\n"

@@ -60,7 +60,7 @@ def test_G3_set_encoder(device):
     g = gold("G3_set_encoder")
     enc = SetEncoder()
     synthetic.init_parameters_(enc)
-    enc = enc.cuda()
+    enc = enc.cuda().eval()
     reps = enc(g["x"].to(device))
     assert (reps.cpu() - g["reps"]).abs().max().item() < 2e-5
     assert (enc.aggregate(reps).cpu() - g["mean"]).abs().max().item() < 2e-5

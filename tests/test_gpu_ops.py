@@ -319,7 +319,7 @@ def test_extractor_batch_sizes(device, B):
     synthetic.init_parameters_(ref)
     fe, _ = create_feature_extractor("resnet18", True, False, False)
     fe.load_state_dict(ref.state_dict())
-    fe = fe.cuda()
+    fe = fe.cuda().eval()
     x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(B))
     with torch.no_grad():
         want = ref(x)

@@ -43,12 +43,13 @@ def build_pair(fe_name, adapt, classifier, clip_length, batch_size, num_lite=16,
 
 def check_task(model, ref, task, to_device):
     ctx, lab, tgt = task["context_clips"], task["context_labels"], task["target_clips"]
-    if to_device:
-        model.personalise(ctx.cuda(), lab.cuda())
-        logits = model.predict(tgt.cuda())
-    else:  # frames stay on the host and are moved per mini-batch, as in the reference's test loop
-        model.personalise(ctx, lab.cuda())
-        logits = model.predict(tgt)
+    with torch.no_grad():  # every test-time caller of the reference does (single-step-learner.py:249,311; notebook)
+        if to_device:
+            model.personalise(ctx.cuda(), lab.cuda())
+            logits = model.predict(tgt.cuda())
+        else:  # frames stay on the host and are moved per mini-batch, as in the reference's test loop
+            model.personalise(ctx, lab.cuda())
+            logits = model.predict(tgt)
     ref.personalise(ctx, lab)
     want = ref.predict(tgt)
     got = logits.cpu()
@@ -141,12 +142,19 @@ def test_learner_test_mode_end_to_end(device, tmp_path):
     stats = main(["--mode", "test", "--feature_extractor", "resnet18", "--classifier", "proto", "--frame_size", "64",
                   "--clip_length", "2", "--batch_size", "16", "--way", "3", "--shots", "2", "--frames_per_shot", "4",
                   "--num_query_videos", "2", "--frames_per_video", "6", "--num_test_tasks", "3",
-                  "--results_path", str(out)])
+                  "--results_path", str(out)])["test"]
     assert stats["num_tasks"] == 3 and 0.0 <= stats["frame_acc"][0] <= 1.0
     assert stats["personalise_ms"][0] > 0 and stats["inference_ms_per_frame"][0] > 0
     assert out.exists()
+    # --mode train: LITE meta-training on the native backward kernels (resnet18); efficientnet_b0 has no training path
+    common = ["--frame_size", "64", "--way", "3", "--shots", "2", "--frames_per_shot", "4", "--num_query_videos", "2",
+              "--frames_per_video", "6", "--batch_size", "8", "--num_lite_samples", "4", "--tasks_per_batch", "2",
+              "--num_train_tasks", "4"]
+    for extra in (["--learn_extractor", "--with_lite"], ["--adapt_features", "--with_lite"], ["--learn_extractor"]):
+        tr = main(["--mode", "train", "--feature_extractor", "resnet18"] + extra + common)["train"]
+        assert tr["num_tasks"] == 4 and np.isfinite(tr["loss"][0]) and tr["loss"][0] > 0
     with pytest.raises(NotImplementedError):
-        main(["--mode", "train", "--learn_extractor", "--feature_extractor", "resnet18", "--frame_size", "64"])
+        main(["--mode", "train", "--learn_extractor", "--with_lite", "--feature_extractor", "efficientnet_b0"] + common)
 
 
 def test_sharded_forms_on_device_world1(device):
