@@ -185,7 +185,8 @@ int orbit_op_mbconv_front(const float* x, const float* w1, const float* scale1, 
  * What `loss.backward()` runs in the reference (single-step-learner.py:234) for the graph recorded by
  * model/few_shot_recognisers.py:99-122 (_get_features, grad enabled), :345-356 (_get_task_embedding on the LITE
  * subset) and model/classifier_heads.py:202-230 (head). BatchNorm mode follows few_shot_recognisers.py:176-183.
- * Available for the resnet18 and set_encoder plans (orbit_extractor_supports_training). */
+ * Available for the resnet18, efficientnet_b0 and set_encoder plans (orbit_extractor_supports_training is 0 only for a
+ * plan built with the opt-in fused MBConv front op). */
 int orbit_extractor_supports_training(const orbit_extractor_t* fe);
 size_t orbit_extractor_tape_bytes(const orbit_extractor_t* fe, int B);
 size_t orbit_extractor_backward_workspace_bytes(const orbit_extractor_t* fe, int B);
@@ -251,6 +252,16 @@ int orbit_op_maxpool2d_train(const float* x, float* y, uint8_t* idx, int B, int 
 int orbit_op_maxpool2d_backward(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, int K,
                                 int stride, int pad, int Ho, int Wo, orbit_stream_t stream);
 int orbit_op_avgpool_backward(const float* dy, float* dx, int B, int HW, int C, orbit_stream_t stream);
+/* depthwise KxK convolution backward (K in {3,5}): dx NHWC [B][H][W][C] and/or dw torch [C][1][K][K] (either may be NULL) */
+int orbit_op_dwconv2d_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, int B, int H, int W,
+                               int C, int K, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                               orbit_stream_t stream);
+/* backward of the squeeze-excite product xg = x * gate(mean_hw(x)) (timm SqueezeExcite: conv_reduce -> SiLU ->
+ * conv_expand -> sigmoid): given dxg writes dx and (all or none) dW1 [R][C], db1 [R], dW2 [C][R], db2 [C].
+ * x NHWC [B][HW][C]; pooled [B][C] = mean over HW of x. */
+int orbit_op_se_gate_backward(const float* dxg, const float* x, const float* pooled, const float* w1, const float* b1,
+                              const float* w2, const float* b2, float* dx, float* dw1, float* db1, float* dw2,
+                              float* db2, int B, int HW, int C, int R, orbit_stream_t stream);
 
 /* ---- measurement: per-launch HIP-event timing of the dominant kernel (conv_igemm, all variants) ---- */
 int orbit_prof_enable(int on);   /* on: reset and start recording an event pair per launch on its stream */

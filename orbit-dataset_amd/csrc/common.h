@@ -105,9 +105,11 @@ int launch_bn_stats(const float* y, int M, int C, float eps, float momentum, con
 int launch_scale_shift_act(const float* y, const float* scale, const float* shift, const float* residual, int act,
                            size_t M, int C, float* out, hipStream_t s);
 // coef: 3*C floats of scratch; dy nullable (reductions only); dres nullable (gradient of the residual input)
+// scale/shift: folded BatchNorm of the forward (needed to rebuild the SiLU pre-activation), else nullable
 int launch_bn_backward(const float* dout, const float* out, const float* y, const float* mean, const float* invstd,
-                       const float* gamma, int train, int act, int M, int C, float* dy, float* dres, int dres_accumulate,
-                       float* dgamma, float* dbeta, float* dbias, float* partial, float* coef, hipStream_t s);
+                       const float* gamma, const float* scale, const float* shift, int train, int act, int M, int C,
+                       float* dy, float* dres, int dres_accumulate, float* dgamma, float* dbeta, float* dbias,
+                       float* partial, float* coef, hipStream_t s);
 int launch_maxpool_idx(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, int K, int stride, int pad,
                        int Ho, int Wo, hipStream_t s);
 int launch_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, int K, int stride,
@@ -116,6 +118,19 @@ int launch_avgpool_bwd(const float* dy, float* dx, int B, int HW, int C, hipStre
 int launch_upsample_zero(const float* src, float* dst, int B, int H, int W, int C, int stride, int Hs, int Ws,
                          hipStream_t s);
 int launch_add_inplace(float* dst, const float* src, size_t n, hipStream_t s);
+// MBConv pieces (train_mbconv.hip)
+int launch_gate_mul(const float* x, const float* gate, float* xg, int B, int HW, int C, hipStream_t s);
+size_t se_bwd_scratch_floats(int B, int C, int R);
+// dxg: gradient of x*gate; writes dx (through the product, the gate MLP and the average pool) and, when dw1 != NULL, the
+// gradients of the four SE tensors (W1 [R][C], b1 [R], W2 [C][R], b2 [C])
+int launch_se_gate_backward(const float* dxg, const float* x, const float* pooled, const float* gate, const float* w1,
+                            const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1,
+                            float* dw2, float* db2, float* scratch, int B, int HW, int C, int R, hipStream_t s);
+int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, int H, int W, int C, int K, int stride,
+                        int pad_t, int pad_l, int Ho, int Wo, hipStream_t s);
+size_t dwconv_wgrad_scratch_floats(int B, int Ho, int Wo, int C, int K);
+int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int C, int K,
+                        int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s);
 size_t conv_wgrad_scratch_floats(int B, int Cin, int Cout, int KH, int KW, int Ho, int Wo);
 int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
                       int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float* scratch, hipStream_t s);

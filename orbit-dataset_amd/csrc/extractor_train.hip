@@ -7,8 +7,9 @@
 // BatchNorm mode follows :176-183: batch statistics (and running-stat updates, also on the no-grad LITE cache
 // passes) iff the extractor is being learned; the set encoder always normalises with running statistics.
 //
-// Generic over the plans made of OP_CONV (+BN, ReLU, residual, fused 2x2 pool) / OP_MAXPOOL / OP_AVGPOOL, i.e.
-// resnet18 and the set encoder. efficientnet_b0 (depthwise / squeeze-excite backward) is the next widening step.
+// Generic over the plan ops: OP_CONV (+BN, ReLU / SiLU, residual, squeeze-excite gate on the input, fused 2x2 pool),
+// OP_DWCONV (+BN, SiLU), OP_SE, OP_MAXPOOL, OP_AVGPOOL — i.e. resnet18, efficientnet_b0 and the set encoder. (The
+// opt-in fused MBConv front op of the inference plan has no training form.)
 #include "extractor.h"
 
 namespace orbit {
@@ -35,25 +36,29 @@ __global__ __launch_bounds__(256) void bn_export_kernel(const BNDev* __restrict_
 }
 
 struct TapeLayout {
-    std::vector<size_t> y, a, p, idx;  // byte offsets per op ((size_t)-1: none)
+    // byte offsets per op ((size_t)-1: none). conv / depthwise: y raw output, a activation, p/idx fused pool, xg gated
+    // input. squeeze-excite: p = pooled means [B][C], a = gate [B][C]. max-pool: p output, idx argmax.
+    std::vector<size_t> y, a, p, idx, xg;
     size_t mean = 0, invstd = 0, scale = 0, shift = 0, partial = 0, total = 0;
 };
 
 static const size_t NONE = (size_t)-1;
 
 static bool plan_trainable(const orbit_extractor* fe) {
-    for (const Op& o : fe->ops)
-        if (o.kind != OP_CONV && o.kind != OP_MAXPOOL && o.kind != OP_AVGPOOL) return false;
-    for (const Op& o : fe->ops)
-        if (o.kind == OP_CONV && (o.bn < 0 || o.use_gate || (o.act != ORBIT_ACT_NONE && o.act != ORBIT_ACT_RELU)))
-            return false;
+    for (const Op& o : fe->ops) {
+        if (o.kind == OP_MBFRONT) return false;
+        if ((o.kind == OP_CONV || o.kind == OP_DWCONV) && o.bn < 0) return false;
+        if (o.kind == OP_CONV && o.use_gate && (o.pool2 || o.x_nchw)) return false;
+    }
     return true;
 }
+
+static bool has_bn(const Op& o) { return o.kind == OP_CONV || o.kind == OP_DWCONV; }
 
 static size_t max_bn_partial_floats(const orbit_extractor* fe, int B) {
     size_t m = 4;
     for (const Op& o : fe->ops)
-        if (o.kind == OP_CONV)
+        if (has_bn(o))
             m = std::max(m, (size_t)bn_reduce_blocks(B * o.Ho * o.Wo, o.Cout) * 2 * o.Cout + 3 * (size_t)o.Cout);
     return m;
 }
@@ -61,7 +66,7 @@ static size_t max_bn_partial_floats(const orbit_extractor* fe, int B) {
 static TapeLayout tape_layout(const orbit_extractor* fe, int B) {
     TapeLayout L;
     const size_t n = fe->ops.size();
-    L.y.assign(n, NONE), L.a.assign(n, NONE), L.p.assign(n, NONE), L.idx.assign(n, NONE);
+    L.y.assign(n, NONE), L.a.assign(n, NONE), L.p.assign(n, NONE), L.idx.assign(n, NONE), L.xg.assign(n, NONE);
     size_t off = 0;
     auto take = [&](size_t bytes) {
         const size_t o = off;
@@ -77,6 +82,12 @@ static TapeLayout tape_layout(const orbit_extractor* fe, int B) {
                 const size_t pe = (size_t)B * (o.Ho / 2) * (o.Wo / 2) * o.Cout;
                 L.p[i] = take(pe * 4), L.idx[i] = take(pe);
             }
+            if (o.use_gate) L.xg[i] = take((size_t)B * o.H * o.W * o.Cin * 4);
+        } else if (o.kind == OP_DWCONV) {
+            const size_t e = (size_t)B * o.Ho * o.Wo * o.Cout;
+            L.y[i] = take(e * 4), L.a[i] = take(e * 4);
+        } else if (o.kind == OP_SE) {
+            L.p[i] = take((size_t)B * o.Cin * 4), L.a[i] = take((size_t)B * o.Cin * 4);
         } else if (o.kind == OP_MAXPOOL) {
             const size_t pe = (size_t)B * o.Ho * o.Wo * o.Cout;
             L.p[i] = take(pe * 4), L.idx[i] = take(pe);
@@ -91,7 +102,7 @@ static TapeLayout tape_layout(const orbit_extractor* fe, int B) {
 
 // which op produced the tensor an op reads (index into ops, -1 = the frames)
 struct Producers {
-    std::vector<int> in, res;
+    std::vector<int> in, res, gate;  // gate: the squeeze-excite op whose output a gated conv multiplies into its input
 };
 static Producers producers(const orbit_extractor* fe) {
     Producers P;
@@ -100,6 +111,7 @@ static Producers producers(const orbit_extractor* fe) {
         const Op& o = fe->ops[i];
         P.in.push_back(o.in >= 0 && last.count(o.in) ? last[o.in] : -1);
         P.res.push_back(o.res >= 0 && last.count(o.res) ? last[o.res] : -1);
+        P.gate.push_back(o.kind == OP_CONV && o.use_gate && last.count(102) ? last[102] : -1);
         last[o.out] = (int)i;
     }
     return P;
@@ -107,13 +119,19 @@ static Producers producers(const orbit_extractor* fe) {
 
 struct BwdLayout {
     static const int NSLOTS = 8;
-    size_t slot_bytes = 0, slots = 0, up = 0, wgrad = 0, partial = 0, total = 0;
+    size_t slot_bytes = 0, slots = 0, up = 0, wgrad = 0, partial = 0, se = 0, total = 0;
 };
 static BwdLayout bwd_layout(const orbit_extractor* fe, int B) {
     BwdLayout L;
-    size_t slot = 4, up = 4, wg = 4;
+    size_t slot = 4, up = 4, wg = 4, se = 4;
     for (const Op& o : fe->ops) {
-        if (o.kind == OP_CONV) {
+        if (o.kind == OP_DWCONV) {
+            slot = std::max(slot, (size_t)B * o.H * o.W * o.Cin);
+            slot = std::max(slot, (size_t)B * o.Ho * o.Wo * o.Cout);
+            wg = std::max(wg, dwconv_wgrad_scratch_floats(B, o.Ho, o.Wo, o.Cin, o.KH));
+        } else if (o.kind == OP_SE) {
+            se = std::max(se, se_bwd_scratch_floats(B, o.Cin, o.R));
+        } else if (o.kind == OP_CONV) {
             slot = std::max(slot, (size_t)B * o.Ho * o.Wo * o.Cout);
             if (!o.x_nchw) slot = std::max(slot, (size_t)B * o.H * o.W * o.Cin);
             if (o.stride > 1 && !o.x_nchw) up = std::max(up, (size_t)B * o.H * o.W * o.Cout);
@@ -128,6 +146,7 @@ static BwdLayout bwd_layout(const orbit_extractor* fe, int B) {
     L.up = off, off += align_up(up * 4, 256);
     L.wgrad = off, off += align_up(wg * 4, 256);
     L.partial = off, off += align_up(max_bn_partial_floats(fe, B) * 4, 256);
+    L.se = off, off += align_up(se * 4, 256);
     L.total = off;
     return L;
 }
@@ -247,13 +266,20 @@ int orbit_extractor_train_forward(orbit_extractor_t* fe, const float* frames, in
     }
     std::map<int, const float*> cur;  // buffer id -> tensor currently held
     cur[-1] = frames;
+    int last_dw = -1;
     for (size_t i = 0; i < fe->ops.size(); ++i) {
         const Op& o = fe->ops[i];
         int rc = ORBIT_OK;
         if (o.kind == OP_CONV) {
             const BNDesc& bn = fe->bns[o.bn];
+            const float* xin = cur[o.in];
+            if (o.use_gate) {  // squeeze-excite: the projection reads x * gate; the product is kept for the filter gradient
+                rc = launch_gate_mul(xin, cur[102], fl(L.xg[i]), B, o.H * o.W, o.Cin, s);
+                if (rc != ORBIT_OK) return rc;
+                xin = fl(L.xg[i]);
+            }
             ConvDesc d;
-            d.x = cur[o.in], d.w_packed = fe->d_packed + o.packed_off, d.y = fl(L.y[i]);
+            d.x = xin, d.w_packed = fe->d_packed + o.packed_off, d.y = fl(L.y[i]);
             d.scale = d.shift = d.residual = d.gate = nullptr;
             d.B = B, d.H = o.H, d.W = o.W, d.Cin = o.Cin, d.Cout = o.Cout, d.KH = o.KH, d.KW = o.KW;
             d.stride = o.stride, d.pad_t = o.pad_t, d.pad_l = o.pad_l, d.Ho = o.Ho, d.Wo = o.Wo;
@@ -282,6 +308,37 @@ int orbit_extractor_train_forward(orbit_extractor_t* fe, const float* frames, in
             } else {
                 cur[o.out] = fl(L.a[i]);
             }
+        } else if (o.kind == OP_DWCONV) {
+            const BNDesc& bn = fe->bns[o.bn];
+            float* y = fl(L.y[i]);
+            rc = launch_dwconv_se(cur[o.in], fe->d_packed + o.packed_off, y, nullptr, nullptr, nullptr, B, o.H, o.W, o.Cin,
+                                  o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, ORBIT_ACT_NONE, s);
+            if (rc != ORBIT_OK) return rc;
+            const int M = B * o.Ho * o.Wo;
+            if (bn_train) {
+                const bool fm = film && bn.film_off >= 0;
+                rc = launch_bn_stats(y, M, o.Cout, bn.eps, momentum,
+                                     fm ? film_gamma + bn.film_off : fe->d_pool + fe->params[bn.gamma].off,
+                                     fm ? film_beta + bn.film_off : fe->d_pool + fe->params[bn.beta].off, nullptr,
+                                     mean + bn.fold_off, invstd + bn.fold_off, scale + bn.fold_off, shift + bn.fold_off,
+                                     fe->d_pool + fe->params[bn.mean].off, fe->d_pool + fe->params[bn.var].off,
+                                     fl(L.partial), s);
+                if (rc != ORBIT_OK) return rc;
+            }
+            rc = launch_scale_shift_act(y, scale + bn.fold_off, shift + bn.fold_off, nullptr, o.act, (size_t)M, o.Cout,
+                                        fl(L.a[i]), s);
+            cur[o.out] = fl(L.a[i]);
+            last_dw = (int)i;
+        } else if (o.kind == OP_SE) {
+            // squeeze (mean over the depthwise output) + excite MLP -> gate [B][C]
+            if (last_dw < 0) return set_err(ORBIT_ERR_STATE, "extractor_train_forward: squeeze-excite without a producer");
+            const Op& dw = fe->ops[last_dw];
+            rc = launch_avgpool(fl(L.a[last_dw]), fl(L.p[i]), B, dw.Ho * dw.Wo, o.Cin, s);
+            if (rc != ORBIT_OK) return rc;
+            rc = launch_se_gate(fl(L.p[i]), fe->d_pool + fe->params[o.se_w1].off, fe->d_pool + fe->params[o.se_b1].off,
+                                fe->d_pool + fe->params[o.se_w2].off, fe->d_pool + fe->params[o.se_b2].off, fl(L.a[i]), B,
+                                o.Cin, o.R, s);
+            cur[102] = fl(L.a[i]);
         } else if (o.kind == OP_MAXPOOL) {
             rc = launch_maxpool_idx(cur[o.in], fl(L.p[i]), reinterpret_cast<uint8_t*>(tp + L.idx[i]), B, o.H, o.W, o.Cin,
                                     o.pool_k, o.stride, o.pool_pad, o.Ho, o.Wo, s);
@@ -332,7 +389,8 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
     float* up = reinterpret_cast<float*>(ws + W.up);
     float* wgrad_scratch = reinterpret_cast<float*>(ws + W.wgrad);
     float* partial = reinterpret_cast<float*>(ws + W.partial);
-    const float *mean = tf(L.mean), *invstd = tf(L.invstd);
+    float* se_scratch = reinterpret_cast<float*>(ws + W.se);
+    const float *mean = tf(L.mean), *invstd = tf(L.invstd), *scale = tf(L.scale), *shift = tf(L.shift);
 
     const Producers P = producers(fe);
     const int n = (int)fe->ops.size();
@@ -340,7 +398,7 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
     int first_needed = n;
     for (int i = 0; i < n && first_needed == n; ++i) {
         const Op& o = fe->ops[i];
-        if (o.kind != OP_CONV) continue;
+        if (!has_bn(o)) continue;
         if (param_grads || (dfilm_gamma && fe->bns[o.bn].film_off >= 0)) first_needed = i;
     }
 
@@ -362,6 +420,7 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
         if (i < 0) return frames;
         const Op& o = fe->ops[i];
         if (o.kind == OP_CONV) return o.pool2 ? tf(L.p[i]) : tf(L.a[i]);
+        if (o.kind == OP_DWCONV) return tf(L.a[i]);
         return tf(L.p[i]);
     };
 #define SLOT_OR_FAIL(var)                                                                      \
@@ -390,6 +449,48 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
                 grad_slot[src] = k;
             }
             release(g), grad_slot[i] = -1;
+        } else if (o.kind == OP_SE) {
+            continue;  // handled together with the gated convolution that consumes the gate
+        } else if (o.kind == OP_DWCONV) {
+            const int g = grad_slot[i];
+            if (g < 0) continue;
+            const BNDesc& bn = fe->bns[o.bn];
+            const int M = B * o.Ho * o.Wo;
+            const bool fm = film && bn.film_off >= 0;
+            const float* gamma = fm ? film_gamma + bn.film_off : fe->d_pool + fe->params[bn.gamma].off;
+            float *dgam = nullptr, *dbet = nullptr;
+            if (fm) {
+                if (dfilm_gamma) dgam = dfilm_gamma + bn.film_off, dbet = dfilm_beta + bn.film_off;
+            } else if (param_grads) {
+                dgam = param_grads + fe->params[bn.gamma].off, dbet = param_grads + fe->params[bn.beta].off;
+            }
+            const int src = P.in[i];
+            const bool need_dx = src >= first_needed;
+            const bool need_dy = need_dx || param_grads != nullptr;
+            int kdy = -1;
+            if (need_dy) {
+                kdy = alloc();
+                if (kdy < 0) return set_err(ORBIT_ERR_STATE, "extractor_backward: gradient slots exhausted");
+            }
+            float* coef = partial + (size_t)bn_reduce_blocks(M, o.Cout) * 2 * o.Cout;
+            rc = launch_bn_backward(slot_ptr(g), tf(L.a[i]), tf(L.y[i]), mean + bn.fold_off, invstd + bn.fold_off, gamma,
+                                    scale + bn.fold_off, shift + bn.fold_off, bn_train, o.act, M, o.Cout,
+                                    need_dy ? slot_ptr(kdy) : nullptr, nullptr, 0, dgam, dbet, nullptr, partial, coef, s);
+            if (rc != ORBIT_OK) return rc;
+            release(g), grad_slot[i] = -1;
+            if (param_grads) {
+                rc = launch_dwconv_wgrad(out_tensor(src), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
+                                         wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+                if (rc != ORBIT_OK) return rc;
+            }
+            if (need_dx) {
+                ORBIT_REQUIRE(grad_slot[src] < 0, "extractor_backward: unexpected fan-out into a depthwise convolution");
+                SLOT_OR_FAIL(k);
+                grad_slot[src] = k;
+                rc = launch_dwconv_dgrad(slot_ptr(kdy), fe->d_packed + o.packed_off, slot_ptr(k), B, o.H, o.W, o.Cin, o.KH,
+                                         o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+            }
+            release(kdy);
         } else {  // OP_CONV
             int g = grad_slot[i];
             if (g < 0) continue;  // no gradient reaches this op
@@ -434,8 +535,8 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
             // partial holds [blocks][2][C] followed by the 3*C apply coefficients
             float* coef = partial + (size_t)bn_reduce_blocks(M, o.Cout) * 2 * o.Cout;
             rc = launch_bn_backward(slot_ptr(g), tf(L.a[i]), tf(L.y[i]), mean + bn.fold_off, invstd + bn.fold_off, gamma,
-                                    bn_train, o.act, M, o.Cout, need_dy ? slot_ptr(kdy) : nullptr, dres, dres_acc, dgam,
-                                    dbet, dbias, partial, coef, s);
+                                    scale + bn.fold_off, shift + bn.fold_off, bn_train, o.act, M, o.Cout,
+                                    need_dy ? slot_ptr(kdy) : nullptr, dres, dres_acc, dgam, dbet, dbias, partial, coef, s);
             if (rc != ORBIT_OK) return rc;
             if (!need_dy && dres) {
                 // reductions only, but the residual branch still needs g: rerun the apply pass is not available
@@ -444,12 +545,34 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
             }
             release(g), grad_slot[i] = -1;
             if (param_grads) {
-                rc = launch_conv_wgrad(out_tensor(src), o.x_nchw, slot_ptr(kdy), param_grads + fe->params[o.weight].off, B,
+                rc = launch_conv_wgrad(o.use_gate ? tf(L.xg[i]) : out_tensor(src), o.x_nchw, slot_ptr(kdy),
+                                       param_grads + fe->params[o.weight].off, B,
                                        o.H, o.W, o.Cin, o.Cout, o.KH, o.KW, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo,
                                        wgrad_scratch, s);
                 if (rc != ORBIT_OK) return rc;
             }
-            if (need_dx) {
+            if (need_dx && o.use_gate) {
+                // d(x * gate): data gradient of the product, then squeeze-excite backward (gate MLP + average pool)
+                const int se = P.gate[i];
+                ORBIT_REQUIRE(se >= 0 && grad_slot[src] < 0, "extractor_backward: malformed squeeze-excite block");
+                const Op& so = fe->ops[se];
+                SLOT_OR_FAIL(kt);
+                rc = launch_conv_dgrad(slot_ptr(kdy), st->d_dgrad + st->dgrad_off[i], nullptr, slot_ptr(kt), up, B, o.H, o.W,
+                                       o.Cin, o.Cout, o.KH, o.KW, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+                if (rc != ORBIT_OK) return rc;
+                SLOT_OR_FAIL(k);
+                grad_slot[src] = k;
+                float* pg = param_grads;
+                rc = launch_se_gate_backward(slot_ptr(kt), out_tensor(src), tf(L.p[se]), tf(L.a[se]),
+                                             fe->d_pool + fe->params[so.se_w1].off, fe->d_pool + fe->params[so.se_b1].off,
+                                             fe->d_pool + fe->params[so.se_w2].off, fe->d_pool + fe->params[so.se_b2].off,
+                                             slot_ptr(k), pg ? pg + fe->params[so.se_w1].off : nullptr,
+                                             pg ? pg + fe->params[so.se_b1].off : nullptr,
+                                             pg ? pg + fe->params[so.se_w2].off : nullptr,
+                                             pg ? pg + fe->params[so.se_b2].off : nullptr, se_scratch, B, o.H * o.W, o.Cin,
+                                             so.R, s);
+                release(kt);
+            } else if (need_dx) {
                 const float* acc = nullptr;
                 if (grad_slot[src] < 0) {
                     SLOT_OR_FAIL(k);

@@ -1,0 +1,390 @@
+// Training kernels of the MBConv-specific pieces of efficientnet_b0 (timm tf_efficientnet_b0 blocks; reference
+// model/feature_extractors.py:39-43 builds the network, single-step-learner.py:234 backpropagates through it):
+//   depthwise convolution: data gradient (gather form) and filter gradient (per-tap reduction over B*Ho*Wo),
+//   squeeze-excite: gate multiply, its backward (d gate = sum_hw dxg * x; dx = dxg * gate + d pooled / HW), the SE MLP
+//   backward and its parameter gradients.
+// NHWC fp32, float4 over channels; every reduction has a fixed order (deterministic, no atomics). All HBM-bound.
+#include "common.h"
+
+namespace orbit {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+static int grid_for(size_t total) {
+    size_t b = (total + 255) / 256;
+    return (int)(b > 8192 ? 8192 : (b ? b : 1));
+}
+
+// ---- squeeze-excite gate -------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gate_mul_kernel(const float* __restrict__ x, const float* __restrict__ gate,
+                                                       float* __restrict__ xg, int HW, int C4, size_t total4) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        const size_t b = i / ((size_t)HW * C4);
+        reinterpret_cast<f32x4*>(xg)[i] = reinterpret_cast<const f32x4*>(x)[i] *
+                                          reinterpret_cast<const f32x4*>(gate)[b * C4 + q];
+    }
+}
+
+// dgate[b][c] = sum_hw dxg[b][hw][c] * x[b][hw][c]; block = (frame b, group of G channel quads), R row lanes
+__global__ __launch_bounds__(256) void gate_bwd_reduce_kernel(const float* __restrict__ dxg,
+                                                              const float* __restrict__ x, float* __restrict__ dgate,
+                                                              int HW, int C4, int G, int R) {
+    __shared__ f32x4 red[256];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int rl = tid / G, qi = tid - rl * G, q = blockIdx.y * G + qi;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (rl < R && q < C4) {
+        const size_t base = (size_t)b * HW * C4 + q;
+        for (int r = rl; r < HW; r += R)
+            s += reinterpret_cast<const f32x4*>(dxg)[base + (size_t)r * C4] *
+                 reinterpret_cast<const f32x4*>(x)[base + (size_t)r * C4];
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (rl == 0 && q < C4) {
+        for (int j = 1; j < R; ++j) s += red[j * G + qi];
+        reinterpret_cast<f32x4*>(dgate)[(size_t)b * C4 + q] = s;
+    }
+}
+
+// dx = dxg * gate + dpooled / HW   (the second term is the gradient through the SE average pool)
+__global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __restrict__ dxg,
+                                                             const float* __restrict__ gate,
+                                                             const float* __restrict__ dpooled,
+                                                             float* __restrict__ dx, int HW, int C4, size_t total4) {
+    const float inv = 1.0f / (float)HW;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        const size_t b = i / ((size_t)HW * C4);
+        reinterpret_cast<f32x4*>(dx)[i] =
+            reinterpret_cast<const f32x4*>(dxg)[i] * reinterpret_cast<const f32x4*>(gate)[b * C4 + q] +
+            reinterpret_cast<const f32x4*>(dpooled)[b * C4 + q] * inv;
+    }
+}
+
+// SE MLP backward for one frame per block: pooled p[C] -> v = W1 p + b1 -> h = silu(v) -> u = W2 h + b2 -> g = sigmoid(u)
+// given dgate: du = dgate g (1-g); dh = W2^T du; dv = dh silu'(v); dp = W1^T dv.  W1 [R][C], W2 [C][R].
+// Writes du[b][C], dv[b][R], h[b][R] (for the parameter gradients) and dp[b][C].
+__global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
+                                                     const float* __restrict__ b1, const float* __restrict__ w2,
+                                                     const float* __restrict__ b2, const float* __restrict__ dgate,
+                                                     float* __restrict__ du_out, float* __restrict__ dv_out,
+                                                     float* __restrict__ h_out, float* __restrict__ dp_out, int C,
+                                                     int R) {
+    extern __shared__ float sm[];  // p[C] du[C] v[R] h[R] dv[R]
+    float* p = sm;
+    float* du = sm + C;
+    float* v = sm + 2 * C;
+    float* h = v + R;
+    float* dv = h + R;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    for (int c = tid; c < C; c += 256) p[c] = pooled[(size_t)b * C + c];
+    __syncthreads();
+    // v[r]: 16 lanes per hidden unit (R <= 64 in efficientnet_b0), fixed shuffle-free order through LDS
+    for (int r = tid >> 4; r < R; r += 16) {
+        const int l = tid & 15;
+        float acc = 0.f;
+        for (int c = l; c < C; c += 16) acc = fmaf(w1[(size_t)r * C + c], p[c], acc);
+        // reduce the 16 lanes
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+        if (l == 0) {
+            const float vv = acc + b1[r];
+            v[r] = vv;
+            h[r] = vv * __builtin_amdgcn_rcpf(1.0f + __expf(-vv));
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float u = b2[c];
+        for (int r = 0; r < R; ++r) u = fmaf(w2[(size_t)c * R + r], h[r], u);
+        const float g = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
+        const float d = dgate[(size_t)b * C + c] * g * (1.0f - g);
+        du[c] = d;
+        du_out[(size_t)b * C + c] = d;
+    }
+    __syncthreads();
+    for (int r = tid >> 4; r < R; r += 16) {
+        const int l = tid & 15;
+        float acc = 0.f;
+        for (int c = l; c < C; c += 16) acc = fmaf(du[c], w2[(size_t)c * R + r], acc);
+#pragma unroll
+        for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
+        if (l == 0) {
+            const float vv = v[r];
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-vv));
+            const float d = acc * sg * (1.0f + vv * (1.0f - sg));
+            dv[r] = d;
+            dv_out[(size_t)b * R + r] = d;
+            h_out[(size_t)b * R + r] = h[r];
+        }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += 256) {
+        float d = 0.f;
+        for (int r = 0; r < R; ++r) d = fmaf(dv[r], w1[(size_t)r * C + c], d);
+        dp_out[(size_t)b * C + c] = d;
+    }
+}
+
+// dW2[c][r] = sum_b du[b][c] h[b][r]; db2[c] = sum_b du[b][c]; dW1[r][c] = sum_b dv[b][r] p[b][c]; db1[r] = sum_b dv[b][r]
+__global__ __launch_bounds__(256) void se_param_grad_kernel(const float* __restrict__ du, const float* __restrict__ dv,
+                                                            const float* __restrict__ h,
+                                                            const float* __restrict__ pooled, int B, int C, int R,
+                                                            float* __restrict__ dw1, float* __restrict__ db1,
+                                                            float* __restrict__ dw2, float* __restrict__ db2) {
+    const int total = 2 * C * R + C + R;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        float s = 0.f;
+        if (i < C * R) {  // dW2[c][r]
+            const int c = i / R, r = i - c * R;
+            for (int b = 0; b < B; ++b) s = fmaf(du[(size_t)b * C + c], h[(size_t)b * R + r], s);
+            dw2[i] = s;
+        } else if (i < 2 * C * R) {  // dW1[r][c]
+            const int j = i - C * R, r = j / C, c = j - r * C;
+            for (int b = 0; b < B; ++b) s = fmaf(dv[(size_t)b * R + r], pooled[(size_t)b * C + c], s);
+            dw1[j] = s;
+        } else if (i < 2 * C * R + C) {
+            const int c = i - 2 * C * R;
+            for (int b = 0; b < B; ++b) s += du[(size_t)b * C + c];
+            db2[c] = s;
+        } else {
+            const int r = i - 2 * C * R - C;
+            for (int b = 0; b < B; ++b) s += dv[(size_t)b * R + r];
+            db1[r] = s;
+        }
+    }
+}
+
+// ---- depthwise convolution ------------------------------------------------------------------------------------------
+// dx[b][h][w][c] = sum_{kh,kw} dy[b][(h+pt-kh)/s][(w+pl-kw)/s][c] * w[kh][kw][c]   (terms with non-integral / out-of-range
+// source positions vanish); w_khwc is the packed forward filter [K][K][C]
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                           float* __restrict__ dx, int B, int H, int W, int C4,
+                                                           int stride, int pad_t, int pad_l, int Ho, int Wo) {
+    const size_t total = (size_t)B * H * W * C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int q = (int)(i % C4);
+        size_t r = i / C4;
+        const int wx = (int)(r % W);
+        r /= W;
+        const int h = (int)(r % H);
+        const int b = (int)(r / H);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kh = 0; kh < K; ++kh) {
+            const int t = h + pad_t - kh;
+            if (t < 0 || t % stride) continue;
+            const int ho = t / stride;
+            if (ho >= Ho) continue;
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const int u = wx + pad_l - kw;
+                if (u < 0 || u % stride) continue;
+                const int wo = u / stride;
+                if (wo >= Wo) continue;
+                acc += reinterpret_cast<const f32x4*>(dy)[(((size_t)b * Ho + ho) * Wo + wo) * C4 + q] *
+                       reinterpret_cast<const f32x4*>(w)[(size_t)(kh * K + kw) * C4 + q];
+            }
+        }
+        reinterpret_cast<f32x4*>(dx)[i] = acc;
+    }
+}
+
+// partial[chunk][tap][c] = sum over the chunk's output pixels of dy * x(tap); block = (chunk of rows, group of G quads)
+template <int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_partial_kernel(const float* __restrict__ x,
+                                                                   const float* __restrict__ dy,
+                                                                   float* __restrict__ partial, int B, int H, int W,
+                                                                   int C4, int stride, int pad_t, int pad_l, int Ho,
+                                                                   int Wo, int rows_per_block, int G, int R) {
+    __shared__ f32x4 red[256];
+    const int tid = threadIdx.x;
+    const int rl = tid / G, qi = tid - rl * G, q = blockIdx.y * G + qi;
+    const bool active = rl < R && q < C4;
+    const size_t M = (size_t)B * Ho * Wo;
+    const size_t r0 = (size_t)blockIdx.x * rows_per_block;
+    const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    f32x4 acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        for (size_t m = r0 + rl; m < r1; m += R) {
+            const int wo = (int)(m % Wo);
+            const size_t t2 = m / Wo;
+            const int ho = (int)(t2 % Ho);
+            const int b = (int)(t2 / Ho);
+            const f32x4 d = reinterpret_cast<const f32x4*>(dy)[m * C4 + q];
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) {
+                const int hi = ho * stride - pad_t + kh;
+                if ((unsigned)hi >= (unsigned)H) continue;
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) {
+                    const int wi = wo * stride - pad_l + kw;
+                    if ((unsigned)wi >= (unsigned)W) continue;
+                    acc[kh * K + kw] += d * reinterpret_cast<const f32x4*>(x)[(((size_t)b * H + hi) * W + wi) * C4 + q];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) {
+        red[tid] = acc[t];
+        __syncthreads();
+        if (rl == 0 && q < C4) {
+            f32x4 s = acc[t];
+            for (int j = 1; j < R; ++j) s += red[j * G + qi];
+            reinterpret_cast<f32x4*>(partial)[((size_t)blockIdx.x * K * K + t) * C4 + q] = s;
+        }
+        __syncthreads();
+    }
+}
+
+// dw[c][0][kh][kw] = sum over chunks (ascending) of partial[chunk][tap][c]
+__global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, int KK,
+                                                                  int C, float* __restrict__ dw) {
+    const int total = KK * C;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int tap = i / C, c = i - tap * C;
+        float s = 0.f;
+        for (int k = 0; k < chunks; ++k) s += partial[((size_t)k * KK + tap) * C + c];
+        dw[(size_t)c * KK + tap] = s;
+    }
+}
+
+static void dw_layout(int C, int& G, int& R, int& ygroups) {
+    const int Q = C / 4;
+    G = Q < 64 ? Q : 64;
+    R = 256 / G;
+    ygroups = cdiv(Q, G);
+}
+
+int dwconv_wgrad_chunks(int B, int Ho, int Wo, int C) {
+    int G, R, yg;
+    dw_layout(C, G, R, yg);
+    const size_t M = (size_t)B * Ho * Wo;
+    size_t rows = (M + 1023) / 1024;
+    if (rows < (size_t)4 * R) rows = (size_t)4 * R;
+    return (int)((M + rows - 1) / rows);
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------
+int launch_gate_mul(const float* x, const float* gate, float* xg, int B, int HW, int C, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0, "gate_mul: C %% 4 != 0");
+    const size_t total4 = (size_t)B * HW * (C / 4);
+    gate_mul_kernel<<<grid_for(total4), 256, 0, s>>>(x, gate, xg, HW, C / 4, total4);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+// scratch: du [B*C] | dv [B*R] | h [B*R] | dgate [B*C] | dpooled [B*C]
+size_t se_bwd_scratch_floats(int B, int C, int R) { return (size_t)B * (3 * (size_t)C + 2 * (size_t)R) + 16; }
+
+int launch_se_gate_backward(const float* dxg, const float* x, const float* pooled, const float* gate, const float* w1,
+                            const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1,
+                            float* dw2, float* db2, float* scratch, int B, int HW, int C, int R, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0 && R > 0 && R <= 256, "se_gate_backward: bad sizes (C=%d R=%d)", C, R);
+    float* du = scratch;
+    float* dv = du + (size_t)B * C;
+    float* h = dv + (size_t)B * R;
+    float* dgate = h + (size_t)B * R;
+    float* dp = dgate + (size_t)B * C;
+    int G, Rl, yg;
+    dw_layout(C, G, Rl, yg);
+    gate_bwd_reduce_kernel<<<dim3(B, yg), 256, 0, s>>>(dxg, x, dgate, HW, C / 4, G, Rl);
+    ORBIT_LAUNCH_CHECK();
+    const size_t lds = (size_t)(2 * C + 3 * R) * sizeof(float);
+    se_bwd_kernel<<<B, 256, lds, s>>>(pooled, w1, b1, w2, b2, dgate, du, dv, h, dp, C, R);
+    ORBIT_LAUNCH_CHECK();
+    if (dw1) {
+        se_param_grad_kernel<<<cdiv(2 * C * R + C + R, 256), 256, 0, s>>>(du, dv, h, pooled, B, C, R, dw1, db1, dw2, db2);
+        ORBIT_LAUNCH_CHECK();
+    }
+    const size_t total4 = (size_t)B * HW * (C / 4);
+    gate_bwd_apply_kernel<<<grid_for(total4), 256, 0, s>>>(dxg, gate, dp, dx, HW, C / 4, total4);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, int H, int W, int C, int K, int stride,
+                        int pad_t, int pad_l, int Ho, int Wo, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0 && (K == 3 || K == 5), "dwconv_dgrad: C %% 4 != 0 or K not in {3,5}");
+    const int grid = grid_for((size_t)B * H * W * (C / 4));
+    if (K == 3) dwconv_dgrad_kernel<3><<<grid, 256, 0, s>>>(dy, w_khwc, dx, B, H, W, C / 4, stride, pad_t, pad_l, Ho, Wo);
+    else dwconv_dgrad_kernel<5><<<grid, 256, 0, s>>>(dy, w_khwc, dx, B, H, W, C / 4, stride, pad_t, pad_l, Ho, Wo);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+size_t dwconv_wgrad_scratch_floats(int B, int Ho, int Wo, int C, int K) {
+    return (size_t)dwconv_wgrad_chunks(B, Ho, Wo, C) * K * K * C;
+}
+
+int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int C, int K,
+                        int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0 && (K == 3 || K == 5), "dwconv_wgrad: C %% 4 != 0 or K not in {3,5}");
+    int G, R, yg;
+    dw_layout(C, G, R, yg);
+    const int chunks = dwconv_wgrad_chunks(B, Ho, Wo, C);
+    const size_t M = (size_t)B * Ho * Wo;
+    const int rows = (int)((M + chunks - 1) / chunks);
+    dim3 grid(chunks, yg);
+    if (K == 3)
+        dwconv_wgrad_partial_kernel<3><<<grid, 256, 0, s>>>(x, dy, scratch, B, H, W, C / 4, stride, pad_t, pad_l, Ho, Wo,
+                                                           rows, G, R);
+    else
+        dwconv_wgrad_partial_kernel<5><<<grid, 256, 0, s>>>(x, dy, scratch, B, H, W, C / 4, stride, pad_t, pad_l, Ho, Wo,
+                                                           rows, G, R);
+    ORBIT_LAUNCH_CHECK();
+    dwconv_wgrad_reduce_kernel<<<cdiv(K * K * C, 256), 256, 0, s>>>(scratch, chunks, K * K, C, dw);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+}  // namespace orbit
+
+using namespace orbit;
+
+extern "C" {
+
+int orbit_op_dwconv2d_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, int B, int H, int W,
+                               int C, int K, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                               orbit_stream_t stream) {
+    ORBIT_REQUIRE(x && w && dy, "op_dwconv2d_backward: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    float* tmp = nullptr;
+    const size_t npack = (size_t)(C * K * K + 3) / 4 * 4;
+    const size_t nscr = dwconv_wgrad_scratch_floats(B, Ho, Wo, C, K);
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), (npack + nscr) * sizeof(float), s));
+    int rc = dwconv_pack_weights(w, tmp, C, K, s);
+    if (rc == ORBIT_OK && dx)
+        rc = launch_dwconv_dgrad(dy, tmp, dx, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, s);
+    if (rc == ORBIT_OK && dw)
+        rc = launch_dwconv_wgrad(x, dy, dw, tmp + npack, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, s);
+    (void)hipFreeAsync(tmp, s);
+    return rc;
+}
+
+int orbit_op_se_gate_backward(const float* dxg, const float* x, const float* pooled, const float* w1, const float* b1,
+                              const float* w2, const float* b2, float* dx, float* dw1, float* db1, float* dw2,
+                              float* db2, int B, int HW, int C, int R, orbit_stream_t stream) {
+    ORBIT_REQUIRE(dxg && x && pooled && w1 && b1 && w2 && b2 && dx, "op_se_gate_backward: null pointer");
+    ORBIT_REQUIRE((dw1 == nullptr) == (db1 == nullptr) && (dw1 == nullptr) == (dw2 == nullptr) &&
+                      (dw1 == nullptr) == (db2 == nullptr),
+                  "op_se_gate_backward: parameter gradients come all or none");
+    hipStream_t s = (hipStream_t)stream;
+    float* tmp = nullptr;
+    const size_t nscr = se_bwd_scratch_floats(B, C, R);
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), (nscr + (size_t)B * C) * sizeof(float), s));
+    float* gate = tmp + nscr;
+    int rc = launch_se_gate(pooled, w1, b1, w2, b2, gate, B, C, R, s);
+    if (rc == ORBIT_OK)
+        rc = launch_se_gate_backward(dxg, x, pooled, gate, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, tmp, B, HW, C, R, s);
+    (void)hipFreeAsync(tmp, s);
+    return rc;
+}
+
+}  // extern "C"

@@ -144,6 +144,16 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
     }
 }
 
+// d silu(z) / dz = s (1 + z (1 - s)), s = sigmoid(z); same fast exp/rcp as the forward activation
+__device__ __forceinline__ f32x4 silu_grad(f32x4 g, f32x4 z) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z[k]));
+        g[k] *= sg * (1.0f + z[k] * (1.0f - sg));
+    }
+    return g;
+}
+
 __device__ __forceinline__ f32x4 relu_mask(f32x4 g, f32x4 a) {
     g[0] = a[0] > 0.f ? g[0] : 0.f, g[1] = a[1] > 0.f ? g[1] : 0.f;
     g[2] = a[2] > 0.f ? g[2] : 0.f, g[3] = a[3] > 0.f ? g[3] : 0.f;
@@ -156,7 +166,9 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
                                                              const float* __restrict__ out,
                                                              const float* __restrict__ y,
                                                              const float* __restrict__ mean,
-                                                             const float* __restrict__ invstd, int act, int M, int C,
+                                                             const float* __restrict__ invstd,
+                                                             const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, int act, int M, int C,
                                                              int rows_per_block, int G, int R,
                                                              float* __restrict__ partial) {
     __shared__ f32x4 red[2][256];
@@ -169,11 +181,17 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
     if (active) {
         const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4);
         const f32x4 is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f}, sh = {0.f, 0.f, 0.f, 0.f};
+        if (act == ORBIT_ACT_SILU) {
+            sc = *reinterpret_cast<const f32x4*>(scale + q * 4), sh = *reinterpret_cast<const f32x4*>(shift + q * 4);
+        }
         for (int r = r0 + rl; r < r1; r += R) {
             const size_t o = (size_t)r * C + q * 4;
             f32x4 g = *reinterpret_cast<const f32x4*>(dout + o);
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
             if (act == ORBIT_ACT_RELU) g = relu_mask(g, *reinterpret_cast<const f32x4*>(out + o));
-            const f32x4 xh = (*reinterpret_cast<const f32x4*>(y + o) - mu) * is;
+            else if (act == ORBIT_ACT_SILU) g = silu_grad(g, yv * sc + sh);
+            const f32x4 xh = (yv - mu) * is;
             s += g;
             sx += g * xh;
         }
@@ -212,6 +230,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ y,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
+                                                           const float* __restrict__ scale,
+                                                           const float* __restrict__ shift,
                                                            const float* __restrict__ coef, int act, size_t total4,
                                                            int C4, float* __restrict__ dy, float* __restrict__ dres,
                                                            int dres_accumulate) {
@@ -219,9 +239,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
         const int q = (int)(i % C4);
         f32x4 g = reinterpret_cast<const f32x4*>(dout)[i];
+        const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
         if (act == ORBIT_ACT_RELU) g = relu_mask(g, reinterpret_cast<const f32x4*>(out)[i]);
-        const f32x4 xh = (reinterpret_cast<const f32x4*>(y)[i] - reinterpret_cast<const f32x4*>(mean)[q]) *
-                         reinterpret_cast<const f32x4*>(invstd)[q];
+        else if (act == ORBIT_ACT_SILU)
+            g = silu_grad(g, yv * reinterpret_cast<const f32x4*>(scale)[q] + reinterpret_cast<const f32x4*>(shift)[q]);
+        const f32x4 xh = (yv - reinterpret_cast<const f32x4*>(mean)[q]) * reinterpret_cast<const f32x4*>(invstd)[q];
         const f32x4 k1 = reinterpret_cast<const f32x4*>(coef)[q];
         const f32x4 k2 = reinterpret_cast<const f32x4*>(coef + C)[q];
         const f32x4 k3 = reinterpret_cast<const f32x4*>(coef + 2 * C)[q];
@@ -367,13 +389,15 @@ int launch_scale_shift_act(const float* y, const float* scale, const float* shif
 }
 
 int launch_bn_backward(const float* dout, const float* out, const float* y, const float* mean, const float* invstd,
-                       const float* gamma, int train, int act, int M, int C, float* dy, float* dres, int dres_accumulate,
-                       float* dgamma, float* dbeta, float* dbias, float* partial, float* coef, hipStream_t s) {
+                       const float* gamma, const float* scale, const float* shift, int train, int act, int M, int C,
+                       float* dy, float* dres, int dres_accumulate, float* dgamma, float* dbeta, float* dbias,
+                       float* partial, float* coef, hipStream_t s) {
     ORBIT_REQUIRE(C % 4 == 0 && M > 0, "bn_backward: C %% 4 != 0 or empty batch");
-    ORBIT_REQUIRE(act == ORBIT_ACT_NONE || act == ORBIT_ACT_RELU, "bn_backward: only identity / ReLU activations");
+    ORBIT_REQUIRE(act != ORBIT_ACT_SILU || (scale && shift), "bn_backward: SiLU needs the folded scale/shift");
+    ORBIT_REQUIRE(act != ORBIT_ACT_RELU || out, "bn_backward: ReLU needs the activation output");
     const ColLayout L = col_layout(C);
     const int nblk = bn_reduce_blocks(M, C);
-    bn_bwd_partial_kernel<<<dim3(nblk, L.ygroups), 256, 0, s>>>(dout, out, y, mean, invstd, act, M, C,
+    bn_bwd_partial_kernel<<<dim3(nblk, L.ygroups), 256, 0, s>>>(dout, out, y, mean, invstd, scale, shift, act, M, C,
                                                                 bn_rows_per_block(M, C), L.G, L.R, partial);
     ORBIT_LAUNCH_CHECK();
     bn_bwd_finalize_kernel<<<cdiv(C, 16), 256, 0, s>>>(partial, nblk, M, C, train, gamma, invstd, dgamma, dbeta, dbias,
@@ -381,8 +405,8 @@ int launch_bn_backward(const float* dout, const float* out, const float* y, cons
     ORBIT_LAUNCH_CHECK();
     if (dy) {
         const size_t total4 = (size_t)M * (C / 4);
-        bn_bwd_apply_kernel<<<grid_for(total4), 256, 0, s>>>(dout, out, y, mean, invstd, coef, act, total4, C / 4, dy,
-                                                             dres, dres_accumulate);
+        bn_bwd_apply_kernel<<<grid_for(total4), 256, 0, s>>>(dout, out, y, mean, invstd, scale, shift, coef, act, total4,
+                                                             C / 4, dy, dres, dres_accumulate);
         ORBIT_LAUNCH_CHECK();
     }
     return ORBIT_OK;
@@ -530,8 +554,9 @@ int orbit_op_bn_backward(const float* dout, const float* out, const float* y, in
     float* tmp = nullptr;
     const size_t npart = (size_t)bn_reduce_blocks(M, C) * 2 * C;
     ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), (npart + 3 * (size_t)C) * sizeof(float), s));
-    const int rc = launch_bn_backward(dout, out, y, mean, invstd, gamma, train, act, M, C, dy, dres, 0, dgamma, dbeta,
-                                      nullptr, tmp, tmp + npart, s);
+    ORBIT_REQUIRE(act != ORBIT_ACT_SILU, "op_bn_backward: SiLU is exercised through the network-level entry points");
+    const int rc = launch_bn_backward(dout, out, y, mean, invstd, gamma, nullptr, nullptr, train, act, M, C, dy, dres, 0,
+                                      dgamma, dbeta, nullptr, tmp, tmp + npart, s);
     (void)hipFreeAsync(tmp, s);
     return rc;
 }

@@ -256,9 +256,8 @@ class HipNetwork(nn.Module):
         lib = _lib.load()
         if not lib.orbit_extractor_supports_training(plan.handle):
             raise NotImplementedError(
-                "%s has no native training path yet (train-mode BatchNorm / backward are built for resnet18 and the "
-                "set encoder); for inference call it in eval() under torch.no_grad(), as the reference's test loops do"
-                % self.native_name)
+                "this %s plan has no native training path (it was built with the fused MBConv front op, "
+                "ORBIT_MBCONV_FUSION=1); for inference call it in eval() under torch.no_grad()" % self.native_name)
         B = x.shape[0]
         gamma, beta = film if film is not None else (None, None)
         if use_tape:

@@ -12,8 +12,7 @@ per mini-batch, as in the reference) or already resident in HBM.
 
 Meta-training: with autograd enabled the same calls record native tapes and
 `loss.backward()` runs the native backward kernels (model/autograd.py) — train-mode BatchNorm, conv dgrad/wgrad,
-FiLM-generator and set-encoder gradients — for the resnet18 extractor. efficientnet_b0 has no training path yet and
-raises NotImplementedError outside test mode instead of silently falling back to another backend.
+depthwise / squeeze-excite / SiLU backward, FiLM-generator and set-encoder gradients — for both extractors.
 """
 import numpy as np
 import torch

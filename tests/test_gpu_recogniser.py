@@ -146,15 +146,15 @@ def test_learner_test_mode_end_to_end(device, tmp_path):
     assert stats["num_tasks"] == 3 and 0.0 <= stats["frame_acc"][0] <= 1.0
     assert stats["personalise_ms"][0] > 0 and stats["inference_ms_per_frame"][0] > 0
     assert out.exists()
-    # --mode train: LITE meta-training on the native backward kernels (resnet18); efficientnet_b0 has no training path
+    # --mode train: LITE meta-training on the native backward kernels
     common = ["--frame_size", "64", "--way", "3", "--shots", "2", "--frames_per_shot", "4", "--num_query_videos", "2",
               "--frames_per_video", "6", "--batch_size", "8", "--num_lite_samples", "4", "--tasks_per_batch", "2",
               "--num_train_tasks", "4"]
     for extra in (["--learn_extractor", "--with_lite"], ["--adapt_features", "--with_lite"], ["--learn_extractor"]):
         tr = main(["--mode", "train", "--feature_extractor", "resnet18"] + extra + common)["train"]
         assert tr["num_tasks"] == 4 and np.isfinite(tr["loss"][0]) and tr["loss"][0] > 0
-    with pytest.raises(NotImplementedError):
-        main(["--mode", "train", "--learn_extractor", "--with_lite", "--feature_extractor", "efficientnet_b0"] + common)
+    tr = main(["--mode", "train", "--learn_extractor", "--with_lite", "--feature_extractor", "efficientnet_b0"] + common)
+    assert tr["train"]["num_tasks"] == 4 and np.isfinite(tr["train"]["loss"][0])
 
 
 def test_sharded_forms_on_device_world1(device):

@@ -262,3 +262,63 @@ def test_proto_predict_backward(device, cosine, M, T, D, C, scale):
                                                 _lib.dptr(df), _st()), "proto_predict_backward")
     torch.cuda.synchronize()
     assert rel_err(df.cpu(), feats.grad) < 2e-5
+
+
+# ---- MBConv pieces: depthwise convolution and squeeze-excite backward -----------------------------------------------
+DW_CASES = [
+    # B, C, H, W, K, stride, pad_top/left, pad_bottom/right
+    (3, 32, 14, 14, 3, 1, 1, 1),
+    (2, 96, 16, 16, 3, 2, 0, 1),     # TF "SAME" at an even size: all padding on the bottom/right
+    (2, 144, 15, 13, 5, 2, 2, 2),
+    (2, 240, 9, 9, 5, 1, 2, 2),
+    (4, 24, 20, 20, 5, 2, 1, 2),     # TF "SAME": 1 before, 2 after
+    (2, 1152, 4, 4, 3, 1, 1, 1),
+]
+
+
+@pytest.mark.parametrize("case", DW_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_dwconv_backward(device, case):
+    lib = _lib.load()
+    B, C, H, W, K, stride, p0, p1 = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, C, H, W, generator=g).requires_grad_(True)
+    w = (torch.randn(C, 1, K, K, generator=g) / K).requires_grad_(True)
+    y = F.conv2d(F.pad(x, [p0, p1, p0, p1]), w, None, stride, 0, 1, C)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    Ho, Wo = y.shape[2:]
+    t_x, t_w, t_dy = nhwc(x.detach()).to(device), w.detach().to(device).contiguous(), nhwc(dy).to(device)
+    dx = torch.full((B, H, W, C), float("nan"), device=device)
+    dw = torch.full((C, 1, K, K), float("nan"), device=device)
+    _lib.check(lib.orbit_op_dwconv2d_backward(_lib.dptr(t_x), _lib.dptr(t_w), _lib.dptr(t_dy), _lib.dptr(dx), _lib.dptr(dw),
+                                              B, H, W, C, K, stride, p0, p0, Ho, Wo, _st()), "dwconv2d_backward")
+    torch.cuda.synchronize()
+    assert rel_err(nchw(dx.cpu()), x.grad) < 2e-5
+    assert rel_err(dw.cpu(), w.grad) < 2e-5
+
+
+@pytest.mark.parametrize("B,HW,C,R", [(5, 49, 96, 4), (3, 16, 1152, 48), (2, 196, 144, 6), (7, 9, 32, 8)])
+def test_se_gate_backward(device, B, HW, C, R):
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B * C + R)
+    x = torch.randn(B, HW, C, generator=g, dtype=torch.float64).requires_grad_(True)
+    w1 = (torch.randn(R, C, generator=g, dtype=torch.float64) / C ** 0.5).requires_grad_(True)
+    b1 = (0.1 * torch.randn(R, generator=g, dtype=torch.float64)).requires_grad_(True)
+    w2 = (torch.randn(C, R, generator=g, dtype=torch.float64) / R ** 0.5).requires_grad_(True)
+    b2 = (0.1 * torch.randn(C, generator=g, dtype=torch.float64)).requires_grad_(True)
+    pooled = x.mean(dim=1)
+    gate = torch.sigmoid(F.silu(pooled @ w1.t() + b1) @ w2.t() + b2)
+    xg = x * gate[:, None, :]
+    dxg = torch.randn(B, HW, C, generator=g, dtype=torch.float64)
+    xg.backward(dxg)
+    f = lambda t: t.detach().float().to(device).contiguous()
+    ts = [f(dxg), f(x), f(pooled), f(w1), f(b1), f(w2), f(b2)]
+    dx = torch.full((B, HW, C), float("nan"), device=device)
+    outs = [torch.empty(R, C, device=device), torch.empty(R, device=device), torch.empty(C, R, device=device),
+            torch.empty(C, device=device)]
+    _lib.check(lib.orbit_op_se_gate_backward(*[_lib.dptr(t) for t in ts], _lib.dptr(dx), *[_lib.dptr(t) for t in outs], B,
+                                             HW, C, R, _st()), "se_gate_backward")
+    torch.cuda.synchronize()
+    assert rel_err(dx.cpu(), x.grad) < 2e-5
+    for got, ref in zip(outs, (w1, b1, w2, b2)):
+        assert rel_err(got.cpu(), ref.grad) < 5e-5
