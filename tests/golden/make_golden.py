@@ -288,6 +288,50 @@ def g8_lite_learn_extractor(fsr):
     save("G8_lite_learn_extractor", **out)
 
 
+def g9_lite_efficientnet(fsr):
+    """The README's main recipe (`--feature_extractor efficientnet_b0 --learn_extractor --with_lite`): one LITE step of
+    the reference with the tf_efficientnet_b0-layout extractor unfrozen (train-mode BatchNorm), variant b adds FiLM."""
+    import torch.nn.functional as F
+    task = synthetic.make_task(51, way=3, shots=1, frames_per_shot=3, num_query=6, frame_size=64)
+    ctx, lab, tgt, tlab = task["context_clips"], task["context_labels"], task["target_clips"], task["target_labels"]
+    num_lite, tasks_per_batch, batch_size = 3, 2, 6
+    out = {"context_clips": ctx, "context_labels": lab, "target_clips": tgt, "target_labels": tlab,
+           "num_lite_samples": num_lite, "tasks_per_batch": tasks_per_batch, "batch_size": batch_size}
+    watched = ("feature_extractor.conv_stem.weight", "feature_extractor.bn1.weight",
+               "feature_extractor.blocks.0.0.conv_dw.weight", "feature_extractor.blocks.0.0.se.conv_reduce.weight",
+               "feature_extractor.blocks.1.0.conv_pw.weight", "feature_extractor.blocks.1.1.conv_dw.weight",
+               "feature_extractor.blocks.2.0.se.conv_expand.bias", "feature_extractor.blocks.3.2.bn2.weight",
+               "feature_extractor.blocks.4.1.conv_pwl.weight", "feature_extractor.blocks.5.3.conv_dw.weight",
+               "feature_extractor.blocks.6.0.bn3.weight", "feature_extractor.conv_head.weight",
+               "feature_extractor.bn2.bias", "set_encoder.encoder.layer1.0.weight", "film_generator.regularizers.5")
+    stats = ("feature_extractor.bn1.running_mean", "feature_extractor.blocks.3.1.bn2.running_var",
+             "feature_extractor.bn2.running_var")
+    for tag, adapt in (("a", False), ("b", True)):
+        model = make_reference_recogniser(fsr, "efficientnet_b0", adapt, "proto", 1, batch_size, num_lite,
+                                          film_strength=0.02, learn_extractor=True)
+        model.set_test_mode(False)
+        model._clear_caches()
+        model.zero_grad()
+        np.random.seed(900)
+        model.personalise_with_lite(ctx, lab)
+        logits = model.predict_a_batch(tgt)
+        loss = len(lab) / (num_lite * tasks_per_batch) * F.cross_entropy(logits, tlab)
+        loss = loss + 0.001 * model.film_generator.regularization_term()
+        loss.backward()
+        out[tag + "_logits_0"], out[tag + "_loss_0"] = logits, loss
+        model._reset()
+        params = dict(model.named_parameters())
+        for name in watched:
+            if name in params and params[name].grad is not None:
+                flat = params[name].grad.flatten()
+                out["%s_grad__%s" % (tag, name)] = flat[::max(1, flat.numel() // 4096)][:4096].clone()
+                out["%s_gnorm__%s" % (tag, name)] = flat.double().norm().float()
+        sd = model.state_dict()
+        for name in stats:
+            out["%s_stat__%s" % (tag, name)] = sd[name].float()
+    save("G9_lite_efficientnet", **out)
+
+
 def g7_utils():
     from data.utils import attach_frame_history, get_batch_indices
     frames = torch.arange(6 * 3 * 2 * 2, dtype=torch.float32).reshape(6, 3, 2, 2)
@@ -309,6 +353,7 @@ def main():
     g5_recogniser(fsr)
     g6_lite(fsr)
     g8_lite_learn_extractor(fsr)
+    g9_lite_efficientnet(fsr)
 
 
 if __name__ == "__main__":

@@ -41,9 +41,9 @@ def gold(name):
             for k, v in np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False).items()}
 
 
-def native(adapt, batch_size, num_lite, learn_extractor):
-    m = SingleStepFewShotRecogniser("resnet18", adapt, "proto", 1, batch_size, learn_extractor, num_lite, 1.0)
-    synthetic.init_parameters_(m)
+def native(adapt, batch_size, num_lite, learn_extractor, fe_name="resnet18", film_strength=0.1):
+    m = SingleStepFewShotRecogniser(fe_name, adapt, "proto", 1, batch_size, learn_extractor, num_lite, 1.0)
+    synthetic.init_parameters_(m, film_strength=film_strength)
     if adapt:
         m.film_generator.initial_film_parameters = get_film_parameters(m.film_parameter_names, m.feature_extractor)
     m._set_device("cuda:0")
@@ -56,15 +56,15 @@ def rel(got, ref):
     return float((got.double().cpu() - ref).abs().max() / max(float(ref.abs().max()), 1e-30))
 
 
-def lite_steps(m, g, seed0, prefix=""):
-    """Learner.train_task_with_lite's loop (single-step-learner.py:212-243) over the two query batches."""
+def lite_steps(m, g, seed0, prefix="", batches=2):
+    """Learner.train_task_with_lite's loop (single-step-learner.py:212-243) over the query batches."""
     nl, tpb, bs = int(g["num_lite_samples"]), int(g["tasks_per_batch"]), int(g["batch_size"])
     dev = torch.device("cuda:0")
     ctx, lab = g["context_clips"].to(dev), g["context_labels"].to(dev)
     m.set_test_mode(False)
     m._clear_caches()
     m.zero_grad()
-    for b in range(2):
+    for b in range(batches):
         np.random.seed(seed0 + b)
         m.personalise_with_lite(ctx, lab)
         logits = m.predict_a_batch(g["target_clips"][b * bs:(b + 1) * bs].to(dev))
@@ -72,7 +72,7 @@ def lite_steps(m, g, seed0, prefix=""):
         assert (logits.detach().cpu() - want).abs().max().item() < 1e-3, "logits of batch %d" % b
         loss = len(lab) / (nl * tpb) * F.cross_entropy(logits, g["target_labels"][b * bs:(b + 1) * bs].to(dev))
         loss = loss + 0.001 * m.film_generator.regularization_term()
-        assert abs(float(loss) - float(g[prefix + "loss_%d" % b])) < 1e-3
+        assert abs(loss.item() - float(g[prefix + "loss_%d" % b])) < 1e-3
         loss.backward()
         m._reset()
 
@@ -120,6 +120,32 @@ def test_G8_lite_unfrozen_extractor(device, tag, adapt):
             assert rel(sd[name].float(), want) < 1e-4, name
     has = params["feature_extractor.bn1.weight"].grad is not None
     assert has == bool(g[tag + "_bn1_weight_has_grad"])
+
+
+@pytest.mark.parametrize("tag,adapt", [("a", False), ("b", True)])
+def test_G9_lite_efficientnet(device, tag, adapt):
+    """The README's main recipe on the efficientnet_b0 plan: gradients recorded from the reference's loss.backward().
+    Smooth activations only (SiLU / sigmoid): no mask flips, so the bar is 1e-3 on every sampled gradient."""
+    g = gold("G9_lite_efficientnet")
+    m = native(adapt, int(g["batch_size"]), int(g["num_lite_samples"]), True, "efficientnet_b0", 0.02)
+    lite_steps(m, g, 900, prefix=tag + "_", batches=1)
+    params = dict(m.named_parameters())
+    top = max(float(g[k].abs().max()) for k in g if k.startswith(tag + "_grad__"))
+    checked = 0
+    for key in g:
+        if not key.startswith(tag + "_grad__"):
+            continue
+        name = key[len(tag + "_grad__"):]
+        flat = params[name].grad.flatten()
+        sample = flat[::max(1, flat.numel() // 4096)][:4096].cpu()
+        err = float((sample.double() - g[key].double()).abs().max()) / max(float(g[key].abs().max()), 1e-4 * top)
+        assert err < 1e-3, (name, err)
+        checked += 1
+    assert checked >= 10
+    sd = m.state_dict()
+    for key in g:
+        if key.startswith(tag + "_stat__"):
+            assert rel(sd[key[len(tag + "_stat__"):]].float(), g[key]) < 1e-4, key
 
 
 # ---- extractor level, against torch autograd on the oracle modules ---------------------------------------------------

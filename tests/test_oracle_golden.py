@@ -144,9 +144,17 @@ def test_G6_lite_forward():
     assert not bool(g["extractor_has_grad"])
 
 
-def _lite_trainer(adapt, learn_extractor, bs, nl, tpb):
+def _lite_trainer(adapt, learn_extractor, bs, nl, tpb, fe_name="resnet18", film_strength=0.1):
     from oracle.training import LiteTrainer
-    ref = oracle_recogniser(adapt, "proto", 1, bs, num_lite=nl)
+    if fe_name == "resnet18":
+        ref = oracle_recogniser(adapt, "proto", 1, bs, num_lite=nl)
+    else:
+        ref = OracleRecogniser(fe_name, adapt, "proto", 1, bs, nl, 1.0)
+        synthetic.init_parameters_(ref.fe, film_strength=film_strength)
+        if adapt:
+            synthetic.init_parameters_(ref.set_encoder)
+            synthetic.init_parameters_(ref.build_film_generator(), prefix="film_generator.",
+                                       film_strength=film_strength)
     return LiteTrainer(ref, learn_extractor, tpb)
 
 
@@ -204,6 +212,36 @@ def test_G8_lite_gradients_unfrozen_extractor(tag, adapt):
         if key.startswith(tag + "_stat__"):
             assert _rel(sd[key[len(tag + "_stat__"):]].float(), torch.as_tensor(g[key]).float()) < 1e-5, key
     assert (named["feature_extractor.bn1.weight"].grad is not None) == bool(g[tag + "_bn1_weight_has_grad"])
+
+
+@pytest.mark.parametrize("tag,adapt", [("a", False), ("b", True)])
+def test_G9_lite_gradients_efficientnet(tag, adapt):
+    """The same for the efficientnet_b0-layout extractor (depthwise / squeeze-excite / SiLU in the graph)."""
+    g = gold("G9_lite_efficientnet")
+    nl, tpb, bs = int(g["num_lite_samples"]), int(g["tasks_per_batch"]), int(g["batch_size"])
+    tr = _lite_trainer(adapt, True, bs, nl, tpb, fe_name="efficientnet_b0", film_strength=0.02)
+    (logits, loss), = tr.train_task_with_lite(g["context_clips"], g["context_labels"], g["target_clips"],
+                                              g["target_labels"], seeds=(900,))
+    assert (logits - g[tag + "_logits_0"]).abs().max().item() < 2e-4
+    assert abs(float(loss) - float(g[tag + "_loss_0"])) < 1e-4
+    named = {"feature_extractor." + n: p for n, p in tr.r.fe.named_parameters()}
+    if adapt:
+        named.update({"set_encoder." + n: p for n, p in tr.r.set_encoder.named_parameters()})
+        named.update({"film_generator." + n: p for n, p in tr.r.film_generator.named_parameters()})
+    checked = 0
+    for key in g:
+        if not key.startswith(tag + "_grad__"):
+            continue
+        name = key[len(tag + "_grad__"):]
+        flat = named[name].grad.flatten()
+        sample = flat[::max(1, flat.numel() // 4096)][:4096]
+        assert _rel(sample, g[key]) < 1e-3, name
+        checked += 1
+    assert checked >= 10
+    sd = {"feature_extractor." + k: v for k, v in tr.r.fe.state_dict().items()}
+    for key in g:
+        if key.startswith(tag + "_stat__"):
+            assert _rel(sd[key[len(tag + "_stat__"):]].float(), torch.as_tensor(g[key]).float()) < 1e-5, key
 
 
 def test_C_restatement_of_head_against_golden():
