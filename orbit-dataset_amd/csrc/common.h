@@ -119,6 +119,7 @@ int launch_upsample_zero(const float* src, float* dst, int B, int H, int W, int 
                          hipStream_t s);
 int launch_add_inplace(float* dst, const float* src, size_t n, hipStream_t s);
 // MBConv pieces (train_mbconv.hip)
+int launch_colmean(const float* x, float* pooled, int B, int HW, int C, hipStream_t s);  // [B][HW][C] -> means [B][C]
 int launch_gate_mul(const float* x, const float* gate, float* xg, int B, int HW, int C, hipStream_t s);
 size_t se_bwd_scratch_floats(int B, int C, int R);
 // dxg: gradient of x*gate; writes dx (through the product, the gate MLP and the average pool) and, when dw1 != NULL, the

@@ -164,21 +164,31 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
     }
 }
 
-// dw (OIHW) = sum over splits, in ascending split order; MODE 0 columns (kh,kw,ci) -> (ci,kh,kw)
+// dw (OIHW) = sum over splits; MODE 0 columns (kh,kw,ci) -> (ci,kh,kw). 16 outputs per block, 16 lanes per output take
+// every 16th split, combined through LDS in a fixed order (deterministic; a single thread walking up to ~2000 splits is
+// a latency chain of hundreds of microseconds)
 __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __restrict__ partial, int splits, int Cout,
                                                                 int NC, int Cin, int KH, int KW, int mode,
                                                                 float* __restrict__ dw) {
+    __shared__ float sh[16][16];
     const size_t total = (size_t)Cout * NC;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        float s = 0.f;
-        for (int k = 0; k < splits; ++k) s += partial[(size_t)k * total + i];
-        if (mode == 1) {
-            dw[i] = s;
-        } else {
-            const int co = (int)(i / NC), n = (int)(i % NC);
-            const int tap = n / Cin, ci = n - tap * Cin;
-            dw[((size_t)co * Cin + ci) * KH * KW + tap] = s;
-        }
+    const int ol = threadIdx.x & 15, ln = threadIdx.x >> 4;
+    const size_t i = (size_t)blockIdx.x * 16 + ol;
+    float s = 0.f;
+    if (i < total) {
+#pragma unroll 4
+        for (int k = ln; k < splits; k += 16) s += partial[(size_t)k * total + i];
+    }
+    sh[ln][ol] = s;
+    __syncthreads();
+    if (ln != 0 || i >= total) return;
+    for (int j = 1; j < 16; ++j) s += sh[j][ol];
+    if (mode == 1) {
+        dw[i] = s;
+    } else {
+        const int co = (int)(i / NC), n = (int)(i % NC);
+        const int tap = n / Cin, ci = n - tap * Cin;
+        dw[((size_t)co * Cin + ci) * KH * KW + tap] = s;
     }
 }
 
@@ -222,8 +232,7 @@ int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oih
     prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();
     const size_t total = (size_t)Cout * p.NC;
-    int rblocks = (int)((total + 255) / 256);
-    if (rblocks > 4096) rblocks = 4096;
+    const int rblocks = (int)((total + 15) / 16);
     conv_wgrad_reduce_kernel<<<rblocks, 256, 0, s>>>(scratch, p.splits, Cout, p.NC, Cin, KH, KW, x_nchw ? 1 : 0, dw_oihw);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;

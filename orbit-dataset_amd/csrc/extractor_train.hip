@@ -333,11 +333,12 @@ int orbit_extractor_train_forward(orbit_extractor_t* fe, const float* frames, in
             // squeeze (mean over the depthwise output) + excite MLP -> gate [B][C]
             if (last_dw < 0) return set_err(ORBIT_ERR_STATE, "extractor_train_forward: squeeze-excite without a producer");
             const Op& dw = fe->ops[last_dw];
-            rc = launch_avgpool(fl(L.a[last_dw]), fl(L.p[i]), B, dw.Ho * dw.Wo, o.Cin, s);
+            rc = launch_colmean(fl(L.a[last_dw]), fl(L.p[i]), B, dw.Ho * dw.Wo, o.Cin, s);
             if (rc != ORBIT_OK) return rc;
-            rc = launch_se_gate(fl(L.p[i]), fe->d_pool + fe->params[o.se_w1].off, fe->d_pool + fe->params[o.se_b1].off,
-                                fe->d_pool + fe->params[o.se_w2].off, fe->d_pool + fe->params[o.se_b2].off, fl(L.a[i]), B,
-                                o.Cin, o.R, s);
+            // the inference gate kernel, fed with the means as a single "partial sum" over one element
+            rc = launch_se_gate2(fl(L.p[i]), 1, 1, fe->d_pool + fe->params[o.se_w1].off,
+                                 fe->d_pool + fe->params[o.se_b1].off, fe->d_packed + o.packed_off,
+                                 fe->d_pool + fe->params[o.se_b2].off, fl(L.a[i]), B, o.Cin, o.R, s);
             cur[102] = fl(L.a[i]);
         } else if (o.kind == OP_MAXPOOL) {
             rc = launch_maxpool_idx(cur[o.in], fl(L.p[i]), reinterpret_cast<uint8_t*>(tp + L.idx[i]), B, o.H, o.W, o.Cin,

@@ -10,6 +10,13 @@ namespace orbit {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
+static void dw_layout(int C, int& G, int& R, int& ygroups) {
+    const int Q = C / 4;
+    G = Q < 64 ? Q : 64;
+    R = 256 / G;
+    ygroups = cdiv(Q, G);
+}
+
 static int grid_for(size_t total) {
     size_t b = (total + 255) / 256;
     return (int)(b > 8192 ? 8192 : (b ? b : 1));
@@ -23,6 +30,27 @@ __global__ __launch_bounds__(256) void gate_mul_kernel(const float* __restrict__
         const size_t b = i / ((size_t)HW * C4);
         reinterpret_cast<f32x4*>(xg)[i] = reinterpret_cast<const f32x4*>(x)[i] *
                                           reinterpret_cast<const f32x4*>(gate)[b * C4 + q];
+    }
+}
+
+// pooled[b][c] = mean_hw x[b][hw][c] (the squeeze of squeeze-excite over the LARGE depthwise outputs: HW up to 112*112);
+// block = (frame b, group of G channel quads), R row lanes, float4 loads, fixed-order LDS combine
+__global__ __launch_bounds__(256) void colmean_kernel(const float* __restrict__ x, float* __restrict__ pooled, int HW,
+                                                      int C4, int G, int R) {
+    __shared__ f32x4 red[256];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const int rl = tid / G, qi = tid - rl * G, q = blockIdx.y * G + qi;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (rl < R && q < C4) {
+        const size_t base = (size_t)b * HW * C4 + q;
+#pragma unroll 4
+        for (int r = rl; r < HW; r += R) s += reinterpret_cast<const f32x4*>(x)[base + (size_t)r * C4];
+    }
+    red[tid] = s;
+    __syncthreads();
+    if (rl == 0 && q < C4) {
+        for (int j = 1; j < R; ++j) s += red[j * G + qi];
+        reinterpret_cast<f32x4*>(pooled)[(size_t)b * C4 + q] = s * (1.0f / (float)HW);
     }
 }
 
@@ -243,23 +271,26 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_partial_kernel(const float* 
     }
 }
 
-// dw[c][0][kh][kw] = sum over chunks (ascending) of partial[chunk][tap][c]
+// dw[c][0][kh][kw] = sum over chunks of partial[chunk][tap][c]: 16 outputs per block, 16 lanes per output take every
+// 16th chunk, fixed-order LDS combine (a single thread walking ~1000 chunks is a 200 us latency chain)
 __global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, int KK,
                                                                   int C, float* __restrict__ dw) {
+    __shared__ float sh[16][16];
     const int total = KK * C;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int ol = threadIdx.x & 15, ln = threadIdx.x >> 4;
+    const int i = blockIdx.x * 16 + ol;
+    float s = 0.f;
+    if (i < total) {
+#pragma unroll 4
+        for (int k = ln; k < chunks; k += 16) s += partial[(size_t)k * total + i];
+    }
+    sh[ln][ol] = s;
+    __syncthreads();
+    if (ln == 0 && i < total) {
+        for (int j = 1; j < 16; ++j) s += sh[j][ol];
         const int tap = i / C, c = i - tap * C;
-        float s = 0.f;
-        for (int k = 0; k < chunks; ++k) s += partial[((size_t)k * KK + tap) * C + c];
         dw[(size_t)c * KK + tap] = s;
     }
-}
-
-static void dw_layout(int C, int& G, int& R, int& ygroups) {
-    const int Q = C / 4;
-    G = Q < 64 ? Q : 64;
-    R = 256 / G;
-    ygroups = cdiv(Q, G);
 }
 
 int dwconv_wgrad_chunks(int B, int Ho, int Wo, int C) {
@@ -272,6 +303,15 @@ int dwconv_wgrad_chunks(int B, int Ho, int Wo, int C) {
 }
 
 // ---- launchers ---------------------------------------------------------------------------------------------------
+int launch_colmean(const float* x, float* pooled, int B, int HW, int C, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0, "colmean: C %% 4 != 0");
+    int G, R, yg;
+    dw_layout(C, G, R, yg);
+    colmean_kernel<<<dim3(B, yg), 256, 0, s>>>(x, pooled, HW, C / 4, G, R);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
 int launch_gate_mul(const float* x, const float* gate, float* xg, int B, int HW, int C, hipStream_t s) {
     ORBIT_REQUIRE(C % 4 == 0, "gate_mul: C %% 4 != 0");
     const size_t total4 = (size_t)B * HW * (C / 4);
@@ -339,7 +379,7 @@ int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scrat
         dwconv_wgrad_partial_kernel<5><<<grid, 256, 0, s>>>(x, dy, scratch, B, H, W, C / 4, stride, pad_t, pad_l, Ho, Wo,
                                                            rows, G, R);
     ORBIT_LAUNCH_CHECK();
-    dwconv_wgrad_reduce_kernel<<<cdiv(K * K * C, 256), 256, 0, s>>>(scratch, chunks, K * K, C, dw);
+    dwconv_wgrad_reduce_kernel<<<cdiv(K * K * C, 16), 256, 0, s>>>(scratch, chunks, K * K, C, dw);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }

@@ -308,8 +308,7 @@ def test_efficientnet_backward_matches_autograd(device, bn_train, size, B):
         assert errs[worst] < 2e-4, (worst, errs[worst])
         return errs[worst]
 
-    for seed in range(2 if size == 64 else 1):
-        run(seed)
+    run(0)
 
 
 def test_efficientnet_film_gradients_frozen_extractor(device):
@@ -329,8 +328,8 @@ def test_efficientnet_film_gradients_frozen_extractor(device):
         bvec = b0 + 0.02 * torch.randn(b0.shape, generator=gen, dtype=torch.float64)
         film_ref[n + ".weight"], film_ref[n + ".bias"] = gvec.requires_grad_(True), bvec.requires_grad_(True)
         gam.append(gvec.detach().float()), bet.append(bvec.detach().float())
-    x = torch.randn(3, 3, 224, 224, generator=gen)
-    dfeat = torch.randn(3, 1280, generator=gen)
+    x = torch.randn(2, 3, 128, 128, generator=gen)
+    dfeat = torch.randn(2, 1280, generator=gen)
     functional_call(ref, film_ref, (x.double(),)).backward(dfeat.double())
     gamma = torch.cat(gam).to(device).requires_grad_(True)
     beta = torch.cat(bet).to(device).requires_grad_(True)
