@@ -39,7 +39,11 @@ WORKLOADS = {
     "efficientnet_b0_224": ("efficientnet_b0", False, 224),
     "resnet18_224": ("resnet18", False, 224),
     "cnaps_resnet18_224": ("resnet18", True, 224),
+    # the README's other two single-step recipes (heads of SURVEY §8f rank 2), inference only
+    "cnaps_versa_resnet18_224": ("resnet18", True, 224),
+    "simple_cnaps_resnet18_224": ("resnet18", True, 224),
 }
+HEADS = {"cnaps_versa_resnet18_224": "versa", "simple_cnaps_resnet18_224": "mahalanobis"}
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 WAY, SHOTS, FRAMES_PER_SHOT, NUM_QUERY = 5, 5, 8, 200
 
@@ -52,7 +56,8 @@ def build_model(workload, device, batch_size=256, train=False):
     # meta-training recipes of the reference README: ProtoNets learn the extractor; CNAPs keep it frozen and learn the
     # set encoder + FiLM generator
     learn_extractor = bool(train and not adapt)
-    model = SingleStepFewShotRecogniser(fe_name, adapt, "proto", 1, batch_size, learn_extractor, NUM_LITE, 1.0)
+    model = SingleStepFewShotRecogniser(fe_name, adapt, HEADS.get(workload, "proto"), 1, batch_size, learn_extractor,
+                                        NUM_LITE, 1.0)
     synthetic.init_parameters_(model)
     if adapt:
         from orbit_dataset_amd.model.film import get_film_parameters
@@ -140,8 +145,12 @@ def cpu_baseline(workload, model, train=False):
     """The oracle (CPU restatement of the reference path) on ONE task of the same workload, all host cores."""
     from oracle.recogniser import OracleRecogniser
     fe_name, adapt, size = WORKLOADS[workload]
-    ref = OracleRecogniser(fe_name, adapt, "proto", 1, 256, num_lite_samples=NUM_LITE)
+    ref = OracleRecogniser(fe_name, adapt, HEADS.get(workload, "proto"), 1, 256, num_lite_samples=NUM_LITE)
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
+    if HEADS.get(workload) == "versa":
+        for name in ("weight_processor", "bias_processor"):
+            getattr(ref, name).load_state_dict({k[len("classifier.%s." % name):]: v for k, v in sd.items()
+                                                if k.startswith("classifier.%s." % name)})
     ref.fe.load_state_dict({k[len("feature_extractor."):]: v for k, v in sd.items() if k.startswith("feature_extractor.")})
     if adapt:
         ref.set_encoder.load_state_dict({k[len("set_encoder."):]: v for k, v in sd.items() if k.startswith("set_encoder.")})

@@ -52,6 +52,7 @@ typedef void* orbit_stream_t; /* hipStream_t */
 #define ORBIT_ACT_NONE 0
 #define ORBIT_ACT_RELU 1
 #define ORBIT_ACT_SILU 2
+#define ORBIT_ACT_ELU 3   /* alpha = 1; only orbit_dense_rows */
 
 /* ---- library ---------------------------------------------------------------------------------- */
 int orbit_version(void);
@@ -180,6 +181,28 @@ int orbit_op_mbconv_front(const float* x, const float* w1, const float* scale1, 
                           const float* wdw, const float* scale2, const float* shift2, float* y, float* pool_partial,
                           int B, int H, int W, int Cin, int mid, int K, int stride, int pad_top, int pad_left,
                           int Ho, int Wo, orbit_stream_t stream);
+
+/* ---- Versa / Mahalanobis heads -----------------------------------------------------------
+ * y[r][o] = act(x[r] . W[o] + b[o]) (+ residual[r][o]) for a few rows r < R <= 16 (one row per class): the layers of
+ * the Versa hyper-networks, model/mlps.py:33-50 DenseResidualBlock (linear -> ELU -> linear -> ELU -> linear (+ x)),
+ * applied to the class means by VersaClassifier.configure, model/classifier_heads.py:158-180. W is torch [out][in]. */
+int orbit_dense_rows(const float* x, int R, int in, const float* W, const float* b, int out, int act,
+                     const float* residual, float* y, orbit_stream_t stream);
+/* batched inverse of `batch` symmetric positive definite n x n matrices (in-place blocked Gauss-Jordan, no pivoting);
+ * replaces torch.inverse in MahalanobisClassifier.configure (classifier_heads.py:288,311). A == Ainv allowed. */
+int orbit_spd_inverse(const float* A, float* Ainv, int n, int batch, orbit_stream_t stream);
+size_t orbit_mahalanobis_workspace_bytes(int N, int M, int D, int C);
+/* MahalanobisClassifier.configure (classifier_heads.py:284-327): features [N][D], labels [N], class_ids [C] ascending
+ * -> means [C][D], task_mean [D], precisions [C][D][D] = inverse(l cov_c + (1-l) cov_task + I), l = n_c/(n_c+1),
+ * task_precision [D][D] = inverse(cov_task + I); covariances are torch.cov(correction=1), a single-example class takes
+ * the reference's scalar branch (:361-364). */
+int orbit_mahalanobis_configure(const float* features, const int64_t* labels, const int64_t* class_ids, int N, int D,
+                                int C, float* means, float* task_mean, float* precisions, float* task_precision,
+                                void* workspace, size_t workspace_bytes, orbit_stream_t stream);
+/* MahalanobisClassifier.predict (:329-347): logits[m][c] = -scale * (mu_c - q_m)^T P_c (mu_c - q_m). D % 4 == 0. */
+int orbit_mahalanobis_predict(const float* features, const float* means, const float* precisions, int M, int D, int C,
+                              float logit_scale, float* logits, void* workspace, size_t workspace_bytes,
+                              orbit_stream_t stream);
 
 /* ---- training (LITE meta-training step) -----------------------------------------------------
  * What `loss.backward()` runs in the reference (single-step-learner.py:234) for the graph recorded by

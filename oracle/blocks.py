@@ -145,3 +145,65 @@ class FilmParameterGenerator(nn.Module):
             l2 = l2 + (self.regularizers[i] ** 2).sum()                         # :76
         self.l2_term = l2
         return film
+
+
+# ---- model/mlps.py:33-50 + model/classifier_heads.py:121-180 (Versa) and :265-368 (Mahalanobis) -------------------------
+class DenseResidualBlock(nn.Module):
+    """reference model/mlps.py:33-50"""
+
+    def __init__(self, in_size, out_size):
+        super().__init__()
+        self.linear1 = nn.Linear(in_size, out_size)
+        self.linear2 = nn.Linear(out_size, out_size)
+        self.linear3 = nn.Linear(out_size, out_size)
+        self.elu = nn.ELU()
+
+    def forward(self, x):
+        out = self.linear3(self.elu(self.linear2(self.elu(self.linear1(x)))))
+        return out + x if x.shape[-1] == out.shape[-1] else out
+
+
+def _class_rows(features, labels):
+    ids = torch.unique(labels)                                   # ascending = column order (:137-139, :292)
+    return ids, [features[labels == c] for c in ids]
+
+
+def versa_configure(features, labels, weight_processor, bias_processor):
+    """reference classifier_heads.py:158-180 -> (class ids, weight [C, D], bias [C])"""
+    ids, rows = _class_rows(features, labels)
+    nus = [r.mean(dim=0, keepdim=True) for r in rows]            # _mean_pooling, :115-119
+    weight = torch.cat([weight_processor(nu) for nu in nus], dim=0)
+    bias = torch.cat([bias_processor(nu) for nu in nus], dim=1).reshape(len(ids))
+    return ids, weight.detach(), bias.detach()
+
+
+def estimate_cov(examples):
+    """reference classifier_heads.py:349-368 (_estimate_cov), including its single-example branch, which centres the one
+    example by its own mean over the features and returns a SCALAR that later broadcasts over the matrix"""
+    if examples.size(0) > 1:
+        return torch.cov(examples.t(), correction=1)
+    factor = 1.0 / (examples.size(1) - 1)
+    examples = examples - torch.mean(examples, dim=1, keepdim=True)
+    return factor * examples.matmul(examples.t()).squeeze()
+
+
+def mahalanobis_configure(features, labels):
+    """reference classifier_heads.py:284-327 -> (ids, means [C, D], precisions [C, D, D], task_mean, task_precision)"""
+    D = features.size(1)
+    eye = torch.eye(D, dtype=features.dtype)
+    task_cov = estimate_cov(features)
+    task_precision = torch.inverse(task_cov + eye)
+    ids, rows = _class_rows(features, labels)
+    means, precisions = [], []
+    for r in rows:
+        means.append(r.mean(dim=0))
+        lam = r.size(0) / (r.size(0) + 1)
+        precisions.append(torch.inverse(lam * estimate_cov(r) + (1 - lam) * task_cov + eye))
+    return ids, torch.stack(means), torch.stack(precisions), features.mean(dim=0), task_precision
+
+
+def mahalanobis_predict(features, means, precisions, logit_scale=1.0):
+    """reference classifier_heads.py:329-347"""
+    diff = means[:, None, :] - features[None, :, :]              # [C, M, D]
+    first_half = torch.matmul(diff, precisions)
+    return logit_scale * (-(first_half * diff).sum(dim=2).transpose(1, 0))

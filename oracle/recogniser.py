@@ -15,9 +15,14 @@ from . import blocks, extractors
 class OracleRecogniser:
     def __init__(self, feature_extractor_name, adapt_features, classifier, clip_length, batch_size,
                  num_lite_samples=16, logit_scale=1.0):
-        if classifier not in ("proto", "proto_cosine"):
+        if classifier not in ("proto", "proto_cosine", "versa", "mahalanobis"):
             raise ValueError(f"Classifier {classifier} not valid.")
+        self.classifier = classifier
         self.fe = extractors.create(feature_extractor_name).eval()
+        if classifier == "versa":  # hyper-networks of the Versa head (classifier_heads.py:134-135)
+            D = self.fe.output_size
+            self.weight_processor = blocks.DenseResidualBlock(D, D).eval()
+            self.bias_processor = blocks.DenseResidualBlock(D, 1).eval()
         self.adapt_features = adapt_features
         self.distance_fn = "cosine" if classifier == "proto_cosine" else "euclidean"
         self.clip_length, self.batch_size = clip_length, batch_size
@@ -66,13 +71,29 @@ class OracleRecogniser:
     def _film(self, z):
         return self.film_generator(z) if self.film_generator is not None else {}
 
+    def _configure(self, f, labels):
+        if self.classifier == "versa":
+            self.class_ids, self.W, self.b = blocks.versa_configure(f, labels, self.weight_processor, self.bias_processor)
+        elif self.classifier == "mahalanobis":
+            self.class_ids, self.means, self.precisions, _, _ = blocks.mahalanobis_configure(f, labels)
+            self.W = self.b = True  # "configured" markers
+        else:
+            self.class_ids, self.W, self.b = blocks.proto_configure(f, labels, self.distance_fn)
+
+    def _logits(self, f):
+        if self.classifier == "versa":
+            return self.logit_scale * (f @ self.W.t() + self.b)
+        if self.classifier == "mahalanobis":
+            return blocks.mahalanobis_predict(f, self.means, self.precisions, self.logit_scale)
+        return blocks.proto_predict(f, self.W, self.b, self.logit_scale, self.distance_fn)
+
     # ---- API ----
     @torch.no_grad()
     def personalise(self, context_clips, context_labels):
         z = self._task_embedding_in_batches(context_clips)
         self.film_dict = self._film(z)
         f = blocks.mean_pool(self._features_in_batches(context_clips, self.film_dict), self.clip_length)
-        self.class_ids, self.W, self.b = blocks.proto_configure(f, context_labels, self.distance_fn)
+        self._configure(f, context_labels)
 
     @torch.no_grad()
     def personalise_with_lite(self, context_clips, context_labels):
@@ -94,7 +115,7 @@ class OracleRecogniser:
     @torch.no_grad()
     def predict(self, target_clips):
         f = blocks.mean_pool(self._features_in_batches(target_clips, self.film_dict), self.clip_length)
-        return blocks.proto_predict(f, self.W, self.b, self.logit_scale, self.distance_fn)
+        return self._logits(f)
 
     def reset(self):
         self.film_dict, self.W, self.b, self.class_ids = {}, None, None, None

@@ -11,8 +11,9 @@ Semantics kept from the reference:
   * the configured weight/bias are detached from the support features (the reference re-wraps them in
     nn.Parameter, :261-263, which cuts the autograd graph);
   * predict before configure raises AttributeError (:210-211).
-Only the 'proto' / 'proto_cosine' heads are on the hot path named by BASELINE.json; 'versa', 'mahalanobis'
-and 'linear' are out of scope of this build.
+The 'proto' / 'proto_cosine' heads are the hot path named by BASELINE.json. 'versa' (CNAPs) and 'mahalanobis' (Simple
+CNAPs), the other two single-step recipes of the reference README, are built on csrc/heads_extra.hip (SURVEY §8f rank 2);
+'linear' belongs to the multi-step finetuner and is out of scope.
 """
 import torch
 import torch.nn as nn
@@ -124,14 +125,151 @@ class PrototypicalClassifier(nn.Module):
         return (logits, argmax) if return_argmax else logits
 
 
+def _class_means(features, labels, class_ids, T=1):
+    """Per-class means [C, D] through the prototype kernels (ascending row order, fused clip pooling)."""
+    lib, st = _lib.load(), _lib.stream_handle()
+    feats = features.detach().contiguous().float()
+    C, D = int(class_ids.numel()), feats.shape[1]
+    N = feats.shape[0] // T
+    sums = torch.empty(C, D, device=feats.device)
+    counts = torch.empty(C, device=feats.device)
+    _lib.check(lib.orbit_proto_configure(_lib.dptr(feats), _lib.dptr(labels, torch.int64), _lib.dptr(class_ids, torch.int64),
+                                         1, N, T, D, C, _lib.dptr(sums), _lib.dptr(counts), st), "orbit_proto_configure")
+    means = torch.empty(C, D, device=feats.device)
+    _lib.check(lib.orbit_proto_finalize(_lib.dptr(sums), _lib.dptr(counts), 1, C, D, 1, _lib.dptr(means), _lib.dptr(None),
+                                        st), "orbit_proto_finalize")
+    return means.mul_(0.5)  # the kernel writes the prototype-head weight 2*mu (exact halving)
+
+
+class VersaClassifier(nn.Module):
+    """CNAPs head (reference classifier_heads.py:121-180): two hyper-networks map each class mean to the weight row and
+    the bias of a linear layer; predict is s * (q . W^T + b). As in the reference the generated weight / bias are
+    re-wrapped (detached) before use (:179-180)."""
+
+    unique_labels = PrototypicalClassifier.unique_labels
+
+    def __init__(self, in_size, logit_scale: float = 1.0):
+        super().__init__()
+        from .mlps import DenseResidualBlock
+        self.logit_scale = logit_scale
+        self.weight_processor = DenseResidualBlock(in_size, in_size)
+        self.bias_processor = DenseResidualBlock(in_size, 1)
+        self.reset()
+
+    def reset(self):
+        self.weight = None
+        self.bias = None
+        self.class_ids = None
+
+    def configure(self, context_features, context_labels, ops_counter=None, class_ids=None):
+        _lib.require_gpu()
+        assert context_features.size(0) == context_labels.size(0), "context features and labels are different sizes!"
+        dev = context_features.device
+        labels = context_labels.to(device=dev, dtype=torch.int64).contiguous()
+        if class_ids is None:
+            class_ids = PrototypicalClassifier.unique_labels(labels, dev)
+        means = _class_means(context_features, labels, class_ids)
+        C = means.shape[0]
+        weight, bias = [], []
+        for lo in range(0, C, 16):  # the dense-rows kernel takes up to 16 classes per launch
+            weight.append(self.weight_processor(means[lo:lo + 16]))
+            bias.append(self.bias_processor(means[lo:lo + 16]))
+        self.weight = torch.cat(weight, dim=0)
+        self.bias = torch.cat(bias, dim=0).reshape(C)
+        self.class_ids = class_ids
+
+    def predict(self, target_features, ops_counter=None):
+        if self.weight is None or self.bias is None:
+            raise AttributeError("Weight and/or bias not set - is model personalised?")
+        _lib.require_gpu()
+        if target_features.requires_grad and torch.is_grad_enabled():
+            from .autograd import ProtoPredictFunction
+            return ProtoPredictFunction.apply(target_features, self.weight, self.bias, 1, float(self.logit_scale), 0)
+        q = target_features.detach().contiguous().float()
+        M, D = q.shape
+        C = self.weight.size(0)
+        logits = torch.empty(M, C, device=q.device, dtype=torch.float32)
+        if M > 0:
+            _lib.check(_lib.load().orbit_proto_predict(_lib.dptr(q), _lib.dptr(self.weight), _lib.dptr(self.bias), 1, M, 1,
+                                                       D, C, float(self.logit_scale), 0, _lib.dptr(logits), _lib.dptr(None),
+                                                       _lib.stream_handle()), "orbit_proto_predict")
+        return logits
+
+
+class MahalanobisClassifier(nn.Module):
+    """Simple CNAPs head (reference classifier_heads.py:265-368): class means + regularised class covariances inverted
+    to precisions; logits are negative squared Mahalanobis distances."""
+
+    unique_labels = PrototypicalClassifier.unique_labels
+
+    def __init__(self, logit_scale: float = 1.0):
+        super().__init__()
+        self.logit_scale = logit_scale
+        self.reset()
+
+    def reset(self):
+        self.means = None
+        self.precisions = None
+        self.task_mean = None
+        self.task_precision = None
+        self.class_ids = None
+
+    def configure(self, context_features, context_labels, ops_counter=None, class_ids=None):
+        _lib.require_gpu()
+        assert context_features.size(0) == context_labels.size(0), "context features and labels are different sizes!"
+        feats = context_features.detach().contiguous().float()
+        dev = feats.device
+        labels = context_labels.to(device=dev, dtype=torch.int64).contiguous()
+        if class_ids is None:
+            class_ids = PrototypicalClassifier.unique_labels(labels, dev)
+        N, D = feats.shape
+        C = int(class_ids.numel())
+        lib = _lib.load()
+        ws = torch.empty(lib.orbit_mahalanobis_workspace_bytes(N, 1, D, C), dtype=torch.uint8, device=dev)
+        means = torch.empty(C, D, device=dev)
+        task_mean = torch.empty(D, device=dev)
+        precisions = torch.empty(C, D, D, device=dev)
+        task_precision = torch.empty(D, D, device=dev)
+        _lib.check(lib.orbit_mahalanobis_configure(_lib.dptr(feats), _lib.dptr(labels, torch.int64),
+                                                   _lib.dptr(class_ids, torch.int64), N, D, C, _lib.dptr(means),
+                                                   _lib.dptr(task_mean), _lib.dptr(precisions), _lib.dptr(task_precision),
+                                                   _lib.dptr(ws, torch.uint8), ws.numel(), _lib.stream_handle()),
+                   "orbit_mahalanobis_configure")
+        self.means, self.task_mean, self.precisions, self.task_precision = means, task_mean, precisions, task_precision
+        self.class_ids = class_ids
+
+    def predict(self, target_features, ops_counter=None):
+        if self.means is None or self.precisions is None:
+            raise AttributeError("Means and/or precisions not set - is model personalised?")
+        _lib.require_gpu()
+        if target_features.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("gradients through the Mahalanobis head are not built; use it under torch.no_grad()")
+        q = target_features.detach().contiguous().float()
+        M, D = q.shape
+        C = self.means.size(0)
+        lib = _lib.load()
+        logits = torch.empty(M, C, device=q.device, dtype=torch.float32)
+        if M > 0:
+            ws = torch.empty(lib.orbit_mahalanobis_workspace_bytes(2, M, D, C), dtype=torch.uint8, device=q.device)
+            _lib.check(lib.orbit_mahalanobis_predict(_lib.dptr(q), _lib.dptr(self.means), _lib.dptr(self.precisions), M, D,
+                                                     C, float(self.logit_scale), _lib.dptr(logits),
+                                                     _lib.dptr(ws, torch.uint8), ws.numel(), _lib.stream_handle()),
+                       "orbit_mahalanobis_predict")
+        return logits
+
+
 def create_classifier(classifier: str, feat_dim: int, logit_scale: float):
     """Head factory used by FewShotRecogniser.__init__ (reference few_shot_recognisers.py:70-84)."""
     if classifier == "proto":
         return PrototypicalClassifier(logit_scale)
     if classifier == "proto_cosine":
         return PrototypicalClassifier(logit_scale, distance_fn="cosine")
-    if classifier in ("linear", "versa", "mahalanobis"):
+    if classifier == "versa":
+        return VersaClassifier(feat_dim, logit_scale)
+    if classifier == "mahalanobis":
+        return MahalanobisClassifier(logit_scale)
+    if classifier == "linear":
         raise NotImplementedError(
-            f"Classifier '{classifier}' is outside the prototype-head hot path this build implements "
-            "(SURVEY.md §8f lists it as a next row).")
+            "Classifier 'linear' belongs to the multi-step finetuner, which this build does not implement "
+            "(SURVEY.md §8f rank 4).")
     raise ValueError(f"Classifier {classifier} not valid.")

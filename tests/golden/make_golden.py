@@ -332,6 +332,34 @@ def g9_lite_efficientnet(fsr):
     save("G9_lite_efficientnet", **out)
 
 
+def g10_heads_versa_mahalanobis():
+    """The other two single-step heads, run by the reference's own classes on small feature sets (D = 64 / 96; the
+    second case has a single-example class, which takes _estimate_cov's scalar branch)."""
+    from model.classifier_heads import MahalanobisClassifier, VersaClassifier
+    out = {}
+    for tag, D, labels in (("w5", 64, [0] * 6 + [1] * 5 + [2] * 7 + [3] * 4 + [4] * 6),
+                           ("single", 96, [3] * 5 + [7] * 1 + [9] * 6)):
+        g = torch.Generator().manual_seed(1200 + D)
+        lab = torch.tensor(labels)[torch.randperm(len(labels), generator=g)]
+        cls = {c: 0.8 * torch.randn(D, generator=g) for c in set(labels)}
+        feats = torch.stack([cls[int(c)] for c in lab]) + torch.randn(len(labels), D, generator=g)
+        q = torch.stack([cls[int(c)] for c in lab[:9]]) + torch.randn(9, D, generator=g)
+        out[tag + "_features"], out[tag + "_labels"], out[tag + "_query"] = feats, lab, q
+        versa = VersaClassifier(D, logit_scale=2.0)
+        synthetic.init_parameters_(versa, prefix="classifier.")
+        with torch.no_grad():
+            versa.configure(feats, lab)
+            out[tag + "_versa_weight"], out[tag + "_versa_bias"] = versa.weight.detach(), versa.bias.detach()
+            out[tag + "_versa_logits"] = versa.predict(q)
+        maha = MahalanobisClassifier(logit_scale=1.0)
+        with torch.no_grad():
+            maha.configure(feats, lab)
+            out[tag + "_maha_means"], out[tag + "_maha_precisions"] = maha.means.detach(), maha.precisions.detach()
+            out[tag + "_maha_task_precision"] = maha.task_precision.detach()
+            out[tag + "_maha_logits"] = maha.predict(q)
+    save("G10_heads_versa_mahalanobis", **out)
+
+
 def g7_utils():
     from data.utils import attach_frame_history, get_batch_indices
     frames = torch.arange(6 * 3 * 2 * 2, dtype=torch.float32).reshape(6, 3, 2, 2)
@@ -349,6 +377,7 @@ def main():
     g3_set_encoder()
     g4_film_generator()
     g7_utils()
+    g10_heads_versa_mahalanobis()
     import model.few_shot_recognisers as fsr
     g5_recogniser(fsr)
     g6_lite(fsr)

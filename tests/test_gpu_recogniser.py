@@ -96,6 +96,42 @@ def test_config4_cnaps_adaptation(device, fe_name, size):
     assert float(model.film_generator.regularization_term()) > 0
 
 
+@pytest.mark.parametrize("classifier", ["versa", "mahalanobis"])
+def test_cnaps_and_simple_cnaps_heads_end_to_end(device, classifier):
+    """The README's CNAPs (versa) and Simple CNAPs (mahalanobis) recipes: FiLM-adapted extractor + the head, against the
+    oracle's restatement of the head applied to the same (natively extracted) features."""
+    model = SingleStepFewShotRecogniser("resnet18", True, classifier, 1, 16, False, 16, 1.0)
+    synthetic.init_parameters_(model)
+    from orbit_dataset_amd.model.film import get_film_parameters
+    model.film_generator.initial_film_parameters = get_film_parameters(model.film_parameter_names, model.feature_extractor)
+    model._set_device("cuda:0")
+    model._send_to_device()
+    model.set_test_mode(True)
+    task = synthetic.make_task(9, way=4, shots=2, frames_per_shot=5, num_query=24, frame_size=84)
+    ctx, lab, tgt = task["context_clips"].cuda(), task["context_labels"].cuda(), task["target_clips"].cuda()
+    with torch.no_grad():
+        model.personalise(ctx, lab)
+        logits = model.predict(tgt).cpu()
+        fc = model._get_features_in_batches(ctx, model.film_dict).cpu().double()
+        fq = model._get_features_in_batches(tgt, model.film_dict).cpu().double()
+    labels = task["context_labels"]
+    if classifier == "versa":
+        wp, bp = blocks.DenseResidualBlock(512, 512), blocks.DenseResidualBlock(512, 1)
+        wp.load_state_dict({k: v.cpu() for k, v in model.classifier.weight_processor.state_dict().items()})
+        bp.load_state_dict({k: v.cpu() for k, v in model.classifier.bias_processor.state_dict().items()})
+        with torch.no_grad():
+            _, W, b = blocks.versa_configure(fc, labels, wp.double(), bp.double())
+        want = fq @ W.t() + b
+    else:
+        _, means, precisions, _, _ = blocks.mahalanobis_configure(fc, labels)
+        want = blocks.mahalanobis_predict(fq, means, precisions)
+    assert (logits.double() - want).abs().max().item() < 1e-3 * want.abs().max().item()
+    assert torch.equal(logits.argmax(1), want.argmax(1))
+    model._reset()
+    with pytest.raises(AttributeError):
+        model.predict(tgt)
+
+
 def test_config3_efficientnet_224(device):
     model, ref = build_pair("efficientnet_b0", False, "proto", 1, 16)
     task = synthetic.make_task(5, way=5, shots=1, frames_per_shot=4, num_query=12, frame_size=224)

@@ -81,8 +81,12 @@ def test_recogniser_wiring_and_state_dict_names():
     m2 = SingleStepFewShotRecogniser("resnet18", False, "proto_cosine", 8, 4, False, 16, 32.0)
     assert m2.classifier.distance_fn == "cosine" and m2.film_generator.regularization_term() == 0
     assert m2.film_generator(None) == {}
+    m5 = SingleStepFewShotRecogniser("resnet18", True, "versa", 1, 4, False, 16)
+    keys5 = set(m5.state_dict())
+    assert {"classifier.weight_processor.linear1.weight", "classifier.bias_processor.linear3.bias"} <= keys5
+    assert SingleStepFewShotRecogniser("resnet18", True, "mahalanobis", 1, 4, False, 16).classifier.means is None
     with pytest.raises(NotImplementedError):
-        SingleStepFewShotRecogniser("resnet18", False, "mahalanobis", 1, 4, False, 16)
+        SingleStepFewShotRecogniser("resnet18", False, "linear", 1, 4, False, 16)
     m3 = SingleStepFewShotRecogniser("resnet18", False, "proto", 1, 4, True, 16)
     m3.set_test_mode(False)
     # BatchNorm policy of the reference (few_shot_recognisers.py:176-183): everything eval(), the extractor train()

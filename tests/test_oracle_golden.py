@@ -244,6 +244,35 @@ def test_G9_lite_gradients_efficientnet(tag, adapt):
             assert _rel(sd[key[len(tag + "_stat__"):]].float(), torch.as_tensor(g[key]).float()) < 1e-5, key
 
 
+@pytest.mark.parametrize("tag,D", [("w5", 64), ("single", 96)])
+def test_G10_versa_and_mahalanobis_heads(tag, D):
+    """oracle/blocks.py restatements of VersaClassifier / MahalanobisClassifier against the reference's outputs."""
+    g = gold("G10_heads_versa_mahalanobis")
+    feats, lab, q = g[tag + "_features"], g[tag + "_labels"], g[tag + "_query"]
+
+    class Versa(torch.nn.Module):  # same parameter names as the reference module
+        def __init__(self):
+            super().__init__()
+            self.weight_processor = blocks.DenseResidualBlock(D, D)
+            self.bias_processor = blocks.DenseResidualBlock(D, 1)
+
+    v = Versa()
+    synthetic.init_parameters_(v, prefix="classifier.")
+    with torch.no_grad():
+        ids, W, b = blocks.versa_configure(feats, lab, v.weight_processor, v.bias_processor)
+        logits = 2.0 * (q @ W.t() + b)
+    assert (W - g[tag + "_versa_weight"]).abs().max().item() < 1e-5
+    assert (b - g[tag + "_versa_bias"]).abs().max().item() < 1e-5
+    assert (logits - g[tag + "_versa_logits"]).abs().max().item() < 1e-4
+    ids, means, precisions, task_mean, task_precision = blocks.mahalanobis_configure(feats, lab)
+    assert (means - g[tag + "_maha_means"]).abs().max().item() < 1e-6
+    assert (precisions - g[tag + "_maha_precisions"]).abs().max().item() < 1e-5
+    assert (task_precision - g[tag + "_maha_task_precision"]).abs().max().item() < 1e-5
+    want = g[tag + "_maha_logits"]
+    got = blocks.mahalanobis_predict(q, means, precisions)
+    assert (got - want).abs().max().item() < 1e-3 * want.abs().max().item()
+
+
 def test_C_restatement_of_head_against_golden():
     """oracle/proto_head.c (double accumulation) against the reference's golden logits."""
     import ctypes

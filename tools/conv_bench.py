@@ -64,7 +64,10 @@ def main():
             return 1e3 * ms.value / n.value, fl.value / ms.value / 1e9, nm.value.decode()
 
         us, tf, nm = measure(0)
-        line = "%-14s M=%7d N=%4d K=%5d  %-26s %8.1f us %6.1f TF" % (name, B * Ho * Ho, Cout, Cin * K * K, nm, us, tf)
+        Mr, Kr = B * Ho * Ho, Cin * K * K
+        ideal = 1e6 * max(2.0 * Mr * Cout * Kr / 157.3e12, 4.0 * (B * H * H * Cin + Mr * Cout + Cout * Kr) / 8e12)
+        line = "%-14s M=%7d N=%4d K=%5d  %-26s %8.1f us %6.1f TF  roof %6.1f us (%.2f)" % (
+            name, Mr, Cout, Kr, nm, us, tf, ideal, ideal / us)
         if len(sys.argv) > 2 and sys.argv[2] == "bk":
             res = {}
             for bk in (32, 16, 8):
