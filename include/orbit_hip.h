@@ -204,6 +204,12 @@ int orbit_mahalanobis_predict(const float* features, const float* means, const f
                               float logit_scale, float* logits, void* workspace, size_t workspace_bytes,
                               orbit_stream_t stream);
 
+/* d(features) of orbit_mahalanobis_predict (means / precisions are constants, as in the reference :324-327):
+ * dfeatures[m] = scale * sum_c dlogits[m][c] (P_c + P_c^T)(mu_c - q_m) */
+int orbit_mahalanobis_predict_backward(const float* dlogits, const float* features, const float* means,
+                                       const float* precisions, int M, int D, int C, float logit_scale, float* dfeatures,
+                                       void* workspace, size_t workspace_bytes, orbit_stream_t stream);
+
 /* ---- training (LITE meta-training step) -----------------------------------------------------
  * What `loss.backward()` runs in the reference (single-step-learner.py:234) for the graph recorded by
  * model/few_shot_recognisers.py:99-122 (_get_features, grad enabled), :345-356 (_get_task_embedding on the LITE

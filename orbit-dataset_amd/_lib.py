@@ -56,6 +56,7 @@ _SIGNATURES = {
     "orbit_mahalanobis_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "orbit_mahalanobis_configure": (c_int, [P, P, P, c_int, c_int, c_int, P, P, P, P, P, c_size_t, P]),
     "orbit_mahalanobis_predict": (c_int, [P, P, P, c_int, c_int, c_int, c_float, P, P, c_size_t, P]),
+    "orbit_mahalanobis_predict_backward": (c_int, [P, P, P, P, c_int, c_int, c_int, c_float, P, P, c_size_t, P]),
     "orbit_extractor_supports_training": (c_int, [P]),
     "orbit_extractor_tape_bytes": (c_size_t, [P, c_int]),
     "orbit_extractor_backward_workspace_bytes": (c_size_t, [P, c_int]),

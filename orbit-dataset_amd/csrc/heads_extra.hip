@@ -299,6 +299,27 @@ __global__ __launch_bounds__(256) void maha_rowdot_kernel(const float* __restric
     if (lane == 0) logits[(size_t)m * C + c] = -scale * s;
 }
 
+// psym = P + P^T (the gradient of d^T P d is (P + P^T) d; the stored precisions are only numerically symmetric)
+__global__ __launch_bounds__(256) void symmetrise_kernel(const float* __restrict__ P, int D, float* __restrict__ out) {
+    const size_t total = (size_t)D * D;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t i = e / D, j = e - i * D;
+        out[e] = P[e] + P[j * D + i];
+    }
+}
+
+// dq[m][:] (+)= scale * dlogits[m][c] * g[m][:]
+__global__ __launch_bounds__(256) void maha_bwd_acc_kernel(const float* __restrict__ g, const float* __restrict__ dlogits,
+                                                           int M, int D, int C, int c, float scale,
+                                                           float* __restrict__ dq) {
+    const size_t total = (size_t)M * D;
+    for (size_t e = (size_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (size_t)gridDim.x * 256) {
+        const size_t m = e / D;
+        const float v = scale * dlogits[m * C + c] * g[e];
+        dq[e] = c == 0 ? v : dq[e] + v;
+    }
+}
+
 __global__ __launch_bounds__(256) void task_mean_kernel(const float* __restrict__ sums, const float* __restrict__ counts,
                                                         int C, int D, float* __restrict__ means,
                                                         float* __restrict__ cnt_out) {
@@ -433,6 +454,40 @@ int orbit_mahalanobis_predict(const float* features, const float* means, const f
         d.Ho = 1, d.Wo = 1, d.act = ORBIT_ACT_NONE, d.pool2 = 0, d.x_nchw = 0;
         if (int rc = launch_conv(d, s)) return rc;
         maha_rowdot_kernel<<<cdiv(M, 4), 256, 0, s>>>(first, diff, M, D, C, c, logit_scale, logits);
+        ORBIT_LAUNCH_CHECK();
+    }
+    return ORBIT_OK;
+}
+
+/* d(features) of orbit_mahalanobis_predict: dq_m = scale * sum_c dlogits[m][c] (P_c + P_c^T)(mu_c - q_m) */
+int orbit_mahalanobis_predict_backward(const float* dlogits, const float* features, const float* means,
+                                       const float* precisions, int M, int D, int C, float logit_scale, float* dfeatures,
+                                       void* workspace, size_t workspace_bytes, orbit_stream_t stream) {
+    ORBIT_REQUIRE(dlogits && features && means && precisions && dfeatures && workspace,
+                  "mahalanobis_predict_backward: null pointer");
+    ORBIT_REQUIRE(M > 0 && D > 0 && D % 4 == 0 && C > 0, "mahalanobis_predict_backward: bad sizes");
+    ORBIT_REQUIRE(workspace_bytes >= orbit_mahalanobis_workspace_bytes(2, M, D, C),
+                  "mahalanobis_predict_backward: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t DD = (size_t)D * D;
+    float* ws = static_cast<float*>(workspace);
+    float* diff = ws;
+    float* g = diff + (size_t)M * D;
+    float* psym = g + (size_t)M * D;
+    float* packed = psym + DD;
+    int blocks = (int)(((size_t)M * D + 255) / 256);
+    if (blocks > 4096) blocks = 4096;
+    for (int c = 0; c < C; ++c) {
+        maha_diff_kernel<<<blocks, 256, 0, s>>>(features, means + (size_t)c * D, M, D, diff);
+        symmetrise_kernel<<<4096, 256, 0, s>>>(precisions + (size_t)c * DD, D, psym);
+        ORBIT_LAUNCH_CHECK();
+        if (int rc = conv_pack_weights(psym, packed, D, D, 1, 1, 0, s)) return rc;
+        ConvDesc d;
+        d.x = diff, d.w_packed = packed, d.y = g, d.scale = d.shift = d.residual = d.gate = nullptr;
+        d.B = M, d.H = 1, d.W = 1, d.Cin = D, d.Cout = D, d.KH = 1, d.KW = 1, d.stride = 1, d.pad_t = 0, d.pad_l = 0;
+        d.Ho = 1, d.Wo = 1, d.act = ORBIT_ACT_NONE, d.pool2 = 0, d.x_nchw = 0;
+        if (int rc = launch_conv(d, s)) return rc;
+        maha_bwd_acc_kernel<<<blocks, 256, 0, s>>>(g, dlogits, M, D, C, c, logit_scale, dfeatures);
         ORBIT_LAUNCH_CHECK();
     }
     return ORBIT_OK;

@@ -5,9 +5,10 @@ The reference trains through plain PyTorch autograd (single-step-learner.py:196-
 C-ABI call; torch only routes the gradients between the nodes and into `param.grad` (so `torch.optim` and
 `zero_grad` work unchanged, as in utils/optim.py:11-33).
 
-  ExtractorFunction      orbit_extractor_train_forward / orbit_extractor_backward   (resnet18, set encoder)
+  ExtractorFunction      orbit_extractor_train_forward / orbit_extractor_backward   (resnet18, efficientnet_b0, set encoder)
   ProtoPredictFunction   orbit_proto_predict / orbit_proto_predict_backward          (gradient w.r.t. query features;
                          the prototypes are constants, classifier_heads.py:261-263 re-wraps them in nn.Parameter)
+  MahalanobisPredictFunction  orbit_mahalanobis_predict / orbit_mahalanobis_predict_backward (w.r.t. query features)
   FilmGeneratorFunction  orbit_filmgen_forward / orbit_filmgen_backward
   MeanPoolFunction       orbit_mean_pool (+ broadcast backward)
   SetMeanFunction        orbit_set_mean  (+ broadcast backward)
@@ -107,6 +108,41 @@ class ProtoPredictFunction(torch.autograd.Function):
                 _lib.dptr(dl), _lib.dptr(q), _lib.dptr(weight), M, T, D, C, scale, cosine, _lib.dptr(dq),
                 _lib.stream_handle()), "orbit_proto_predict_backward")
         return dq, None, None, None, None, None
+
+
+class MahalanobisPredictFunction(torch.autograd.Function):
+    """logits = -s (mu_c - q)^T P_c (mu_c - q); gradient w.r.t. the query features only (means / precisions are the
+    re-wrapped constants of classifier_heads.py:324-327)."""
+
+    @staticmethod
+    def forward(ctx, features, means, precisions, logit_scale):
+        lib = _lib.load()
+        q = features.contiguous().float()
+        M, D = q.shape
+        C = means.size(0)
+        logits = torch.empty(M, C, device=q.device, dtype=torch.float32)
+        ws = _empty_bytes(lib.orbit_mahalanobis_workspace_bytes(2, M, D, C), q.device)
+        _lib.check(lib.orbit_mahalanobis_predict(_lib.dptr(q), _lib.dptr(means), _lib.dptr(precisions), M, D, C,
+                                                 float(logit_scale), _lib.dptr(logits), ctypes.c_void_p(ws.data_ptr()),
+                                                 ws.numel(), _lib.stream_handle()), "orbit_mahalanobis_predict")
+        ctx.save_for_backward(q, means, precisions)
+        ctx.scale = float(logit_scale)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        lib = _lib.load()
+        q, means, precisions = ctx.saved_tensors
+        M, D = q.shape
+        C = means.size(0)
+        dq = torch.empty_like(q)
+        ws = _empty_bytes(lib.orbit_mahalanobis_workspace_bytes(2, M, D, C), q.device)
+        dl = dlogits.contiguous().float()
+        _lib.check(lib.orbit_mahalanobis_predict_backward(_lib.dptr(dl), _lib.dptr(q), _lib.dptr(means),
+                                                          _lib.dptr(precisions), M, D, C, ctx.scale, _lib.dptr(dq),
+                                                          ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+                                                          _lib.stream_handle()), "orbit_mahalanobis_predict_backward")
+        return dq, None, None, None
 
 
 class FilmGeneratorFunction(torch.autograd.Function):

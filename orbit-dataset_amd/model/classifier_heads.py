@@ -242,8 +242,9 @@ class MahalanobisClassifier(nn.Module):
         if self.means is None or self.precisions is None:
             raise AttributeError("Means and/or precisions not set - is model personalised?")
         _lib.require_gpu()
-        if target_features.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError("gradients through the Mahalanobis head are not built; use it under torch.no_grad()")
+        if target_features.requires_grad and torch.is_grad_enabled() and target_features.shape[0] > 0:
+            from .autograd import MahalanobisPredictFunction
+            return MahalanobisPredictFunction.apply(target_features, self.means, self.precisions, float(self.logit_scale))
         q = target_features.detach().contiguous().float()
         M, D = q.shape
         C = self.means.size(0)

@@ -195,3 +195,21 @@ def test_spd_inverse(device):
         torch.cuda.synchronize()
         want = torch.linalg.inv(A)
         assert (out.cpu().double() - want).abs().max().item() < 1e-5 * want.abs().max().item()
+
+
+def test_mahalanobis_predict_backward(device):
+    from oracle import blocks
+    from orbit_dataset_amd.model.classifier_heads import MahalanobisClassifier
+    g = torch.Generator().manual_seed(5)
+    D, way, shots, M = 512, 5, 12, 37
+    lab = torch.arange(way).repeat_interleave(shots)
+    feats = torch.randn(way, D, generator=g)[lab] + 0.7 * torch.randn(way * shots, D, generator=g)
+    q = torch.randn(M, D, generator=g)
+    dl = torch.randn(M, way, generator=g)
+    head = MahalanobisClassifier(2.0)
+    head.configure(feats.to(device), lab.to(device))
+    qd = q.to(device).requires_grad_(True)
+    head.predict(qd).backward(dl.to(device))
+    qr = q.double().requires_grad_(True)
+    blocks.mahalanobis_predict(qr, head.means.cpu().double(), head.precisions.cpu().double(), 2.0).backward(dl.double())
+    assert (qd.grad.cpu().double() - qr.grad).abs().max().item() < 2e-5 * qr.grad.abs().max().item()
