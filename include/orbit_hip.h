@@ -237,12 +237,14 @@ int orbit_extractor_train_forward(orbit_extractor_t* fe, const float* frames, in
  *   param_grads: NULL (frozen extractor) or orbit_extractor_grad_floats() floats; the gradient of parameter i is
  *     WRITTEN at orbit_extractor_param_offset(i) in the parameter's torch layout (OIHW filters). Slots of buffers
  *     (running statistics) and of BatchNorm weight/bias replaced by FiLM vectors are left untouched.
+ *     filter_grads == 0: only the BatchNorm weight / bias gradients are computed (FiLM fine-tuning of a frozen
+ *     extractor, few_shot_recognisers.py:196-199); != 0: every parameter.
  *   dfilm_gamma / dfilm_beta: NULL or film_size floats each, written.
  * Deterministic: fixed reduction order, no atomics. */
 int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
                              const float* film_beta, int bn_train, const float* dfeats, const void* tape,
-                             size_t tape_bytes, float* param_grads, float* dfilm_gamma, float* dfilm_beta,
-                             void* workspace, size_t workspace_bytes, orbit_stream_t stream);
+                             size_t tape_bytes, float* param_grads, int filter_grads, float* dfilm_gamma,
+                             float* dfilm_beta, void* workspace, size_t workspace_bytes, orbit_stream_t stream);
 /* Backward of orbit_filmgen_forward: given d(film_gamma), d(film_beta) (film_size floats each) and d(l2) ([1], NULL = 0)
  * writes the gradients of every generator parameter into `grads` (orbit_filmgen_grad_floats floats; tensor t of
  * generator i at orbit_filmgen_param_offset(g, i, t), same tensor names as orbit_filmgen_load except "init") and
@@ -256,6 +258,12 @@ int orbit_filmgen_backward(orbit_filmgen_t* g, const float* z, const float* dfil
  * dlogits [M][C] -> dfeatures [M*T][D]. C <= 64. */
 int orbit_proto_predict_backward(const float* dlogits, const float* features, const float* weight, int M, int T, int D,
                                  int C, float logit_scale, int cosine, float* dfeatures, orbit_stream_t stream);
+
+/* parameter gradients of a linear head logits = scale * (features . W^T + b) (LinearClassifier.predict,
+ * classifier_heads.py:62-76, trained by the multi-step finetuner few_shot_recognisers.py:209-247): dweight [C][D],
+ * dbias [C] (nullable). The feature gradient is orbit_proto_predict_backward (euclidean form). */
+int orbit_linear_head_backward(const float* dlogits, const float* features, int M, int D, int C, float logit_scale,
+                               float* dweight, float* dbias, orbit_stream_t stream);
 
 /* single training operators (NHWC, [M][C] = [B*H*W][C]), exposed for parity tests against torch autograd */
 /* out = act(BN_train(y) + residual): batch mean / biased variance, saves mean and 1/sqrt(var+eps), updates the running

@@ -83,3 +83,46 @@ class LiteTrainer:
             out.append((logits.detach(), loss.detach()))
             r.reset()
         return out
+
+
+class FineTuner:
+    """Restates reference model/few_shot_recognisers.py:185-269 (MultiStepFewShotRecogniser with the linear head of
+    classifier_heads.py:38-79) for the oracle extractor; pinned by golden G11."""
+
+    def __init__(self, fe, adapt_features, learn_extractor, batch_size, logit_scale=1.0):
+        self.fe, self.batch_size, self.logit_scale = fe.eval(), batch_size, logit_scale  # test-time: eval BatchNorm
+        film = set()
+        if adapt_features:
+            for n in fe.film_slot_names():
+                film.add(n + ".weight"), film.add(n + ".bias")
+        for name, p in fe.named_parameters():
+            p.requires_grad = bool(learn_extractor or name in film)                     # :196-199
+        self.W = self.b = None
+
+    def personalise(self, context_clips, context_labels, num_grad_steps, learning_rate, extractor_lr_scale,
+                    betas=(0.9, 0.999), eps=1e-8):
+        C = len(torch.unique(context_labels))
+        D = self.fe.output_size
+        self.W = torch.zeros(C, D, requires_grad=True)                                     # classifier.init, :56-60
+        self.b = torch.zeros(C, requires_grad=True)
+        # utils/optim.py:28-31 only TAGS the extractor group with lr_scale (timm's scheduler would apply it; no scheduler
+        # runs inside personalise), so both groups step at `learning_rate`
+        del extractor_lr_scale
+        opt = torch.optim.Adam([{"params": [self.W, self.b]}, {"params": list(self.fe.parameters())}],
+                               lr=learning_rate, betas=betas, eps=eps)
+        n = len(context_labels)
+        for _ in range(num_grad_steps):
+            for i in range(int(np.ceil(n / float(self.batch_size)))):
+                lo, hi = blocks.get_batch_indices(i, n, self.batch_size)
+                clips = context_clips[lo:hi]
+                f = self.fe(clips.flatten(end_dim=1) if clips.dim() == 5 else clips)
+                logits = self.logit_scale * F.linear(f, self.W, self.b)
+                loss = F.cross_entropy(logits, context_labels[lo:hi]) * ((hi - lo) / n)
+                loss.backward()
+            opt.step()
+            opt.zero_grad()
+
+    @torch.no_grad()
+    def predict(self, clips):
+        f = self.fe(clips.flatten(end_dim=1) if clips.dim() == 5 else clips)
+        return self.logit_scale * F.linear(f, self.W, self.b)

@@ -65,11 +65,12 @@ _SIGNATURES = {
     "orbit_extractor_bn_stat_floats": (c_size_t, [P]),
     "orbit_extractor_export_bn_stats": (c_int, [P, P, P]),
     "orbit_extractor_train_forward": (c_int, [P, P, c_int, P, P, c_int, c_float, P, P, c_size_t, P]),
-    "orbit_extractor_backward": (c_int, [P, P, c_int, P, P, c_int, P, P, c_size_t, P, P, P, P, c_size_t, P]),
+    "orbit_extractor_backward": (c_int, [P, P, c_int, P, P, c_int, P, P, c_size_t, P, c_int, P, P, P, c_size_t, P]),
     "orbit_filmgen_grad_floats": (c_size_t, [P]),
     "orbit_filmgen_param_offset": (c_size_t, [P, c_int, c_char_p]),
     "orbit_filmgen_backward": (c_int, [P, P, P, P, P, P, P, P]),
     "orbit_proto_predict_backward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P, P]),
+    "orbit_linear_head_backward": (c_int, [P, P, c_int, c_int, c_int, c_float, P, P, P]),
     "orbit_op_bn_train_forward": (c_int, [P, c_int, c_int, P, P, c_float, c_float, P, P, P, c_int, P, P, P, P]),
     "orbit_op_bn_backward": (c_int, [P, P, P, c_int, c_int, P, P, P, c_int, c_int, P, P, P, P, P]),
     "orbit_op_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 12 + [P]),

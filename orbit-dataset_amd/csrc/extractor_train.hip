@@ -361,8 +361,8 @@ int orbit_extractor_train_forward(orbit_extractor_t* fe, const float* frames, in
 
 int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
                              const float* film_beta, int bn_train, const float* dfeats, const void* tape,
-                             size_t tape_bytes, float* param_grads, float* dfilm_gamma, float* dfilm_beta,
-                             void* workspace, size_t workspace_bytes, orbit_stream_t stream) {
+                             size_t tape_bytes, float* param_grads, int filter_grads, float* dfilm_gamma,
+                             float* dfilm_beta, void* workspace, size_t workspace_bytes, orbit_stream_t stream) {
     ORBIT_REQUIRE(fe && frames && dfeats && tape && workspace, "extractor_backward: null pointer");
     ORBIT_REQUIRE(B > 0, "extractor_backward: empty batch");
     if (!fe->finalized) return set_err(ORBIT_ERR_STATE, "extractor_backward: call orbit_extractor_finalize first");
@@ -373,6 +373,9 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
     const bool film = film_gamma && film_beta && fe->film_size > 0;
     ORBIT_REQUIRE(!dfilm_gamma || film, "extractor_backward: FiLM gradients requested without FiLM inputs");
     if (!param_grads && !dfilm_gamma) return ORBIT_OK;  // nothing to compute
+    // filter_grads == 0: only the BatchNorm weight / bias gradients are wanted (FiLM fine-tuning of a frozen extractor,
+    // few_shot_recognisers.py:196-199): skip every filter / squeeze-excite / bias gradient
+    const bool wg = param_grads != nullptr && filter_grads != 0;
     const TapeLayout L = tape_layout(fe, B);
     const BwdLayout W = bwd_layout(fe, B);
     ORBIT_REQUIRE(tape_bytes >= L.total, "extractor_backward: tape too small");
@@ -467,7 +470,7 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
             }
             const int src = P.in[i];
             const bool need_dx = src >= first_needed;
-            const bool need_dy = need_dx || param_grads != nullptr;
+            const bool need_dy = need_dx || wg;
             int kdy = -1;
             if (need_dy) {
                 kdy = alloc();
@@ -479,7 +482,7 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
                                     need_dy ? slot_ptr(kdy) : nullptr, nullptr, 0, dgam, dbet, nullptr, partial, coef, s);
             if (rc != ORBIT_OK) return rc;
             release(g), grad_slot[i] = -1;
-            if (param_grads) {
+            if (wg) {
                 rc = launch_dwconv_wgrad(out_tensor(src), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
                                          wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
                 if (rc != ORBIT_OK) return rc;
@@ -513,7 +516,7 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
             } else if (param_grads) {
                 dgam = param_grads + fe->params[bn.gamma].off, dbet = param_grads + fe->params[bn.beta].off;
             }
-            if (param_grads && bn.conv_bias >= 0) dbias = param_grads + fe->params[bn.conv_bias].off;
+            if (wg && bn.conv_bias >= 0) dbias = param_grads + fe->params[bn.conv_bias].off;
             float* dres = nullptr;
             int dres_acc = 0;
             const int rsrc = o.res >= 0 ? P.res[i] : -1;
@@ -527,7 +530,7 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
             }
             const int src = P.in[i];
             const bool need_dx = src >= first_needed;
-            const bool need_dy = need_dx || param_grads != nullptr;
+            const bool need_dy = need_dx || wg;
             int kdy = -1;
             if (need_dy) {
                 kdy = alloc();
@@ -545,7 +548,7 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
                 return set_err(ORBIT_ERR_STATE, "extractor_backward: residual fan-out without a data gradient");
             }
             release(g), grad_slot[i] = -1;
-            if (param_grads) {
+            if (wg) {
                 rc = launch_conv_wgrad(o.use_gate ? tf(L.xg[i]) : out_tensor(src), o.x_nchw, slot_ptr(kdy),
                                        param_grads + fe->params[o.weight].off, B,
                                        o.H, o.W, o.Cin, o.Cout, o.KH, o.KW, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo,
@@ -563,7 +566,7 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
                 if (rc != ORBIT_OK) return rc;
                 SLOT_OR_FAIL(k);
                 grad_slot[src] = k;
-                float* pg = param_grads;
+                float* pg = wg ? param_grads : nullptr;
                 rc = launch_se_gate_backward(slot_ptr(kt), out_tensor(src), tf(L.p[se]), tf(L.a[se]),
                                              fe->d_pool + fe->params[so.se_w1].off, fe->d_pool + fe->params[so.se_b1].off,
                                              fe->d_pool + fe->params[so.se_w2].off, fe->d_pool + fe->params[so.se_b2].off,

@@ -522,11 +522,47 @@ __global__ __launch_bounds__(256) void proto_predict_bwd_kernel(const float* __r
     }
 }
 
+// linear head parameter gradients: dW[c][d] = scale * sum_m dl[m][c] q[m][d], db[c] = scale * sum_m dl[m][c];
+// thread = one feature column d, classes in chunks of 16 accumulators, rows in ascending order (deterministic)
+__global__ __launch_bounds__(256) void linear_head_wgrad_kernel(const float* __restrict__ dl, const float* __restrict__ q,
+                                                                int M, int D, int C, float scale,
+                                                                float* __restrict__ dW, float* __restrict__ db) {
+    const int d = blockIdx.x * 256 + threadIdx.x;
+    const int c0 = blockIdx.y * 16;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    float bacc = 0.f;  // thread d == 0..15 of block x == 0 also reduces the bias of class c0 + d
+    for (int m = 0; m < M; ++m) {
+        const float x = d < D ? q[(size_t)m * D + d] : 0.f;
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (c0 + j < C) acc[j] = fmaf(dl[(size_t)m * C + c0 + j], x, acc[j]);
+        if (blockIdx.x == 0 && threadIdx.x < 16 && c0 + threadIdx.x < C) bacc += dl[(size_t)m * C + c0 + threadIdx.x];
+    }
+    if (d < D) {
+#pragma unroll
+        for (int j = 0; j < 16; ++j)
+            if (c0 + j < C) dW[(size_t)(c0 + j) * D + d] = scale * acc[j];
+    }
+    if (db && blockIdx.x == 0 && threadIdx.x < 16 && c0 + threadIdx.x < C) db[c0 + threadIdx.x] = scale * bacc;
+}
+
 }  // namespace orbit
 
 using namespace orbit;
 
 extern "C" {
+
+int orbit_linear_head_backward(const float* dlogits, const float* features, int M, int D, int C, float logit_scale,
+                               float* dweight, float* dbias, orbit_stream_t stream) {
+    ORBIT_REQUIRE(dlogits && features && dweight, "linear_head_backward: null pointer");
+    ORBIT_REQUIRE(M > 0 && D > 0 && C > 0, "linear_head_backward: bad sizes");
+    linear_head_wgrad_kernel<<<dim3(cdiv(D, 256), cdiv(C, 16)), 256, 0, (hipStream_t)stream>>>(dlogits, features, M, D, C,
+                                                                                             logit_scale, dweight, dbias);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
 
 int orbit_op_bn_train_forward(const float* y, int M, int C, const float* gamma, const float* beta, float eps,
                               float momentum, float* running_mean, float* running_var, const float* residual, int act,

@@ -34,6 +34,7 @@ from . import dist as odist
 from . import synthetic
 from .data.utils import attach_frame_history
 from .model.few_shot_recognisers import SingleStepFewShotRecogniser
+from .optim import apply_lr_scale, cross_entropy, init_optimizer  # noqa: F401  (re-exported: bench.py, tools)
 
 
 def build_parser():
@@ -92,32 +93,6 @@ def mean_ci(values):
     """mean and 95 % confidence half-width, as the reference's evaluators report (utils/eval_metrics.py:24-25)."""
     v = np.asarray(values, dtype=np.float64)
     return float(v.mean()), float(1.96 * v.std() / math.sqrt(len(v))) if len(v) > 1 else 0.0
-
-
-def cross_entropy(test_logits, test_labels, reduction="mean"):
-    """reference utils/optim.py:8-9"""
-    return torch.nn.functional.cross_entropy(test_logits, test_labels, reduction=reduction)
-
-
-def init_optimizer(model, lr, optimizer_type, args=None, extractor_lr_scale=0.1):
-    """Parameter groups of reference utils/optim.py:11-33: everything but the extractor / the extractor. The reference
-    tags the second group with `lr_scale` for timm's scheduler; without a scheduler the scale is applied directly."""
-    extractor_ids = set(map(id, model.feature_extractor.parameters()))
-    base_params = [p for p in model.parameters() if id(p) not in extractor_ids]
-    groups = [{"params": base_params},
-              {"params": list(model.feature_extractor.parameters()), "lr": lr * extractor_lr_scale,
-               "lr_scale": extractor_lr_scale}]
-    if optimizer_type == "adam":
-        opt = torch.optim.Adam(groups, lr=lr, eps=getattr(args, "epsilon", 1e-8),
-                               weight_decay=getattr(args, "weight_decay", 0.0),
-                               betas=tuple(getattr(args, "betas", (0.9, 0.999))))
-    elif optimizer_type == "sgd":
-        opt = torch.optim.SGD(groups, lr=lr, momentum=getattr(args, "momentum", 0.0),
-                              weight_decay=getattr(args, "weight_decay", 0.0))
-    else:
-        raise ValueError("optimizer %s not valid" % optimizer_type)
-    opt.zero_grad()
-    return opt
 
 
 class Learner:
@@ -230,6 +205,7 @@ class Learner:
     def train(self):
         a = self.args
         self.optimizer = init_optimizer(self.model, a.learning_rate, a.optimizer, a, a.extractor_lr_scale)
+        apply_lr_scale(self.optimizer, a.learning_rate)  # constant schedule (the reference's timm scheduler applies it)
         train_task_fn = self.train_task_with_lite if a.with_lite else self.train_task
         losses, accs, times = [], [], []
         prev = torch.is_grad_enabled()
@@ -318,9 +294,90 @@ class Learner:
         return stats
 
 
+class MultiStepLearner(Learner):
+    """Counterpart of the reference's multi-step-learner.py (FineTuner, test only): per task a fresh copy of the model is
+    personalised by `personalize_num_grad_steps` optimizer steps on the context set, then evaluated per target video
+    (multi-step-learner.py:132-196)."""
+
+    def init_model(self):
+        a = self.args
+        from .model.few_shot_recognisers import MultiStepFewShotRecogniser
+        self.model = MultiStepFewShotRecogniser(a.feature_extractor, a.adapt_features, a.classifier, a.clip_length,
+                                                a.batch_size, a.learn_extractor, a.logit_scale)
+        if a.model_path:
+            self.model.load_state_dict(torch.load(a.model_path, map_location="cpu"), strict=False)
+        else:
+            synthetic.init_parameters_(self.model, seed=a.seed,
+                                       film_strength=0.02 if a.feature_extractor == "efficientnet_b0" else 0.1)
+        self.model._set_device(self.device)
+        self.model._send_to_device()
+        self.base_state = {k: v.clone() for k, v in self.model.state_dict().items()}
+
+    def run(self):
+        return {"test": self.test()}
+
+    def test(self):
+        a = self.args
+        learning_args = {"num_grad_steps": a.personalize_num_grad_steps, "learning_rate": a.personalize_learning_rate,
+                         "extractor_lr_scale": a.personalize_extractor_lr_scale, "loss_fn": cross_entropy,
+                         "optimizer": a.personalize_optimizer, "momentum": a.personalize_momentum,
+                         "weight_decay": a.personalize_weight_decay, "betas": tuple(a.personalize_betas),
+                         "epsilon": a.personalize_epsilon}
+        self.model.set_test_mode(True)
+        task_acc, personalise_ms, inference_ms = [], [], []
+        for t in odist.tasks_for_rank(a.num_test_tasks, self.rank, self.world):
+            context_clips, context_labels, videos = self.make_task(t)
+            # the finetuner starts every task from the initial parameters (multi-step-learner.py:153-154)
+            self.model.load_state_dict(self.base_state, strict=False)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            self.model.personalise(context_clips, context_labels.to(self.device), dict(learning_args))
+            torch.cuda.synchronize()
+            personalise_ms.append(1e3 * (time.perf_counter() - t0))
+            accs = []
+            with torch.no_grad():
+                for frames, labels in videos:
+                    clips = attach_frame_history(frames, a.clip_length)
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    logits = self.model.predict(clips)
+                    torch.cuda.synchronize()
+                    inference_ms.append(1e3 * (time.perf_counter() - t0) / float(len(clips) * self.model.clip_length))
+                    accs.append(frame_accuracy(logits.cpu(), labels))
+            task_acc.append(float(np.mean(accs)))
+            self.model._reset()
+        stats = {"frame_acc": mean_ci(task_acc), "personalise_ms": mean_ci(personalise_ms),
+                 "inference_ms_per_frame": mean_ci(inference_ms), "num_tasks": len(task_acc), "world_size": self.world}
+        if self.rank == 0:
+            print("finetuner test: frame_acc %.2f (%.2f) %% | time to personalise %.2f (%.2f) ms (%d steps) | inference "
+                  "%.4f (%.4f) ms/frame | %d tasks" % (100 * stats["frame_acc"][0], 100 * stats["frame_acc"][1],
+                                                       *stats["personalise_ms"], a.personalize_num_grad_steps,
+                                                       *stats["inference_ms_per_frame"], stats["num_tasks"]))
+        return stats
+
+
+def build_multistep_parser():
+    p = build_parser()
+    p.set_defaults(classifier="linear", mode="test")
+    p.add_argument("--personalize_num_grad_steps", type=int, default=50)
+    p.add_argument("--personalize_learning_rate", type=float, default=0.001)
+    p.add_argument("--personalize_optimizer", default="adam", choices=["sgd", "adam"])
+    p.add_argument("--personalize_weight_decay", type=float, default=0.0)
+    p.add_argument("--personalize_extractor_lr_scale", type=float, default=1.0)
+    p.add_argument("--personalize_epsilon", type=float, default=1e-8)
+    p.add_argument("--personalize_betas", type=float, nargs=2, default=(0.9, 0.999))
+    p.add_argument("--personalize_momentum", type=float, default=0.0)
+    return p
+
+
 def main(argv=None):
     args = build_parser().parse_args(argv)
     return Learner(args).run()
+
+
+def main_multistep(argv=None):
+    args = build_multistep_parser().parse_args(argv)
+    return MultiStepLearner(args).run()
 
 
 if __name__ == "__main__":

@@ -62,10 +62,14 @@ class ExtractorFunction(torch.autograd.Function):
         dbeta = torch.empty_like(beta) if need_film else None
         ws = _empty_bytes(lib.orbit_extractor_backward_workspace_bytes(plan.handle, B), dev)
         dfeats = dfeats.contiguous().float()
+        # only BatchNorm weights / biases trainable (FiLM fine-tuning of a frozen extractor): skip the filter gradients
+        filter_grads = any(need and not is_bn for need, (_, _, is_bn) in zip(ctx.needs_input_grad[n_fixed:],
+                                                                            ctx.param_index))
         _lib.check(lib.orbit_extractor_backward(
             plan.handle, _lib.dptr(frames, torch.float32), B, _lib.dptr(gamma), _lib.dptr(beta), ctx.bn_train,
             _lib.dptr(dfeats), ctypes.c_void_p(ctx.tape.data_ptr()), ctx.tape.numel(), _lib.dptr(flat),
-            _lib.dptr(dgamma), _lib.dptr(dbeta), ctypes.c_void_p(ws.data_ptr()), ws.numel(), _lib.stream_handle()),
+            int(filter_grads), _lib.dptr(dgamma), _lib.dptr(dbeta), ctypes.c_void_p(ws.data_ptr()), ws.numel(),
+            _lib.stream_handle()),
             "orbit_extractor_backward")
         ctx.tape = None
         if need_film:
@@ -108,6 +112,43 @@ class ProtoPredictFunction(torch.autograd.Function):
                 _lib.dptr(dl), _lib.dptr(q), _lib.dptr(weight), M, T, D, C, scale, cosine, _lib.dptr(dq),
                 _lib.stream_handle()), "orbit_proto_predict_backward")
         return dq, None, None, None, None, None
+
+
+class LinearPredictFunction(torch.autograd.Function):
+    """logits = s (q . W^T + b) with gradients for the features, W and b (the multi-step finetuner's head)."""
+
+    @staticmethod
+    def forward(ctx, features, weight, bias, logit_scale):
+        q = features.contiguous().float()
+        M, D = q.shape
+        C = weight.size(0)
+        w, b = weight.detach().contiguous().float(), bias.detach().contiguous().float()
+        logits = torch.empty(M, C, device=q.device, dtype=torch.float32)
+        if M > 0:
+            _lib.check(_lib.load().orbit_proto_predict(_lib.dptr(q), _lib.dptr(w), _lib.dptr(b), 1, M, 1, D, C,
+                                                       float(logit_scale), 0, _lib.dptr(logits), _lib.dptr(None),
+                                                       _lib.stream_handle()), "orbit_proto_predict")
+        ctx.save_for_backward(q, w)
+        ctx.scale = float(logit_scale)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        lib = _lib.load()
+        q, w = ctx.saved_tensors
+        M, D = q.shape
+        C = w.size(0)
+        dl = dlogits.contiguous().float()
+        dq = dw = db = None
+        if M > 0 and ctx.needs_input_grad[0]:
+            dq = torch.empty_like(q)
+            _lib.check(lib.orbit_proto_predict_backward(_lib.dptr(dl), _lib.dptr(q), _lib.dptr(w), M, 1, D, C, ctx.scale, 0,
+                                                        _lib.dptr(dq), _lib.stream_handle()), "orbit_proto_predict_backward")
+        if M > 0 and (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            dw, db = torch.empty_like(w), torch.empty(C, device=q.device, dtype=torch.float32)
+            _lib.check(lib.orbit_linear_head_backward(_lib.dptr(dl), _lib.dptr(q), M, D, C, ctx.scale, _lib.dptr(dw),
+                                                      _lib.dptr(db), _lib.stream_handle()), "orbit_linear_head_backward")
+        return dq, dw, db, None
 
 
 class MahalanobisPredictFunction(torch.autograd.Function):

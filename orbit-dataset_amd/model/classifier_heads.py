@@ -13,7 +13,7 @@ Semantics kept from the reference:
   * predict before configure raises AttributeError (:210-211).
 The 'proto' / 'proto_cosine' heads are the hot path named by BASELINE.json. 'versa' (CNAPs) and 'mahalanobis' (Simple
 CNAPs), the other two single-step recipes of the reference README, are built on csrc/heads_extra.hip (SURVEY §8f rank 2);
-'linear' belongs to the multi-step finetuner and is out of scope.
+'linear' is the head of the multi-step finetuner (MultiStepFewShotRecogniser).
 """
 import torch
 import torch.nn as nn
@@ -123,6 +123,32 @@ class PrototypicalClassifier(nn.Module):
                 1, M, T, D, C, float(self.logit_scale), self._cosine, _lib.dptr(logits), _lib.dptr(argmax),
                 _lib.stream_handle()), "orbit_proto_predict")
         return (logits, argmax) if return_argmax else logits
+
+
+class LinearClassifier(nn.Module):
+    """Linear head of the multi-step finetuner (reference classifier_heads.py:38-79): `init(num_classes)` creates zero
+    weight / bias Parameters per task, `predict` is s * F.linear on the prototype-distance kernel (euclidean form)."""
+
+    def __init__(self, feat_dim, logit_scale: float = 1.0):
+        super().__init__()
+        self.feat_dim = feat_dim
+        self.logit_scale = logit_scale
+
+    def init(self, num_classes: int):
+        self.weight = nn.Parameter(torch.zeros(num_classes, self.feat_dim), requires_grad=True)
+        self.bias = nn.Parameter(torch.zeros(num_classes), requires_grad=True)
+
+    def predict(self, features, ops_counter=None):
+        _lib.require_gpu()
+        from .autograd import LinearPredictFunction
+        if torch.is_grad_enabled() and (features.requires_grad or self.weight.requires_grad):
+            return LinearPredictFunction.apply(features, self.weight, self.bias, float(self.logit_scale))
+        with torch.no_grad():
+            return LinearPredictFunction.apply(features, self.weight, self.bias, float(self.logit_scale))
+
+    def reset(self):
+        self.weight = None
+        self.bias = None
 
 
 def _class_means(features, labels, class_ids, T=1):
@@ -270,7 +296,5 @@ def create_classifier(classifier: str, feat_dim: int, logit_scale: float):
     if classifier == "mahalanobis":
         return MahalanobisClassifier(logit_scale)
     if classifier == "linear":
-        raise NotImplementedError(
-            "Classifier 'linear' belongs to the multi-step finetuner, which this build does not implement "
-            "(SURVEY.md §8f rank 4).")
+        return LinearClassifier(feat_dim, logit_scale)
     raise ValueError(f"Classifier {classifier} not valid.")

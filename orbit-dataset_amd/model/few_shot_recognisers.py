@@ -4,6 +4,7 @@ Drop-in mirror of the reference API (reference model/few_shot_recognisers.py):
   FewShotRecogniser            :46-183   wiring, batched feature extraction, BN-state policy
   SingleStepFewShotRecogniser  :271-473  personalise / personalise_with_lite / predict / predict_a_batch /
                                          _reset / _clear_caches
+  MultiStepFewShotRecogniser   :185-269  FineTuner: personalise(context, labels, learning_args) by gradient steps
 Same constructor arguments, method names, argument meaning, side effects (`film_dict`, classifier state,
 LITE caches) and errors. What differs is where the arithmetic runs: every frame batch goes through
 `orbit_extractor_forward` (hand-written gfx950 kernels), FiLM parameters come from one grouped generator
@@ -125,6 +126,73 @@ class FewShotRecogniser(nn.Module):
             self.eval()
         if want_train and not self.feature_extractor.training:
             self.feature_extractor.train()
+
+
+class MultiStepFewShotRecogniser(FewShotRecogniser):
+    """Few-shot model personalised by gradient steps on the context set — the FineTuner (reference :185-269).
+
+    `personalise` adds a fresh linear head and takes `num_grad_steps` optimizer steps on the whole context set
+    (gradient accumulated over mini-batches of `batch_size` clips, each scaled by its share of the set); with
+    `adapt_features` the FiLM-tagged BatchNorm weights / biases of the extractor are unfrozen, with `learn_extractor`
+    everything is. All gradients come from the native backward kernels; test-time BatchNorm stays in eval mode
+    (the learner calls set_test_mode(True), multi-step-learner.py:119-123)."""
+
+    def __init__(self, feature_extractor_name: str, adapt_features: bool, classifier: str, clip_length: int,
+                 batch_size: int, learn_extractor: bool, logit_scale: float = 1.0):
+        FewShotRecogniser.__init__(self, feature_extractor_name, adapt_features, classifier, clip_length, batch_size,
+                                   learn_extractor, logit_scale)
+        if self.adapt_features:
+            from .film import unfreeze_film
+            self.film_parameter_sizes = get_film_parameter_sizes(self.film_parameter_names, self.feature_extractor)
+            unfreeze_film(self.film_parameter_names, self.feature_extractor)
+
+    def _reset(self):
+        self.classifier.reset()
+
+    def personalise(self, context_clips, context_labels, learning_args, ops_counter=None):
+        from argparse import Namespace
+
+        from ..optim import init_optimizer
+        self._set_batch_norm_state()
+        learning_args = dict(learning_args)
+        num_grad_steps = learning_args.pop("num_grad_steps")
+        learning_rate = learning_args.pop("learning_rate")
+        optimizer = learning_args.pop("optimizer")
+        loss_fn = learning_args.pop("loss_fn")
+        extractor_lr_scale = learning_args.pop("extractor_lr_scale")
+        optimizer_kwargs = Namespace(**learning_args)
+
+        num_classes = len(torch.unique(context_labels))
+        self.init_classifier(num_classes)
+        personalize_optimizer = init_optimizer(self, learning_rate, optimizer, optimizer_kwargs, extractor_lr_scale)
+
+        set_size = len(context_labels)
+        num_batches = int(np.ceil(float(set_size) / float(self.batch_size)))
+        with torch.enable_grad():
+            for _ in range(num_grad_steps):
+                for batch in range(num_batches):
+                    lo, hi = get_batch_indices(batch, set_size, self.batch_size)
+                    batch_features = self._get_features(context_clips[lo:hi])
+                    batch_features = self._pool_features(batch_features)
+                    batch_logits = self.classifier.predict(batch_features)
+                    loss = loss_fn(batch_logits, context_labels[lo:hi].to(self.device))
+                    loss = loss * ((hi - lo) / set_size)
+                    loss.backward()
+                personalize_optimizer.step()
+                personalize_optimizer.zero_grad()
+
+    def predict(self, clips, ops_counter=None):
+        self._set_batch_norm_state()
+        features = self._get_features_in_batches(clips)
+        features = self._pool_features(features)
+        return self.classifier.predict(features)
+
+    def personalise_with_lite(self, context_clips, context_labels):
+        raise NotImplementedError  # the reference leaves this unimplemented as well (:258-259)
+
+    def init_classifier(self, num_classes: int):
+        self.classifier.init(num_classes)
+        self.classifier.to(self.device)
 
 
 class SingleStepFewShotRecogniser(FewShotRecogniser):

@@ -1,0 +1,35 @@
+"""Loss and optimizer set-up of the learners (mirror of reference utils/optim.py:8-33)."""
+import torch
+
+
+def cross_entropy(test_logits, test_labels, reduction="mean"):
+    """reference utils/optim.py:8-9"""
+    return torch.nn.functional.cross_entropy(test_logits, test_labels, reduction=reduction)
+
+
+def init_optimizer(model, lr, optimizer_type, args=None, extractor_lr_scale=0.1):
+    """Parameter groups of reference utils/optim.py:11-33: everything but the extractor / the extractor. As in the
+    reference the second group only carries the TAG `lr_scale`: it is timm's scheduler that multiplies it into the
+    group's lr on every update (single-step learner; `apply_lr_scale` below does the same), so where no scheduler runs
+    — the finetuner's personalise(), few_shot_recognisers.py:224 — the extractor trains at the full learning rate."""
+    extractor_ids = set(map(id, model.feature_extractor.parameters()))
+    base_params = [p for p in model.parameters() if id(p) not in extractor_ids]
+    groups = [{"params": base_params},
+              {"params": list(model.feature_extractor.parameters()), "lr_scale": extractor_lr_scale}]
+    if optimizer_type == "adam":
+        opt = torch.optim.Adam(groups, lr=lr, eps=getattr(args, "epsilon", 1e-8),
+                               weight_decay=getattr(args, "weight_decay", 0.0),
+                               betas=tuple(getattr(args, "betas", (0.9, 0.999))))
+    elif optimizer_type == "sgd":
+        opt = torch.optim.SGD(groups, lr=lr, momentum=getattr(args, "momentum", 0.0),
+                              weight_decay=getattr(args, "weight_decay", 0.0))
+    else:
+        raise ValueError("optimizer %s not valid" % optimizer_type)
+    opt.zero_grad()
+    return opt
+
+
+def apply_lr_scale(optimizer, lr):
+    """What timm's Scheduler.update_groups does on every step: group lr = value * group['lr_scale']."""
+    for group in optimizer.param_groups:
+        group["lr"] = lr * group.get("lr_scale", 1.0)

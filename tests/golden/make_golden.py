@@ -360,6 +360,50 @@ def g10_heads_versa_mahalanobis():
     save("G10_heads_versa_mahalanobis", **out)
 
 
+def g11_finetuner(fsr):
+    """MultiStepFewShotRecogniser (the FineTuner baseline): 3 Adam steps on the context set in mini-batches of 4, then
+    predict — head only / + FiLM parameters unfrozen / whole extractor unfrozen (few_shot_recognisers.py:185-269)."""
+    import torch.nn.functional as F
+    task = synthetic.make_task(61, way=3, shots=1, frames_per_shot=3, num_query=6, frame_size=32)
+    ctx, lab, tgt = task["context_clips"], task["context_labels"], task["target_clips"]
+    out = {"context_clips": ctx, "context_labels": lab, "target_clips": tgt}
+
+    def factory(feature_extractor_name, pretrained, with_film=False, learn_extractor=True):
+        fe = oracle_extractors.create(feature_extractor_name)
+        synthetic.init_parameters_(fe)
+        if not learn_extractor:
+            for p in fe.parameters():
+                p.requires_grad = False
+        names = None
+        if with_film:
+            mods = dict(fe.named_modules())
+            for n in fe.film_slot_names():
+                mods[n].film = True
+            from model.film import get_film_parameter_names
+            names = get_film_parameter_names(feature_extractor_name, fe)
+        return fe, names
+
+    fsr.create_feature_extractor = factory
+    for tag, adapt, learn in (("head", False, False), ("film", True, False), ("full", False, True)):
+        model = fsr.MultiStepFewShotRecogniser("resnet18", adapt, "linear", 1, 4, learn, 1.0)
+        model._set_device(torch.device("cpu"))
+        model._send_to_device()
+        model.set_test_mode(True)
+        args = {"num_grad_steps": 3, "learning_rate": 0.01, "extractor_lr_scale": 0.5, "loss_fn": F.cross_entropy,
+                "optimizer": "adam", "momentum": 0.0, "weight_decay": 0.0, "betas": (0.9, 0.999), "epsilon": 1e-8}
+        model.personalise(ctx, lab, args)
+        with torch.no_grad():
+            out[tag + "_logits"] = model.predict(tgt)
+        out[tag + "_classifier_weight"] = model.classifier.weight.detach()
+        out[tag + "_classifier_bias"] = model.classifier.bias.detach()
+        sd = model.state_dict()
+        out[tag + "_bn1_weight"] = sd["feature_extractor.bn1.weight"]
+        out[tag + "_layer4_bn2_bias"] = sd["feature_extractor.layer4.1.bn2.bias"]
+        flat = sd["feature_extractor.layer3.0.conv1.weight"].flatten()
+        out[tag + "_layer3_conv1_weight"] = flat[::max(1, flat.numel() // 4096)][:4096].clone()
+    save("G11_finetuner", **out)
+
+
 def g7_utils():
     from data.utils import attach_frame_history, get_batch_indices
     frames = torch.arange(6 * 3 * 2 * 2, dtype=torch.float32).reshape(6, 3, 2, 2)
@@ -383,6 +427,7 @@ def main():
     g6_lite(fsr)
     g8_lite_learn_extractor(fsr)
     g9_lite_efficientnet(fsr)
+    g11_finetuner(fsr)
 
 
 if __name__ == "__main__":

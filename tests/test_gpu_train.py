@@ -148,6 +148,40 @@ def test_G9_lite_efficientnet(device, tag, adapt):
             assert rel(sd[key[len(tag + "_stat__"):]].float(), g[key]) < 1e-4, key
 
 
+@pytest.mark.parametrize("tag,adapt,learn", [("head", False, False), ("film", True, False), ("full", False, True)])
+def test_G11_finetuner(device, tag, adapt, learn):
+    """MultiStepFewShotRecogniser (FineTuner) on the native backward kernels against the reference's run: 3 Adam steps
+    over mini-batches of 4 context clips — linear head only / + FiLM BatchNorm parameters / whole extractor."""
+    from orbit_dataset_amd.model.few_shot_recognisers import MultiStepFewShotRecogniser
+    from orbit_dataset_amd.optim import cross_entropy
+    g = gold("G11_finetuner")
+    m = MultiStepFewShotRecogniser("resnet18", adapt, "linear", 1, 4, learn, 1.0)
+    synthetic.init_parameters_(m)
+    m._set_device("cuda:0")
+    m._send_to_device()
+    m.set_test_mode(True)
+    args = {"num_grad_steps": 3, "learning_rate": 0.01, "extractor_lr_scale": 0.5, "loss_fn": cross_entropy,
+            "optimizer": "adam", "momentum": 0.0, "weight_decay": 0.0, "betas": (0.9, 0.999), "epsilon": 1e-8}
+    m.personalise(g["context_clips"].to(device), g["context_labels"].to(device), args)
+    with torch.no_grad():
+        logits = m.predict(g["target_clips"].to(device)).cpu()
+    want = g[tag + "_logits"]
+    # Adam normalises every gradient by its own magnitude, so elements whose gradient is rounding noise move by
+    # +-lr per step in an implementation-dependent direction: parameters are compared at 3 steps x lr = 3e-2 worst case,
+    # the logits (which average over 512 features) tightly
+    assert (logits - want).abs().max().item() < 2e-2 * max(1.0, want.abs().max().item())
+    assert torch.equal(logits.argmax(1), want.argmax(1))
+    sd = m.state_dict()
+    assert (sd["classifier.weight"].cpu() - g[tag + "_classifier_weight"]).abs().max().item() < 3.1e-2
+    frozen = not (adapt or learn)
+    tol = 0.0 if frozen else 1.6e-2
+    assert (sd["feature_extractor.bn1.weight"].cpu() - g[tag + "_bn1_weight"]).abs().max().item() <= tol
+    if not learn:  # filters untouched unless the whole extractor is unfrozen
+        flat = sd["feature_extractor.layer3.0.conv1.weight"].flatten().cpu()
+        assert torch.equal(flat[::max(1, flat.numel() // 4096)][:4096], g[tag + "_layer3_conv1_weight"])
+    m._reset()
+
+
 # ---- extractor level, against torch autograd on the oracle modules ---------------------------------------------------
 def _oracle_and_native(name, device, requires_grad=True):
     if name == "set_encoder":

@@ -273,6 +273,36 @@ def test_G10_versa_and_mahalanobis_heads(tag, D):
     assert (got - want).abs().max().item() < 1e-3 * want.abs().max().item()
 
 
+@pytest.mark.parametrize("tag,adapt,learn", [("head", False, False), ("film", True, False), ("full", False, True)])
+def test_G11_finetuner(tag, adapt, learn):
+    """oracle/training.py FineTuner against the reference's MultiStepFewShotRecogniser (3 Adam steps, batches of 4)."""
+    from oracle import extractors
+    from oracle.training import FineTuner
+    g = gold("G11_finetuner")
+    fe = extractors.create("resnet18")
+    synthetic.init_parameters_(fe)
+    ft = FineTuner(fe, adapt, learn, 4)
+    threads = torch.get_num_threads()
+    torch.set_num_threads(4)  # the fixture was recorded with 4 intra-op threads: Adam turns the rounding noise of
+    try:                      # near-zero gradients into +-lr steps, so the summation order has to match
+        ft.personalise(g["context_clips"], g["context_labels"], 3, 0.01, 0.5)
+        logits = ft.predict(g["target_clips"])
+    finally:
+        torch.set_num_threads(threads)
+    # with every filter trainable a handful of weights still step the other way (3 steps x lr = 3e-2 each)
+    tol = 3e-2 if learn else 1e-3
+    assert (logits - g[tag + "_logits"]).abs().max().item() < tol
+    assert (ft.W.detach() - g[tag + "_classifier_weight"]).abs().max().item() < (3.1e-2 if learn else 1e-4)
+    sd = fe.state_dict()
+    assert (sd["bn1.weight"] - g[tag + "_bn1_weight"]).abs().max().item() < (3.1e-2 if learn else 1e-4)
+    assert (sd["layer4.1.bn2.bias"] - g[tag + "_layer4_bn2_bias"]).abs().max().item() < (3.1e-2 if learn else 1e-4)
+    flat = sd["layer3.0.conv1.weight"].flatten()
+    diff = (flat[::max(1, flat.numel() // 4096)][:4096] - g[tag + "_layer3_conv1_weight"]).abs()
+    assert diff.max().item() < (6.1e-2 if learn else 1e-7)
+    if learn:  # ... but almost all of them agree
+        assert (diff < 1e-4).float().mean().item() > 0.9
+
+
 def test_C_restatement_of_head_against_golden():
     """oracle/proto_head.c (double accumulation) against the reference's golden logits."""
     import ctypes
