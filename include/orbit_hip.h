@@ -114,6 +114,10 @@ size_t orbit_extractor_param_numel(const orbit_extractor_t* fe, int i);
 
 /* copy one tensor (host or device pointer, fp32, torch layout) into the extractor. */
 int orbit_extractor_load(orbit_extractor_t* fe, const char* key, const float* data, size_t numel);
+/* Same for a source already resident in HBM: stream-ordered device-to-device copy (no host synchronisation); how the
+ * parameters follow optimizer steps during meta-training. */
+int orbit_extractor_load_async(orbit_extractor_t* fe, const char* key, const float* device_data, size_t numel,
+                               orbit_stream_t stream);
 /* repack conv weights for the kernels, precompute folded BN for the non-FiLM case. Call after loads. */
 int orbit_extractor_finalize(orbit_extractor_t* fe, orbit_stream_t stream);
 

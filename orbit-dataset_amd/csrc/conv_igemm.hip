@@ -90,7 +90,10 @@ __device__ __forceinline__ void decode_row(const ConvParams& p, int m, int& b, i
 }
 
 // MODE 0: NHWC activations, Cin % 4 == 0 (float4 gathers).  MODE 1: NCHW frames, tiny Cin (stems).
-template <int BM, int BN, int WGM, int WGN, int BK, int MODE, bool POOL2, bool GATE>
+// PF: software-pipeline depth of the global->register->LDS staging, in K-tiles (1 or 2). With PF = 2 the loads of tile
+// kt+2 are issued before the MFMAs of tile kt, so each load has two tile-times to land (a 64x64xBK16 tile is only 512
+// matrix-pipe cycles, a quarter of an L2 round trip).
+template <int BM, int BN, int WGM, int WGN, int BK, int MODE, bool POOL2, bool GATE, int PF>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     static_assert(BK == 8 || BK == 16 || BK == 32, "BK");
@@ -151,15 +154,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const bool b_row_ok = BN % RPP == 0 || lrow < BN;  // BK = 8 with BN = 64: half of the threads stage B
     const float* b_ptr = p.w + (size_t)(n0 + (b_row_ok ? lrow : 0)) * p.KT + c4 * 4;
 
-    f32x4 a_stage[MODE == 0 ? AR : KPT / 4];
-    f32x4 b_stage[BR];
+    constexpr int NAS = MODE == 0 ? AR : KPT / 4;
+    f32x4 a_stage0[NAS], b_stage0[BR];
+    f32x4 a_stage1[PF == 2 ? NAS : 1], b_stage1[PF == 2 ? BR : 1];
 
     const int nk = p.KT / BK;
     const int cpt = MODE == 0 ? p.cin_pad / BK : 1;  // K-tiles per filter tap
     const int ktot = p.KH * p.KW * p.Cin;            // true K (stem mode)
     (void)ktot;
 
-    auto load_tile = [&](int kt) {
+    auto load_tile = [&](int kt, f32x4* a_stage, f32x4* b_stage) {
         if (MODE == 0) {
             const int tap = kt / cpt;
             const int ci = (kt - tap * cpt) * BK + c4 * 4;
@@ -196,7 +200,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             b_stage[j] = *reinterpret_cast<const f32x4*>(b_ptr + (size_t)(RPP * j) * p.KT + kt * BK);
     };
 
-    auto store_tile = [&](int buf) {
+    auto store_tile = [&](int buf, const f32x4* a_stage, const f32x4* b_stage) {
         float* A = As + buf * BM * LDS_STRIDE;
         float* Bq = Bs + buf * BN * LDS_STRIDE;
         if (MODE == 0) {
@@ -223,14 +227,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    load_tile(0);
-    store_tile(0);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
-        if (kt + 1 < nk) load_tile(kt + 1);  // global loads in flight under the MFMAs below
-
+    auto compute_tile = [&](int cur) {
         const float* A = As + cur * BM * LDS_STRIDE + (wm + l31) * LDS_STRIDE + lh * 4;
         const float* Bq = Bs + cur * BN * LDS_STRIDE + (wn + l31) * LDS_STRIDE + lh * 4;
         // fragment reads are register double-buffered: group g+1 is fetched from LDS while the MFMAs of group g
@@ -268,8 +265,36 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
         }
 
-        if (kt + 1 < nk) store_tile(cur ^ 1);  // the other buffer was last read before the previous barrier
+    };
+
+    if (PF == 1) {
+        load_tile(0, a_stage0, b_stage0);
+        store_tile(0, a_stage0, b_stage0);
         __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) load_tile(kt + 1, a_stage0, b_stage0);  // global loads in flight under the MFMAs below
+            compute_tile(cur);
+            if (kt + 1 < nk) store_tile(cur ^ 1, a_stage0, b_stage0);  // the other buffer was last read before the previous barrier
+            __syncthreads();
+        }
+    } else {
+        // tile t is staged through register set t & 1 and LDS buffer t & 1
+        load_tile(0, a_stage0, b_stage0);
+        if (nk > 1) load_tile(1, a_stage1, b_stage1);
+        store_tile(0, a_stage0, b_stage0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; kt += 2) {
+            if (kt + 2 < nk) load_tile(kt + 2, a_stage0, b_stage0);
+            compute_tile(0);
+            if (kt + 1 < nk) store_tile(1, a_stage1, b_stage1);  // waits for tile kt+1 only; kt+2 stays in flight
+            __syncthreads();
+            if (kt + 1 >= nk) break;
+            if (kt + 3 < nk) load_tile(kt + 3, a_stage1, b_stage1);
+            compute_tile(1);
+            if (kt + 2 < nk) store_tile(0, a_stage0, b_stage0);
+            __syncthreads();
+        }
     }
 
     // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -439,14 +464,14 @@ void prof_stop(int idx, hipStream_t s) {
     if (idx >= 0 && idx < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx].stop, s);
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int MODE, bool POOL2, bool GATE>
+template <int BM, int BN, int WGM, int WGN, int BK, int MODE, bool POOL2, bool GATE, int PF = 1>
 static int launch_cfg(ConvParams& p, hipStream_t s) {
     p.m_tiles = cdiv(p.M, BM);
     p.n_tiles = cdiv(p.Cout, BN);
     const size_t lds_pipe = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
     const size_t lds_epi = (size_t)(POOL2 ? BM / 4 : BM) * (BN + 4) * sizeof(float);
     const size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
-    auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, BK, MODE, POOL2, GATE>;
+    auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, BK, MODE, POOL2, GATE, PF>;
     static bool attr_set = false;  // >64 KiB dynamic LDS needs the opt-in once per kernel
     if (!attr_set && lds > 64 * 1024) {
         ORBIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -455,8 +480,8 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
     }
     if (g_prof_on) {
         char name[48];
-        snprintf(name, sizeof(name), "conv_igemm<%d,%d,%d,%s%s%s>", BM, BN, BK, MODE ? "nchw" : "nhwc",
-                 POOL2 ? ",pool2" : "", GATE ? ",gate" : "");
+        snprintf(name, sizeof(name), "conv_igemm<%d,%d,%d,%s%s%s%s>", BM, BN, BK, MODE ? "nchw" : "nhwc",
+                 POOL2 ? ",pool2" : "", GATE ? ",gate" : "", PF == 2 ? ",pf2" : "");
         ProfRec r;
         r.start = prof_event(), r.stop = prof_event(), r.variant = prof_variant(name);
         const double pix = POOL2 ? (double)p.B * p.HoP * p.WoP * 4 : (double)p.B * p.Ho * p.Wo;
@@ -491,8 +516,15 @@ static int launch_tiled(ConvParams& p, hipStream_t s) {
     // padding (Cout <= 32, or e.g. Cout = 80, 96, 144).
     const double waste64 = (double)(cdiv(p.Cout, 64) * 64 - p.Cout) / p.Cout;
     const double waste32 = (double)(cdiv(p.Cout, 32) * 32 - p.Cout) / p.Cout;
-    if (p.Cout <= 32 || waste64 - waste32 >= 0.15) return launch_cfg<128, 32, 4, 1, BK, MODE, POOL2, GATE>(p, s);
-    return launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
+    // staging depth (conv_prefetch = 2): measured on MI355X with tools/conv_bench.py <net> pf — two K-tiles of loads in
+    // flight cost 30 extra VGPRs (occupancy 8 -> 4 on the short-K layers) and do not pay: -6..-17 % on efficientnet's
+    // BK 8/16 layers, +-2 % on the long-K resnet layers (whose bubble is not load latency). Kept opt-in for A/B only.
+    const bool pf2 = get_option("conv_prefetch") == 2;
+    if (p.Cout <= 32 || waste64 - waste32 >= 0.15)
+        return pf2 ? launch_cfg<128, 32, 4, 1, BK, MODE, POOL2, GATE, 2>(p, s)
+                   : launch_cfg<128, 32, 4, 1, BK, MODE, POOL2, GATE, 1>(p, s);
+    return pf2 ? launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE, 2>(p, s)
+               : launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE, 1>(p, s);
 }
 
 template <int MODE, bool POOL2, bool GATE>

@@ -299,6 +299,22 @@ int orbit_extractor_load(orbit_extractor_t* fe, const char* key, const float* da
     return ORBIT_OK;
 }
 
+int orbit_extractor_load_async(orbit_extractor_t* fe, const char* key, const float* device_data, size_t numel,
+                               orbit_stream_t stream) {
+    ORBIT_REQUIRE(fe && key && device_data, "extractor_load_async: null pointer");
+    auto it = fe->index.find(key);
+    ORBIT_REQUIRE(it != fe->index.end(), "extractor_load_async: unexpected key '%s' for %s", key, fe->name.c_str());
+    Param& p = fe->params[it->second];
+    ORBIT_REQUIRE(p.numel == numel, "extractor_load_async: '%s' has %zu elements, expected %zu", key, numel, p.numel);
+    if (int rc = fe->ensure_device()) return rc;
+    ORBIT_HIP_CHECK(hipMemcpyAsync(fe->d_pool + p.off, device_data, numel * sizeof(float), hipMemcpyDeviceToDevice,
+                                   (hipStream_t)stream));
+    p.loaded = true;
+    fe->finalized = false;
+    extractor_train_invalidate(fe);
+    return ORBIT_OK;
+}
+
 int orbit_extractor_finalize(orbit_extractor_t* fe, orbit_stream_t stream) {
     ORBIT_REQUIRE(fe, "extractor_finalize: null pointer");
     for (const Param& p : fe->params)

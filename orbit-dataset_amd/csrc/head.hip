@@ -34,7 +34,8 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"mbconv_fusion", "ORBIT_MBCONV_FUSION", 0, false},
                              {"graph", "ORBIT_GRAPH", 2, false},
                              {"conv_tile", "ORBIT_CONV_TILE", 0, false},
-                             {"conv_bk", "ORBIT_CONV_BK", 0, false}};
+                             {"conv_bk", "ORBIT_CONV_BK", 0, false},
+                             {"conv_prefetch", "ORBIT_CONV_PREFETCH", 0, false}};
 static Option* find_option(const char* name) {
     for (Option& o : g_options)
         if (strcmp(o.name, name) == 0) {

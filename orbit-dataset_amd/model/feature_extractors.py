@@ -163,8 +163,13 @@ class HipNetwork(nn.Module):
                 if own is not None and not isinstance(t, nn.Parameter):
                     t = own
                 t = t.detach().contiguous().float()
-                _lib.check(lib.orbit_extractor_load(pl.handle, key.encode(), ctypes.c_void_p(t.data_ptr()),
-                                                    t.numel()), "orbit_extractor_load(%s)" % key)
+                if t.is_cuda:  # stream-ordered copy: no host sync while parameters follow optimizer steps
+                    _lib.check(lib.orbit_extractor_load_async(pl.handle, key.encode(), ctypes.c_void_p(t.data_ptr()),
+                                                              t.numel(), _lib.stream_handle()),
+                               "orbit_extractor_load_async(%s)" % key)
+                else:
+                    _lib.check(lib.orbit_extractor_load(pl.handle, key.encode(), ctypes.c_void_p(t.data_ptr()),
+                                                        t.numel()), "orbit_extractor_load(%s)" % key)
             _lib.check(lib.orbit_extractor_finalize(pl.handle, _lib.stream_handle()), "orbit_extractor_finalize")
             pl.stamp = stamp
 

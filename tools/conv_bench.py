@@ -75,6 +75,13 @@ def main():
                 res[bk] = measure(0)
             lib.orbit_set_option(b"conv_bk", 0)
             line += "  | " + "  ".join("BK<=%d %.1f us (%s)" % (bk, r[0], r[2].split("<")[1][:9]) for bk, r in res.items())
+        if len(sys.argv) > 2 and sys.argv[2] == "pf":
+            res = {}
+            for pf in (1, 2):
+                lib.orbit_set_option(b"conv_prefetch", pf)
+                res[pf] = measure(0)
+            lib.orbit_set_option(b"conv_prefetch", 0)
+            line += "  | pf1 %.1f us  pf2 %.1f us  (%+.0f%%)" % (res[1][0], res[2][0], 100 * (res[1][0] / res[2][0] - 1))
         if sweep:
             res = {t: measure(t)[0] for t in (1, 2, 3, 4) if not (t == 4 and Cout > 32 and False)}
             best = min(res, key=res.get)
