@@ -106,6 +106,9 @@ class Learner:
         torch.cuda.set_device(index)
         self.device = torch.device("cuda", index)
         self.init_model()
+        import gc
+        gc.collect()
+        gc.freeze()  # keep torch + the model out of the cyclic collector's working set (full collections cost ms)
 
     def init_model(self):
         a = self.args

@@ -115,6 +115,28 @@ class FewShotRecogniser(nn.Module):
     def _pool_features(self, features, ops_counter=None):
         return self.frame_pooler(features)
 
+    def _index_to_device(self, idx):
+        """Host index array (LITE's numpy permutation) -> int64 tensor on the model device WITHOUT stalling the host: a
+        pageable host-to-device copy issued on the compute stream waits for every kernel queued before it (that made
+        the LITE step host-bound); an idle side stream performs it at once and the compute stream waits on its event."""
+        if isinstance(idx, torch.Tensor) and idx.is_cuda:
+            return idx
+        t = torch.as_tensor(idx, dtype=torch.int64)
+        side = self.__dict__.get("_copy_stream")
+        if side is None:
+            side = self.__dict__["_copy_stream"] = torch.cuda.Stream(device=self.device)
+        main = torch.cuda.current_stream(self.device)
+        with torch.cuda.stream(side):
+            d = t.to(self.device)
+        main.wait_stream(side)
+        d.record_stream(main)
+        return d
+
+    @staticmethod
+    def _take(x, idx_host, idx_dev):
+        """Rows of x selected by the same indices given twice: host array for host tensors, device tensor otherwise."""
+        return x.index_select(0, idx_dev) if x.is_cuda else x[idx_host]
+
     def set_test_mode(self, test_mode):
         self.test_mode = test_mode
 
@@ -248,15 +270,22 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         every call, the rest comes from the per-task caches; features/labels are reordered by the permutation.
         The permutation comes from np.random, exactly as in the reference (seed numpy to reproduce)."""
         self._set_batch_norm_state()
+        # the label SET is permutation-invariant: resolve it from the task's own label tensor (memoised per task, so the
+        # one device sync it may need happens once per task and not once per query batch)
+        class_ids = self.classifier.unique_labels(context_labels, self.device)
         shuffled_idxs = np.random.permutation(len(context_clips))
         grad_idxs = shuffled_idxs[0:self.num_lite_samples]
         no_grad_idxs = shuffled_idxs[self.num_lite_samples:]
+        # one stall-free upload of the permutation; the split-batch helpers slice it on the device
+        perm_dev = self._index_to_device(shuffled_idxs)
+        self._lite_idx = (grad_idxs, perm_dev[:self.num_lite_samples], no_grad_idxs, perm_dev[self.num_lite_samples:])
         task_embedding = self._get_task_embedding_with_split_batch(context_clips, grad_idxs, no_grad_idxs)
         self.film_dict = self._generate_film_params(task_embedding)
         context_features = self._get_features_with_split_batch(context_clips, self.film_dict, grad_idxs, no_grad_idxs)
         context_features = self._pool_features(context_features)
-        labels = context_labels[torch.as_tensor(shuffled_idxs, device=context_labels.device)]
-        self.classifier.configure(context_features, labels)
+        labels = self._take(context_labels, shuffled_idxs, perm_dev)
+        self._lite_idx = None
+        self.classifier.configure(context_features, labels, class_ids=class_ids)
 
     # ---- task embedding ------------------------------------------------------------------------------
     def _get_task_embedding(self, context_clips, ops_counter=None, aggregation="mean"):
@@ -295,8 +324,9 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         if self.reps_cache is None:
             with torch.no_grad():
                 self.reps_cache = self._get_task_embedding_in_batches(context_clips, aggregation="none")
-        reps_with_grads = self._get_task_embedding(context_clips[grad_idxs], aggregation="none")
-        reps_without_grads = self.reps_cache[torch.as_tensor(no_grad_idxs, device=self.reps_cache.device)]
+        grad_dev, no_grad_dev = self._split_indices(grad_idxs, no_grad_idxs)
+        reps_with_grads = self._get_task_embedding(self._take(context_clips, grad_idxs, grad_dev), aggregation="none")
+        reps_without_grads = self.reps_cache.index_select(0, no_grad_dev)
         # mean over the concatenation (reference :413 returns a [64] vector here, not [1,64])
         return self.set_encoder.aggregate(torch.cat((reps_with_grads, reps_without_grads)), "mean").reshape(-1)
 
@@ -305,17 +335,25 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         if self.features_cache is None:
             with torch.no_grad():
                 self.features_cache = self._get_features_in_batches(context_clips, film_dict)
-        features_with_grads = self._get_features(context_clips[grad_idxs], film_dict)
+        grad_dev, no_grad_dev = self._split_indices(grad_idxs, no_grad_idxs)
+        features_with_grads = self._get_features(self._take(context_clips, grad_idxs, grad_dev), film_dict)
         if context_clips.dim() == 5 and context_clips.shape[1] > 1:
             # the cache holds frame features [N*T, D]; the reference indexes it with clip indices (:434),
             # which is only meaningful for T == 1 — keep clip granularity here
             T = context_clips.shape[1]
-            idx = torch.as_tensor(no_grad_idxs, device=self.features_cache.device)
-            frame_idx = (idx[:, None] * T + torch.arange(T, device=idx.device)[None, :]).reshape(-1)
-            features_without_grads = self.features_cache[frame_idx]
+            frame_idx = (no_grad_dev[:, None] * T + torch.arange(T, device=no_grad_dev.device)[None, :]).reshape(-1)
+            features_without_grads = self.features_cache.index_select(0, frame_idx)
         else:
-            features_without_grads = self.features_cache[torch.as_tensor(no_grad_idxs, device=self.features_cache.device)]
+            features_without_grads = self.features_cache.index_select(0, no_grad_dev)
         return torch.cat((features_with_grads, features_without_grads))
+
+    def _split_indices(self, grad_idxs, no_grad_idxs):
+        """Device copies of the LITE index arrays: the slices personalise_with_lite prepared, or (when the helpers are
+        called on their own, as the reference allows) fresh stall-free uploads."""
+        cached = getattr(self, "_lite_idx", None)
+        if cached is not None and cached[0] is grad_idxs and cached[2] is no_grad_idxs:
+            return cached[1], cached[3]
+        return self._index_to_device(grad_idxs), self._index_to_device(no_grad_idxs)
 
     def _generate_film_params(self, task_embedding, ops_counter=None):
         film_dict = self.film_generator(task_embedding)
