@@ -136,7 +136,7 @@ def head_roofline(device, n_tasks=64, M=200, D=1280, C=5, reps=40):
     us = 1e3 * e0.elapsed_time(e1) / reps
     nbytes = 4.0 * (M * D + C * D + C + M * C) * n_tasks
     gbs = nbytes / (us * 1e-6) / 1e9
-    return {"kernel": "orbit::proto_predict_kernel<5> (64 tasks x 200 queries x 1280, euclidean)", "bound": "hbm",
+    return {"kernel": "orbit::proto_predict_lds_kernel<5> (64 tasks x 200 queries x 1280, euclidean)", "bound": "hbm",
             "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "avg_launch_us": us,
             "bytes_per_launch": nbytes, "traffic": None}
 

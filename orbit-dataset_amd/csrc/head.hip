@@ -35,7 +35,8 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"graph", "ORBIT_GRAPH", 2, false},
                              {"conv_tile", "ORBIT_CONV_TILE", 0, false},
                              {"conv_bk", "ORBIT_CONV_BK", 0, false},
-                             {"conv_prefetch", "ORBIT_CONV_PREFETCH", 0, false}};
+                             {"conv_prefetch", "ORBIT_CONV_PREFETCH", 0, false},
+                             {"head_lds", "ORBIT_HEAD_LDS", 1, false}};
 static Option* find_option(const char* name) {
     for (Option& o : g_options)
         if (strcmp(o.name, name) == 0) {
@@ -53,10 +54,22 @@ int get_option(const char* name) {
     return o ? o->value : 0;
 }
 
+// wave64 sum on the VALU with DPP lane permutes (quad swaps, half-row / row mirrors, then row broadcasts), result
+// broadcast from lane 63. __shfl_xor lowers to ds_bpermute_b32, an LDS-pipe round trip per step: with 20 reductions per
+// wave in the distance kernel those 120 dependent round trips, not HBM, set the kernel time.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int moved = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+    return v + __int_as_float(moved);
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-    return v;
+    v = dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = dpp_add<0x141, 0xf>(v);  // row_half_mirror
+    v = dpp_add<0x140, 0xf>(v);  // row_mirror: every lane of a 16-lane row holds the row sum
+    v = dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3: lane 63 holds the wave sum
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
 // ---- configure: segmented sum by class --------------------------------------------------------
@@ -228,6 +241,106 @@ __global__ __launch_bounds__(256) void proto_predict_kernel(
     }
 }
 
+// LDS-staged form for launches with many rows (the batched multi-task launch, and single tasks with >= 64 query rows):
+// the block copies the task's weight matrix [C][D] into LDS once, then each of its 4 waves scores 4 query rows at a
+// time against it. The one-wave-per-row form above re-reads W from L2 for every row, i.e. C x the query bytes of L2
+// traffic (~11 TB/s at 64 tasks x 200 rows x 1280 — L2-bound at 1.7-2.3 TB/s of HBM); here W costs one L2 read per 16
+// rows and the query stream is the only HBM traffic. Same per-lane accumulation order as the form above.
+template <int CT, int R>
+__global__ __launch_bounds__(256) void proto_predict_lds_kernel(
+    const float* __restrict__ Q, const float* __restrict__ W, const float* __restrict__ bias, int M, int T, int D, int C,
+    float logit_scale, int cosine, float* __restrict__ logits, int32_t* __restrict__ argmax) {
+    extern __shared__ __attribute__((aligned(16))) float Ws[];  // [C][D] weights, then [C] norms
+    const int task = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const float* Wt = W + (size_t)task * C * D;
+    for (int i = tid * 4; i < C * D; i += 1024) *reinterpret_cast<float4*>(Ws + i) = *reinterpret_cast<const float4*>(Wt + i);
+    __syncthreads();
+    float* wn = Ws + (size_t)C * D;
+    if (cosine) {
+        for (int c = wave; c < C; c += 4) {
+            float s = 0.f;
+            for (int d = lane * 4; d < D; d += 256) {
+                const float4 w = *reinterpret_cast<const float4*>(Ws + (size_t)c * D + d);
+                s += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+            }
+            s = wave_sum(s);
+            if (lane == 0) wn[c] = sqrtf(s);
+        }
+        __syncthreads();
+    }
+    const int m0 = (blockIdx.x * 4 + wave) * R;
+    if (m0 >= M) return;
+    const float invT = 1.0f / (float)T;
+    const float* q[R];
+    bool row_ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        row_ok[r] = m0 + r < M;
+        q[r] = Q + ((size_t)task * M + (row_ok[r] ? m0 + r : m0)) * T * D;
+    }
+    float best[R], qn2[R];
+    int best_c[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) best[r] = -INFINITY, best_c[r] = 0, qn2[r] = 0.f;
+    for (int c0 = 0; c0 < C; c0 += CT) {
+        float dot[R][CT], qq[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            qq[r] = 0.f;
+#pragma unroll
+            for (int j = 0; j < CT; ++j) dot[r][j] = 0.f;
+        }
+#pragma unroll 2
+        for (int d = lane * 4; d < D; d += 256) {
+            float4 x[R];
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                x[r] = *reinterpret_cast<const float4*>(q[r] + d);
+                for (int t = 1; t < T; ++t) {
+                    const float4 y = *reinterpret_cast<const float4*>(q[r] + (size_t)t * D + d);
+                    x[r].x += y.x, x[r].y += y.y, x[r].z += y.z, x[r].w += y.w;
+                }
+                if (T > 1) x[r].x *= invT, x[r].y *= invT, x[r].z *= invT, x[r].w *= invT;
+                qq[r] += x[r].x * x[r].x + x[r].y * x[r].y + x[r].z * x[r].z + x[r].w * x[r].w;
+            }
+#pragma unroll
+            for (int j = 0; j < CT; ++j) {
+                if (c0 + j < C) {
+                    const float4 w = *reinterpret_cast<const float4*>(Ws + (size_t)(c0 + j) * D + d);
+#pragma unroll
+                    for (int r = 0; r < R; ++r) dot[r][j] += x[r].x * w.x + x[r].y * w.y + x[r].z * w.z + x[r].w * w.w;
+                }
+            }
+        }
+        if (c0 == 0 && cosine) {
+#pragma unroll
+            for (int r = 0; r < R; ++r) qn2[r] = wave_sum(qq[r]);
+        }
+#pragma unroll
+        for (int j = 0; j < CT; ++j) {
+            if (c0 + j >= C) break;
+            const float bj = cosine ? 0.f : bias[(size_t)task * C + c0 + j];
+            const float wnj = cosine ? wn[c0 + j] : 0.f;
+#pragma unroll
+            for (int r = 0; r < R; ++r) {
+                float v = wave_sum(dot[r][j]);
+                if (cosine)
+                    v = logit_scale * (v / (fmaxf(sqrtf(qn2[r]), 1e-8f) * fmaxf(wnj, 1e-8f)));
+                else
+                    v = logit_scale * (v + bj);
+                if (lane == 0 && row_ok[r]) logits[((size_t)task * M + m0 + r) * C + c0 + j] = v;
+                if (v > best[r]) best[r] = v, best_c[r] = c0 + j;
+            }
+        }
+    }
+    if (argmax != nullptr && lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (row_ok[r]) argmax[(size_t)task * M + m0 + r] = best_c[r];
+    }
+}
+
 // ---- MeanPooler --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mean_pool_kernel(const float* __restrict__ x, int N, int T, int D,
                                                         float* __restrict__ out) {
@@ -313,6 +426,25 @@ int orbit_proto_predict(const float* Q, const float* W, const float* b, int n_ta
     hipStream_t s = (hipStream_t)stream;
     // rows per wave: measured on MI355X (64 tasks x 200 x 1280): R = 1 with the row loop unrolled streams faster than
     // R = 4 (more waves in flight beats W reuse: W is L1/L2-resident anyway); the R > 1 forms stay for very wide heads
+    const size_t lds = ((size_t)C * D + C) * sizeof(float);
+    if ((D & 3) == 0 && lds <= 60 * 1024 && (long)M * n_tasks >= 64 && get_option("head_lds")) {
+        const int opt = get_option("head_lds");  // 1: 4 rows per wave (16 per block), 2: 8 rows per wave (32 per block)
+        if (opt == 2) {
+            const dim3 grid(cdiv(M, 32), n_tasks);
+            if (C <= 5)
+                proto_predict_lds_kernel<5, 8><<<grid, 256, lds, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine, logits, argmax);
+            else
+                proto_predict_lds_kernel<10, 8><<<grid, 256, lds, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine, logits, argmax);
+        } else {
+            const dim3 grid(cdiv(M, 16), n_tasks);
+            if (C <= 5)
+                proto_predict_lds_kernel<5, 4><<<grid, 256, lds, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine, logits, argmax);
+            else
+                proto_predict_lds_kernel<10, 4><<<grid, 256, lds, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine, logits, argmax);
+        }
+        ORBIT_LAUNCH_CHECK();
+        return ORBIT_OK;
+    }
     const long blocks4 = (long)cdiv(M, 16) * n_tasks;
     if (C <= 5) {
         if (blocks4 >= (1L << 30))
