@@ -256,6 +256,8 @@ class Learner:
     def test(self):
         a = self.args
         self.model.set_test_mode(True)
+        # synthetic tasks live on the host and are uploaded per mini-batch, so the query pass may run on its own stream
+        self.model.overlap_query = True
         task_acc, personalise_ms, inference_ms = [], [], []
         with torch.no_grad():
             for t in odist.tasks_for_rank(a.num_test_tasks, self.rank, self.world):

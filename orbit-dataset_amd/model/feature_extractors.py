@@ -174,11 +174,16 @@ class HipNetwork(nn.Module):
             pl.stamp = stamp
 
     def _workspace(self, plan, B, device):
-        ws = plan.workspaces.get(B)
+        # one workspace per (batch size, stream): forwards issued on different streams (the query pass overlapped with the
+        # support pass, few_shot_recognisers.predict) must not share activation buffers
+        key = (B, _lib.stream_handle().value or 0)
+        ws = plan.workspaces.get(key)
         if ws is None or ws.device != device:
             nbytes = _lib.load().orbit_extractor_workspace_bytes(plan.handle, B)
             ws = torch.empty(nbytes, dtype=torch.uint8, device=device)
-            plan.workspaces = {B: ws}  # keep only the most recent batch size
+            # keep the most recent batch size per stream
+            plan.workspaces = {k: v for k, v in plan.workspaces.items() if k[1] != key[1]}
+            plan.workspaces[key] = ws
         return ws
 
     def macs_per_frame(self, H, W):

@@ -243,10 +243,19 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         self._generated_film_dict = None
         self.reps_cache = None
         self.features_cache = None
+        # overlap_query: in test mode predict() runs the query clips through the extractor on a second HIP stream, so it
+        # overlaps with the support pass personalise() queued on the caller's stream (the two passes are independent
+        # given the FiLM parameters; small late layers do not fill the chip on their own: -18 % per efficientnet task,
+        # tools/overlap_probe.py). Opt-in because the query clips must then be READY when predict() is called: clips that
+        # an earlier, still pending operation on the caller's stream produces after personalise() would be read too early
+        # (host-resident clips are always safe: their upload is issued on the second stream).
+        self.overlap_query = False
+        self._film_ready = None
 
     def _reset(self):
         self.film_dict = None
         self._generated_film_dict = None
+        self._film_ready = None
         self.classifier.reset()
 
     def _clear_caches(self):
@@ -261,6 +270,9 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         class_ids = self.classifier.unique_labels(context_labels, self.device)
         task_embedding = self._get_task_embedding_in_batches(context_clips, ops_counter)
         self.film_dict = self._generate_film_params(task_embedding, ops_counter)
+        if self.overlap_query and self.film_dict:
+            self._film_ready = torch.cuda.Event()
+            self._film_ready.record(torch.cuda.current_stream(self.device))
         context_features = self._get_features_in_batches(context_clips, self.film_dict, ops_counter)
         context_features = self._pool_features(context_features, ops_counter)
         self.classifier.configure(context_features, context_labels, ops_counter, class_ids=class_ids)
@@ -363,7 +375,19 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
     # ---- predict ----------------------------------------------------------------------------------------
     def predict(self, target_clips):
         self._set_batch_norm_state()
-        target_features = self._get_features_in_batches(target_clips, self.film_dict)
+        if self.overlap_query and not torch.is_grad_enabled() and not self.feature_extractor.training:
+            side = self.__dict__.get("_query_stream")
+            if side is None:
+                side = self.__dict__["_query_stream"] = torch.cuda.Stream(device=self.device)
+            main = torch.cuda.current_stream(self.device)
+            if self.film_dict and self._film_ready is not None:
+                side.wait_event(self._film_ready)  # the only thing the query pass needs from personalise()
+            with torch.cuda.stream(side):
+                target_features = self._get_features_in_batches(target_clips, self.film_dict)
+            main.wait_stream(side)
+            target_features.record_stream(main)
+        else:
+            target_features = self._get_features_in_batches(target_clips, self.film_dict)
         target_features = self._pool_features(target_features)
         return self.classifier.predict(target_features)
 

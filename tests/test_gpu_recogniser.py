@@ -132,6 +132,36 @@ def test_cnaps_and_simple_cnaps_heads_end_to_end(device, classifier):
         model.predict(tgt)
 
 
+@pytest.mark.parametrize("fe_name,adapt,size", [("resnet18", False, 84), ("resnet18", True, 84),
+                                                ("efficientnet_b0", False, 128)])
+def test_overlap_query_stream_is_bit_identical(device, fe_name, adapt, size):
+    """overlap_query: the query pass of predict() on a second stream, concurrent with the support pass. Same kernels, same
+    inputs -> bit-identical logits, for resident and for host-side clips, over repeated tasks."""
+    model, _ = build_pair(fe_name, adapt, "proto", 1, 16)
+    tasks = [synthetic.make_task(20 + i, way=4, shots=2, frames_per_shot=6, num_query=40, frame_size=size) for i in range(3)]
+
+    def run(overlap, on_device):
+        model.overlap_query = overlap
+        outs = []
+        with torch.no_grad():
+            for t in tasks:
+                ctx, tgt = t["context_clips"], t["target_clips"]
+                if on_device:
+                    ctx, tgt = ctx.cuda(), tgt.cuda()
+                    torch.cuda.synchronize()  # the contract of overlap_query: resident query clips are ready
+                model.personalise(ctx, t["context_labels"].cuda())
+                outs.append(model.predict(tgt))
+                model._reset()
+        torch.cuda.synchronize()
+        return [o.cpu() for o in outs]
+
+    base = run(False, True)
+    for on_device in (True, False):
+        got = run(True, on_device)
+        assert all(torch.equal(a, b) for a, b in zip(base, got))
+    model.overlap_query = False
+
+
 def test_config3_efficientnet_224(device):
     model, ref = build_pair("efficientnet_b0", False, "proto", 1, 16)
     task = synthetic.make_task(5, way=5, shots=1, frames_per_shot=4, num_query=12, frame_size=224)
