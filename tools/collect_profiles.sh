@@ -9,7 +9,10 @@ OUT=${1:-gpurun_out/profiles}; TAG=${2:-r01}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$R/$OUT"; O="$R/$OUT"
 cd /tmp && export TMPDIR=/tmp
-for W in efficientnet_b0_224 resnet18_84; do
+# kernels must run one at a time for their durations / counters to be attributable: the support/query stream overlap of
+# the timed leg is switched off here, exactly as bench.py does for its own roofline leg
+export ORBIT_BENCH_OVERLAP=0
+for W in efficientnet_b0_224 resnet18_84 resnet18_224; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- \
       python $R/bench.py --workload $W --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_$W.json 2> $O/${TAG}_bench_$W.err
   cp $(ls $O/stats_$W/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_$W.csv
