@@ -202,8 +202,8 @@ def cpu_baseline(workload, model, train=False):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=40)
+    ap.add_argument("--warmup", type=int, default=10)  # fresh boxes with a slow host need ~10 tasks to reach steady state
     ap.add_argument("--workload", default="efficientnet_b0_224", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="inference", choices=["inference", "lite_train"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
