@@ -144,7 +144,7 @@ def head_roofline(device, n_tasks=64, M=200, D=1280, C=5, reps=40):
             "bytes_per_launch": nbytes, "traffic": None}
 
 
-def cpu_baseline(workload, model, train=False):
+def cpu_baseline(workload, model, train=False, way=WAY):
     """The oracle (CPU restatement of the reference path) on ONE task of the same workload, all host cores."""
     from oracle.recogniser import OracleRecogniser
     fe_name, adapt, size = WORKLOADS[workload]
@@ -159,7 +159,7 @@ def cpu_baseline(workload, model, train=False):
         ref.set_encoder.load_state_dict({k[len("set_encoder."):]: v for k, v in sd.items() if k.startswith("set_encoder.")})
         ref.build_film_generator().load_state_dict(
             {k[len("film_generator."):]: v for k, v in sd.items() if k.startswith("film_generator.")})
-    task = synthetic.make_task(0, WAY, SHOTS, FRAMES_PER_SHOT, NUM_QUERY, size)
+    task = synthetic.make_task(0, way, 1, WAY * SHOTS * FRAMES_PER_SHOT // way, NUM_QUERY, size)
     # pick the intra-op thread count that is fastest on this host (more threads than the small convolutions
     # can use slows PyTorch-CPU down badly on many-core hosts); `cores` reports the count actually used
     warm = synthetic.make_task(1, WAY, 1, 4, 12, size)
@@ -206,6 +206,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)  # fresh boxes with a slow host need ~10 tasks to reach steady state
     ap.add_argument("--workload", default="efficientnet_b0_224", choices=sorted(WORKLOADS))
     ap.add_argument("--mode", default="inference", choices=["inference", "lite_train"])
+    ap.add_argument("--way", type=int, default=5, help="classes per task (BASELINE config 5 is 10-way: 20 support frames "
+                                                       "per class instead of 40, same 200 + 200 frames)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-tasks", type=int, default=4, help="tasks resident in HBM, cycled through")
     ap.add_argument("--batch-size", type=int, default=256, help="clips per extractor call (reference --batch_size)")
@@ -237,7 +239,11 @@ def main():
     model = build_model(args.workload, device, args.batch_size, train=train)
     run_step = LiteTrainStep(model, world, args.batch_size) if train else run_task
     # each rank owns its own tasks (task index = rank + world * i): weak scaling, independent units
-    tasks = [synthetic.make_task_on_device(rank + world * i, WAY, SHOTS, FRAMES_PER_SHOT, NUM_QUERY, size, 1, device)
+    way = args.way
+    if (WAY * SHOTS * FRAMES_PER_SHOT) % way:
+        raise SystemExit("--way must divide %d support frames" % (WAY * SHOTS * FRAMES_PER_SHOT))
+    frames_per_class = WAY * SHOTS * FRAMES_PER_SHOT // way  # keep 200 support frames per task
+    tasks = [synthetic.make_task_on_device(rank + world * i, way, 1, frames_per_class, NUM_QUERY, size, 1, device)
              for i in range(max(1, args.distinct_tasks))]
     # label sets of the resident tasks are resolved here (memoised per label tensor, classifier_heads.unique_labels): the
     # one device sync torch.unique needs per NEW task otherwise lands in the timed region for every task the warm-up
@@ -334,8 +340,9 @@ def main():
                                    args.workload,
                                    " LITE meta-training step (H=%d, fwd+bwd+Adam%s)" % (
                                        NUM_LITE, ", gradient all-reduce" if world > 1 else "") if train else "",
-                                   fe_name, " + CNAPs FiLM adaptation" if adapt else "", size, size, WAY,
-                                   WAY * SHOTS * FRAMES_PER_SHOT, SHOTS, FRAMES_PER_SHOT, NUM_QUERY),
+                                   fe_name, " + CNAPs FiLM adaptation" if adapt else "", size, size, way,
+                                   WAY * SHOTS * FRAMES_PER_SHOT, SHOTS if way == WAY else 1,
+                                   FRAMES_PER_SHOT if way == WAY else frames_per_class, NUM_QUERY),
                    "tasks_per_step": 1, "parallelism": "task-parallel x%d (independent tasks per rank)" % world},
         "frame_accuracy": float(correct[0].item() / max(correct[1].item(), 1)),
         "host_enqueue_ms_per_step": 1e3 * issued / args.steps,
@@ -357,7 +364,7 @@ def main():
     out["head_roofline"] = head_roofline(device)
     if not args.no_cpu_baseline and world == 1:
         sd_before = {k: v.clone() for k, v in model.state_dict().items()} if train else None
-        base, task, want = cpu_baseline(args.workload, model, train=train)
+        base, task, want = cpu_baseline(args.workload, model, train=train, way=way)
         if train:  # the same LITE step on the same weights and permutation
             import numpy as np
             model.load_state_dict(sd_before)

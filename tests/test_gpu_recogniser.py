@@ -216,7 +216,9 @@ def test_learner_test_mode_end_to_end(device, tmp_path):
     common = ["--frame_size", "64", "--way", "3", "--shots", "2", "--frames_per_shot", "4", "--num_query_videos", "2",
               "--frames_per_video", "6", "--batch_size", "8", "--num_lite_samples", "4", "--tasks_per_batch", "2",
               "--num_train_tasks", "4"]
-    for extra in (["--learn_extractor", "--with_lite"], ["--adapt_features", "--with_lite"], ["--learn_extractor"]):
+    for extra in (["--learn_extractor", "--with_lite"], ["--adapt_features", "--with_lite"], ["--learn_extractor"],
+                  ["--adapt_features", "--with_lite", "--classifier", "versa"],          # README: CNAPs
+                  ["--adapt_features", "--with_lite", "--classifier", "mahalanobis"]):   # README: Simple CNAPs
         tr = main(["--mode", "train", "--feature_extractor", "resnet18"] + extra + common)["train"]
         assert tr["num_tasks"] == 4 and np.isfinite(tr["loss"][0]) and tr["loss"][0] > 0
     tr = main(["--mode", "train", "--learn_extractor", "--with_lite", "--feature_extractor", "efficientnet_b0"] + common)
