@@ -307,6 +307,12 @@ int orbit_op_se_gate_backward(const float* dxg, const float* x, const float* poo
                               const float* w2, const float* b2, float* dx, float* dw1, float* db1, float* dw2,
                               float* db2, int B, int HW, int C, int R, orbit_stream_t stream);
 
+/* ---- input side: 8-bit frames -> normalised fp32 NCHW ([B][3][H][W], what the extractors consume) -------------------
+ * frames: device pointer, [B][H][W][3] when layout_hwc != 0 (decoded images) or [B][3][H][W]; mean3 / std3: HOST arrays.
+ * out = ((u8 / 255) - mean) / std per channel: to_tensor + normalize of data/datasets.py:422-431, bit-identical. */
+int orbit_frames_from_uint8(const uint8_t* frames, int layout_hwc, int B, int H, int W, const float* mean3,
+                            const float* std3, float* out_nchw, orbit_stream_t stream);
+
 /* ---- measurement: per-launch HIP-event timing of the dominant kernel (conv_igemm, all variants) ---- */
 int orbit_prof_enable(int on);   /* on: reset and start recording an event pair per launch on its stream */
 /* waits for the recorded launches, returns summed duration, summed ALGORITHMIC flops and launch count */

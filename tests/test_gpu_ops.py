@@ -325,3 +325,17 @@ def test_extractor_batch_sizes(device, B):
         want = ref(x)
     got = fe(x.to(device)).cpu()
     assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("channels_last", [True, False])
+@pytest.mark.parametrize("method", ["imagenet", "openai_clip"])
+def test_frames_from_uint8_is_bit_identical_to_the_reference_transform(device, channels_last, method):
+    """to_tensor (HWC uint8 -> CHW float / 255) + normalize((x - mean) / std), data/datasets.py:422-431."""
+    from orbit_dataset_amd.data.utils import NORMALIZE_STATS, frames_from_uint8
+    g = torch.Generator().manual_seed(3)
+    hwc = torch.randint(0, 256, (5, 2, 37, 41, 3), generator=g, dtype=torch.uint8)  # [clips, T, H, W, 3]
+    mean, std = (torch.tensor(v)[None, None, :, None, None] for v in NORMALIZE_STATS[method])
+    want = (hwc.permute(0, 1, 4, 2, 3).float().div(255) - mean) / std
+    src = hwc if channels_last else hwc.permute(0, 1, 4, 2, 3).contiguous()
+    got = frames_from_uint8(src.pin_memory(), device, method, channels_last=channels_last)
+    assert got.shape == want.shape and torch.equal(got.cpu(), want)
