@@ -144,6 +144,38 @@ def head_roofline(device, n_tasks=64, M=200, D=1280, C=5, reps=40):
             "bytes_per_launch": nbytes, "traffic": None}
 
 
+def metric_variants(model, tasks, device, steps):
+    """The two side measurements SURVEY.md §8(d) asks for next to `value` (never reported as `value`):
+    predict-only frames/s (one personalise(), then predict() of the 200 query frames repeatedly) and the H2D-inclusive
+    rate (support and query clips start in pinned host memory and are uploaded per mini-batch inside the timed region,
+    602 KB per 224x224 frame, as the reference's loops do)."""
+    def timed(fn, n):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n):
+            fn(i)
+        torch.cuda.synchronize()
+        return time.perf_counter() - t0
+
+    task = tasks[0]
+    with torch.no_grad():
+        model.personalise(task["context_clips"], task["context_labels"])
+        pred = lambda i: model.predict(tasks[i % len(tasks)]["target_clips"])
+        timed(pred, 3)
+        t_pred = timed(pred, steps)
+    model._reset()
+    host = [{k: (v.cpu().pin_memory() if isinstance(v, torch.Tensor) and k.endswith("clips") else v) for k, v in t.items()}
+            for t in tasks[:2]]
+    h2d = lambda i: run_task(model, host[i % len(host)])
+    timed(h2d, 2)
+    t_h2d = timed(h2d, steps)
+    return {"predict_only_query_frames_per_s": NUM_QUERY * steps / t_pred,
+            "h2d_inclusive_query_frames_per_s": NUM_QUERY * steps / t_h2d,
+            "note": "predict-only: predict() of 200 resident query frames after one personalise(); h2d-inclusive: whole "
+                    "task with support + query clips uploaded from pinned host memory per mini-batch inside the timed "
+                    "region (fp32 frames; data/utils.frames_from_uint8 would upload a quarter of the bytes)"}
+
+
 def cpu_baseline(workload, model, train=False, way=WAY):
     """The oracle (CPU restatement of the reference path) on ONE task of the same workload, all host cores."""
     from oracle.recogniser import OracleRecogniser
@@ -362,6 +394,8 @@ def main():
                      "variants": variants},
     }
     out["head_roofline"] = head_roofline(device)
+    if not train and world == 1:
+        out["variants_of_the_metric"] = metric_variants(model, tasks, device, min(args.steps, 20))
     if not args.no_cpu_baseline and world == 1:
         sd_before = {k: v.clone() for k, v in model.state_dict().items()} if train else None
         base, task, want = cpu_baseline(args.workload, model, train=train, way=way)
