@@ -137,3 +137,17 @@ def test_graph_replay_matches_eager(device):
         assert r.returncode == 0, r.stderr[-2000:]
         res[flag] = r.stdout.strip().splitlines()[-1]
     assert res["0"].startswith("True") and res["0"] == res["1"] == res["2"], res
+
+
+def test_largest_forward_of_the_reference_configuration(device):
+    """batch_size 256 clips x clip_length 8 = 2048 frames of 224x224 in ONE forward: the biggest activation has 2.5e9
+    elements (> 2^31), so this pins the 64-bit indexing of every kernel; rows are independent, hence bit-identical to the
+    same frames pushed through in 8 forwards of 256."""
+    fe, _ = create_feature_extractor("efficientnet_b0", True, False, False)
+    synthetic.init_parameters_(fe)
+    fe = fe.cuda().eval()
+    x = torch.randn(2048, 3, 224, 224, device=device, generator=torch.Generator(device=device).manual_seed(1))
+    with torch.no_grad():
+        big = fe(x)
+        small = torch.cat([fe(x[i:i + 256]) for i in range(0, 2048, 256)])
+    assert torch.isfinite(big).all() and torch.equal(big, small)
