@@ -244,7 +244,8 @@ __global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__
     const int b = blockIdx.x;
     for (int c = threadIdx.x; c < C; c += 256) {
         float s = 0.f;
-        for (int k = 0; k < chunks; ++k) s += partial[((size_t)b * chunks + k) * C + c];
+#pragma unroll 8
+        for (int k = 0; k < chunks; ++k) s += partial[((size_t)b * chunks + k) * C + c];  // loads batched, adds in order
         sp[c] = s * inv_hw;
     }
     __syncthreads();
@@ -265,8 +266,12 @@ __global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__
             for (; c < C; c += 16) a0 = fmaf(wr[c], sp[c], a0);
         }
         float s = (a0 + a1) + (a2 + a3);
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+        // sum over the 16 lanes of the unit with DPP permutes on the VALU (quad swaps, half-row and row mirrors): every
+        // lane of the 16-lane row ends up with the row sum; __shfl_xor would be four ds_bpermute round trips
+        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xf, 0xf, false));
+        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xf, 0xf, false));
+        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x141, 0xf, 0xf, false));
+        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x140, 0xf, 0xf, false));
         if (r < R && sub == 0) {
             s += b1[r];
             hid[r] = s / (1.0f + expf(-s));
@@ -276,6 +281,7 @@ __global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__
     for (int c = threadIdx.x; c < C; c += 256) {
         float a0 = b2[c], a1 = 0.f, a2 = 0.f, a3 = 0.f;
         int r = 0;
+#pragma unroll 2
         for (; r + 3 < R; r += 4) {
             a0 = fmaf(w2t[(size_t)r * C + c], hid[r], a0);
             a1 = fmaf(w2t[(size_t)(r + 1) * C + c], hid[r + 1], a1);
