@@ -102,6 +102,10 @@ int orbit_proto_predict(const float* Q, const float* W, const float* b,
 /* out[i][d] = mean_t x[i*T+t][d]  (poolers.py:13-16) */
 int orbit_mean_pool(const float* x, int N, int T, int D, float* out, orbit_stream_t stream);
 
+/* Clip pooling of a video's sliding windows without duplicating frames: x [F][D] per-frame features, out [F][D] with
+ * out[f] = mean_{j<T} x[max(f-T+1+j, 0)] — attach_frame_history (data/utils.py:8-28) + MeanPooler (poolers.py:13-16) on
+ * features instead of on frames, bit-identical to pooling the T-times larger clip tensor. */
+int orbit_history_mean_pool(const float* x, int F, int T, int D, float* out, orbit_stream_t stream);
 /* out[d] = (1/n) Σ_i x[i][d]  (set_encoders.py:70-71; also the LITE concat-mean) */
 int orbit_set_mean(const float* x, int n, int D, float* out, orbit_stream_t stream);
 

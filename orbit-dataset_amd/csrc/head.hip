@@ -355,6 +355,24 @@ __global__ __launch_bounds__(256) void mean_pool_kernel(const float* __restrict_
     }
 }
 
+// Clip pooling for a video whose clips are sliding windows of its frames (reference data/utils.py:8-28
+// attach_frame_history followed by MeanPooler): out[f] = mean_{j<T} x[max(f - T + 1 + j, 0)], summed in clip order, so
+// the frame features are computed ONCE per frame instead of once per (frame, window position).
+__global__ __launch_bounds__(256) void history_mean_pool_kernel(const float* __restrict__ x, int F, int T, int D,
+                                                                float* __restrict__ out) {
+    const size_t total = (size_t)F * D;
+    const float invT = 1.0f / (float)T;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int f = (int)(i / D), d = (int)(i % D);
+        float s = 0.f;
+        for (int j = 0; j < T; ++j) {
+            const int src = f - T + 1 + j;
+            s += x[(size_t)(src < 0 ? 0 : src) * D + d];
+        }
+        out[i] = s * invT;
+    }
+}
+
 // out[d] = mean_i x[i][d]; one thread per column, rows in ascending order (n is a few hundred)
 __global__ __launch_bounds__(64) void set_mean_kernel(const float* __restrict__ x, int n, int D,
                                                       float* __restrict__ out) {
@@ -471,6 +489,16 @@ int orbit_mean_pool(const float* x, int N, int T, int D, float* out, orbit_strea
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     mean_pool_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, N, T, D, out);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int orbit_history_mean_pool(const float* x, int F, int T, int D, float* out, orbit_stream_t stream) {
+    ORBIT_REQUIRE(x && out && F > 0 && T > 0 && D > 0, "history_mean_pool: bad arguments");
+    const size_t total = (size_t)F * D;
+    int blocks = (int)((total + 255) / 256);
+    if (blocks > 2048) blocks = 2048;
+    history_mean_pool_kernel<<<blocks, 256, 0, (hipStream_t)stream>>>(x, F, T, D, out);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }

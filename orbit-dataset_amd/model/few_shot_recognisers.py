@@ -391,6 +391,27 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         target_features = self._pool_features(target_features)
         return self.classifier.predict(target_features)
 
+    def predict_video(self, video_frames):
+        """Logits for every frame of ONE video, equal to `predict(attach_frame_history(video_frames, clip_length))` (the
+        reference's test loop, single-step-learner.py:327-334) but with each frame through the extractor once: the clips
+        of a video are sliding windows over its frames, so for clip_length T the reference's tensor repeats every frame
+        T times. Frame features are pooled over the windows by orbit_history_mean_pool (same summation order as
+        MeanPooler on the expanded clips: bit-identical logits in test mode)."""
+        if video_frames.dim() != 4:
+            raise ValueError("expected the frames of one video [F,3,H,W], got %s" % (tuple(video_frames.shape),))
+        T = int(self.clip_length)
+        if T == 1 or torch.is_grad_enabled():
+            from ..data.utils import attach_frame_history
+            return self.predict(attach_frame_history(video_frames, T))
+        self._set_batch_norm_state()
+        feats = self._get_features_in_batches(video_frames, self.film_dict)  # [F, D], mini-batches of batch_size frames
+        F_, D = feats.shape
+        pooled = torch.empty_like(feats)
+        if F_ > 0:
+            _lib.check(_lib.load().orbit_history_mean_pool(_lib.dptr(feats, torch.float32), F_, T, D, _lib.dptr(pooled),
+                                                           _lib.stream_handle()), "orbit_history_mean_pool")
+        return self.classifier.predict(pooled)
+
     def predict_a_batch(self, target_clips):
         self._set_batch_norm_state()
         target_features = self._get_features(target_clips, self.film_dict)

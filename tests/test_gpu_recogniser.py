@@ -162,6 +162,21 @@ def test_overlap_query_stream_is_bit_identical(device, fe_name, adapt, size):
     model.overlap_query = False
 
 
+def test_predict_video_equals_predict_on_frame_history(device):
+    """predict_video: each frame through the extractor once, windows pooled on the features — bit-identical to the
+    reference's attach_frame_history -> predict on the T-times larger clip tensor."""
+    from orbit_dataset_amd.data.utils import attach_frame_history
+    for T in (3, 8):
+        model, _ = build_pair("resnet18", False, "proto", T, 4)
+        t = synthetic.make_task(30 + T, way=3, shots=1, frames_per_shot=2 * T, num_query=1, frame_size=64, clip_length=T)
+        video = synthetic.make_task(31, way=3, shots=1, frames_per_shot=1, num_query=11, frame_size=64)["target_clips"][:, 0]
+        with torch.no_grad():
+            model.personalise(t["context_clips"].cuda(), t["context_labels"].cuda())
+            want = model.predict(attach_frame_history(video.cuda(), T))
+            got = model.predict_video(video.cuda())
+        assert got.shape == want.shape == (11, 3) and torch.equal(got, want)
+
+
 def test_config3_efficientnet_224(device):
     model, ref = build_pair("efficientnet_b0", False, "proto", 1, 16)
     task = synthetic.make_task(5, way=5, shots=1, frames_per_shot=4, num_query=12, frame_size=224)
