@@ -169,11 +169,20 @@ def metric_variants(model, tasks, device, steps):
     h2d = lambda i: run_task(model, host[i % len(host)])
     timed(h2d, 2)
     t_h2d = timed(h2d, steps)
+    # the same with the clips held as 8-bit frames on the host (random bytes: throughput only) and normalised on the GPU
+    shape = lambda t, k: t[k].shape
+    host8 = [{k: (torch.randint(0, 256, shape(t, k), dtype=torch.uint8).pin_memory() if k.endswith("clips") else v)
+              for k, v in t.items()} for t in tasks[:2]]
+    h2d8 = lambda i: run_task(model, host8[i % len(host8)])
+    timed(h2d8, 2)
+    t_h2d8 = timed(h2d8, steps)
     return {"predict_only_query_frames_per_s": NUM_QUERY * steps / t_pred,
             "h2d_inclusive_query_frames_per_s": NUM_QUERY * steps / t_h2d,
+            "h2d_inclusive_uint8_query_frames_per_s": NUM_QUERY * steps / t_h2d8,
             "note": "predict-only: predict() of 200 resident query frames after one personalise(); h2d-inclusive: whole "
                     "task with support + query clips uploaded from pinned host memory per mini-batch inside the timed "
-                    "region (fp32 frames; data/utils.frames_from_uint8 would upload a quarter of the bytes)"}
+                    "region; the uint8 variant uploads 8-bit frames (a quarter of the bytes) and applies to_tensor + normalize on "
+                    "the GPU (orbit_frames_from_uint8)"}
 
 
 def cpu_baseline(workload, model, train=False, way=WAY):

@@ -79,7 +79,7 @@ class FewShotRecogniser(nn.Module):
         """clips [n,T,3,H,W] or frames [B,3,H,W] -> frame features [n*T, D] (reference :99-122)."""
         if clips.dim() == 5:
             clips = clips.flatten(end_dim=1)
-        clips = clips.to(self.device, non_blocking=True)
+        clips = self._upload(clips)
         return self.feature_extractor(clips, film=self._film_vectors(film_dict))
 
     def _get_features_in_batches(self, clips, film_dict={}, ops_counter=None):
@@ -97,7 +97,7 @@ class FewShotRecogniser(nn.Module):
                 batch_clips = clips[lo:hi]
                 if batch_clips.dim() == 5:
                     batch_clips = batch_clips.flatten(end_dim=1)
-                parts.append(self.feature_extractor(batch_clips.to(self.device, non_blocking=True), film=film,
+                parts.append(self.feature_extractor(self._upload(batch_clips), film=film,
                                                     check_sync=(batch == 0)))
             return torch.cat(parts, dim=0)
         features = torch.empty(num_clips * frames_per_clip, D, device=self.device, dtype=torch.float32)
@@ -106,7 +106,7 @@ class FewShotRecogniser(nn.Module):
             batch_clips = clips[lo:hi]
             if batch_clips.dim() == 5:
                 batch_clips = batch_clips.flatten(end_dim=1)
-            batch_clips = batch_clips.to(self.device, non_blocking=True)
+            batch_clips = self._upload(batch_clips)
             self.feature_extractor(batch_clips, film=film,
                                    out=features[lo * frames_per_clip: hi * frames_per_clip],
                                    check_sync=(batch == 0))
@@ -114,6 +114,17 @@ class FewShotRecogniser(nn.Module):
 
     def _pool_features(self, features, ops_counter=None):
         return self.frame_pooler(features)
+
+    frame_norm_method = "imagenet"  # statistics applied to 8-bit clips (reference data/datasets.py:82-87)
+
+    def _upload(self, clips):
+        """Mini-batch of clips -> the model device. fp32 clips are moved as the reference does (:112,142). 8-bit clips
+        ([..., 3, H, W] uint8, decoded but not yet normalised) cross PCIe as bytes and get the reference's
+        to_tensor + normalize on the GPU (data/utils.frames_from_uint8): a quarter of the upload, same values."""
+        if clips.dtype == torch.uint8:
+            from ..data.utils import frames_from_uint8
+            return frames_from_uint8(clips, self.device, self.frame_norm_method, channels_last=False)
+        return clips.to(self.device, non_blocking=True)
 
     def _index_to_device(self, idx):
         """Host index array (LITE's numpy permutation) -> int64 tensor on the model device WITHOUT stalling the host: a
@@ -301,7 +312,7 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
 
     # ---- task embedding ------------------------------------------------------------------------------
     def _get_task_embedding(self, context_clips, ops_counter=None, aggregation="mean"):
-        context_clips = context_clips.to(self.device, non_blocking=True)
+        context_clips = self._upload(context_clips)
         reps = self.set_encoder(context_clips)
         return self.set_encoder.aggregate(reps, aggregation=aggregation)
 
@@ -315,14 +326,14 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
             parts = []
             for batch in range(num_batches):
                 lo, hi = get_batch_indices(batch, num_clips, self.batch_size)
-                parts.append(self.set_encoder(context_clips[lo:hi].to(self.device, non_blocking=True),
+                parts.append(self.set_encoder(self._upload(context_clips[lo:hi]),
                                               check_sync=(batch == 0)))
             return self.set_encoder.aggregate(parts, aggregation=aggregation)
         reps = torch.empty(num_clips * frames_per_clip, self.set_encoder.output_size, device=self.device,
                            dtype=torch.float32)
         for batch in range(num_batches):
             lo, hi = get_batch_indices(batch, num_clips, self.batch_size)
-            batch_clips = context_clips[lo:hi].to(self.device, non_blocking=True)
+            batch_clips = self._upload(context_clips[lo:hi])
             if batch_clips.dim() == 5:
                 batch_clips = batch_clips.flatten(end_dim=1)
             self.set_encoder(batch_clips, out=reps[lo * frames_per_clip: hi * frames_per_clip],

@@ -177,6 +177,25 @@ def test_predict_video_equals_predict_on_frame_history(device):
         assert got.shape == want.shape == (11, 3) and torch.equal(got, want)
 
 
+def test_uint8_clips_match_host_side_normalisation(device):
+    """8-bit clips are normalised on the GPU exactly as the reference's loader does on the host: same logits."""
+    from orbit_dataset_amd.data.utils import NORMALIZE_STATS
+    model, _ = build_pair("resnet18", False, "proto", 1, 16)
+    g = torch.Generator().manual_seed(5)
+    ctx8 = torch.randint(0, 256, (12, 1, 3, 64, 64), generator=g, dtype=torch.uint8)
+    tgt8 = torch.randint(0, 256, (9, 1, 3, 64, 64), generator=g, dtype=torch.uint8)
+    labels = torch.arange(3).repeat_interleave(4)
+    mean, std = (torch.tensor(v)[None, None, :, None, None] for v in NORMALIZE_STATS["imagenet"])
+    norm = lambda u8: (u8.float().div(255) - mean) / std
+    with torch.no_grad():
+        model.personalise(norm(ctx8), labels.cuda())
+        want = model.predict(norm(tgt8))
+        model._reset()
+        model.personalise(ctx8.pin_memory(), labels.cuda())
+        got = model.predict(tgt8)
+    assert torch.equal(got, want)
+
+
 def test_config3_efficientnet_224(device):
     model, ref = build_pair("efficientnet_b0", False, "proto", 1, 16)
     task = synthetic.make_task(5, way=5, shots=1, frames_per_shot=4, num_query=12, frame_size=224)
