@@ -37,6 +37,23 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // zero-padded 32. LDS rows are padded to BK + 4 floats: for 12/20/36-float strides the 16-lane groups of a
 // ds_read_b128 land on 16 distinct 16-byte bank slots (conflict-free).
 
+// Division by a launch-time constant: q = (umulhi(n, mul) + n) >> shift, exact for n < 2^31 (Granlund-Montgomery
+// round-up magic). A 32-bit integer division is ~25 VALU / ~40 SALU instructions on gfx950; the row decode below and the
+// stem's k decode are made of them, and on the short-K EfficientNet layers that index arithmetic (not the MFMAs, not
+// HBM) was the busiest pipe (rocprofv3 SQ counters, tools/conv_pmc.sh).
+struct FastDiv {
+    unsigned mul, shift;
+};
+static FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    unsigned l = 0;
+    while ((1u << l) < d) ++l;  // ceil(log2 d)
+    f.mul = (unsigned)(((((unsigned long long)1 << l) - d) << 32) / d + 1);
+    f.shift = l;
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return (__umulhi(n, f.mul) + n) >> f.shift; }
+
 struct ConvParams {
     const float* x;
     const float* w;
@@ -52,6 +69,8 @@ struct ConvParams {
     int cin_pad;    // per-tap padded Cin (vector mode)
     int act;
     int m_tiles, n_tiles;
+    FastDiv fd_per, fd_wo;   // / (Ho*Wo), / Wo  (pool2: / (HoP*WoP), / WoP)
+    FastDiv fd_cin, fd_kw;   // stem mode: / Cin, / KW
     float prof_flop_scale;
 };
 
@@ -74,30 +93,37 @@ template <bool POOL2>
 __device__ __forceinline__ void decode_row(const ConvParams& p, int m, int& b, int& ho, int& wo) {
     if (POOL2) {
         const int win = m >> 2, q = m & 3;
-        const int per = p.HoP * p.WoP;
-        b = win / per;
-        const int r = win - b * per;
-        const int hp = r / p.WoP, wp = r - hp * p.WoP;
+        b = (int)fdiv((unsigned)win, p.fd_per);
+        const int r = win - b * (p.HoP * p.WoP);
+        const int hp = (int)fdiv((unsigned)r, p.fd_wo), wp = r - hp * p.WoP;
         ho = hp * 2 + (q >> 1);
         wo = wp * 2 + (q & 1);
     } else {
-        const int per = p.Ho * p.Wo;
-        b = m / per;
-        const int r = m - b * per;
-        ho = r / p.Wo;
+        b = (int)fdiv((unsigned)m, p.fd_per);
+        const int r = m - b * (p.Ho * p.Wo);
+        ho = (int)fdiv((unsigned)r, p.fd_wo);
         wo = r - ho * p.Wo;
     }
 }
 
 // MODE 0: NHWC activations, Cin % 4 == 0 (float4 gathers).  MODE 1: NCHW frames, tiny Cin (stems).
-// PF: software-pipeline depth of the global->register->LDS staging, in K-tiles (1 or 2). With PF = 2 the loads of tile
-// kt+2 are issued before the MFMAs of tile kt, so each load has two tile-times to land (a 64x64xBK16 tile is only 512
-// matrix-pipe cycles, a quarter of an L2 round trip).
-template <int BM, int BN, int WGM, int WGN, int BK, int MODE, bool POOL2, bool GATE, int PF>
+// PW: pointwise (1x1, no padding) convolution - every EfficientNet conv but the stem: no tap walk, no bounds tests.
+//
+// Addressing is split into a per-thread part fixed for the whole K loop (one 64-bit pointer per staged row, computed in
+// the prologue) and a wave-uniform part that walks K (filter tap + channel offset, kept in SGPRs and advanced
+// incrementally - no division, no per-tile 64-bit multiply): a staged load costs one 64-bit add.
+// WGK: waves along K. The 4 waves of a block form a WGM x WGN x WGK grid; with WGK > 1 the waves of a K-group share the
+// staged K-tile, each takes every WGK-th 8-deep k-group of it, and the partial accumulators are summed through LDS in
+// the epilogue. That buys 2-4x more (smaller) output tiles for layers whose 64x64 tiling leaves the chip short of blocks
+// (M = 9 800 rows in EfficientNet's 7x7 stages, 1 800-7 200 in resnet18 @84's layer3/4).
+template <int BM, int BN, int WGM, int WGN, int WGK, int BK, int MODE, bool POOL2, bool GATE, bool PW>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
-    static_assert(WGM * WGN == 4, "4 waves per block");
+    static_assert(WGM * WGN * WGK == 4, "4 waves per block");
+    static_assert(WGK == 1 || !POOL2, "the fused max-pool is not linear in the K-split partial sums");
     static_assert(BK == 8 || BK == 16 || BK == 32, "BK");
     static_assert(MODE == 0 || BK == 32, "the stem gather is written for BK = 32");
+    static_assert(!(PW && (MODE == 1 || POOL2)), "pointwise specialisation: NHWC, no fused pooling");
+    static_assert(!(GATE && (MODE == 1 || POOL2)), "the squeeze-excite gate prologue: NHWC, no fused pooling");
     constexpr int LDS_STRIDE = BK + 4;
     constexpr int WM = BM / WGM, WN = BN / WGN;  // wave tile
     constexpr int TM = WM / 32, TN = WN / 32;    // 32x32 accumulator tiles per wave
@@ -108,6 +134,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     constexpr int BR = (BN + RPP - 1) / RPP;     // float4 B loads per thread per K-tile
     constexpr int KPT = BM / 8;                  // scalar A loads per thread per K-tile (stem mode)
     constexpr int NG = BK / 8;                   // k-groups of 8 per K-tile
+    static_assert(NG % WGK == 0, "K-split needs BK / 8 divisible by the number of K-waves");
+    constexpr int NGW = NG / WGK;                // k-groups per wave per K-tile
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* As = smem;                            // [2][BM][LDS_STRIDE]
@@ -116,91 +144,118 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;
+    const int wk = wave / (WGM * WGN), wmn = wave % (WGM * WGN);
+    const int wm = (wmn / WGN) * WM, wn = (wmn % WGN) * WN;
 
+    // One output tile per block. (A persistent form - grid sized to the co-resident blocks, each block walking several
+    // tiles and requesting the next tile's first K-tile before its epilogue - was measured on MI355X: 0..-16 % on every
+    // layer of resnet18 and efficientnet_b0; the hardware dispatcher's dynamic placement beats the static walk.)
     const int tile = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
     const int m0 = (tile / p.n_tiles) * BM;
     const int n0 = (tile % p.n_tiles) * BN;
 
     // ---- per-thread gather bookkeeping (rows are fixed for the whole K loop) ----
-    // vector mode: thread owns float4 column c4 of rows (tid>>3) + 32*i
+    // vector mode: thread owns float4 column c4 of rows lrow + RPP*i; a_ptr[i] points at (tap (0,0), channel c4*4) of
+    //              the row's receptive field (it may lie outside the tensor for padded rows - those are never loaded)
     // stem mode:   thread owns KPT consecutive k of row tid % BM
     const int c4 = tid % TPR, lrow = tid / TPR;  // this thread's float4 column / first row of the tile
-    const float* a_base[MODE == 0 ? AR : 1];
+    const float* a_ptr[MODE == 0 ? AR : 1];
     int a_hi0[MODE == 0 ? AR : 1], a_wi0[MODE == 0 ? AR : 1];
-    const float* a_gate[MODE == 0 ? AR : 1];
+    const float* g_ptr[GATE ? AR : 1];
+    // wave-uniform K walk of the staging loads (tiles are loaded strictly in order): channel offset inside the tap,
+    // tap coordinates, element offset of the tap in the input, element offset in the packed filter row
+    int ld_ci = 0, ld_kh = 0, ld_kw = 0, ld_tap = 0, ld_k = 0;
+
     if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             const int m = m0 + lrow + RPP * i;
-            int b = 0, ho = 0, wo = 0;
             const bool ok = m < p.M && (BM % RPP == 0 || lrow + RPP * i < BM);
-            if (ok) decode_row<POOL2>(p, m, b, ho, wo);
-            a_base[i] = p.x + (size_t)b * p.H * p.W * p.Cin;
-            a_hi0[i] = ok ? ho * p.stride - p.pad_t : -(1 << 28);  // invalid rows fail the bounds test
-            a_wi0[i] = wo * p.stride - p.pad_l;
-            a_gate[i] = GATE ? p.gate + (size_t)b * p.Cin : nullptr;
+            int b = 0, ho = 0, wo = 0;
+            long off;
+            if (PW && p.stride == 1) {  // NHWC rows of a stride-1 pointwise conv ARE the GEMM rows
+                off = (long)m * p.Cin;
+                if (GATE) b = (int)fdiv((unsigned)(ok ? m : 0), p.fd_per);
+                a_hi0[i] = ok ? 0 : -(1 << 28);
+                a_wi0[i] = 0;
+            } else {
+                if (ok) decode_row<POOL2>(p, m, b, ho, wo);
+                const int hi0 = ho * p.stride - p.pad_t, wi0 = wo * p.stride - p.pad_l;
+                off = (((long)b * p.H + hi0) * p.W + wi0) * p.Cin;
+                a_hi0[i] = ok ? hi0 : -(1 << 28);  // invalid rows fail the bounds test
+                a_wi0[i] = wi0;
+            }
+            a_ptr[i] = p.x + (ok ? off : 0) + c4 * 4;
+            if (GATE) g_ptr[i] = p.gate + (size_t)b * p.Cin + c4 * 4;
         }
     } else {
         const int m = m0 + (tid % BM);
         int b = 0, ho = 0, wo = 0;
         const bool ok = m < p.M;
         if (ok) decode_row<POOL2>(p, m, b, ho, wo);
-        a_base[0] = p.x + (size_t)b * p.Cin * p.H * p.W;
+        a_ptr[0] = p.x + (size_t)b * p.Cin * p.H * p.W;
         a_hi0[0] = ok ? ho * p.stride - p.pad_t : -(1 << 28);
         a_wi0[0] = wo * p.stride - p.pad_l;
-        a_gate[0] = nullptr;
     }
     const bool b_row_ok = BN % RPP == 0 || lrow < BN;  // BK = 8 with BN = 64: half of the threads stage B
     const float* b_ptr = p.w + (size_t)(n0 + (b_row_ok ? lrow : 0)) * p.KT + c4 * 4;
 
     constexpr int NAS = MODE == 0 ? AR : KPT / 4;
-    f32x4 a_stage0[NAS], b_stage0[BR];
-    f32x4 a_stage1[PF == 2 ? NAS : 1], b_stage1[PF == 2 ? BR : 1];
+    f32x4 a_stage[NAS], b_stage[BR];
 
     const int nk = p.KT / BK;
-    const int cpt = MODE == 0 ? p.cin_pad / BK : 1;  // K-tiles per filter tap
     const int ktot = p.KH * p.KW * p.Cin;            // true K (stem mode)
     (void)ktot;
 
-    auto load_tile = [&](int kt, f32x4* a_stage, f32x4* b_stage) {
+    auto load_tile = [&]() {
         if (MODE == 0) {
-            const int tap = kt / cpt;
-            const int ci = (kt - tap * cpt) * BK + c4 * 4;
-            const int kh = tap / p.KW, kw = tap - kh * p.KW;
-            const bool ci_ok = ci < p.Cin;
+            const bool ci_ok = ld_ci + c4 * 4 < p.Cin;
+            const long koff = (long)ld_tap + ld_ci;
 #pragma unroll
             for (int i = 0; i < AR; ++i) {
-                const int hi = a_hi0[i] + kh, wi = a_wi0[i] + kw;
+                bool ok;
+                if (PW) ok = ci_ok && a_hi0[i] >= 0;
+                else ok = ci_ok && (unsigned)(a_hi0[i] + ld_kh) < (unsigned)p.H && (unsigned)(a_wi0[i] + ld_kw) < (unsigned)p.W;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ci_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
-                    v = *reinterpret_cast<const f32x4*>(a_base[i] + ((size_t)hi * p.W + wi) * p.Cin + ci);
-                    if (GATE) v *= *reinterpret_cast<const f32x4*>(a_gate[i] + ci);
+                if (ok) {
+                    v = *reinterpret_cast<const f32x4*>(a_ptr[i] + koff);
+                    if (GATE) v *= *reinterpret_cast<const f32x4*>(g_ptr[i] + ld_ci);
                 }
                 a_stage[i] = v;
             }
         } else {
-            // tid / BM is wave-uniform (BM is a multiple of 64): keep the k decode on the scalar unit
-            const int kb = kt * BK + __builtin_amdgcn_readfirstlane(tid / BM) * KPT;
-            const size_t plane = (size_t)p.H * p.W;
+            // tid / BM is wave-uniform (BM is a multiple of 64): the k decode stays on the scalar unit
+            const int kb = ld_k + __builtin_amdgcn_readfirstlane(tid / BM) * KPT;
+            const int plane = p.H * p.W;
 #pragma unroll
             for (int j = 0; j < KPT; ++j) {
                 const int k = kb + j;
-                const int tap = k / p.Cin, ci = k - tap * p.Cin;
-                const int kh = tap / p.KW, kw = tap - kh * p.KW;
+                const int tap = (int)fdiv((unsigned)k, p.fd_cin), ci = k - tap * p.Cin;
+                const int kh = (int)fdiv((unsigned)tap, p.fd_kw), kw = tap - kh * p.KW;
                 const int hi = a_hi0[0] + kh, wi = a_wi0[0] + kw;
                 float v = 0.f;
                 if (k < ktot && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                    v = a_base[0][ci * plane + (size_t)hi * p.W + wi];
+                    v = a_ptr[0][(size_t)ci * plane + hi * p.W + wi];
                 a_stage[j >> 2][j & 3] = v;
             }
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j)
-            b_stage[j] = *reinterpret_cast<const f32x4*>(b_ptr + (size_t)(RPP * j) * p.KT + kt * BK);
+            b_stage[j] = *reinterpret_cast<const f32x4*>(b_ptr + ((size_t)(RPP * j) * p.KT + ld_k));
+        // advance to the next K-tile
+        ld_k += BK;
+        if (MODE == 0 && !PW) {
+            ld_ci += BK;
+            if (ld_ci >= p.cin_pad) {
+                ld_ci = 0, ld_tap += p.Cin;
+                if (++ld_kw == p.KW) ld_kw = 0, ++ld_kh, ld_tap += (p.W - p.KW) * p.Cin;
+            }
+        } else if (MODE == 0) {
+            ld_ci += BK;
+        }
     };
 
-    auto store_tile = [&](int buf, const f32x4* a_stage, const f32x4* b_stage) {
+    auto store_tile = [&](int buf) {
         float* A = As + buf * BM * LDS_STRIDE;
         float* Bq = Bs + buf * BN * LDS_STRIDE;
         if (MODE == 0) {
@@ -228,8 +283,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     auto compute_tile = [&](int cur) {
-        const float* A = As + cur * BM * LDS_STRIDE + (wm + l31) * LDS_STRIDE + lh * 4;
-        const float* Bq = Bs + cur * BN * LDS_STRIDE + (wn + l31) * LDS_STRIDE + lh * 4;
+        const float* A = As + cur * BM * LDS_STRIDE + (wm + l31) * LDS_STRIDE + lh * 4 + wk * 8;
+        const float* Bq = Bs + cur * BN * LDS_STRIDE + (wn + l31) * LDS_STRIDE + lh * 4 + wk * 8;
         // fragment reads are register double-buffered: group g+1 is fetched from LDS while the MFMAs of group g
         // issue, so only the first read of a K-tile is exposed
         f32x4 af[2][TM], bf[2][TN];
@@ -238,14 +293,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[0][j] = *reinterpret_cast<const f32x4*>(Bq + j * 32 * LDS_STRIDE);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) {
+        for (int g = 0; g < NGW; ++g) {
+            if (g + 1 < NGW) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    af[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDS_STRIDE + (g + 1) * 8);
+                    af[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(A + i * 32 * LDS_STRIDE + (g + 1) * 8 * WGK);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    bf[(g + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Bq + j * 32 * LDS_STRIDE + (g + 1) * 8);
+                    bf[(g + 1) & 1][j] = *reinterpret_cast<const f32x4*>(Bq + j * 32 * LDS_STRIDE + (g + 1) * 8 * WGK);
             }
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
@@ -260,41 +315,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         // 0x008 = MFMA); without it the scheduler batches the reads behind all issued MFMAs and exposes LDS latency
         __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
 #pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            if (g + 1 < NG) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
+        for (int g = 0; g < NGW; ++g) {
+            if (g + 1 < NGW) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
         }
-
     };
 
-    if (PF == 1) {
-        load_tile(0, a_stage0, b_stage0);
-        store_tile(0, a_stage0, b_stage0);
+    load_tile();
+    store_tile(0);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        if (kt + 1 < nk) load_tile();  // global loads in flight under the MFMAs below
+        compute_tile(cur);
+        if (kt + 1 < nk) store_tile(cur ^ 1);  // the other buffer was last read before the previous barrier
         __syncthreads();
-        for (int kt = 0; kt < nk; ++kt) {
-            const int cur = kt & 1;
-            if (kt + 1 < nk) load_tile(kt + 1, a_stage0, b_stage0);  // global loads in flight under the MFMAs below
-            compute_tile(cur);
-            if (kt + 1 < nk) store_tile(cur ^ 1, a_stage0, b_stage0);  // the other buffer was last read before the previous barrier
-            __syncthreads();
-        }
-    } else {
-        // tile t is staged through register set t & 1 and LDS buffer t & 1
-        load_tile(0, a_stage0, b_stage0);
-        if (nk > 1) load_tile(1, a_stage1, b_stage1);
-        store_tile(0, a_stage0, b_stage0);
-        __syncthreads();
-        for (int kt = 0; kt < nk; kt += 2) {
-            if (kt + 2 < nk) load_tile(kt + 2, a_stage0, b_stage0);
-            compute_tile(0);
-            if (kt + 1 < nk) store_tile(1, a_stage1, b_stage1);  // waits for tile kt+1 only; kt+2 stays in flight
-            __syncthreads();
-            if (kt + 1 >= nk) break;
-            if (kt + 3 < nk) load_tile(kt + 3, a_stage1, b_stage1);
-            compute_tile(1);
-            if (kt + 2 < nk) store_tile(0, a_stage0, b_stage0);
-            __syncthreads();
-        }
     }
 
     // ---- epilogue. C/D layout of the 32x32 MFMA: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
@@ -304,13 +339,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // EfficientNet layers).
     constexpr int CS = BN + 4;                    // LDS row stride (floats), keeps float4 rows 16-B aligned
     constexpr int OROWS = POOL2 ? BM / 4 : BM;    // output rows of this tile
-    float* Cs = smem;
+    float* Cs = smem + wk * (OROWS * CS);        // [WGK][OROWS][CS]: one partial tile per K-wave group
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn + j * 32 + l31;
         const bool n_ok = n < p.Cout;
         const float sc = (n_ok && p.scale) ? p.scale[n] : 1.0f;
-        const float sh = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+        const float sh = (n_ok && p.shift && wk == 0) ? p.shift[n] : 0.0f;  // the shift enters the sum once
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -342,7 +377,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             for (int r = tid / TPO; r < OROWS; r += RPO) {
                 const int m = mo0 + r;
                 if (m >= mout) break;
-                f32x4 v = *reinterpret_cast<const f32x4*>(Cs + r * CS + oc);
+                f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * CS + oc);
+#pragma unroll
+                for (int q = 1; q < WGK; ++q) v += *reinterpret_cast<const f32x4*>(smem + (q * OROWS + r) * CS + oc);
                 if (!POOL2) {
                     if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.Cout + n);
                     v[0] = apply_act(v[0], p.act), v[1] = apply_act(v[1], p.act);
@@ -464,24 +501,25 @@ void prof_stop(int idx, hipStream_t s) {
     if (idx >= 0 && idx < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx].stop, s);
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, int MODE, bool POOL2, bool GATE, int PF = 1>
+template <int BM, int BN, int WGM, int WGN, int WGK, int BK, int MODE, bool POOL2, bool GATE, bool PW>
 static int launch_cfg(ConvParams& p, hipStream_t s) {
     p.m_tiles = cdiv(p.M, BM);
     p.n_tiles = cdiv(p.Cout, BN);
     const size_t lds_pipe = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
-    const size_t lds_epi = (size_t)(POOL2 ? BM / 4 : BM) * (BN + 4) * sizeof(float);
+    const size_t lds_epi = (size_t)WGK * (POOL2 ? BM / 4 : BM) * (BN + 4) * sizeof(float);
     const size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
-    auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, BK, MODE, POOL2, GATE, PF>;
+    auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, WGK, BK, MODE, POOL2, GATE, PW>;
     static bool attr_set = false;  // >64 KiB dynamic LDS needs the opt-in once per kernel
     if (!attr_set && lds > 64 * 1024) {
         ORBIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
+    const int grid = p.m_tiles * p.n_tiles;
     if (g_prof_on) {
         char name[48];
-        snprintf(name, sizeof(name), "conv_igemm<%d,%d,%d,%s%s%s%s>", BM, BN, BK, MODE ? "nchw" : "nhwc",
-                 POOL2 ? ",pool2" : "", GATE ? ",gate" : "", PF == 2 ? ",pf2" : "");
+        snprintf(name, sizeof(name), "conv_igemm<%d,%d,%d,%s%s%s%s%s>", BM, BN, BK, MODE ? "nchw" : "nhwc",
+                 POOL2 ? ",pool2" : "", GATE ? ",gate" : "", PW ? ",pw" : "", WGK == 2 ? ",k2" : WGK == 4 ? ",k4" : "");
         ProfRec r;
         r.start = prof_event(), r.stop = prof_event(), r.variant = prof_variant(name);
         const double pix = POOL2 ? (double)p.B * p.HoP * p.WoP * 4 : (double)p.B * p.Ho * p.Wo;
@@ -490,23 +528,26 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
         r.bytes = 4.0 * ((double)p.B * p.H * p.W * p.Cin + (POOL2 ? pix / 4 : pix) * p.Cout * (p.residual ? 2.0 : 1.0) +
                          (double)p.Cout * p.KH * p.KW * p.Cin);
         (void)hipEventRecord(r.start, s);
-        kern<<<p.m_tiles * p.n_tiles, 256, lds, s>>>(p);
+        kern<<<grid, 256, lds, s>>>(p);
         (void)hipEventRecord(r.stop, s);
         g_prof_recs.push_back(r);
     } else {
-        kern<<<p.m_tiles * p.n_tiles, 256, lds, s>>>(p);
+        kern<<<grid, 256, lds, s>>>(p);
     }
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
 
-template <int BK, int MODE, bool POOL2, bool GATE>
+template <int BK, int MODE, bool POOL2, bool GATE, bool PW>
 static int launch_tiled(ConvParams& p, hipStream_t s) {
     switch (get_option("conv_tile")) {  // tuning sweeps (tools/conv_bench.py): 0 = heuristic below
-        case 1: return launch_cfg<128, 128, 2, 2, BK, MODE, POOL2, GATE>(p, s);
-        case 2: return launch_cfg<128, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
-        case 3: return launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE>(p, s);
-        case 4: return launch_cfg<128, 32, 4, 1, BK, MODE, POOL2, GATE>(p, s);
+        case 1: return launch_cfg<128, 128, 2, 2, 1, BK, MODE, POOL2, GATE, PW>(p, s);
+        case 2: return launch_cfg<128, 64, 2, 2, 1, BK, MODE, POOL2, GATE, PW>(p, s);
+        case 3: return launch_cfg<64, 64, 2, 2, 1, BK, MODE, POOL2, GATE, PW>(p, s);
+        case 4: return launch_cfg<128, 32, 4, 1, 1, BK, MODE, POOL2, GATE, PW>(p, s);
+        case 5: if constexpr (MODE == 0 && !POOL2 && BK >= 16) return launch_cfg<64, 32, 2, 1, 2, BK, MODE, POOL2, GATE, PW>(p, s); break;
+        case 6: if constexpr (MODE == 0 && !POOL2 && BK >= 32) return launch_cfg<32, 32, 1, 1, 4, BK, MODE, POOL2, GATE, PW>(p, s); break;
+        case 7: if constexpr (MODE == 0 && !POOL2 && BK >= 16) return launch_cfg<32, 64, 1, 2, 2, BK, MODE, POOL2, GATE, PW>(p, s); break;
         default: break;
     }
     // Measured sweep on MI355X (tools/conv_bench.py <net> sweep, in-process A/B over every layer shape of resnet18 @84
@@ -514,24 +555,23 @@ static int launch_tiled(ConvParams& p, hipStream_t s) {
     // the fastest on EVERY layer, including the large MFMA-bound ones (+10..24 % over 128x128 / 128x64, whose 2 blocks
     // per CU cover the per-K-tile bubble worse). 128x32 wins only where the last 64-wide column tile would be mostly
     // padding (Cout <= 32, or e.g. Cout = 80, 96, 144).
+    // (A second K-tile of staged loads in flight was also measured: 30 more VGPRs, -6..-17 % on the short-K layers,
+    // +-2 % on the long-K ones - removed.)
     const double waste64 = (double)(cdiv(p.Cout, 64) * 64 - p.Cout) / p.Cout;
     const double waste32 = (double)(cdiv(p.Cout, 32) * 32 - p.Cout) / p.Cout;
-    // staging depth (conv_prefetch = 2): measured on MI355X with tools/conv_bench.py <net> pf — two K-tiles of loads in
-    // flight cost 30 extra VGPRs (occupancy 8 -> 4 on the short-K layers) and do not pay: -6..-17 % on efficientnet's
-    // BK 8/16 layers, +-2 % on the long-K resnet layers (whose bubble is not load latency). Kept opt-in for A/B only.
-    const bool pf2 = get_option("conv_prefetch") == 2;
-    if (p.Cout <= 32 || waste64 - waste32 >= 0.15)
-        return pf2 ? launch_cfg<128, 32, 4, 1, BK, MODE, POOL2, GATE, 2>(p, s)
-                   : launch_cfg<128, 32, 4, 1, BK, MODE, POOL2, GATE, 1>(p, s);
-    return pf2 ? launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE, 2>(p, s)
-               : launch_cfg<64, 64, 2, 2, BK, MODE, POOL2, GATE, 1>(p, s);
+    if (p.Cout <= 32 || waste64 - waste32 >= 0.15) return launch_cfg<128, 32, 4, 1, 1, BK, MODE, POOL2, GATE, PW>(p, s);
+    return launch_cfg<64, 64, 2, 2, 1, BK, MODE, POOL2, GATE, PW>(p, s);
 }
 
-template <int MODE, bool POOL2, bool GATE>
+template <int MODE, bool POOL2, bool GATE, bool PW>
 static int launch_bk(ConvParams& p, int bk, hipStream_t s) {
-    if (MODE == 1 || bk == 32) return launch_tiled<32, MODE, POOL2, GATE>(p, s);
-    if (MODE == 0 && bk == 16) return launch_tiled<16, 0, POOL2, GATE>(p, s);
-    return launch_tiled<8, 0, POOL2, GATE>(p, s);
+    if constexpr (MODE == 1) {
+        return launch_tiled<32, 1, POOL2, false, false>(p, s);
+    } else {
+        if (bk == 32) return launch_tiled<32, 0, POOL2, GATE, PW>(p, s);
+        if (bk == 16) return launch_tiled<16, 0, POOL2, GATE, PW>(p, s);
+        return launch_tiled<8, 0, POOL2, GATE, PW>(p, s);
+    }
 }
 
 int launch_conv(const ConvDesc& d, hipStream_t s) {
@@ -542,7 +582,8 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
                   "conv: NHWC path needs Cin %% 4 == 0, NCHW stem path needs Cin <= 4 (Cin=%d)", d.Cin);
     ORBIT_REQUIRE(!(d.pool2 && d.residual), "conv: pool2 cannot be combined with a residual input");
     ORBIT_REQUIRE(d.Cout % 4 == 0, "conv: Cout %% 4 != 0 (Cout=%d): the epilogue writes float4 rows", d.Cout);
-    ORBIT_REQUIRE(!(d.gate && d.x_nchw), "conv: gate is only supported on the NHWC path");
+    const bool pw = !d.x_nchw && d.KH == 1 && d.KW == 1 && d.pad_t == 0 && d.pad_l == 0;
+    ORBIT_REQUIRE(!d.gate || (!d.x_nchw && !d.pool2), "conv: the squeeze-excite gate needs the NHWC path without fused pooling");
     const ConvPackGeom g = conv_pack_geom(d.Cin, d.Cout, d.KH, d.KW, d.x_nchw);
     ConvParams p;
     p.x = d.x, p.w = d.w_packed, p.y = d.y, p.scale = d.scale, p.shift = d.shift;
@@ -555,18 +596,18 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     if (d.pool2) {
         ORBIT_REQUIRE(p.HoP > 0 && p.WoP > 0, "conv: pool2 needs Ho, Wo >= 2");
         p.M = d.B * p.HoP * p.WoP * 4;
+        p.fd_per = make_fastdiv((unsigned)(p.HoP * p.WoP)), p.fd_wo = make_fastdiv((unsigned)p.WoP);
     } else {
         p.M = d.B * d.Ho * d.Wo;
+        p.fd_per = make_fastdiv((unsigned)(d.Ho * d.Wo)), p.fd_wo = make_fastdiv((unsigned)d.Wo);
     }
+    p.fd_cin = make_fastdiv((unsigned)d.Cin), p.fd_kw = make_fastdiv((unsigned)d.KW);
+    ORBIT_REQUIRE((long long)d.B * d.H * d.W * d.Cin < (1ll << 40) && p.M > 0, "conv: tensor too large");
     const int bk = choose_bk(d.Cin, d.x_nchw);
-    if (d.x_nchw) {
-        return d.pool2 ? launch_bk<1, true, false>(p, bk, s) : launch_bk<1, false, false>(p, bk, s);
-    }
-    if (d.gate) {
-        ORBIT_REQUIRE(!d.pool2, "conv: gate + pool2 is not instantiated");
-        return launch_bk<0, false, true>(p, bk, s);
-    }
-    return d.pool2 ? launch_bk<0, true, false>(p, bk, s) : launch_bk<0, false, false>(p, bk, s);
+    if (d.x_nchw) return d.pool2 ? launch_bk<1, true, false, false>(p, bk, s) : launch_bk<1, false, false, false>(p, bk, s);
+    if (pw && !d.pool2) return d.gate ? launch_bk<0, false, true, true>(p, bk, s) : launch_bk<0, false, false, true>(p, bk, s);
+    if (d.gate) return launch_bk<0, false, true, false>(p, bk, s);
+    return d.pool2 ? launch_bk<0, true, false, false>(p, bk, s) : launch_bk<0, false, false, false>(p, bk, s);
 }
 
 }  // namespace orbit

@@ -267,12 +267,21 @@ def test_mbconv_front_fused(lib, device, Cin, mid, K, stride, H, W):
     assert (pool.cpu().sum(1) - want.sum((2, 3))).abs().max().item() < 2e-3 * max(1.0, want.sum((2, 3)).abs().max().item())
 
 
-def test_conv_random_shapes(lib, device):
-    """40 seeded random geometries through the implicit-GEMM kernel: every BK path (Cin % 32 / % 16 / % 8 / % 4), all
-    tile choices, odd spatial sizes, strides 1-2, 1x1 / 3x3 / 5x5 taps, asymmetric (TF-SAME) padding, and random
+@pytest.mark.parametrize("tile", [0, 2, 3, 4, 5, 6, 7])
+def test_conv_random_shapes(lib, device, tile):
+    """Forced tile configurations (conv_tile option; 0 = the launch heuristic; 5-7 = K-split waves) x 40 seeded random
+    geometries through the implicit-GEMM kernel: every BK path (Cin % 32 / % 16 / % 8 / % 4), odd spatial sizes, strides 1-2, 1x1 / 3x3 / 5x5 taps, asymmetric (TF-SAME) padding, and random
     subsets of the fused epilogue features (BN, residual, SE gate, ReLU/SiLU, 2x2 pool)."""
     import random
     rnd = random.Random(20240928)
+    lib.orbit_set_option(b"conv_tile", tile)
+    try:
+        _conv_random_cases(lib, device, rnd)
+    finally:
+        lib.orbit_set_option(b"conv_tile", 0)
+
+
+def _conv_random_cases(lib, device, rnd):
     for case in range(40):
         Cin = rnd.choice([4, 8, 12, 16, 24, 40, 48, 64, 80, 96, 144, 160])
         Cout = rnd.choice([4, 8, 16, 24, 40, 64, 72, 128, 192, 320])

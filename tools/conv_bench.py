@@ -28,7 +28,7 @@ SHAPES = {
         ("se_l1", 200, 224, 3, 64, 3, 1, 1, 1), ("se_l2", 200, 112, 64, 64, 3, 1, 1, 0), ("se_l3", 200, 56, 64, 64, 3, 1, 1, 0),
         ("se_l4", 200, 28, 64, 64, 3, 1, 1, 0), ("se_l5", 200, 14, 64, 64, 3, 1, 1, 0)],
 }
-TILES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32"}
+TILES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "64x32k2", 6: "32x32k4", 7: "32x64k2"}
 
 
 def main():
@@ -75,15 +75,8 @@ def main():
                 res[bk] = measure(0)
             lib.orbit_set_option(b"conv_bk", 0)
             line += "  | " + "  ".join("BK<=%d %.1f us (%s)" % (bk, r[0], r[2].split("<")[1][:9]) for bk, r in res.items())
-        if len(sys.argv) > 2 and sys.argv[2] == "pf":
-            res = {}
-            for pf in (1, 2):
-                lib.orbit_set_option(b"conv_prefetch", pf)
-                res[pf] = measure(0)
-            lib.orbit_set_option(b"conv_prefetch", 0)
-            line += "  | pf1 %.1f us  pf2 %.1f us  (%+.0f%%)" % (res[1][0], res[2][0], 100 * (res[1][0] / res[2][0] - 1))
         if sweep:
-            res = {t: measure(t)[0] for t in (1, 2, 3, 4) if not (t == 4 and Cout > 32 and False)}
+            res = {t: measure(t)[0] for t in (2, 3, 4, 5, 6, 7)}
             best = min(res, key=res.get)
             line += "  | " + "  ".join("%s %.1f" % (TILES[t], res[t]) for t in res) + "  -> best %s (%.0f%% vs auto)" % (
                 TILES[best], 100 * (us / res[best] - 1))
