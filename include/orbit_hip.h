@@ -62,6 +62,8 @@ int orbit_device_count(void);
 /* tuning switches (initial value from the environment ORBIT_DW_WINDOW / ORBIT_MBCONV_FUSION / ORBIT_GRAPH):
  *   "dw_window"     register-window depthwise kernel: 1 = where it wins (3x3, stride 1, >= 14 rows; default), 0 = never,
  *                   2 = always
+ *   "dw_lds"        depthwise kernel that stages its input patch in LDS: 1 = stride-1 5x5 and small 3x3 maps (default), 0 = never,
+ *                   2 = whenever the patch fits in 64 KiB
  *   "mbconv_fusion" fused expand+depthwise kernel, default 0 (takes effect for extractors created afterwards)
  *   "graph"         HIP-graph replay of extractor forwards: 0 = never, 1 = always, 2 = adaptive (default: only while an
  *                   eager kernel launch costs > ~12 us of host time on this host)

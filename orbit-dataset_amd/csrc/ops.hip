@@ -232,65 +232,210 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
     }
 }
 
+// ---- depthwise through an LDS input patch -----------------------------------------------------------------------------
+// The streaming kernels above read every input K*NCOL/NOUT times from the vector L1 (10x for 5x5): on the 5x5 layers that
+// L1 traffic, not HBM, is the limit (1.8-2.0 TB/s of algorithmic bytes, tools/dw_bench.py). Here a block stages the input
+// patch of (row chunk) x (full width) x (cs4 channel quads) in LDS once - every input element crosses the L1 exactly
+// once - and the taps are ds_read_b128 (4x the L1's bytes per clock). Pixel stride is padded by one quad so that the
+// lanes of a read (same channel quad, neighbouring pixels) spread over the banks.
+// Thread = channel quad x (4-column output group, row lane); outputs, pooling partials and chunking as dwconv_se_kernel.
+template <int K, int S>
+__global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         float* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift,
+                                                         float* __restrict__ pool_partial, int H, int W, int C,
+                                                         int pad_t, int pad_l, int Ho, int Wo, int act, int cs4,
+                                                         int rows_per_chunk, int G, int IWA) {
+    constexpr int NCOL = 3 * S + K;
+    extern __shared__ __attribute__((aligned(16))) float sml[];
+    const int CSP = cs4 * 4 + 4;                     // padded pixel stride (floats)
+    const int b = blockIdx.z, chunk = blockIdx.y;
+    const int c0 = blockIdx.x * cs4 * 4;
+    const int ho0 = chunk * rows_per_chunk;
+    const int TH = min(Ho, ho0 + rows_per_chunk) - ho0;
+    const int IH = (TH - 1) * S + K;
+    const int IHmax = (rows_per_chunk - 1) * S + K;
+    float* tile = sml;                               // [IH][IWA][CSP]
+    v4f* wl = reinterpret_cast<v4f*>(sml + (size_t)IHmax * IWA * CSP);  // [K*K][cs4]
+    v4f* red = wl + K * K * cs4;                     // [P][cs4]
+    const int tid = threadIdx.x;
+    const int lc = tid % cs4, p = tid / cs4, P = 256 / cs4;
+    const int c = c0 + lc * 4;
+    for (int i = tid; i < K * K * cs4; i += 256) {
+        const int tap = i / cs4, cc = i % cs4;
+        wl[i] = *reinterpret_cast<const v4f*>(w + (size_t)tap * C + c0 + cc * 4);
+    }
+    {   // stage the patch (zero outside the image: TF-SAME / symmetric padding alike). A thread walks the patch pixels
+        // p, p + P, ... of its channel quad; the loads of a batch of 8 are all issued before the first LDS store (one
+        // load -> store round trip per pixel would serialise 5-8 HBM latencies per block)
+        constexpr int U = 8;
+        const int hi0 = ho0 * S - pad_t;
+        const float* xb = x + (size_t)b * H * W * C + c;
+        const int n_items = IH * IWA;
+        const int dr = P / IWA, dc = P % IWA;   // walk step in (row, col)
+        int r = p / IWA, col = p % IWA;
+        for (int i0 = p; i0 < n_items; i0 += U * P) {
+            v4f v[U];
+            int dst[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const bool in = i0 + u * P < n_items;
+                const int hi = hi0 + r, wi = col - pad_l;
+                v[u] = (v4f){0.f, 0.f, 0.f, 0.f};
+                dst[u] = in ? (r * IWA + col) * CSP + lc * 4 : -1;
+                if (in && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                    v[u] = *reinterpret_cast<const v4f*>(xb + ((size_t)hi * W + wi) * C);
+                r += dr, col += dc;
+                if (col >= IWA) col -= IWA, ++r;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (dst[u] >= 0) *reinterpret_cast<v4f*>(tile + dst[u]) = v[u];
+        }
+    }
+    __syncthreads();
+    v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, psum = {0.f, 0.f, 0.f, 0.f};
+    if (scale) sc = *reinterpret_cast<const v4f*>(scale + c);
+    if (shift) sh = *reinterpret_cast<const v4f*>(shift + c);
+    const int RL = P / G;                            // row lanes
+    const int g = p % G, rl = p / G;
+    float* yb = y + (size_t)b * Ho * Wo * C + c;
+    if (rl < RL) {
+        for (int ro = rl; ro < TH; ro += RL) {
+            v4f acc[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+            const float* t0 = tile + ((size_t)(ro * S) * IWA + g * 4 * S) * CSP + lc * 4;
+            const v4f* wk = wl + lc;
+            // a real loop over the tap rows: fully unrolled, the compiler hoists all K*(NCOL + K) LDS reads (260 VGPRs,
+            // one wave per SIMD); one tap row is NCOL + K reads in flight and 4*K quad FMAs
+#pragma unroll 1
+            for (int kh = 0; kh < K; ++kh) {
+                v4f col[NCOL];
+#pragma unroll
+                for (int q = 0; q < NCOL; ++q) col[q] = *reinterpret_cast<const v4f*>(t0 + q * CSP);
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) {
+                    const v4f f = wk[kw * cs4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) acc[j] += col[j * S + kw] * f;
+                }
+                t0 += IWA * CSP;
+                wk += K * cs4;
+            }
+            const int ho = ho0 + ro;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int wo = g * 4 + j;
+                if (wo < Wo) {
+                    v4f o = acc[j] * sc + sh;
+                    o[0] = act_fn(o[0], act), o[1] = act_fn(o[1], act), o[2] = act_fn(o[2], act), o[3] = act_fn(o[3], act);
+                    *reinterpret_cast<v4f*>(yb + ((size_t)ho * Wo + wo) * C) = o;
+                    psum += o;
+                }
+            }
+        }
+    }
+    if (pool_partial == nullptr) return;
+    red[p * cs4 + lc] = psum;
+    __syncthreads();
+    if (tid < cs4) {
+        v4f t = red[tid];
+        for (int l = 1; l < P; ++l) t += red[l * cs4 + tid];
+        *reinterpret_cast<v4f*>(pool_partial + ((size_t)b * gridDim.y + chunk) * C + c0 + tid * 4) = t;
+    }
+}
+
 // squeeze-excite gate from pooling partials: pooled[c] = (sum_chunks partial[b][chunk][c]) / HW, then
 // g = sigmoid(W2 silu(W1 pooled + b1) + b2). w2t is W2 transposed to [R][C] so the second layer reads coalesced.
+// One block per frame; the block pulls both weight matrices (up to 2 x 221 KB at C = 1152) through one CU's L1, so the
+// kernel is a chain of L2 latencies: everything is float4 and every phase keeps 16-20 independent loads per lane in
+// flight (layer 1: one wave per hidden unit, four units at a time; layer 2: eight hidden units per step).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float se_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float se_wave_sum(float v) {  // lane 63 holds the sum; returned wave-uniform
+    v = se_dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = se_dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = se_dpp_add<0x141, 0xf>(v);  // row_half_mirror
+    v = se_dpp_add<0x140, 0xf>(v);  // row_mirror
+    v = se_dpp_add<0x142, 0xa>(v);  // row_bcast:15
+    v = se_dpp_add<0x143, 0xc>(v);  // row_bcast:31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 __global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__ partial, int chunks, float inv_hw,
                                                        const float* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ w2t, const float* __restrict__ b2,
                                                        float* __restrict__ gate, int C, int R) {
-    extern __shared__ float sm2[];  // [C] pooled, [R] hidden
-    float* sp = sm2;
+    extern __shared__ __attribute__((aligned(16))) float sm2[];  // [C] pooled, [R] hidden
+    v4f* sp4 = reinterpret_cast<v4f*>(sm2);
     float* hid = sm2 + C;
-    const int b = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float s = 0.f;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int C4 = C >> 2;
+    const v4f* part4 = reinterpret_cast<const v4f*>(partial) + (size_t)b * chunks * C4;
+    for (int c4 = tid; c4 < C4; c4 += 256) {
+        v4f s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-        for (int k = 0; k < chunks; ++k) s += partial[((size_t)b * chunks + k) * C + c];  // loads batched, adds in order
-        sp[c] = s * inv_hw;
+        for (int k = 0; k < chunks; ++k) s += part4[(size_t)k * C4 + c4];  // loads batched, adds in chunk order
+        sp4[c4] = s * inv_hw;
     }
     __syncthreads();
-    // layer 1: 16 lanes per hidden unit (16 units in flight per pass), 4 independent accumulators per lane
-    const int sub = threadIdx.x & 15, grp = threadIdx.x >> 4;
-    for (int r0 = 0; r0 < R; r0 += 16) {
-        const int r = r0 + grp;
-        float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-        if (r < R) {
-            const float* wr = w1 + (size_t)r * C;
-            int c = sub;
-            for (; c + 48 < C; c += 64) {
-                a0 = fmaf(wr[c], sp[c], a0);
-                a1 = fmaf(wr[c + 16], sp[c + 16], a1);
-                a2 = fmaf(wr[c + 32], sp[c + 32], a2);
-                a3 = fmaf(wr[c + 48], sp[c + 48], a3);
+    // layer 1: wave w takes hidden units w, w + 4, ...; four units at a time, lanes stride the channel quads
+    const int lane = tid & 63, wave = tid >> 6;
+    const v4f* w14 = reinterpret_cast<const v4f*>(w1);
+    for (int r0 = wave; r0 < R; r0 += 16) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int cb = 0; cb < C4; cb += 320) {  // 5 quads per lane per pass: C <= 1280 is a single pass
+            v4f wv[4][5], pv[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int c4 = cb + lane + 64 * j;
+                const bool ok = c4 < C4;
+                pv[j] = ok ? sp4[c4] : (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int r = r0 + 4 * u;
+                    wv[u][j] = (ok && r < R) ? w14[(size_t)r * C4 + c4] : (v4f){0.f, 0.f, 0.f, 0.f};
+                }
             }
-            for (; c < C; c += 16) a0 = fmaf(wr[c], sp[c], a0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const v4f t = wv[u][j] * pv[j];
+                    acc[u] += (t[0] + t[1]) + (t[2] + t[3]);
+                }
         }
-        float s = (a0 + a1) + (a2 + a3);
-        // sum over the 16 lanes of the unit with DPP permutes on the VALU (quad swaps, half-row and row mirrors): every
-        // lane of the 16-lane row ends up with the row sum; __shfl_xor would be four ds_bpermute round trips
-        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0xB1, 0xf, 0xf, false));
-        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x4E, 0xf, 0xf, false));
-        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x141, 0xf, 0xf, false));
-        s += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(s), 0x140, 0xf, 0xf, false));
-        if (r < R && sub == 0) {
-            s += b1[r];
-            hid[r] = s / (1.0f + expf(-s));
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int r = r0 + 4 * u;
+            const float sum = se_wave_sum(acc[u]);
+            if (r < R && lane == 0) {
+                const float t = sum + b1[r];
+                hid[r] = t / (1.0f + expf(-t));
+            }
         }
     }
     __syncthreads();
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float a0 = b2[c], a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    // layer 2: thread = channel quad, eight hidden units (eight independent 16-byte loads) per step
+    const v4f* w24 = reinterpret_cast<const v4f*>(w2t);
+    for (int c4 = tid; c4 < C4; c4 += 256) {
+        v4f a = *reinterpret_cast<const v4f*>(b2 + 4 * c4);
         int r = 0;
-#pragma unroll 2
-        for (; r + 3 < R; r += 4) {
-            a0 = fmaf(w2t[(size_t)r * C + c], hid[r], a0);
-            a1 = fmaf(w2t[(size_t)(r + 1) * C + c], hid[r + 1], a1);
-            a2 = fmaf(w2t[(size_t)(r + 2) * C + c], hid[r + 2], a2);
-            a3 = fmaf(w2t[(size_t)(r + 3) * C + c], hid[r + 3], a3);
+        for (; r + 8 <= R; r += 8) {
+            v4f wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w24[(size_t)(r + u) * C4 + c4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += wv[u] * hid[r + u];
         }
-        for (; r < R; ++r) a0 = fmaf(w2t[(size_t)r * C + c], hid[r], a0);
-        const float s = (a0 + a1) + (a2 + a3);
-        gate[(size_t)b * C + c] = 1.0f / (1.0f + expf(-s));
+        for (; r < R; ++r) a += w24[(size_t)r * C4 + c4] * hid[r];
+        v4f g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = 1.0f / (1.0f + expf(-a[q]));
+        reinterpret_cast<v4f*>(gate)[(size_t)b * C4 + c4] = g;
     }
 }
 
@@ -396,7 +541,11 @@ static int dw_cb4(int C) {
         if (c4 % d == 0) return d;
     return 1;
 }
-int dwconv_se_rows_per_chunk(int Ho) { return Ho >= 56 ? 8 : (Ho >= 14 ? 7 : Ho); }
+int dwconv_se_rows_per_chunk(int Ho) {
+    static const char* env = getenv("ORBIT_DW_RPC");  // tuning experiments only: rows per chunk for maps of <= 28 rows
+    if (env && Ho <= 28 && atoi(env) > 0) return atoi(env) < Ho ? atoi(env) : Ho;
+    return Ho >= 56 ? 8 : (Ho >= 14 ? 7 : Ho);
+}
 int dwconv_se_chunks(int Ho) { return cdiv(Ho, dwconv_se_rows_per_chunk(Ho)); }
 
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
@@ -407,6 +556,42 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     ORBIT_REQUIRE((K == 3 || K == 5) && (stride == 1 || stride == 2), "dwconv_se: K=%d stride=%d not instantiated", K,
                   stride);
     const int cb4 = dw_cb4(C), rpc = dwconv_se_rows_per_chunk(Ho);
+    // LDS-patch kernel (dw_lds: 1 = auto: the 5x5 layers, 0 = never, 2 = whenever it fits): channel quads per block sized
+    // so that a pixel's slice is >= 64 contiguous bytes and enough (column group, row) positions remain per block
+    const int lds_opt = get_option("dw_lds");
+    // measured (tools/dw_bench.py, 200 frames): 5x5 stride 1 -39..-41 % time (28x240, 14x480, 14x672), -15 % at 7x1152;
+    // 3x3 stride 1 on <= 14 rows -10..-20 %; stride 2 and the large 3x3 maps are faster through the streaming kernels
+    if (lds_opt == 2 || (lds_opt == 1 && stride == 1 && (K == 5 || Ho <= 14))) {
+        const int c4 = C / 4;
+        const int G = cdiv(Wo, 4);
+        // channel quads per block: the widest slice (longest contiguous run per pixel) whose (256 / cs4) / G row lanes
+        // cover the chunk's rows in at most two passes; else the narrowest that fits
+        int cs4 = 0;
+        for (int cand : {16, 8, 4}) {
+            if (c4 % cand != 0 || G > 256 / cand) continue;
+            cs4 = cand;
+            if (2 * ((256 / cand) / G) >= rpc) break;
+        }
+        if (cs4 != 0) {
+            const int IWA = (4 * G - 1) * stride + K;
+            const int IHmax = (rpc - 1) * stride + K;
+            const size_t ldsb = ((size_t)IHmax * IWA * (cs4 * 4 + 4)) * sizeof(float) +
+                                (size_t)(K * K * cs4 + 256) * sizeof(float4);
+            if (ldsb <= 64 * 1024) {
+                dim3 gl(c4 / cs4, cdiv(Ho, rpc), B);
+#define ORBIT_DWL(KK, SS)                                                                                          \
+    dwconv_lds_kernel<KK, SS><<<gl, 256, ldsb, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t, pad_l, \
+                                                    Ho, Wo, act, cs4, rpc, G, IWA)
+                if (K == 3 && stride == 1) ORBIT_DWL(3, 1);
+                else if (K == 3) ORBIT_DWL(3, 2);
+                else if (stride == 1) ORBIT_DWL(5, 1);
+                else ORBIT_DWL(5, 2);
+#undef ORBIT_DWL
+                ORBIT_LAUNCH_CHECK();
+                return ORBIT_OK;
+            }
+        }
+    }
     dim3 grid(C / 4 / cb4, cdiv(Ho, rpc), B);
     const size_t lds = (size_t)(K * K * cb4 + (256 / cb4) * cb4) * sizeof(float4);
     // register-window kernel: measured in-process on MI355X against the plain streaming kernel (tools/dw_bench.py):
@@ -440,6 +625,7 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
 int launch_se_gate2(const float* partial, int chunks, int HW, const float* w1, const float* b1, const float* w2t,
                     const float* b2, float* gate, int B, int C, int R, hipStream_t s) {
     ORBIT_REQUIRE(partial && w1 && b1 && w2t && b2 && gate, "se_gate2: null pointer");
+    ORBIT_REQUIRE(C % 4 == 0, "se_gate2: C %% 4 != 0 (C=%d)", C);
     se_gate2_kernel<<<B, 256, (size_t)(C + R) * sizeof(float), s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2,
                                                                      gate, C, R);
     ORBIT_LAUNCH_CHECK();
