@@ -560,6 +560,10 @@ static int launch_tiled(ConvParams& p, hipStream_t s) {
     const double waste64 = (double)(cdiv(p.Cout, 64) * 64 - p.Cout) / p.Cout;
     const double waste32 = (double)(cdiv(p.Cout, 32) * 32 - p.Cout) / p.Cout;
     if (p.Cout <= 32 || waste64 - waste32 >= 0.15) return launch_cfg<128, 32, 4, 1, 1, BK, MODE, POOL2, GATE, PW>(p, s);
+    // fewer 64x64 tiles than CUs (resnet18 @84 layer4: 29 x 8 tiles for 256 CUs): 32x32 tiles with the four waves
+    // splitting K give 4x the blocks (-7..-11 % time on those layers; neutral or worse everywhere else)
+    if constexpr (MODE == 0 && !POOL2 && BK == 32)
+        if (cdiv(p.M, 64) * cdiv(p.Cout, 64) < 256) return launch_cfg<32, 32, 1, 1, 4, BK, MODE, POOL2, GATE, PW>(p, s);
     return launch_cfg<64, 64, 2, 2, 1, BK, MODE, POOL2, GATE, PW>(p, s);
 }
 
