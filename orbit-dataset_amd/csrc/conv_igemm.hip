@@ -202,6 +202,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 
     constexpr int NAS = MODE == 0 ? AR : KPT / 4;
     f32x4 a_stage[NAS], b_stage[BR];
+    f32x4 g_stage[GATE ? AR : 1];  // the gate is multiplied in when the tile is written to LDS: doing it at load time
+                                   // would wait for the loads right there and expose their latency every K-tile
 
     const int nk = p.KT / BK;
     const int ktot = p.KH * p.KW * p.Cin;            // true K (stem mode)
@@ -217,11 +219,14 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 if (PW) ok = ci_ok && a_hi0[i] >= 0;
                 else ok = ci_ok && (unsigned)(a_hi0[i] + ld_kh) < (unsigned)p.H && (unsigned)(a_wi0[i] + ld_kw) < (unsigned)p.W;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) {
-                    v = *reinterpret_cast<const f32x4*>(a_ptr[i] + koff);
-                    if (GATE) v *= *reinterpret_cast<const f32x4*>(g_ptr[i] + ld_ci);
-                }
+                if (ok) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + koff);
                 a_stage[i] = v;
+                if (GATE) {
+                    f32x4 g = {0.f, 0.f, 0.f, 0.f};  // (one shared gate quad per thread when all its rows are in one frame
+                    // was measured: slower on the 14x14 / 7x7 layers, whose tiles straddle frames)
+                    if (ok) g = *reinterpret_cast<const f32x4*>(g_ptr[i] + ld_ci);
+                    g_stage[i] = g;
+                }
             }
         } else {
             // tid / BM is wave-uniform (BM is a multiple of 64): the k decode stays on the scalar unit
@@ -262,7 +267,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
             for (int i = 0; i < AR; ++i)
                 if (BM % RPP == 0 || lrow + RPP * i < BM)
-                    *reinterpret_cast<f32x4*>(A + (lrow + RPP * i) * LDS_STRIDE + c4 * 4) = a_stage[i];
+                    *reinterpret_cast<f32x4*>(A + (lrow + RPP * i) * LDS_STRIDE + c4 * 4) =
+                        GATE ? a_stage[i] * g_stage[i] : a_stage[i];
         } else {
             float* dst = A + (tid % BM) * LDS_STRIDE + (tid / BM) * KPT;
 #pragma unroll

@@ -43,9 +43,12 @@ def main():
         w = torch.randn(Cout, Cin, K, K, device=dev)
         y = torch.empty(B, Ho, Ho, Cout, device=dev)
         sc, sh = torch.rand(Cout, device=dev), torch.rand(Cout, device=dev)
+        use_gate = len(sys.argv) > 2 and sys.argv[2] == "gate" and not nchw and K == 1
+        gate = torch.rand(B, Cin, device=dev) if use_gate else None
 
         def run():
-            _lib.check(lib.orbit_op_conv2d(_lib.dptr(x), nchw, _lib.dptr(w), _lib.dptr(y), _lib.dptr(sc), _lib.dptr(sh), None, None,
+            _lib.check(lib.orbit_op_conv2d(_lib.dptr(x), nchw, _lib.dptr(w), _lib.dptr(y), _lib.dptr(sc), _lib.dptr(sh), None,
+                                           _lib.dptr(gate) if use_gate else None,
                                            B, H, H, Cin, Cout, K, K, stride, pad, pad, Ho, Ho, 1, 0, _lib.stream_handle()))
 
         def measure(tile):
