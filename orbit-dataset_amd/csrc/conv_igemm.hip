@@ -116,7 +116,7 @@ __device__ __forceinline__ void decode_row(const ConvParams& p, int m, int& b, i
 // staged K-tile, each takes every WGK-th 8-deep k-group of it, and the partial accumulators are summed through LDS in
 // the epilogue. That buys 2-4x more (smaller) output tiles for layers whose 64x64 tiling leaves the chip short of blocks
 // (M = 9 800 rows in EfficientNet's 7x7 stages, 1 800-7 200 in resnet18 @84's layer3/4).
-template <int BM, int BN, int WGM, int WGN, int WGK, int BK, int MODE, bool POOL2, bool GATE, bool PW>
+template <int BM, int BN, int WGM, int WGN, int WGK, int BK, int MODE, bool POOL2, bool GATE, bool PW, bool UL>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     static_assert(WGM * WGN * WGK == 4, "4 waves per block");
     static_assert(WGK == 1 || !POOL2, "the fused max-pool is not linear in the K-split partial sums");
@@ -209,7 +209,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const int ktot = p.KH * p.KW * p.Cin;            // true K (stem mode)
     (void)ktot;
 
+    // Staged loads are UNCONDITIONAL: an element outside the image / beyond M / in the K padding is fetched from a safe
+    // address instead and zeroed when the tile is written to LDS (a_mask). Predicated loads compile to an exec-mask
+    // branch per load, and hipcc then waits for earlier loads inside the sequence (vmcnt(0) between the stem's loads,
+    // and at the gate multiply), which exposes the load latency every K-tile.
+    unsigned a_mask = 0;
     auto load_tile = [&]() {
+        unsigned mask = 0;
         if (MODE == 0) {
             const bool ci_ok = ld_ci + c4 * 4 < p.Cin;
             const long koff = (long)ld_tap + ld_ci;
@@ -218,15 +224,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 bool ok;
                 if (PW) ok = ci_ok && a_hi0[i] >= 0;
                 else ok = ci_ok && (unsigned)(a_hi0[i] + ld_kh) < (unsigned)p.H && (unsigned)(a_wi0[i] + ld_kw) < (unsigned)p.W;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (ok) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + koff);
-                a_stage[i] = v;
-                if (GATE) {
-                    f32x4 g = {0.f, 0.f, 0.f, 0.f};  // (one shared gate quad per thread when all its rows are in one frame
-                    // was measured: slower on the 14x14 / 7x7 layers, whose tiles straddle frames)
-                    if (ok) g = *reinterpret_cast<const f32x4*>(g_ptr[i] + ld_ci);
-                    g_stage[i] = g;
+                if (UL) {
+                    a_stage[i] = *reinterpret_cast<const f32x4*>(ok ? a_ptr[i] + koff : p.x);
+                    if (GATE) g_stage[i] = *reinterpret_cast<const f32x4*>(ok ? g_ptr[i] + ld_ci : p.gate);
+                } else {
+                    f32x4 v = {0.f, 0.f, 0.f, 0.f}, g = {0.f, 0.f, 0.f, 0.f};
+                    if (ok) v = *reinterpret_cast<const f32x4*>(a_ptr[i] + koff);
+                    if (GATE && ok) g = *reinterpret_cast<const f32x4*>(g_ptr[i] + ld_ci);
+                    a_stage[i] = v;
+                    if (GATE) g_stage[i] = g;
                 }
+                mask |= (ok ? 1u : 0u) << i;
             }
         } else {
             // tid / BM is wave-uniform (BM is a multiple of 64): the k decode stays on the scalar unit
@@ -238,12 +246,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 const int tap = (int)fdiv((unsigned)k, p.fd_cin), ci = k - tap * p.Cin;
                 const int kh = (int)fdiv((unsigned)tap, p.fd_kw), kw = tap - kh * p.KW;
                 const int hi = a_hi0[0] + kh, wi = a_wi0[0] + kw;
-                float v = 0.f;
-                if (k < ktot && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                    v = a_ptr[0][(size_t)ci * plane + hi * p.W + wi];
-                a_stage[j >> 2][j & 3] = v;
+                const bool ok = k < ktot && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                if (UL) {
+                    a_stage[j >> 2][j & 3] = a_ptr[0][ok ? ci * plane + hi * p.W + wi : 0];
+                } else {
+                    float v = 0.f;
+                    if (ok) v = a_ptr[0][ci * plane + hi * p.W + wi];
+                    a_stage[j >> 2][j & 3] = v;
+                }
+                mask |= (ok ? 1u : 0u) << j;
             }
         }
+        a_mask = mask;
 #pragma unroll
         for (int j = 0; j < BR; ++j)
             b_stage[j] = *reinterpret_cast<const f32x4*>(b_ptr + ((size_t)(RPP * j) * p.KT + ld_k));
@@ -263,16 +277,24 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     auto store_tile = [&](int buf) {
         float* A = As + buf * BM * LDS_STRIDE;
         float* Bq = Bs + buf * BN * LDS_STRIDE;
+        const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
         if (MODE == 0) {
 #pragma unroll
             for (int i = 0; i < AR; ++i)
-                if (BM % RPP == 0 || lrow + RPP * i < BM)
+                if (BM % RPP == 0 || lrow + RPP * i < BM) {
+                    const f32x4 v = GATE ? a_stage[i] * g_stage[i] : a_stage[i];
                     *reinterpret_cast<f32x4*>(A + (lrow + RPP * i) * LDS_STRIDE + c4 * 4) =
-                        GATE ? a_stage[i] * g_stage[i] : a_stage[i];
+                        (!UL || ((a_mask >> i) & 1u)) ? v : zero;
+                }
         } else {
             float* dst = A + (tid % BM) * LDS_STRIDE + (tid / BM) * KPT;
 #pragma unroll
-            for (int j = 0; j < KPT / 4; ++j) *reinterpret_cast<f32x4*>(dst + 4 * j) = a_stage[j];
+            for (int j = 0; j < KPT / 4; ++j) {
+                f32x4 v = a_stage[j];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = (!UL || ((a_mask >> (4 * j + q)) & 1u)) ? v[q] : 0.f;
+                *reinterpret_cast<f32x4*>(dst + 4 * j) = v;
+            }
         }
 #pragma unroll
         for (int j = 0; j < BR; ++j)
@@ -507,14 +529,14 @@ void prof_stop(int idx, hipStream_t s) {
     if (idx >= 0 && idx < (int)g_prof_recs.size()) (void)hipEventRecord(g_prof_recs[idx].stop, s);
 }
 
-template <int BM, int BN, int WGM, int WGN, int WGK, int BK, int MODE, bool POOL2, bool GATE, bool PW>
-static int launch_cfg(ConvParams& p, hipStream_t s) {
+template <int BM, int BN, int WGM, int WGN, int WGK, int BK, int MODE, bool POOL2, bool GATE, bool PW, bool UL>
+static int launch_cfg2(ConvParams& p, hipStream_t s) {
     p.m_tiles = cdiv(p.M, BM);
     p.n_tiles = cdiv(p.Cout, BN);
     const size_t lds_pipe = (size_t)2 * (BM + BN) * (BK + 4) * sizeof(float);
     const size_t lds_epi = (size_t)WGK * (POOL2 ? BM / 4 : BM) * (BN + 4) * sizeof(float);
     const size_t lds = lds_pipe > lds_epi ? lds_pipe : lds_epi;
-    auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, WGK, BK, MODE, POOL2, GATE, PW>;
+    auto kern = conv_igemm_kernel<BM, BN, WGM, WGN, WGK, BK, MODE, POOL2, GATE, PW, UL>;
     static bool attr_set = false;  // >64 KiB dynamic LDS needs the opt-in once per kernel
     if (!attr_set && lds > 64 * 1024) {
         ORBIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -542,6 +564,19 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
     }
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
+}
+
+template <int BM, int BN, int WGM, int WGN, int WGK, int BK, int MODE, bool POOL2, bool GATE, bool PW>
+static int launch_cfg(ConvParams& p, hipStream_t s) {
+    // staged loads unconditional (+ zeroing at the LDS store) or predicated. In-process A/B on MI355X
+    // (tools/conv_bench.py <net> ab conv_uncond): the gated projections gain +8..21 % from the unconditional form (the
+    // gate and tile loads then share one wait), plain 1x1 convs are neutral, 3x3 convs and the stems lose 1-4 % to the
+    // extra selects.
+    // conv_uncond: 1 = that rule (default), 0 = never, 2 = always.
+    const int opt = get_option("conv_uncond");
+    if (opt == 2 || (opt == 1 && GATE))
+        return launch_cfg2<BM, BN, WGM, WGN, WGK, BK, MODE, POOL2, GATE, PW, true>(p, s);
+    return launch_cfg2<BM, BN, WGM, WGN, WGK, BK, MODE, POOL2, GATE, PW, false>(p, s);
 }
 
 template <int BK, int MODE, bool POOL2, bool GATE, bool PW>

@@ -43,7 +43,7 @@ def main():
         w = torch.randn(Cout, Cin, K, K, device=dev)
         y = torch.empty(B, Ho, Ho, Cout, device=dev)
         sc, sh = torch.rand(Cout, device=dev), torch.rand(Cout, device=dev)
-        use_gate = len(sys.argv) > 2 and sys.argv[2] == "gate" and not nchw and K == 1
+        use_gate = len(sys.argv) > 2 and sys.argv[2] in ("gate", "abgate") and not nchw and K == 1
         gate = torch.rand(B, Cin, device=dev) if use_gate else None
 
         def run():
@@ -78,6 +78,16 @@ def main():
                 res[bk] = measure(0)
             lib.orbit_set_option(b"conv_bk", 0)
             line += "  | " + "  ".join("BK<=%d %.1f us (%s)" % (bk, r[0], r[2].split("<")[1][:9]) for bk, r in res.items())
+        if len(sys.argv) > 2 and sys.argv[2] in ("ab", "abgate"):  # in-process A/B of a runtime option (interleaved)
+            opt = sys.argv[3].encode()
+            res = {0: [], 1: []}
+            for rep_ in range(3):
+                for v in (0, 1):
+                    lib.orbit_set_option(opt, 2 * v if sys.argv[3] == "conv_uncond" else v)
+                    res[v].append(measure(0)[0])
+            a0, a1 = min(res[0]), min(res[1])
+            line += "  | %s=0 %.1f us  =1 %.1f us  (%+.1f%%)" % (sys.argv[3], a0, a1, 100 * (a0 / a1 - 1))
+            lib.orbit_set_option(opt, 1)
         if sweep:
             res = {t: measure(t)[0] for t in (2, 3, 4, 5, 6, 7)}
             best = min(res, key=res.get)
