@@ -71,8 +71,8 @@ int orbit_device_count(void);
  *                   4 = 128x32 (tuning sweeps only)
  *   "conv_bk"       cap the K-tile width: 0 = widest of 32/16/8 dividing Cin (default), 8, 16, 32 (tuning sweeps only;
  *                   read when weights are packed AND at launch, so set it before creating/finalizing an extractor)
- *   "conv_uncond"   staged conv loads unconditional + zeroed at the LDS store: 1 = gated projections only (default),
- *                   0 = never, 2 = always (A/B)
+ *   "conv_uncond"   staged conv loads without predicates: 1 = pointwise convs only (default), 0 = never,
+ *                   2 = everywhere (A/B)
  *   "head_lds"      1 (default) = the distance kernel stages the class weights in LDS for launches with >= 64 query
  *                   rows; 0 = always the one-wave-per-row form */
 int orbit_set_option(const char* name, int value);

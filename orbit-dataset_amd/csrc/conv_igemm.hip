@@ -169,7 +169,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     if (MODE == 0) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
-            const int m = m0 + lrow + RPP * i;
+            // pointwise + UL: rows beyond M are clamped to the last row instead of predicated - what they compute is never
+            // stored, and the staging path then has no predicate, mask or select at all
+            const int m = (PW && UL) ? min(m0 + lrow + RPP * i, p.M - 1) : m0 + lrow + RPP * i;
             const bool ok = m < p.M && (BM % RPP == 0 || lrow + RPP * i < BM);
             int b = 0, ho = 0, wo = 0;
             long off;
@@ -224,7 +226,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 bool ok;
                 if (PW) ok = ci_ok && a_hi0[i] >= 0;
                 else ok = ci_ok && (unsigned)(a_hi0[i] + ld_kh) < (unsigned)p.H && (unsigned)(a_wi0[i] + ld_kw) < (unsigned)p.W;
-                if (UL) {
+                if (UL && PW) {  // launch guarantees Cin % BK == 0 here: every element of the tile exists
+                    a_stage[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + koff);
+                    if (GATE) g_stage[i] = *reinterpret_cast<const f32x4*>(g_ptr[i] + ld_ci);
+                } else if (UL) {
                     a_stage[i] = *reinterpret_cast<const f32x4*>(ok ? a_ptr[i] + koff : p.x);
                     if (GATE) g_stage[i] = *reinterpret_cast<const f32x4*>(ok ? g_ptr[i] + ld_ci : p.gate);
                 } else {
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 if (BM % RPP == 0 || lrow + RPP * i < BM) {
                     const f32x4 v = GATE ? a_stage[i] * g_stage[i] : a_stage[i];
                     *reinterpret_cast<f32x4*>(A + (lrow + RPP * i) * LDS_STRIDE + c4 * 4) =
-                        (!UL || ((a_mask >> i) & 1u)) ? v : zero;
+                        (!UL || PW || ((a_mask >> i) & 1u)) ? v : zero;
                 }
         } else {
             float* dst = A + (tid % BM) * LDS_STRIDE + (tid / BM) * KPT;
@@ -568,13 +573,15 @@ static int launch_cfg2(ConvParams& p, hipStream_t s) {
 
 template <int BM, int BN, int WGM, int WGN, int WGK, int BK, int MODE, bool POOL2, bool GATE, bool PW>
 static int launch_cfg(ConvParams& p, hipStream_t s) {
-    // staged loads unconditional (+ zeroing at the LDS store) or predicated. In-process A/B on MI355X
-    // (tools/conv_bench.py <net> ab conv_uncond): the gated projections gain +8..21 % from the unconditional form (the
-    // gate and tile loads then share one wait), plain 1x1 convs are neutral, 3x3 convs and the stems lose 1-4 % to the
-    // extra selects.
-    // conv_uncond: 1 = that rule (default), 0 = never, 2 = always.
+    // UL = staged loads without predicates. Pointwise convs (every element of a tile exists once the rows beyond M are
+    // clamped): no predicate, mask or select at all; other convs: loads from a safe address, zeroed at the LDS store.
+    // In-process A/B on MI355X (tools/conv_bench.py <net> ab|abgate conv_uncond): pointwise +1..2 % on most layers,
+    // +16..20 % on the 128x32 projections, gated projections +3..21 % (the gate and tile loads then share one wait;
+    // predicated, hipcc waits for the tile load before it issues the gate load); 3x3 convs and the stems lose 1-4 % to
+    // the selects. conv_uncond: 1 = pointwise only (default), 0 = never, 2 = everywhere.
     const int opt = get_option("conv_uncond");
-    if (opt == 2 || (opt == 1 && GATE))
+    const bool ul_ok = !PW || p.cin_pad == p.Cin;  // the clamped pointwise form has no K-padding predicate
+    if (ul_ok && (opt == 2 || (opt == 1 && PW)))
         return launch_cfg2<BM, BN, WGM, WGN, WGK, BK, MODE, POOL2, GATE, PW, true>(p, s);
     return launch_cfg2<BM, BN, WGM, WGN, WGK, BK, MODE, POOL2, GATE, PW, false>(p, s);
 }
