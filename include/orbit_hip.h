@@ -64,6 +64,8 @@ int orbit_device_count(void);
  *                   2 = always
  *   "dw_lds"        depthwise kernel that stages its input patch in LDS: 1 = stride-1 5x5 and small 3x3 maps (default), 0 = never,
  *                   2 = whenever the patch fits in 64 KiB
+ *   "dw_pipe"       streaming depthwise kernel with unconditional, software-pipelined tap-row loads: 1 = large stride-2
+ *                   layers (default), 0 = never, 2 = always
  *   "mbconv_fusion" fused expand+depthwise kernel, default 0 (takes effect for extractors created afterwards)
  *   "graph"         HIP-graph replay of extractor forwards: 0 = never, 1 = always, 2 = adaptive (default: only while an
  *                   eager kernel launch costs > ~12 us of host time on this host)

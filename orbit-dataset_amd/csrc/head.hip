@@ -32,6 +32,7 @@ struct Option {
 };
 static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"dw_lds", "ORBIT_DW_LDS", 1, false},
+                             {"dw_pipe", "ORBIT_DW_PIPE", 1, false},
                              {"mbconv_fusion", "ORBIT_MBCONV_FUSION", 0, false},
                              {"graph", "ORBIT_GRAPH", 2, false},
                              {"conv_tile", "ORBIT_CONV_TILE", 0, false},

@@ -154,12 +154,13 @@ def test_conv_transpose_detecting(lib, device):
 
 @pytest.mark.parametrize("C,K,stride,HW", [(32, 3, 1, 28), (96, 3, 2, 28), (144, 5, 2, 28), (480, 5, 1, 14),
                                            (672, 5, 2, 14), (1152, 3, 1, 7), (240, 3, 2, 15)])
-@pytest.mark.parametrize("window,patch", [(0, 0), (2, 0), (1, 2)])
-def test_dwconv(lib, device, C, K, stride, HW, window, patch):
-    """the three depthwise kernels (streaming / register-window / LDS input patch) on every EfficientNet-B0 (channels,
-    kernel, stride) combo"""
+@pytest.mark.parametrize("window,patch,pipe", [(0, 0, 0), (2, 0, 0), (1, 2, 0), (0, 0, 2)])
+def test_dwconv(lib, device, C, K, stride, HW, window, patch, pipe):
+    """the four depthwise kernels (streaming / register-window / LDS input patch / software-pipelined streaming) on every
+    EfficientNet-B0 (channels, kernel, stride) combo"""
     lib.orbit_set_option(b"dw_window", window)
     lib.orbit_set_option(b"dw_lds", patch)
+    lib.orbit_set_option(b"dw_pipe", pipe)
     g = torch.Generator().manual_seed(C + K)
     B = 3
     x = torch.randn(B, C, HW, HW, generator=g)
@@ -178,6 +179,7 @@ def test_dwconv(lib, device, C, K, stride, HW, window, patch):
     want = F.silu(F.conv2d(xp, w, None, stride, 0, 1, C) * scale[None, :, None, None] + shift[None, :, None, None])
     lib.orbit_set_option(b"dw_window", 1)
     lib.orbit_set_option(b"dw_lds", 1)
+    lib.orbit_set_option(b"dw_pipe", 1)
     err = (nchw(y.cpu()) - want).abs().max().item()
     assert err < 2e-5, err
 

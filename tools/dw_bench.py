@@ -15,8 +15,10 @@ B = 200
 tot = {0: 0.0, 2: 0.0}
 for name, H, C, K, S in SHAPES:
   line = "%-20s" % name
-  for opt in (0, 2, 0, 2):  # in-process A/B: 0 = streaming / register-window kernels (auto), 2 = LDS-patch kernel
-    lib.orbit_set_option(b"dw_lds", opt)
+  OPT = sys.argv[1].encode() if len(sys.argv) > 1 else b"dw_lds"
+  for opt in (0, 2, 0, 2):  # in-process A/B of one option: 0 vs 2 (dw_lds) / 0 vs 1 (others)
+    lib.orbit_set_option(OPT, opt)
+    if OPT == b"dw_pipe": lib.orbit_set_option(b"dw_lds", 0); lib.orbit_set_option(b"dw_window", 0)
     Ho = -(-H // S)
     pad = max((Ho - 1) * S + K - H, 0) // 2
     x = torch.randn(B, H, H, C, device=dev); w = torch.randn(C, 1, K, K, device=dev)
@@ -32,7 +34,6 @@ for name, H, C, K, S in SHAPES:
     us = e0.elapsed_time(e1) * 100
     gb = 4.0 * B * C * (H * H + Ho * Ho) / 1e9
     tot[opt] += us / 2
-    line += "  %s %7.1f us %5.2f TB/s" % ("lds" if opt else "std", us, gb / (us * 1e-6) / 1e3)
+    line += "  %s %7.1f us %5.2f TB/s" % ("on " if opt else "off", us, gb / (us * 1e-6) / 1e3)
   print(line)
-print("sum of one instance each: std/window (auto) %.1f us, LDS patch %.1f us" % (tot[0], tot[2]))
-lib.orbit_set_option(b"dw_lds", 1)
+print("sum of one instance each: off %.1f us, on %.1f us" % (tot[0], tot[2]))
