@@ -352,6 +352,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             if (g + 1 < NGW) __builtin_amdgcn_sched_group_barrier(0x100, TM + TN, 0);
             __builtin_amdgcn_sched_group_barrier(0x008, 4 * TM * TN, 0);
         }
+        // (s_setprio(1) around this cluster was measured: +-2 % on most layers, -10..-17 % on three of the gated
+        // projections - the co-resident blocks are not role-split enough for the arbiter to help)
     };
 
     load_tile();
