@@ -75,6 +75,8 @@ int orbit_device_count(void);
  *                   read when weights are packed AND at launch, so set it before creating/finalizing an extractor)
  *   "conv_uncond"   staged conv loads without predicates: 1 = pointwise convs only (default), 0 = never,
  *                   2 = everywhere (A/B)
+ *   "conv_splitk"   1 (default) = convs with few output tiles and a long reduction are split over K (partial tiles +
+ *                   a deterministic reduce); 0 = never
  *   "head_lds"      1 (default) = the distance kernel stages the class weights in LDS for launches with >= 64 query
  *                   rows; 0 = always the one-wave-per-row form */
 int orbit_set_option(const char* name, int value);

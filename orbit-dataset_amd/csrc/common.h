@@ -54,7 +54,12 @@ struct ConvDesc {
     int pool2;   // fused 2x2/2 max-pool of the activated output
     int x_nchw;  // stem gather from NCHW frames
     float prof_flop_scale = 1.f;  // algorithmic / executed flops (strided dgrad runs on the zero-inserted grid)
+    float* splitk_ws = nullptr;   // scratch for split-K partial tiles (conv_splitk_floats(d) floats) or nullptr: no split
 };
+// split-K (small output, long reduction): number of K splits launch_conv uses for this conv when scratch is provided
+// (1 = none) and the scratch it needs
+int conv_splitk(const ConvDesc& d);
+size_t conv_splitk_floats(const ConvDesc& d);
 
 // geometry of the packed weight matrix for a conv (shared by pack + launch)
 struct ConvPackGeom {

@@ -23,6 +23,7 @@
 // issues once per 64 cycles per SIMD, so one tile of prefetch hides L2/HBM latency).
 // fp32 in, fp32 accumulate: bit-equivalent to an fmaf chain, which is what the 1e-3 logit parity
 // target needs (no TF32-class path exists on gfx950).
+#include <algorithm>
 #include <cstdlib>
 #include <vector>
 #include "common.h"
@@ -72,6 +73,8 @@ struct ConvParams {
     FastDiv fd_per, fd_wo;   // / (Ho*Wo), / Wo  (pool2: / (HoP*WoP), / WoP)
     FastDiv fd_cin, fd_kw;   // stem mode: / Cin, / KW
     float prof_flop_scale;
+    int ksplit, kt_per_split;  // split-K: blockIdx = split * tiles + tile; raw partial tiles go to part[split][M][Cout]
+    float* part;
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -150,9 +153,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     // One output tile per block. (A persistent form - grid sized to the co-resident blocks, each block walking several
     // tiles and requesting the next tile's first K-tile before its epilogue - was measured on MI355X: 0..-16 % on every
     // layer of resnet18 and efficientnet_b0; the hardware dispatcher's dynamic placement beats the static walk.)
-    const int tile = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
+    const int ntiles = p.m_tiles * p.n_tiles;
+    const int split = p.ksplit > 1 ? blockIdx.x / ntiles : 0;  // consecutive blocks share a K range (and its filter rows)
+    const int tile = xcd_remap(p.ksplit > 1 ? blockIdx.x - split * ntiles : blockIdx.x, ntiles);
     const int m0 = (tile / p.n_tiles) * BM;
     const int n0 = (tile % p.n_tiles) * BN;
+    const int kt0 = split * p.kt_per_split;  // first K-tile of this block
 
     // ---- per-thread gather bookkeeping (rows are fixed for the whole K loop) ----
     // vector mode: thread owns float4 column c4 of rows lrow + RPP*i; a_ptr[i] points at (tap (0,0), channel c4*4) of
@@ -164,7 +170,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     const float* g_ptr[GATE ? AR : 1];
     // wave-uniform K walk of the staging loads (tiles are loaded strictly in order): channel offset inside the tap,
     // tap coordinates, element offset of the tap in the input, element offset in the packed filter row
-    int ld_ci = 0, ld_kh = 0, ld_kw = 0, ld_tap = 0, ld_k = 0;
+    int ld_ci = 0, ld_kh = 0, ld_kw = 0, ld_tap = 0, ld_k = kt0 * BK;
+    if (MODE == 0 && kt0 != 0) {  // split-K: start the walk at K-tile kt0 (one wave-uniform division per block)
+        const int cpt = p.cin_pad / BK, tap = kt0 / cpt;
+        ld_ci = (kt0 - tap * cpt) * BK;
+        ld_kh = tap / p.KW, ld_kw = tap - ld_kh * p.KW;
+        ld_tap = (ld_kh * p.W + ld_kw) * p.Cin;
+    }
 
     if (MODE == 0) {
 #pragma unroll
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     f32x4 g_stage[GATE ? AR : 1];  // the gate is multiplied in when the tile is written to LDS: doing it at load time
                                    // would wait for the loads right there and expose their latency every K-tile
 
-    const int nk = p.KT / BK;
+    const int nk = p.ksplit > 1 ? min(p.KT / BK - kt0, p.kt_per_split) : p.KT / BK;  // K-tiles of this block
     const int ktot = p.KH * p.KW * p.Cin;            // true K (stem mode)
     (void)ktot;
 
@@ -379,8 +391,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn + j * 32 + l31;
         const bool n_ok = n < p.Cout;
-        const float sc = (n_ok && p.scale) ? p.scale[n] : 1.0f;
-        const float sh = (n_ok && p.shift && wk == 0) ? p.shift[n] : 0.0f;  // the shift enters the sum once
+        const bool raw = p.ksplit > 1;  // split-K partial: plain sums, the reduce kernel applies the epilogue
+        const float sc = (n_ok && p.scale && !raw) ? p.scale[n] : 1.0f;
+        const float sh = (n_ok && p.shift && wk == 0 && !raw) ? p.shift[n] : 0.0f;  // the shift enters the sum once
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -415,14 +428,34 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * CS + oc);
 #pragma unroll
                 for (int q = 1; q < WGK; ++q) v += *reinterpret_cast<const f32x4*>(smem + (q * OROWS + r) * CS + oc);
-                if (!POOL2) {
+                if (!POOL2 && p.ksplit <= 1) {
                     if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.Cout + n);
                     v[0] = apply_act(v[0], p.act), v[1] = apply_act(v[1], p.act);
                     v[2] = apply_act(v[2], p.act), v[3] = apply_act(v[3], p.act);
                 }
-                *reinterpret_cast<f32x4*>(p.y + (size_t)m * p.Cout + n) = v;
+                float* yout = p.ksplit > 1 ? p.part + (size_t)split * p.M * p.Cout : p.y;
+                *reinterpret_cast<f32x4*>(yout + (size_t)m * p.Cout + n) = v;
             }
         }
+    }
+}
+
+// ---- split-K: sum of the partial tiles in split order (deterministic) + the conv epilogue -------------------------------
+__global__ __launch_bounds__(256) void conv_splitk_reduce_kernel(const float* __restrict__ part, int S, size_t mn4,
+                                                                 int cout4, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift,
+                                                                 const float* __restrict__ residual, int act,
+                                                                 float* __restrict__ y) {
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < mn4; i += (size_t)gridDim.x * 256) {
+        f32x4 v = p4[i];
+        for (int s2 = 1; s2 < S; ++s2) v += p4[(size_t)s2 * mn4 + i];
+        const int n4 = (int)(i % (size_t)cout4);
+        if (scale) v *= reinterpret_cast<const f32x4*>(scale)[n4];
+        if (shift) v += reinterpret_cast<const f32x4*>(shift)[n4];
+        if (residual) v += reinterpret_cast<const f32x4*>(residual)[i];
+        v[0] = apply_act(v[0], act), v[1] = apply_act(v[1], act), v[2] = apply_act(v[2], act), v[3] = apply_act(v[3], act);
+        reinterpret_cast<f32x4*>(y)[i] = v;
     }
 }
 
@@ -550,11 +583,12 @@ static int launch_cfg2(ConvParams& p, hipStream_t s) {
                                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr_set = true;
     }
-    const int grid = p.m_tiles * p.n_tiles;
+    const int grid = p.m_tiles * p.n_tiles * (p.ksplit > 1 ? p.ksplit : 1);
     if (g_prof_on) {
         char name[48];
         snprintf(name, sizeof(name), "conv_igemm<%d,%d,%d,%s%s%s%s%s>", BM, BN, BK, MODE ? "nchw" : "nhwc",
-                 POOL2 ? ",pool2" : "", GATE ? ",gate" : "", PW ? ",pw" : "", WGK == 2 ? ",k2" : WGK == 4 ? ",k4" : "");
+                 POOL2 ? ",pool2" : "", GATE ? ",gate" : "", PW ? ",pw" : "",
+                 p.ksplit > 1 ? ",splitk" : WGK == 2 ? ",k2" : WGK == 4 ? ",k4" : "");
         ProfRec r;
         r.start = prof_event(), r.stop = prof_event(), r.variant = prof_variant(name);
         const double pix = POOL2 ? (double)p.B * p.HoP * p.WoP * 4 : (double)p.B * p.Ho * p.Wo;
@@ -590,6 +624,7 @@ static int launch_cfg(ConvParams& p, hipStream_t s) {
 
 template <int BK, int MODE, bool POOL2, bool GATE, bool PW>
 static int launch_tiled(ConvParams& p, hipStream_t s) {
+    if (p.ksplit > 1) return launch_cfg<64, 64, 2, 2, 1, BK, MODE, POOL2, GATE, PW>(p, s);  // split-K plans on 64x64 tiles
     switch (get_option("conv_tile")) {  // tuning sweeps (tools/conv_bench.py): 0 = heuristic below
         case 1: return launch_cfg<128, 128, 2, 2, 1, BK, MODE, POOL2, GATE, PW>(p, s);
         case 2: return launch_cfg<128, 64, 2, 2, 1, BK, MODE, POOL2, GATE, PW>(p, s);
@@ -628,6 +663,27 @@ static int launch_bk(ConvParams& p, int bk, hipStream_t s) {
     }
 }
 
+// Split-K plan. A conv whose 64x64 tiling leaves the chip short of blocks but whose reduction is long (resnet18 @84
+// layer3/4: 1 800-7 200 output rows, K = 1 152-4 608; EfficientNet's 7x7 projections) is cut into S K-ranges: S x the
+// blocks, each writing a raw partial tile; conv_splitk_reduce_kernel sums them in split order and applies the epilogue.
+int conv_splitk(const ConvDesc& d) {
+    if (get_option("conv_splitk") == 0 || d.x_nchw || d.pool2 || d.Cout <= 32 || d.Cout % 4 != 0) return 1;
+    const ConvPackGeom g = conv_pack_geom(d.Cin, d.Cout, d.KH, d.KW, 0);
+    const int nk = g.kt / choose_bk(d.Cin, 0);
+    const long tiles = (long)cdiv(d.B * d.Ho * d.Wo, 64) * cdiv(d.Cout, 64);
+    // measured with the reduce pass included (tools/conv_bench.py <net> ab conv_splitk): -11..-18 % time at 232 tiles
+    // (resnet18 @84 layer4), break-even at ~450 tiles (layer3, EfficientNet's 7x7 projections)
+    if (tiles >= 320 || nk < 16) return 1;
+    int S = (int)(1280 / tiles);
+    S = S < 2 ? 2 : (S > 4 ? 4 : S);
+    while (S > 1 && cdiv(nk, S) < 6) --S;
+    return S;
+}
+size_t conv_splitk_floats(const ConvDesc& d) {
+    const int S = conv_splitk(d);
+    return S > 1 ? (size_t)S * d.B * d.Ho * d.Wo * d.Cout : 0;
+}
+
 int launch_conv(const ConvDesc& d, hipStream_t s) {
     ORBIT_REQUIRE(d.x && d.w_packed && d.y, "conv: null pointer");
     ORBIT_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Cout > 0 && d.Ho > 0 && d.Wo > 0,
@@ -658,10 +714,23 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     p.fd_cin = make_fastdiv((unsigned)d.Cin), p.fd_kw = make_fastdiv((unsigned)d.KW);
     ORBIT_REQUIRE((long long)d.B * d.H * d.W * d.Cin < (1ll << 40) && p.M > 0, "conv: tensor too large");
     const int bk = choose_bk(d.Cin, d.x_nchw);
-    if (d.x_nchw) return d.pool2 ? launch_bk<1, true, false, false>(p, bk, s) : launch_bk<1, false, false, false>(p, bk, s);
-    if (pw && !d.pool2) return d.gate ? launch_bk<0, false, true, true>(p, bk, s) : launch_bk<0, false, false, true>(p, bk, s);
-    if (d.gate) return launch_bk<0, false, true, false>(p, bk, s);
-    return d.pool2 ? launch_bk<0, true, false, false>(p, bk, s) : launch_bk<0, false, false, false>(p, bk, s);
+    p.ksplit = d.splitk_ws ? conv_splitk(d) : 1;
+    p.kt_per_split = p.ksplit > 1 ? cdiv(g.kt / bk, p.ksplit) : 0;
+    p.part = d.splitk_ws;
+    int rc;
+    if (d.x_nchw) rc = d.pool2 ? launch_bk<1, true, false, false>(p, bk, s) : launch_bk<1, false, false, false>(p, bk, s);
+    else if (pw && !d.pool2) rc = d.gate ? launch_bk<0, false, true, true>(p, bk, s) : launch_bk<0, false, false, true>(p, bk, s);
+    else if (d.gate) rc = launch_bk<0, false, true, false>(p, bk, s);
+    else rc = d.pool2 ? launch_bk<0, true, false, false>(p, bk, s) : launch_bk<0, false, false, false>(p, bk, s);
+    if (rc != ORBIT_OK || p.ksplit <= 1) return rc;
+    const size_t mn4 = (size_t)p.M * p.Cout / 4;
+    const int blocks = (int)std::min<size_t>((mn4 + 255) / 256, 4096);
+    const int rec = prof_start("conv_splitk_reduce", 0.0, 4.0 * (p.ksplit + 1) * (double)p.M * p.Cout, s);
+    conv_splitk_reduce_kernel<<<blocks, 256, 0, s>>>(p.part, p.ksplit, mn4, p.Cout / 4, p.scale, p.shift, p.residual, p.act,
+                                                     p.y);
+    prof_stop(rec, s);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
 }
 
 }  // namespace orbit
@@ -731,7 +800,12 @@ int orbit_op_conv2d(const float* x, int x_nchw, const float* w, float* y, const 
         d.gate = gate, d.B = B, d.H = H, d.W = W, d.Cin = Cin, d.Cout = Cout, d.KH = KH, d.KW = KW;
         d.stride = stride, d.pad_t = pad_top, d.pad_l = pad_left, d.Ho = Ho, d.Wo = Wo, d.act = act;
         d.pool2 = pool2, d.x_nchw = x_nchw;
+        float* sk = nullptr;
+        const size_t skf = conv_splitk_floats(d);
+        if (skf) ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&sk), skf * sizeof(float), s));
+        d.splitk_ws = sk;
         rc = launch_conv(d, s);
+        if (sk) (void)hipFreeAsync(sk, s);
     }
     (void)hipFreeAsync(wp, s);
     return rc;

@@ -217,8 +217,16 @@ static int build_set_encoder(orbit_extractor* fe, int H, int W) {
 
 // ---- workspace layout ------------------------------------------------------------------------------
 struct WsLayout {
-    size_t buf[3], pooled, gate, fold, total;
+    size_t buf[3], pooled, gate, fold, splitk, total;
 };
+static ConvDesc conv_shape(const Op& o, int B) {  // the fields the split-K plan looks at
+    ConvDesc d;
+    d.x = d.w_packed = d.scale = d.shift = d.residual = d.gate = nullptr, d.y = nullptr;
+    d.B = B, d.H = o.H, d.W = o.W, d.Cin = o.Cin, d.Cout = o.Cout, d.KH = o.KH, d.KW = o.KW;
+    d.stride = o.stride, d.pad_t = o.pad_t, d.pad_l = o.pad_l, d.Ho = o.Ho, d.Wo = o.Wo;
+    d.act = o.act, d.pool2 = o.pool2, d.x_nchw = o.x_nchw;
+    return d;
+}
 static WsLayout ws_layout(const orbit_extractor* fe, int B) {
     WsLayout L;
     size_t off = 0;
@@ -232,6 +240,11 @@ static WsLayout ws_layout(const orbit_extractor* fe, int B) {
     off += align_up((size_t)std::max(fe->max_se_c, 1) * B * sizeof(float), 256);
     L.fold = off;
     off += align_up(2 * fe->fold_floats * sizeof(float), 256);
+    L.splitk = off;  // partial tiles of the largest split-K conv at this batch size
+    size_t skf = 0;
+    for (const Op& o : fe->ops)
+        if (o.kind == OP_CONV) skf = std::max(skf, conv_splitk_floats(conv_shape(o, B)));
+    off += align_up(skf * sizeof(float), 256);
     L.total = off;
     return L;
 }
@@ -483,6 +496,7 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
                 d.B = B, d.H = o.H, d.W = o.W, d.Cin = o.Cin, d.Cout = o.Cout, d.KH = o.KH, d.KW = o.KW;
                 d.stride = o.stride, d.pad_t = o.pad_t, d.pad_l = o.pad_l, d.Ho = o.Ho, d.Wo = o.Wo;
                 d.act = o.act, d.pool2 = o.pool2, d.x_nchw = o.x_nchw;
+                d.splitk_ws = reinterpret_cast<float*>(ws + L.splitk);
                 rc = launch_conv(d, s);
                 break;
             }

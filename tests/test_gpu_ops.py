@@ -272,6 +272,32 @@ def test_mbconv_front_fused(lib, device, Cin, mid, K, stride, H, W):
     assert (pool.cpu().sum(1) - want.sum((2, 3))).abs().max().item() < 2e-3 * max(1.0, want.sum((2, 3)).abs().max().item())
 
 
+@pytest.mark.parametrize("Cin,Cout,K,HW,gated", [(256, 128, 3, 15, False), (512, 512, 3, 6, False), (1152, 192, 1, 7, True),
+                                                 (672, 192, 1, 7, True)])
+def test_conv_split_k(lib, device, Cin, Cout, K, HW, gated):
+    """few output tiles + long reduction -> the split-K path (partial tiles + deterministic reduce with the fused
+    epilogue): against the reference, against the unsplit kernel, and bit-identical run to run"""
+    g = torch.Generator().manual_seed(Cin + Cout)
+    B = 4
+    x = torch.randn(B, Cin, HW, HW, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    kw = dict(scale=torch.rand(Cout, generator=g) + 0.5, shift=torch.randn(Cout, generator=g) * 0.1,
+              residual=torch.randn(B, Cout, HW, HW, generator=g), gate=torch.rand(B, Cin, generator=g) if gated else None,
+              act=2 if gated else 1)
+    pad = K // 2
+    want = ref_conv(x, w, 1, pad, pad, HW, HW, **kw)
+    got = run_conv(lib, device, x, w, 1, pad, pad, HW, HW, **kw)
+    again = run_conv(lib, device, x, w, 1, pad, pad, HW, HW, **kw)
+    lib.orbit_set_option(b"conv_splitk", 0)
+    try:
+        unsplit = run_conv(lib, device, x, w, 1, pad, pad, HW, HW, **kw)
+    finally:
+        lib.orbit_set_option(b"conv_splitk", 1)
+    assert torch.equal(got, again)
+    assert (got - want).abs().max().item() < 2e-4
+    assert (got - unsplit).abs().max().item() < 2e-5 and not torch.equal(got, unsplit)  # a different summation order ran
+
+
 @pytest.mark.parametrize("tile", [0, 2, 3, 4, 5, 6, 7])
 def test_conv_random_shapes(lib, device, tile):
     """Forced tile configurations (conv_tile option; 0 = the launch heuristic; 5-7 = K-split waves) x 40 seeded random

@@ -64,7 +64,7 @@ def main():
             lib.orbit_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n))
             nm = ctypes.create_string_buffer(48)
             lib.orbit_prof_variant(0, nm, None, None, None, None)
-            return 1e3 * ms.value / n.value, fl.value / ms.value / 1e9, nm.value.decode()
+            return 1e3 * ms.value / 8, fl.value / ms.value / 1e9, nm.value.decode()  # per run (8 runs), all kernels of the conv
 
         us, tf, nm = measure(0)
         Mr, Kr = B * Ho * Ho, Cin * K * K
