@@ -678,6 +678,8 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
             cs4 = cand;
             if (2 * ((256 / cand) / G) >= rpc) break;
         }
+        static const char* cs_env = getenv("ORBIT_DW_CS4");  // tuning experiments only
+        if (cs_env && atoi(cs_env) > 0 && c4 % atoi(cs_env) == 0 && G <= 256 / atoi(cs_env)) cs4 = atoi(cs_env);
         if (cs4 != 0) {
             const int IWA = (4 * G - 1) * stride + K;
             const int IHmax = (rpc - 1) * stride + K;
