@@ -338,7 +338,12 @@ def main():
             settling += 10
             if os.environ.get("ORBIT_BENCH_TRACE"):
                 print("settle chunk: %.2f ms/step" % (1e2 * dt), file=sys.stderr)
-            if prev is not None and dt >= 0.97 * prev:
+            done = prev is not None and dt >= 0.97 * prev
+            if dist is not None:  # every rank runs the same number of chunks (the training step holds a collective)
+                flag = torch.tensor([1.0 if done else 0.0], device=device)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                done = bool(flag.item() > 0.5)
+            if done:
                 break
             prev = dt
     for i in range(args.warmup):
