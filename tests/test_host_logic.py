@@ -131,3 +131,24 @@ def test_learner_cli_flags_match_reference_names():
         verify_args(p.parse_args(["--mode", "train"]))
     m, ci = mean_ci([0.5, 0.7])
     assert abs(m - 0.6) < 1e-12 and abs(ci - 1.96 * 0.1 / 2 ** 0.5) < 1e-12
+
+
+def test_mark_parameters_changed():
+    """fused optimizers do not bump tensor versions, so the plans' (data_ptr, _version) stamps would miss their updates:
+    the helper invalidates every native plan and the FiLM generator's cached upload"""
+    import types
+    from orbit_dataset_amd.optim import mark_parameters_changed
+    p = torch.nn.Parameter(torch.randn(4))
+    p.grad = torch.randn(4)
+    v0 = p._version
+    torch.optim.Adam([p], lr=0.1, fused=True).step()
+    assert p._version == v0  # the hazard this guards against (if torch ever changes this, the hook is merely redundant)
+    net = torch.nn.Module()
+    net.__dict__["_plans"] = {(8, 8): types.SimpleNamespace(stamp=("x",))}
+    gen = torch.nn.Module()
+    gen.__dict__["_stamp"] = ("y",)
+    root = torch.nn.Module()
+    root.a, root.b = net, gen
+    mark_parameters_changed(root)
+    assert net.__dict__["_plans"][(8, 8)].stamp is None and gen.__dict__["_stamp"] is None
+
