@@ -66,7 +66,10 @@ int orbit_device_count(void);
  *                   2 = whenever the patch fits in 64 KiB
  *   "dw_pipe"       streaming depthwise kernel with unconditional, software-pipelined tap-row loads: 1 = large stride-2
  *                   layers (default), 0 = never, 2 = always
- *   "mbconv_fusion" fused expand+depthwise kernel, default 0 (takes effect for extractors created afterwards)
+ *   "mbconv_fusion" fused expand+depthwise kernel (csrc/mbconv.hip): 2 (default) = where it is measured faster than the
+ *                   kernel pair (EfficientNet's first stride-2 block, 16 -> 96 channels at 112x112: -20 %), 1 = every
+ *                   supported block, 0 = never. Read when an extractor is created. A fused block has no training form:
+ *                   create the extractor with 0 for orbit_extractor_train_forward (the Python modules do)
  *   "graph"         HIP-graph replay of extractor forwards: 0 = never, 1 = always, 2 = adaptive (default: only while an
  *                   eager kernel launch costs > ~12 us of host time on this host)
  *   "conv_tile"     force the implicit-GEMM block tile: 0 = heuristic (default), 1 = 128x128, 2 = 128x64, 3 = 64x64,
@@ -80,6 +83,8 @@ int orbit_device_count(void);
  *   "head_lds"      1 (default) = the distance kernel stages the class weights in LDS for launches with >= 64 query
  *                   rows; 0 = always the one-wave-per-row form */
 int orbit_set_option(const char* name, int value);
+/* current value of an option (after its environment default was applied), -1 for an unknown name */
+int orbit_get_option(const char* name);
 
 /* ---- prototype head ---------------------------------------------------------------------------- */
 /* Per-class sums of per-clip mean-pooled support features.

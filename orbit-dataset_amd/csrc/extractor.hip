@@ -80,7 +80,14 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
     const float eps = 1e-3f;
     // The fused expand+depthwise kernel (csrc/mbconv.hip) is parity-green but, as measured on MI355X, slower than the
     // two tuned kernels it replaces (2.6 ms vs 1.7 ms per 200-frame forward over the five eligible blocks): opt-in.
-    const bool fuse_front = get_option("mbconv_fusion") != 0;
+    // fused expand + depthwise (csrc/mbconv.hip): 1 = every supported block, 2 = only where the fused kernel is measured
+    // faster than the pair (tools/mb_bench.py: 16 -> 96 channels, 3x3 stride 2 at 112x112: 461 vs 587 us per 200 frames;
+    // the other four eligible blocks are 5-140 % slower fused), 0 = never
+    const int fuse_opt = get_option("mbconv_fusion");
+    auto fuse_front_ok = [&](int cin, int mid, int K, int stride) {
+        if (fuse_opt == 0 || !mbconv_front_supported(cin, mid, K, stride)) return false;
+        return fuse_opt == 1 || (cin == 16 && K == 3 && stride == 2);
+    };
     int h, w, pt, pl;
     same_pad(H, 3, 2, h, pt);
     same_pad(W, 3, 2, w, pl);
@@ -151,7 +158,7 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
             int ho, wo;
             const int bn1 = fe->add_bn(p + ".bn1", mid, eps, false);
             int se_chunks;
-            if (fuse_front && mbconv_front_supported(cin, mid, K, stride)) {
+            if (fuse_front_ok(cin, mid, K, stride)) {
                 // expand + depthwise in one kernel: the 6x-expanded tensor never leaves LDS (csrc/mbconv.hip)
                 Op o;
                 o.kind = OP_MBFRONT, o.in = cur, o.out = t2, o.H = h, o.W = w, o.Cin = cin, o.Cout = mid;

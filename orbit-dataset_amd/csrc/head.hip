@@ -33,7 +33,7 @@ struct Option {
 static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"dw_lds", "ORBIT_DW_LDS", 1, false},
                              {"dw_pipe", "ORBIT_DW_PIPE", 1, false},
-                             {"mbconv_fusion", "ORBIT_MBCONV_FUSION", 0, false},
+                             {"mbconv_fusion", "ORBIT_MBCONV_FUSION", 2, false},
                              {"graph", "ORBIT_GRAPH", 2, false},
                              {"conv_tile", "ORBIT_CONV_TILE", 0, false},
                              {"conv_bk", "ORBIT_CONV_BK", 0, false},
@@ -401,6 +401,10 @@ int orbit_set_option(const char* name, int value) {
     ORBIT_REQUIRE(o != nullptr, "set_option: unknown option '%s'", name);
     o->value = value;
     return ORBIT_OK;
+}
+int orbit_get_option(const char* name) {
+    if (!name) return -1;
+    return find_option(name) ? get_option(name) : -1;
 }
 const char* orbit_last_error(void) { return err_buf(); }
 

@@ -50,7 +50,6 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
     constexpr int NCOL = (NOUT - 1) * S + K;
     constexpr int ES = 36;                          // Es row stride (floats)
     static_assert(NOUT >= 1 && TW % NOUT == 0 && 32 / SEG_PER_ROW == TH, "tile/thread mapping");
-    static_assert(PT <= 8, "each wave owns at most two patch row-tiles");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int XS = p.Cin + 4;                       // Xs / Ws row stride (floats)
@@ -69,17 +68,31 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
     const int cin4 = p.Cin >> 2;
 
     // ---- stage the input patch (zero outside the image / beyond P) and the pixel validity flags
+    // (loads of a batch of 4 are all issued before the first LDS store: a load -> store round trip per element would
+    // serialise PR * Cin / 1024 HBM latencies per block)
     const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
-    for (int i = tid; i < PR * cin4; i += 256) {
-        const int px = i / cin4, c4 = i - px * cin4;
-        v4f v = {0.f, 0.f, 0.f, 0.f};
-        if (px < P) {
-            const int iy = px / IW, ix = px - iy * IW;
-            const int hi = hi0 + iy, wi = wi0 + ix;
-            if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
-                v = *reinterpret_cast<const v4f*>(xb + ((size_t)hi * p.W + wi) * p.Cin + c4 * 4);
+    for (int i0 = tid; i0 < PR * cin4; i0 += 4 * 256) {
+        v4f v[4];
+        int dst[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * 256;
+            v[u] = (v4f){0.f, 0.f, 0.f, 0.f};
+            dst[u] = -1;
+            if (i < PR * cin4) {
+                const int px = i / cin4, c4 = i - px * cin4;
+                dst[u] = px * XS + c4 * 4;
+                if (px < P) {
+                    const int iy = px / IW, ix = px - iy * IW;
+                    const int hi = hi0 + iy, wi = wi0 + ix;
+                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
+                        v[u] = *reinterpret_cast<const v4f*>(xb + ((size_t)hi * p.W + wi) * p.Cin + c4 * 4);
+                }
+            }
         }
-        *reinterpret_cast<v4f*>(Xs + px * XS + c4 * 4) = v;
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (dst[u] >= 0) *reinterpret_cast<v4f*>(Xs + dst[u]) = v[u];
     }
     for (int px = tid; px < PR; px += 256) {
         bool ok = false;
@@ -97,21 +110,42 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
     const int ngrp = p.Cin >> 3;
     const int tiles = gridDim.x;
 
+    // chunk weights travel through registers one chunk ahead: requested at the top of a chunk, written to LDS at the top
+    // of the next one, so their latency hides under the MFMA and depthwise phases (loaded in place at the top of every
+    // chunk it was 1-2 us of exposed latency per chunk)
+    constexpr int WR = 2;                       // expand-weight quads per thread: 32 rows x Cin/4 <= 512 (Cin <= 64)
+    v4f wreg[WR], dreg = {0.f, 0.f, 0.f, 0.f};
+    auto load_weights = [&](int c0) {
+#pragma unroll
+        for (int u = 0; u < WR; ++u) {
+            const int i = tid + u * 256;
+            wreg[u] = (v4f){0.f, 0.f, 0.f, 0.f};
+            if (i < 32 * cin4) {
+                const int r = i / cin4, c4 = i - r * cin4;
+                if (c0 + r < p.mid) wreg[u] = *reinterpret_cast<const v4f*>(p.w1 + (size_t)(c0 + r) * p.Cin + c4 * 4);
+            }
+        }
+        dreg = (v4f){0.f, 0.f, 0.f, 0.f};
+        if (tid < K * K * 8) {
+            const int tap = tid >> 3, q = tid & 7;
+            if (c0 + q * 4 < p.mid) dreg = *reinterpret_cast<const v4f*>(p.wdw + (size_t)tap * p.mid + c0 + q * 4);
+        }
+    };
+    load_weights(0);
+
     for (int c0 = 0; c0 < p.mid; c0 += 32) {
         // ---- chunk weights: expand rows c0..c0+31 (zero rows past mid), depthwise taps
-        for (int i = tid; i < 32 * cin4; i += 256) {
-            const int r = i / cin4, c4 = i - r * cin4;
-            v4f v = {0.f, 0.f, 0.f, 0.f};
-            if (c0 + r < p.mid) v = *reinterpret_cast<const v4f*>(p.w1 + (size_t)(c0 + r) * p.Cin + c4 * 4);
-            *reinterpret_cast<v4f*>(Ws + r * XS + c4 * 4) = v;
+#pragma unroll
+        for (int u = 0; u < WR; ++u) {
+            const int i = tid + u * 256;
+            if (i < 32 * cin4) {
+                const int r = i / cin4, c4 = i - r * cin4;
+                *reinterpret_cast<v4f*>(Ws + r * XS + c4 * 4) = wreg[u];
+            }
         }
-        for (int i = tid; i < K * K * 8; i += 256) {
-            const int tap = i >> 3, q = i & 7;
-            v4f v = {0.f, 0.f, 0.f, 0.f};
-            if (c0 + q * 4 < p.mid) v = *reinterpret_cast<const v4f*>(p.wdw + (size_t)tap * p.mid + c0 + q * 4);
-            Ds[i] = v;
-        }
+        if (tid < K * K * 8) Ds[tid] = dreg;
         __syncthreads();  // Xs (first chunk), Ws, Ds visible; previous chunk's readers of Es are done
+        if (c0 + 32 < p.mid) load_weights(c0 + 32);
 
         // ---- expand: E[patch rows][32 ch] = Xs . Ws^T on the fp32 matrix cores; BN1 + SiLU; zero outside the image
         const int ch = c0 + l31;
@@ -145,17 +179,23 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
         v4f acc2[NOUT];
 #pragma unroll
         for (int j = 0; j < NOUT; ++j) acc2[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+        {
+            const float* erow = Es + ((oy * S) * IW + ox0 * S) * ES + lc * 4;
+            const v4f* dk = Ds + lc;
+            // a rolled loop over the tap rows (unrolled, hipcc hoists all K*(NCOL+K) LDS reads: 256 VGPRs at K = 5)
+#pragma unroll 1
+            for (int kh = 0; kh < K; ++kh) {
+                v4f col[NCOL];
 #pragma unroll
-        for (int kh = 0; kh < K; ++kh) {
-            const float* erow = Es + ((oy * S + kh) * IW + ox0 * S) * ES + lc * 4;
-            v4f col[NCOL];
+                for (int q = 0; q < NCOL; ++q) col[q] = *reinterpret_cast<const v4f*>(erow + q * ES);
 #pragma unroll
-            for (int q = 0; q < NCOL; ++q) col[q] = *reinterpret_cast<const v4f*>(erow + q * ES);
+                for (int kw = 0; kw < K; ++kw) {
+                    const v4f f = dk[kw * 8];
 #pragma unroll
-            for (int kw = 0; kw < K; ++kw) {
-                const v4f f = Ds[(kh * K + kw) * 8 + lc];
-#pragma unroll
-                for (int j = 0; j < NOUT; ++j) acc2[j] += col[j * S + kw] * f;
+                    for (int j = 0; j < NOUT; ++j) acc2[j] += col[j * S + kw] * f;
+                }
+                erow += IW * ES;
+                dk += K * 8;
             }
         }
         v4f psum = {0.f, 0.f, 0.f, 0.f};
@@ -185,6 +225,8 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
     }
 }
 
+// (4 x 16 output tiles for stride 2 - better balanced MFMA row tiles, less halo - were measured: 15-40 % SLOWER; the
+// kernel lives on the number of co-resident blocks, not on per-block efficiency)
 static void mb_tile_geom(int stride, int& th, int& tw) { th = stride == 1 ? 8 : 4, tw = 8; }
 
 int mbconv_front_tiles(int Ho, int Wo, int stride) {

@@ -45,10 +45,18 @@ def _ensure_child(module, name, cls=ParamNode):
 class _Plan:
     """One native plan (frame size specific) and the parameter stamp it was last synchronised with."""
 
-    def __init__(self, name, H, W):
+    def __init__(self, name, H, W, trainable=False):
         lib = _lib.load()
         h = ctypes.c_void_p()
-        _lib.check(lib.orbit_extractor_create(name.encode(), H, W, ctypes.byref(h)), "orbit_extractor_create")
+        # the fused MBConv front kernel has no backward form: a plan that will record a tape is built without it
+        prev = lib.orbit_get_option(b"mbconv_fusion")
+        if trainable:
+            lib.orbit_set_option(b"mbconv_fusion", 0)
+        try:
+            _lib.check(lib.orbit_extractor_create(name.encode(), H, W, ctypes.byref(h)), "orbit_extractor_create")
+        finally:
+            if trainable:
+                lib.orbit_set_option(b"mbconv_fusion", prev)
         self.handle = h
         self.stamp = None
         self.workspaces = {}
@@ -132,11 +140,18 @@ class HipNetwork(nn.Module):
         return t if t is not None else node._buffers.get(attr)
 
     # ---- native plan handling ---------------------------------------------------------------------
-    def _plan(self, H, W):
-        plan = self._plans.get((H, W))
+    def _plan(self, H, W, trainable=False):
+        """inference plans may hold fused ops that have no backward form; a forward that records a tape or uses batch
+        statistics gets its own (unfused) plan. Both enumerate the same parameters in the same order."""
+        plan = self._plans.get((H, W, trainable))
         if plan is None:
-            plan = _Plan(self.native_name, H, W)
-            self._plans[(H, W)] = plan
+            plan = _Plan(self.native_name, H, W, trainable)
+            lib = _lib.load()
+            names = [lib.orbit_extractor_param_name(plan.handle, i).decode()
+                     for i in range(lib.orbit_extractor_num_params(plan.handle))]
+            if names != [k for k, _ in self._keys]:
+                raise _lib.OrbitHipError("native plan enumerates different parameters than the module tree")
+            self._plans[(H, W, trainable)] = plan
         return plan
 
     def _stamp(self):
@@ -298,16 +313,16 @@ class HipNetwork(nn.Module):
             raise _lib.OrbitHipError("frames must be on the HIP device (got %s); no CPU fallback" % x.device)
         x = x.contiguous().float()
         B, _, H, W = x.shape
-        plan = self._plan(H, W)
         if film is None and self.film_size > 0:
             film = self._gather_swapped_film()
-        if check_sync or plan.stamp is None:
-            self.sync(plan)
         if film is not None:
             if film[0].numel() != self.film_size or film[1].numel() != self.film_size:
                 raise ValueError("film vectors must have %d elements" % self.film_size)
             film = (film[0].contiguous().float(), film[1].contiguous().float())
         use_tape = B > 0 and self.wants_grad(film)
+        plan = self._plan(H, W, trainable=B > 0 and (use_tape or self.training))
+        if check_sync or plan.stamp is None:
+            self.sync(plan)
         if B > 0 and (use_tape or self.training):
             # batch-statistics BatchNorm and/or a recorded tape: the training runtime (csrc/extractor_train.hip)
             return self._forward_train(plan, x, film, use_tape, self.training, out)

@@ -258,8 +258,8 @@ def test_mbconv_front_fused(lib, device, Cin, mid, K, stride, H, W):
     e = F.silu(F.conv2d(x, w1) * s1[None, :, None, None] + h1[None, :, None, None])
     ep = F.pad(e, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])  # the EXPANDED tensor is zero-padded
     want = F.silu(F.conv2d(ep, wd, None, stride, 0, 1, mid) * s2[None, :, None, None] + h2[None, :, None, None])
-    th = 8 if stride == 1 else 4
-    tiles = -(-Ho // th) * -(-Wo // 8)
+    th, tw = (8, 8) if stride == 1 else (4, 8)
+    tiles = -(-Ho // th) * -(-Wo // tw)
     y = torch.full((B, Ho, Wo, mid), float("nan"), device=device)
     pool = torch.full((B, tiles, mid), float("nan"), device=device)
     dev = [t.to(device).contiguous() for t in (nhwc(x), w1, s1, h1, wd, s2, h2)]
