@@ -54,11 +54,12 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int XS = p.Cin + 4;                       // Xs / Ws row stride (floats)
     float* Xs = smem;                               // [PR][XS]
-    float* Ws = Xs + PR * XS;                       // [32][XS]
-    float* Es = Ws + 32 * XS;                       // [PR][ES]
-    v4f* Ds = reinterpret_cast<v4f*>(Es + PR * ES); // [K*K][8]
-    v4f* red = Ds + K * K * 8;                      // [32][8]
-    unsigned char* valid = reinterpret_cast<unsigned char*>(red + 256);  // [PR] pixel-inside-image flags
+    float* Ws = Xs + PR * XS;                       // [2][32][XS]   (chunk weights are double-buffered: the barrier that
+    float* Es = Ws + 2 * 32 * XS;                   // [PR][ES]       used to close a chunk is gone, see the chunk loop)
+    v4f* Ds = reinterpret_cast<v4f*>(Es + PR * ES); // [2][K*K][8]
+    v4f* redw = Ds + 2 * K * K * 8;                 // [4 waves][64]  wave-private scratch of the pooling reduction
+    v4f* pool_all = redw + 256;                     // [8 chunks][4 waves][8 quads]
+    unsigned char* valid = reinterpret_cast<unsigned char*>(pool_all + 256);  // [PR] pixel-inside-image flags
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
@@ -115,7 +116,19 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
     // chunk it was 1-2 us of exposed latency per chunk)
     constexpr int WR = 2;                       // expand-weight quads per thread: 32 rows x Cin/4 <= 512 (Cin <= 64)
     v4f wreg[WR], dreg = {0.f, 0.f, 0.f, 0.f};
+    // ... and so do the folded BatchNorm vectors of the chunk. NO global load may be issued inside a chunk's phases: hipcc
+    // waits for one with vmcnt(0), which also drains the prefetch issued just before it (that is what made every chunk pay
+    // the full weight-load latency: rocprofv3 showed the waves parked in s_waitcnt / barriers 59 % of their cycles)
+    float s1n = 0.f, h1n = 0.f;
+    v4f s2n = {0.f, 0.f, 0.f, 0.f}, h2n = {0.f, 0.f, 0.f, 0.f};
     auto load_weights = [&](int c0) {
+        {
+            const int ch = c0 + (tid & 31);
+            s1n = ch < p.mid ? p.sc1[ch] : 0.f, h1n = ch < p.mid ? p.sh1[ch] : 0.f;
+            const int cq = c0 + (tid & 7) * 4;
+            s2n = (v4f){0.f, 0.f, 0.f, 0.f}, h2n = (v4f){0.f, 0.f, 0.f, 0.f};
+            if (cq < p.mid) s2n = *reinterpret_cast<const v4f*>(p.sc2 + cq), h2n = *reinterpret_cast<const v4f*>(p.sh2 + cq);
+        }
 #pragma unroll
         for (int u = 0; u < WR; ++u) {
             const int i = tid + u * 256;
@@ -133,30 +146,36 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
     };
     load_weights(0);
 
+    // Two barriers per chunk: (B1) weights + previous chunk's Es readers, (B2) Es complete. Ws / Ds alternate between two
+    // buffers, so a wave that runs ahead into chunk c+1 writes the other pair while slower waves still read chunk c's
+    // (it cannot reach chunk c+2 before everyone passed B1 of c+1); the pooling partials are reduced inside each wave and
+    // parked per chunk, the cross-wave sum happens once after the loop.
     for (int c0 = 0; c0 < p.mid; c0 += 32) {
+        const int ci = c0 >> 5;
+        float* Wc = Ws + (ci & 1) * 32 * XS;
+        v4f* Dc = Ds + (ci & 1) * K * K * 8;
         // ---- chunk weights: expand rows c0..c0+31 (zero rows past mid), depthwise taps
 #pragma unroll
         for (int u = 0; u < WR; ++u) {
             const int i = tid + u * 256;
             if (i < 32 * cin4) {
                 const int r = i / cin4, c4 = i - r * cin4;
-                *reinterpret_cast<v4f*>(Ws + r * XS + c4 * 4) = wreg[u];
+                *reinterpret_cast<v4f*>(Wc + r * XS + c4 * 4) = wreg[u];
             }
         }
-        if (tid < K * K * 8) Ds[tid] = dreg;
+        if (tid < K * K * 8) Dc[tid] = dreg;
+        const float s1 = s1n, h1 = h1n;
+        const v4f s2 = s2n, h2 = h2n;
         __syncthreads();  // Xs (first chunk), Ws, Ds visible; previous chunk's readers of Es are done
         if (c0 + 32 < p.mid) load_weights(c0 + 32);
 
         // ---- expand: E[patch rows][32 ch] = Xs . Ws^T on the fp32 matrix cores; BN1 + SiLU; zero outside the image
-        const int ch = c0 + l31;
-        const bool ch_ok = ch < p.mid;
-        const float s1 = ch_ok ? p.sc1[ch] : 0.f, h1 = ch_ok ? p.sh1[ch] : 0.f;
         for (int t = wave; t < PT; t += 4) {
             f32x16 acc;
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] = 0.f;
             const float* A = Xs + (t * 32 + l31) * XS + lh * 4;
-            const float* Bq = Ws + l31 * XS + lh * 4;
+            const float* Bq = Wc + l31 * XS + lh * 4;
             for (int g = 0; g < ngrp; ++g) {
                 const v4f af = *reinterpret_cast<const v4f*>(A + g * 8);
                 const v4f bf = *reinterpret_cast<const v4f*>(Bq + g * 8);
@@ -164,11 +183,17 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
                 for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[kk], bf[kk], acc, 0, 0, 0);
             }
             // C/D layout: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (patch pixel)
+            // branch-free: SiLU on every element, zeroed through a select (a per-element branch on valid[] costs an exec-mask
+            // branch and a wait each); the four flags of four consecutive patch pixels are one 32-bit LDS read
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int px = t * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                const float e = valid[px] ? silu_f(acc[r] * s1 + h1) : 0.f;
-                Es[px * ES + l31] = e;
+            for (int rq = 0; rq < 4; ++rq) {
+                const int px0 = t * 32 + 8 * rq + 4 * lh;
+                const unsigned vb = *reinterpret_cast<const unsigned*>(valid + px0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float e = silu_f(acc[rq * 4 + j] * s1 + h1);
+                    Es[(px0 + j) * ES + l31] = ((vb >> (8 * j)) & 0xffu) ? e : 0.f;
+                }
             }
         }
         __syncthreads();
@@ -181,7 +206,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
         for (int j = 0; j < NOUT; ++j) acc2[j] = (v4f){0.f, 0.f, 0.f, 0.f};
         {
             const float* erow = Es + ((oy * S) * IW + ox0 * S) * ES + lc * 4;
-            const v4f* dk = Ds + lc;
+            const v4f* dk = Dc + lc;
             // a rolled loop over the tap rows (unrolled, hipcc hoists all K*(NCOL+K) LDS reads: 256 VGPRs at K = 5)
 #pragma unroll 1
             for (int kh = 0; kh < K; ++kh) {
@@ -200,8 +225,6 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
         }
         v4f psum = {0.f, 0.f, 0.f, 0.f};
         if (q_ok) {
-            const v4f s2 = *reinterpret_cast<const v4f*>(p.sc2 + cq);
-            const v4f h2 = *reinterpret_cast<const v4f*>(p.sh2 + cq);
 #pragma unroll
             for (int j = 0; j < NOUT; ++j) {
                 const int wo = tx * TW + ox0 + j;
@@ -213,15 +236,29 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
                 }
             }
         }
-        if (p.pool) red[seg * 8 + lc] = psum;
-        __syncthreads();  // all depthwise reads of Es/Ds done before the next chunk overwrites Ws/Ds (and red complete)
-        if (p.pool && tid < 8 && c0 + tid * 4 < p.mid) {
-            v4f t = red[tid];
+        if (p.pool) {  // this wave's 8 column segments per channel quad, summed in segment order by lanes 0-7
+            redw[wave * 64 + lane] = psum;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS is in-order per wave: the stores above are visible
+            if (lane < 8) {
+                v4f t = redw[wave * 64 + lane];
 #pragma unroll
-            for (int l = 1; l < 32; ++l) t += red[l * 8 + tid];
-            *reinterpret_cast<v4f*>(p.pool + ((size_t)b * tiles + t_idx) * p.mid + c0 + tid * 4) = t;
+                for (int sg = 1; sg < 8; ++sg) t += redw[wave * 64 + sg * 8 + lane];
+                pool_all[(ci * 4 + wave) * 8 + lane] = t;
+            }
         }
-        // red is next written two barriers from here, Es after the barrier at the top of the next chunk
+    }
+    if (p.pool) {
+        __syncthreads();
+        const int nchunk = (p.mid + 31) >> 5;
+        for (int i = tid; i < nchunk * 8; i += 256) {
+            const int ci = i >> 3, q = i & 7;
+            if (ci * 32 + q * 4 < p.mid) {
+                v4f t = pool_all[(ci * 4 + 0) * 8 + q];
+#pragma unroll
+                for (int w2 = 1; w2 < 4; ++w2) t += pool_all[(ci * 4 + w2) * 8 + q];
+                *reinterpret_cast<v4f*>(p.pool + ((size_t)b * tiles + t_idx) * p.mid + ci * 32 + q * 4) = t;
+            }
+        }
     }
 }
 
@@ -237,7 +274,7 @@ int mbconv_front_tiles(int Ho, int Wo, int stride) {
 
 // can this (Cin, K, stride) be served by the fused kernel? (LDS budget: two blocks per CU)
 bool mbconv_front_supported(int Cin, int mid, int K, int stride) {
-    return Cin % 8 == 0 && Cin <= 40 && mid % 4 == 0 && (K == 3 || K == 5) && (stride == 1 || stride == 2);
+    return Cin % 8 == 0 && Cin <= 40 && mid % 4 == 0 && mid <= 256 && (K == 3 || K == 5) && (stride == 1 || stride == 2);
 }
 
 int launch_mbconv_front(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
@@ -255,8 +292,9 @@ int launch_mbconv_front(const float* x, const float* w1, const float* sc1, const
     const int tiles = p.tiles_x * cdiv(Ho, th);
     const int ih = (th - 1) * stride + K, iw = (tw - 1) * stride + K;
     const int pr = (ih * iw + 31) / 32 * 32;
-    const size_t lds = ((size_t)pr * (Cin + 4) + 32 * (Cin + 4) + (size_t)pr * 36) * sizeof(float) +
-                       (size_t)(K * K * 8 + 256) * 16 + pr;
+    ORBIT_REQUIRE(mid <= 256, "mbconv_front: at most 8 chunks of 32 expanded channels (mid=%d)", mid);
+    const size_t lds = ((size_t)pr * (Cin + 4) + 2 * 32 * (Cin + 4) + (size_t)pr * 36) * sizeof(float) +
+                       (size_t)(2 * K * K * 8 + 512) * 16 + pr;
     dim3 grid(tiles, B);
 #define ORBIT_MB(KK, SS, TH_, TW_)                                                                  \
     do {                                                                                            \
