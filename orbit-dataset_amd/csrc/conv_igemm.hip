@@ -73,6 +73,7 @@ struct ConvParams {
     FastDiv fd_per, fd_wo;   // / (Ho*Wo), / Wo  (pool2: / (HoP*WoP), / WoP)
     FastDiv fd_cin, fd_kw;   // stem mode: / Cin, / KW
     float prof_flop_scale;
+    int early_sc;              // epilogue scale/shift loaded before the K loop (conv_early_sc option, A/B)
     int stem_table;            // stem mode: use the interior fast path (conv_stem_fast option, A/B)
     int ksplit, kt_per_split;  // split-K: blockIdx = split * tiles + tile; raw partial tiles go to part[split][M][Cout]
     float* part;
@@ -398,6 +399,19 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         // projections - the co-resident blocks are not role-split enough for the arbiter to help)
     };
 
+    // folded-BatchNorm scale / shift of this wave's output columns: requested before the K loop (conv_early_sc) so the
+    // epilogue does not open with an L2 round trip - on the 1-3 K-tile EfficientNet layers that is a visible share
+    float sc_pre[TN], sh_pre[TN];
+    if (p.early_sc) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn + j * 32 + l31;
+            const bool use = n < p.Cout && p.ksplit <= 1;
+            sc_pre[j] = (use && p.scale) ? p.scale[n] : 1.0f;
+            sh_pre[j] = (use && p.shift && wk == 0) ? p.shift[n] : 0.0f;
+        }
+    }
+
     load_tile();
     store_tile(0);
     __syncthreads();
@@ -422,8 +436,13 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const int n = n0 + wn + j * 32 + l31;
         const bool n_ok = n < p.Cout;
         const bool raw = p.ksplit > 1;  // split-K partial: plain sums, the reduce kernel applies the epilogue
-        const float sc = (n_ok && p.scale && !raw) ? p.scale[n] : 1.0f;
-        const float sh = (n_ok && p.shift && wk == 0 && !raw) ? p.shift[n] : 0.0f;  // the shift enters the sum once
+        float sc, sh;
+        if (p.early_sc) {
+            sc = sc_pre[j], sh = sh_pre[j];
+        } else {
+            sc = (n_ok && p.scale && !raw) ? p.scale[n] : 1.0f;
+            sh = (n_ok && p.shift && wk == 0 && !raw) ? p.shift[n] : 0.0f;  // the shift enters the sum once
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -745,6 +764,7 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     ORBIT_REQUIRE((long long)d.B * d.H * d.W * d.Cin < (1ll << 40) && p.M > 0, "conv: tensor too large");
     const int bk = choose_bk(d.Cin, d.x_nchw);
     p.stem_table = get_option("conv_stem_fast");
+    p.early_sc = get_option("conv_early_sc");
     p.ksplit = d.splitk_ws ? conv_splitk(d) : 1;
     p.kt_per_split = p.ksplit > 1 ? cdiv(g.kt / bk, p.ksplit) : 0;
     p.part = d.splitk_ws;
