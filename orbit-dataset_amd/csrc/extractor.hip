@@ -83,7 +83,7 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
     // fused expand + depthwise (csrc/mbconv.hip): 1 = every supported block, 2 = only where the fused kernel is measured
     // faster than the pair (tools/mb_bench.py, 200 frames: 16 -> 96 channels 3x3/2 at 112x112: 335 vs 553 us; 24 -> 144
     // 3x3/1 at 56x56: 281-306 vs 338-347 us; the 5x5 blocks and 40 -> 240 3x3/2 tie or lose: 282 vs 282, 305 vs 166,
-    // 143 vs 104 us), 0 = never
+    // 143 vs 104 us - fusing the 5x5/2 block as well left the whole-task time unchanged), 0 = never
     const int fuse_opt = get_option("mbconv_fusion");
     auto fuse_front_ok = [&](int cin, int mid, int K, int stride) {
         if (fuse_opt == 0 || !mbconv_front_supported(cin, mid, K, stride)) return false;
