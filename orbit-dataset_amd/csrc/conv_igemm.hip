@@ -73,6 +73,7 @@ struct ConvParams {
     FastDiv fd_per, fd_wo;   // / (Ho*Wo), / Wo  (pool2: / (HoP*WoP), / WoP)
     FastDiv fd_cin, fd_kw;   // stem mode: / Cin, / KW
     float prof_flop_scale;
+    int epi_batch;             // epilogue output rows read / loaded in one batch (conv_epi_batch option, A/B)
     int early_sc;              // epilogue scale/shift loaded before the K loop (conv_early_sc option, A/B)
     int stem_table;            // stem mode: use the interior fast path (conv_stem_fast option, A/B)
     int ksplit, kt_per_split;  // split-K: blockIdx = split * tiles + tile; raw partial tiles go to part[split][M][Cout]
@@ -469,7 +470,38 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const int n = n0 + oc;
         const int mo0 = POOL2 ? (m0 >> 2) : m0;
         const int mout = POOL2 ? (p.M >> 2) : p.M;
-        if (n < p.Cout) {
+        float* yout = p.ksplit > 1 ? p.part + (size_t)split * p.M * p.Cout : p.y;
+        constexpr int ITER = (OROWS + RPO - 1) / RPO;  // output rows per thread (4 for the 64x64 and 128x32 tiles)
+        if (n < p.Cout && p.epi_batch && ITER <= 8) {
+            // batched form: the LDS reads and the residual loads of all of a thread's rows are issued before the first use
+            // (row by row, every row paid an LDS - and with a skip connection an L2 - round trip of its own)
+            f32x4 v[ITER], res[ITER];
+            const bool has_res = !POOL2 && p.ksplit <= 1 && p.residual != nullptr;
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int r = tid / TPO + it * RPO;
+                const bool ok = r < OROWS && mo0 + r < mout;
+                const int rr = ok ? r : 0;
+                v[it] = *reinterpret_cast<const f32x4*>(smem + rr * CS + oc);
+#pragma unroll
+                for (int q = 1; q < WGK; ++q) v[it] += *reinterpret_cast<const f32x4*>(smem + (q * OROWS + rr) * CS + oc);
+                res[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (has_res) res[it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)(ok ? mo0 + r : 0) * p.Cout + n);
+            }
+#pragma unroll
+            for (int it = 0; it < ITER; ++it) {
+                const int r = tid / TPO + it * RPO;
+                if (r < OROWS && mo0 + r < mout) {
+                    f32x4 o = v[it];
+                    if (!POOL2 && p.ksplit <= 1) {
+                        o += res[it];
+                        o[0] = apply_act(o[0], p.act), o[1] = apply_act(o[1], p.act);
+                        o[2] = apply_act(o[2], p.act), o[3] = apply_act(o[3], p.act);
+                    }
+                    *reinterpret_cast<f32x4*>(yout + (size_t)(mo0 + r) * p.Cout + n) = o;
+                }
+            }
+        } else if (n < p.Cout) {
 #pragma unroll 4
             for (int r = tid / TPO; r < OROWS; r += RPO) {
                 const int m = mo0 + r;
@@ -482,7 +514,6 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     v[0] = apply_act(v[0], p.act), v[1] = apply_act(v[1], p.act);
                     v[2] = apply_act(v[2], p.act), v[3] = apply_act(v[3], p.act);
                 }
-                float* yout = p.ksplit > 1 ? p.part + (size_t)split * p.M * p.Cout : p.y;
                 *reinterpret_cast<f32x4*>(yout + (size_t)m * p.Cout + n) = v;
             }
         }
@@ -765,6 +796,7 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     const int bk = choose_bk(d.Cin, d.x_nchw);
     p.stem_table = get_option("conv_stem_fast");
     p.early_sc = get_option("conv_early_sc");
+    p.epi_batch = get_option("conv_epi_batch");
     p.ksplit = d.splitk_ws ? conv_splitk(d) : 1;
     p.kt_per_split = p.ksplit > 1 ? cdiv(g.kt / bk, p.ksplit) : 0;
     p.part = d.splitk_ws;

@@ -41,6 +41,7 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"conv_splitk", "ORBIT_CONV_SPLITK", 1, false},
                              {"conv_stem_fast", "ORBIT_CONV_STEM_FAST", 1, false},
                              {"conv_early_sc", "ORBIT_CONV_EARLY_SC", 1, false},
+                             {"conv_epi_batch", "ORBIT_CONV_EPI_BATCH", 1, false},
                              {"head_lds", "ORBIT_HEAD_LDS", 1, false}};
 static Option* find_option(const char* name) {
     for (Option& o : g_options)
