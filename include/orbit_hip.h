@@ -80,6 +80,9 @@ int orbit_device_count(void);
  *                   2 = everywhere (A/B)
  *   "conv_splitk"   1 (default) = convs with few output tiles and a long reduction are split over K (partial tiles +
  *                   a deterministic reduce); 0 = never
+ *   "conv_stem_fast", "conv_early_sc", "conv_epi_batch"  1 (default) / 0: A/B switches of three conv-kernel details
+ *                   (interior fast path of the NCHW stem gather; epilogue scale/shift requested before the K loop;
+ *                   batched epilogue output pass) - see csrc/conv_igemm.hip
  *   "head_lds"      1 (default) = the distance kernel stages the class weights in LDS for launches with >= 64 query
  *                   rows; 0 = always the one-wave-per-row form */
 int orbit_set_option(const char* name, int value);
