@@ -67,8 +67,8 @@ int orbit_device_count(void);
  *   "dw_pipe"       streaming depthwise kernel with unconditional, software-pipelined tap-row loads: 1 = large stride-2
  *                   layers (default), 0 = never, 2 = always
  *   "mbconv_fusion" fused expand+depthwise kernel (csrc/mbconv.hip): 2 (default) = where it is measured faster than the
- *                   kernel pair (EfficientNet's first stride-2 block, 16 -> 96 channels at 112x112: -20 %), 1 = every
- *                   supported block, 0 = never. Read when an extractor is created. A fused block has no training form:
+ *                   kernel pair (EfficientNet's first two MBConv blocks: -40 % / -12 %), 1 = every supported block and
+ *                   the stem + first depthwise (slower), 0 = never. Read when an extractor is created. A fused block has no training form:
  *                   create the extractor with 0 for orbit_extractor_train_forward (the Python modules do)
  *   "graph"         HIP-graph replay of extractor forwards: 0 = never, 1 = always, 2 = adaptive (default: only while an
  *                   eager kernel launch costs > ~12 us of host time on this host)
@@ -207,6 +207,14 @@ int orbit_op_mbconv_front(const float* x, const float* w1, const float* scale1, 
                           const float* wdw, const float* scale2, const float* shift2, float* y, float* pool_partial,
                           int B, int H, int W, int Cin, int mid, int K, int stride, int pad_top, int pad_left,
                           int Ho, int Wo, orbit_stream_t stream);
+/* The stem form of the same kernel (timm tf_efficientnet_b0: conv_stem -> bn1 -> SiLU -> blocks.0.0.conv_dw -> bn1 ->
+ * SiLU, reached from model/feature_extractors.py:39-43): frames NCHW [B][3][FH][FW], w_stem torch [mid][3][3][3]
+ * (3x3 stride 2, padding spad_top / spad_left before, the rest after), depthwise 3x3 stride 1 on the stem's H x W output
+ * grid; y NHWC [B][Ho][Wo][mid]; pool_partial [B][ceil(Ho/8)*ceil(Wo/8)][mid] or NULL. The stem output never reaches HBM. */
+int orbit_op_stem_dw_front(const float* frames, const float* w_stem, const float* scale1, const float* shift1,
+                           const float* wdw, const float* scale2, const float* shift2, float* y, float* pool_partial,
+                           int B, int FH, int FW, int spad_top, int spad_left, int H, int W, int mid, int pad_top,
+                           int pad_left, int Ho, int Wo, orbit_stream_t stream);
 
 /* ---- Versa / Mahalanobis heads -----------------------------------------------------------
  * y[r][o] = act(x[r] . W[o] + b[o]) (+ residual[r][o]) for a few rows r < R <= 16 (one row per class): the layers of

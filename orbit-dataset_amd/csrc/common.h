@@ -89,6 +89,13 @@ int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_
 // fused expand(1x1, MFMA) + BN + SiLU + depthwise + BN + SiLU (+ SE pooling partials [B][tiles][mid]); csrc/mbconv.hip
 bool mbconv_front_supported(int Cin, int mid, int K, int stride);
 int mbconv_front_tiles(int Ho, int Wo, int stride);
+// stem form of the fused front kernel: conv_stem (NCHW frames, 3x3 stride 2) + BN + SiLU + depthwise 3x3/1 + BN + SiLU
+bool stem_dw_front_supported(int mid, int K, int stride);
+int stem_pack_weights(const float* w_oihw, float* w_packed, int mid, hipStream_t s);  // [mid][27] -> [mid][32]
+int launch_stem_dw_front(const float* frames, const float* w1_packed, const float* sc1, const float* sh1,
+                         const float* wdw, const float* sc2, const float* sh2, float* y, float* pool, int B, int FH, int FW,
+                         int spad_t, int spad_l, int H, int W, int mid, int K, int pad_t, int pad_l, int Ho, int Wo,
+                         hipStream_t s);
 int launch_mbconv_front(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
                         const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
                         int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s);

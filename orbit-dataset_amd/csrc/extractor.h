@@ -43,6 +43,10 @@ struct Op {
     int weight = -1, bias = -1, bn = -1;  // param / BN indices
     size_t packed_off = 0;                // into the packed-weight pool
     int se_w1 = -1, se_b1 = -1, se_w2 = -1, se_b2 = -1, R = 0;
+    // OP_MBFRONT in its stem form (csrc/mbconv.hip): frame size, stem padding, packed [mid][32] stem filter
+    bool stem = false;
+    int stem_h = 0, stem_w = 0, stem_pt = 0, stem_pl = 0;
+    size_t packed_off2 = 0;
     int se_chunks = 0, se_hw = 0;  // squeeze-excite pooling partials produced by the preceding depthwise conv
     int pool_partial = 0;          // depthwise: also emit the pooling partials
     int weight2 = -1, bn2 = -1;    // OP_MBFRONT: depthwise weight (packed at packed_off) and its BatchNorm

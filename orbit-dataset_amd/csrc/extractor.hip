@@ -93,7 +93,13 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
     same_pad(H, 3, 2, h, pt);
     same_pad(W, 3, 2, w, pl);
     int bn = fe->add_bn("bn1", 32, eps, true);  // root bn1 is FiLM-tagged (film.py:45-46)
-    fe->add_conv("conv_stem.weight", bn, -1, 0, -1, H, W, 3, 32, 3, 2, pt, pl, h, w, ORBIT_ACT_SILU, 0, 1, 0);
+    // stem + first depthwise in one kernel (the stem's 112x112x32 output never reaches HBM): only with mbconv_fusion = 1 -
+    // measured in the whole network it is 1.3 % SLOWER than the stem conv + depthwise pair (16 scalar gathers per thread
+    // to build the im2col patch, two blocks per CU)
+    const bool fuse_stem = fuse_opt == 1 && stem_dw_front_supported(32, 3, 1);
+    size_t stem_weight = 0;
+    if (fuse_stem) stem_weight = fe->add_param("conv_stem.weight", (size_t)32 * 27);
+    else fe->add_conv("conv_stem.weight", bn, -1, 0, -1, H, W, 3, 32, 3, 2, pt, pl, h, w, ORBIT_ACT_SILU, 0, 1, 0);
     int cur = 0, cin = 32;
 
     auto add_dw = [&](const std::string& wkey, int bnidx, int in, int out, int C, int K, int stride, int hh,
@@ -139,8 +145,31 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
         (void)dw_slot;
         // conv_dw param is registered inside add_dw, bn1 after it: keep state_dict order cosmetic only
         const int bn1 = fe->add_bn(p + ".bn1", 32, eps, false);
-        add_dw(p + ".conv_dw.weight", bn1, cur, t1, 32, 3, 1, h, w, ho, wo);
-        add_se(p + ".se", t1, 32, 8, ho, wo, dwconv_se_chunks(ho));
+        int se_chunks0;
+        if (fuse_stem) {
+            Op o;
+            o.kind = OP_MBFRONT, o.stem = true, o.in = -1, o.out = t1, o.H = h, o.W = w, o.Cin = 32, o.Cout = 32;
+            o.KH = o.KW = 3, o.stride = 1, o.bn = bn, o.bn2 = bn1;
+            o.stem_h = H, o.stem_w = W, o.stem_pt = pt, o.stem_pl = pl;
+            same_pad(h, 3, 1, o.Ho, o.pad_t);
+            same_pad(w, 3, 1, o.Wo, o.pad_l);
+            o.weight = stem_weight;
+            o.weight2 = fe->add_param(p + ".conv_dw.weight", (size_t)32 * 9);
+            o.packed_off = fe->packed_floats;   // depthwise taps [3][3][32]
+            fe->packed_floats += (size_t)32 * 9;
+            o.packed_off2 = fe->packed_floats;  // stem filter [32][32]
+            fe->packed_floats += (size_t)32 * 32;
+            ho = o.Ho, wo = o.Wo;
+            se_chunks0 = mbconv_front_tiles(ho, wo, 1);
+            fe->max_partial = std::max(fe->max_partial, (size_t)se_chunks0 * 32);
+            fe->note_buf(t1, (size_t)ho * wo * 32);
+            fe->macs += (double)h * w * 27 * 32 + (double)ho * wo * 32 * 9;
+            fe->ops.push_back(o);
+        } else {
+            add_dw(p + ".conv_dw.weight", bn1, cur, t1, 32, 3, 1, h, w, ho, wo);
+            se_chunks0 = dwconv_se_chunks(ho);
+        }
+        add_se(p + ".se", t1, 32, 8, ho, wo, se_chunks0);
         const int bn2 = fe->add_bn(p + ".bn2", 16, eps, false);
         fe->add_conv(p + ".conv_pw.weight", bn2, t1, t2, -1, ho, wo, 32, 16, 1, 1, 0, 0, ho, wo, ORBIT_ACT_NONE,
                      0, 0, 1);
@@ -354,6 +383,8 @@ int orbit_extractor_finalize(orbit_extractor_t* fe, orbit_stream_t stream) {
         } else if (o.kind == OP_MBFRONT) {
             int rc = dwconv_pack_weights(fe->d_pool + fe->params[o.weight2].off, fe->d_packed + o.packed_off, o.Cout,
                                          o.KH, s);
+            if (rc == ORBIT_OK && o.stem)
+                rc = stem_pack_weights(fe->d_pool + fe->params[o.weight].off, fe->d_packed + o.packed_off2, o.Cout, s);
             if (rc != ORBIT_OK) return rc;
         } else if (o.kind == OP_SE) {
             int rc = launch_transpose(fe->d_pool + fe->params[o.se_w2].off, fe->d_packed + o.packed_off, o.Cin, o.R, s);
@@ -515,6 +546,14 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
                                       o.pad_l, o.Ho, o.Wo, o.act, s);
                 break;
             case OP_MBFRONT:
+                if (o.stem) {
+                    rc = launch_stem_dw_front(buf(o.in), fe->d_packed + o.packed_off2, scale + fe->bns[o.bn].fold_off,
+                                              shift + fe->bns[o.bn].fold_off, fe->d_packed + o.packed_off,
+                                              scale + fe->bns[o.bn2].fold_off, shift + fe->bns[o.bn2].fold_off, buf(o.out),
+                                              buf(101), B, o.stem_h, o.stem_w, o.stem_pt, o.stem_pl, o.H, o.W, o.Cout, o.KH,
+                                              o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+                    break;
+                }
                 rc = launch_mbconv_front(buf(o.in), fe->d_pool + fe->params[o.weight].off,
                                          scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off,
                                          fe->d_packed + o.packed_off, scale + fe->bns[o.bn2].fold_off,

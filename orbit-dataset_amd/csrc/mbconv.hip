@@ -37,9 +37,13 @@ struct MbParams {
     float* y;          // [B][Ho][Wo][mid]
     float* pool;       // [B][tiles][mid] or nullptr
     int H, W, Cin, mid, pad_t, pad_l, Ho, Wo, tiles_x;
+    // STEM form: the "expand" stage is the network stem - a 3x3 stride-2 convolution of the NCHW frames - instead of a
+    // 1x1 conv of an NHWC tensor. x = frames [B][3][FH][FW]; (H, W) above is then the stem's output grid; Cin = 32 = the
+    // 27 stem taps (ci, kh, kw) padded; w1 = [mid][32] with zero columns 27..31
+    int FH, FW, spad_t, spad_l;
 };
 
-template <int K, int S, int TH, int TW>
+template <int K, int S, int TH, int TW, bool STEM = false>
 __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
     constexpr int IH = (TH - 1) * S + K, IW = (TW - 1) * S + K;
     constexpr int P = IH * IW;                      // patch pixels
@@ -71,6 +75,28 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
     // ---- stage the input patch (zero outside the image / beyond P) and the pixel validity flags
     // (loads of a batch of 4 are all issued before the first LDS store: a load -> store round trip per element would
     // serialise PR * Cin / 1024 HBM latencies per block)
+    if (STEM) {
+        // im2col of the stem directly into Xs: thread = one tap column k of 8 patch pixels per pass; all 16 scalar loads of
+        // a thread are issued (from clamped addresses) before the first LDS store
+        const int k = tid & 31, ci = k / 9, kh = (k - ci * 9) / 3, kw = k - ci * 9 - kh * 3;
+        const float* xf = p.x + ((size_t)b * 3 + (k < 27 ? ci : 0)) * p.FH * p.FW;
+        constexpr int NU = PR / 8;
+        float v[NU];
+        unsigned ok = 0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int px = (tid >> 5) + 8 * u;
+            const int iy = px / IW, ix = px - iy * IW;
+            const int hi = hi0 + iy, wi = wi0 + ix;           // stem output pixel
+            const int r = hi * 2 - p.spad_t + kh, c = wi * 2 - p.spad_l + kw;
+            const bool in = k < 27 && px < P && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W &&
+                            (unsigned)r < (unsigned)p.FH && (unsigned)c < (unsigned)p.FW;
+            v[u] = xf[in ? r * p.FW + c : 0];
+            ok |= (in ? 1u : 0u) << u;
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) Xs[((tid >> 5) + 8 * u) * XS + k] = ((ok >> u) & 1u) ? v[u] : 0.f;
+    } else {
     const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
     for (int i0 = tid; i0 < PR * cin4; i0 += 4 * 256) {
         v4f v[4];
@@ -94,6 +120,7 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
 #pragma unroll
         for (int u = 0; u < 4; ++u)
             if (dst[u] >= 0) *reinterpret_cast<v4f*>(Xs + dst[u]) = v[u];
+    }
     }
     for (int px = tid; px < PR; px += 256) {
         bool ok = false;
@@ -317,9 +344,66 @@ int launch_mbconv_front(const float* x, const float* w1, const float* sc1, const
     return ORBIT_OK;
 }
 
+// ---- stem form: conv_stem (3 -> mid channels, 3x3 stride 2, TF-SAME) + BN + SiLU + depthwise 3x3/1 + BN + SiLU -----------
+// OIHW [mid][3][3][3] = [mid][27] -> [mid][32] (zero columns 27..31): the "expand weights" of the stem form
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int mid) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < mid * 32; i += gridDim.x * 256) {
+        const int r = i >> 5, k = i & 31;
+        wp[i] = k < 27 ? w[r * 27 + k] : 0.f;
+    }
+}
+int stem_pack_weights(const float* w_oihw, float* w_packed, int mid, hipStream_t s) {
+    stem_pack_kernel<<<cdiv(mid * 32, 256), 256, 0, s>>>(w_oihw, w_packed, mid);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+bool stem_dw_front_supported(int mid, int K, int stride) { return mid % 4 == 0 && mid <= 256 && K == 3 && stride == 1; }
+
+int launch_stem_dw_front(const float* frames, const float* w1_packed, const float* sc1, const float* sh1,
+                         const float* wdw, const float* sc2, const float* sh2, float* y, float* pool, int B, int FH, int FW,
+                         int spad_t, int spad_l, int H, int W, int mid, int K, int pad_t, int pad_l, int Ho, int Wo,
+                         hipStream_t s) {
+    ORBIT_REQUIRE(frames && w1_packed && sc1 && sh1 && wdw && sc2 && sh2 && y, "stem_dw_front: null pointer");
+    ORBIT_REQUIRE(stem_dw_front_supported(mid, K, 1), "stem_dw_front: unsupported shape (mid=%d K=%d)", mid, K);
+    int th, tw;
+    mb_tile_geom(1, th, tw);
+    MbParams p;
+    p.x = frames, p.w1 = w1_packed, p.sc1 = sc1, p.sh1 = sh1, p.wdw = wdw, p.sc2 = sc2, p.sh2 = sh2, p.y = y, p.pool = pool;
+    p.H = H, p.W = W, p.Cin = 32, p.mid = mid, p.pad_t = pad_t, p.pad_l = pad_l, p.Ho = Ho, p.Wo = Wo;
+    p.FH = FH, p.FW = FW, p.spad_t = spad_t, p.spad_l = spad_l;
+    p.tiles_x = cdiv(Wo, tw);
+    const int tiles = p.tiles_x * cdiv(Ho, th);
+    const int ih = th - 1 + K, iw = tw - 1 + K;
+    const int pr = (ih * iw + 31) / 32 * 32;
+    const size_t lds = ((size_t)pr * 36 + 2 * 32 * 36 + (size_t)pr * 36) * sizeof(float) +
+                       (size_t)(2 * K * K * 8 + 512) * 16 + pr;
+    mbconv_front_kernel<3, 1, 8, 8, true><<<dim3(tiles, B), 256, lds, s>>>(p);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
 }  // namespace orbit
 
 using namespace orbit;
+
+// single-operator entry for the parity tests: frames NCHW, w_stem torch [mid][3][3][3], wdw torch [mid][1][3][3]
+extern "C" int orbit_op_stem_dw_front(const float* frames, const float* w_stem, const float* scale1, const float* shift1,
+                                      const float* wdw, const float* scale2, const float* shift2, float* y,
+                                      float* pool_partial, int B, int FH, int FW, int spad_top, int spad_left, int H, int W,
+                                      int mid, int pad_top, int pad_left, int Ho, int Wo, orbit_stream_t stream) {
+    ORBIT_REQUIRE(frames && w_stem && wdw && y, "op_stem_dw_front: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    float* wp = nullptr;
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&wp), (size_t)mid * (32 + 9) * sizeof(float), s));
+    int rc = stem_pack_weights(w_stem, wp, mid, s);
+    if (rc == ORBIT_OK) rc = dwconv_pack_weights(wdw, wp + (size_t)mid * 32, mid, 3, s);
+    if (rc == ORBIT_OK)
+        rc = launch_stem_dw_front(frames, wp, scale1, shift1, wp + (size_t)mid * 32, scale2, shift2, y, pool_partial, B, FH,
+                                  FW, spad_top, spad_left, H, W, mid, 3, pad_top, pad_left, Ho, Wo, s);
+    (void)hipFreeAsync(wp, s);
+    return rc;
+}
 
 // single-operator entry for the parity tests: w1 torch [mid][Cin][1][1], wdw torch [mid][1][K][K]
 extern "C" int orbit_op_mbconv_front(const float* x, const float* w1, const float* scale1, const float* shift1,

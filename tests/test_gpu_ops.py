@@ -272,6 +272,35 @@ def test_mbconv_front_fused(lib, device, Cin, mid, K, stride, H, W):
     assert (pool.cpu().sum(1) - want.sum((2, 3))).abs().max().item() < 2e-3 * max(1.0, want.sum((2, 3)).abs().max().item())
 
 
+@pytest.mark.parametrize("FH,FW,mid", [(64, 64, 32), (37, 45, 32), (30, 30, 32), (21, 52, 16)])
+def test_stem_dw_front_fused(lib, device, FH, FW, mid):
+    """stem conv (NCHW frames, 3x3 stride 2, TF-SAME) + BN + SiLU + depthwise 3x3 (SAME) + BN + SiLU in one kernel, the
+    stem output only in LDS, + SE pooling partials - against the unfused PyTorch-CPU sequence (odd sizes, partial tiles)"""
+    g = torch.Generator().manual_seed(FH * 100 + FW + mid)
+    B = 3
+    x = torch.randn(B, 3, FH, FW, generator=g)
+    ws = torch.randn(mid, 3, 3, 3, generator=g) / 27 ** 0.5
+    wd = torch.randn(mid, 1, 3, 3, generator=g) / 3
+    s1, h1 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.3
+    s2, h2 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.1
+    H, W = -(-FH // 2), -(-FW // 2)
+    ph, pw = max((H - 1) * 2 + 3 - FH, 0), max((W - 1) * 2 + 3 - FW, 0)
+    xp = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
+    e = F.silu(F.conv2d(xp, ws, None, 2) * s1[None, :, None, None] + h1[None, :, None, None])
+    want = F.silu(F.conv2d(e, wd, None, 1, 1, 1, mid) * s2[None, :, None, None] + h2[None, :, None, None])
+    tiles = -(-H // 8) * -(-W // 8)
+    y = torch.full((B, H, W, mid), float("nan"), device=device)
+    pool = torch.full((B, tiles, mid), float("nan"), device=device)
+    dev = [t.to(device).contiguous() for t in (x, ws, s1, h1, wd, s2, h2)]
+    _lib.check(lib.orbit_op_stem_dw_front(*[_lib.dptr(t) for t in dev], _lib.dptr(y), _lib.dptr(pool), B, FH, FW, ph // 2,
+                                          pw // 2, H, W, mid, 1, 1, H, W, _st()), "stem_dw_front")
+    torch.cuda.synchronize()
+    got = nchw(y.cpu())
+    assert not torch.isnan(got).any() and not torch.isnan(pool).any()
+    assert (got - want).abs().max().item() < 5e-5
+    assert (pool.cpu().sum(1) - want.sum((2, 3))).abs().max().item() < 2e-3 * max(1.0, want.sum((2, 3)).abs().max().item())
+
+
 @pytest.mark.parametrize("Cin,Cout,K,HW,gated", [(256, 128, 3, 15, False), (512, 512, 3, 6, False), (1152, 192, 1, 7, True),
                                                  (672, 192, 1, 7, True)])
 def test_conv_split_k(lib, device, Cin, Cout, K, HW, gated):
