@@ -367,9 +367,13 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict
     const int tid = threadIdx.x;
     const int lc = tid % cs4, p = tid / cs4, P = 256 / cs4;
     const int c = c0 + lc * 4;
-    for (int i = tid; i < K * K * cs4; i += 256) {
-        const int tap = i / cs4, cc = i % cs4;
-        wl[i] = *reinterpret_cast<const v4f*>(w + (size_t)tap * C + c0 + cc * 4);
+    // the block's filter taps (<= 2 quads per thread: K*K*cs4 <= 400) are requested first and written to LDS after the
+    // patch loads below have been issued: one round trip for both instead of two in a row
+    v4f wq[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int i = tid + u * 256;
+        if (i < K * K * cs4) wq[u] = *reinterpret_cast<const v4f*>(w + (size_t)(i / cs4) * C + c0 + (i % cs4) * 4);
     }
     {   // stage the patch (zero outside the image: TF-SAME / symmetric padding alike). A thread walks the patch pixels
         // p, p + P, ... of its channel quad; the loads of a batch of 8 are all issued before the first LDS store (one
@@ -398,6 +402,9 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict
                 if (dst[u] >= 0) *reinterpret_cast<v4f*>(tile + dst[u]) = v[u];
         }
     }
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (tid + u * 256 < K * K * cs4) wl[tid + u * 256] = wq[u];
     __syncthreads();
     v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, psum = {0.f, 0.f, 0.f, 0.f};
     if (scale) sc = *reinterpret_cast<const v4f*>(scale + c);
