@@ -15,12 +15,16 @@
 //               a pooling window are the four consecutive accumulator rows a lane already holds.
 //   Prologue:   optional per-(frame, input-channel) squeeze-excite gate multiplied into A.
 //
-// Tiling: 256 threads = 4 waves; block tile BM x BN x 32, wave grid WGM x WGN, each wave owns
-// (BM/WGM/32) x (BN/WGN/32) accumulator tiles of 32x32 (16 VGPRs each). LDS rows are padded to 36 floats:
+// Tiling: 256 threads = 4 waves; block tile BM x BN x BK, wave grid WGM x WGN x WGK (WGK > 1: the waves of a K-group
+// split the K-tile's k-groups and their partial tiles are summed through LDS), each wave owns
+// (BM/WGM/32) x (BN/WGN/32) accumulator tiles of 32x32 (16 VGPRs each); layers with very few output tiles are also
+// split over K across blocks (conv_splitk + conv_splitk_reduce_kernel). LDS rows are padded to BK + 4 floats:
 // the fragment reads are conflict-free ds_read_b128 (lane (i, h) reads k = 8g+4h .. +3 of row i, and
 // register kk of the read feeds MFMA kk, so lanes 0-31 / 32-63 supply k = 8g+kk / 8g+4+kk).
 // Global->LDS staging goes through registers and is software-pipelined one K-tile ahead (the f32 MFMA
-// issues once per 64 cycles per SIMD, so one tile of prefetch hides L2/HBM latency).
+// issues once per 64 cycles per SIMD, so one tile of prefetch hides L2/HBM latency). Addressing is division-free:
+// one 64-bit pointer per staged row + a wave-uniform tap/channel walk in SGPRs; pointwise convs (PW) are a
+// predicate-free specialisation (see the kernel's template comment).
 // fp32 in, fp32 accumulate: bit-equivalent to an fmaf chain, which is what the 1e-3 logit parity
 // target needs (no TF32-class path exists on gfx950).
 #include <algorithm>
