@@ -487,11 +487,31 @@ __global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__
     const int b = blockIdx.x, tid = threadIdx.x;
     const int C4 = C >> 2;
     const v4f* part4 = reinterpret_cast<const v4f*>(partial) + (size_t)b * chunks * C4;
-    for (int c4 = tid; c4 < C4; c4 += 256) {
-        v4f s = {0.f, 0.f, 0.f, 0.f};
+    const int parts = C4 <= 128 ? 256 / C4 : 1;  // thread groups sharing the chunk list of a channel quad
+    if (parts > 1 && chunks > 8) {
+        // many partials (the fused MBConv front writes one per 8x8 / 4x8 tile: up to 98) and few channels: 256 / C4 threads
+        // per quad take every parts-th chunk, the groups' sums are added in group order (fixed order, deterministic)
+        v4f* tmp = reinterpret_cast<v4f*>(sm2 + ((C + R + 3) & ~3));  // [parts][C4]
+        const int q = tid % C4, part = tid / C4;
+        if (part < parts) {
+            v4f s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int k = part; k < chunks; k += parts) s += part4[(size_t)k * C4 + q];
+            tmp[part * C4 + q] = s;
+        }
+        __syncthreads();
+        if (tid < C4) {
+            v4f s = tmp[tid];
+            for (int g = 1; g < parts; ++g) s += tmp[g * C4 + tid];
+            sp4[tid] = s * inv_hw;
+        }
+    } else {
+        for (int c4 = tid; c4 < C4; c4 += 256) {
+            v4f s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
-        for (int k = 0; k < chunks; ++k) s += part4[(size_t)k * C4 + c4];  // loads batched, adds in chunk order
-        sp4[c4] = s * inv_hw;
+            for (int k = 0; k < chunks; ++k) s += part4[(size_t)k * C4 + c4];  // loads batched, adds in chunk order
+            sp4[c4] = s * inv_hw;
+        }
     }
     __syncthreads();
     // layer 1: wave w takes hidden units w, w + 4, ...; four units at a time, lanes stride the channel quads
@@ -764,7 +784,7 @@ int launch_se_gate2(const float* partial, int chunks, int HW, const float* w1, c
                     const float* b2, float* gate, int B, int C, int R, hipStream_t s) {
     ORBIT_REQUIRE(partial && w1 && b1 && w2t && b2 && gate, "se_gate2: null pointer");
     ORBIT_REQUIRE(C % 4 == 0, "se_gate2: C %% 4 != 0 (C=%d)", C);
-    se_gate2_kernel<<<B, 256, (size_t)(C + R) * sizeof(float), s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2,
+    se_gate2_kernel<<<B, 256, (size_t)(((C + R + 3) & ~3) + 4 * 256) * sizeof(float), s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2,
                                                                      gate, C, R);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
