@@ -41,6 +41,23 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 
 // ---- internal launchers shared between the single-op C-ABI and the network runtime -------------
 
+// Division by a launch-time constant: q = (umulhi(n, mul) + n) >> shift, exact for n < 2^31 (Granlund-Montgomery
+// round-up magic). A 32-bit integer division is ~25 VALU / ~40 SALU instructions on gfx950; the row decode below and the
+// stem's k decode are made of them, and on the short-K EfficientNet layers that index arithmetic (not the MFMAs, not
+// HBM) was the busiest pipe (rocprofv3 SQ counters, tools/conv_pmc.sh).
+struct FastDiv {
+    unsigned mul, shift;
+};
+static inline FastDiv make_fastdiv(unsigned d) {
+    FastDiv f;
+    unsigned l = 0;
+    while ((1u << l) < d) ++l;  // ceil(log2 d)
+    f.mul = (unsigned)(((((unsigned long long)1 << l) - d) << 32) / d + 1);
+    f.shift = l;
+    return f;
+}
+__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return (__umulhi(n, f.mul) + n) >> f.shift; }
+
 struct ConvDesc {
     const float* x;         // NHWC activations, or NCHW frames when x_nchw
     const float* w_packed;  // [CoutPad][KT], K = (kh, kw, ci) with ci fastest, zero padded

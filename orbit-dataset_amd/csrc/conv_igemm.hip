@@ -42,23 +42,6 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 // zero-padded 32. LDS rows are padded to BK + 4 floats: for 12/20/36-float strides the 16-lane groups of a
 // ds_read_b128 land on 16 distinct 16-byte bank slots (conflict-free).
 
-// Division by a launch-time constant: q = (umulhi(n, mul) + n) >> shift, exact for n < 2^31 (Granlund-Montgomery
-// round-up magic). A 32-bit integer division is ~25 VALU / ~40 SALU instructions on gfx950; the row decode below and the
-// stem's k decode are made of them, and on the short-K EfficientNet layers that index arithmetic (not the MFMAs, not
-// HBM) was the busiest pipe (rocprofv3 SQ counters, tools/conv_pmc.sh).
-struct FastDiv {
-    unsigned mul, shift;
-};
-static FastDiv make_fastdiv(unsigned d) {
-    FastDiv f;
-    unsigned l = 0;
-    while ((1u << l) < d) ++l;  // ceil(log2 d)
-    f.mul = (unsigned)(((((unsigned long long)1 << l) - d) << 32) / d + 1);
-    f.shift = l;
-    return f;
-}
-__device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return (__umulhi(n, f.mul) + n) >> f.shift; }
-
 struct ConvParams {
     const float* x;
     const float* w;

@@ -28,6 +28,7 @@ struct WgradParams {
     int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo;
     int M, NC;
     int co_tiles, n_tiles, splits, steps_per_split;
+    FastDiv fd_howo, fd_wo;  // row decode m -> (b, ho, wo) without integer division (two per staged row and K-step)
 };
 
 constexpr int WG_BKM = 32;  // rows of m per K-step
@@ -89,9 +90,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
             if (m < m_end) {
                 if (a_col_ok) va = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + co0 + c4 * 4);
                 if (MODE == 0 && b_col_ok) {
-                    const int b = m / HoWo;
+                    const int b = (int)fdiv((unsigned)m, p.fd_howo);
                     const int r = m - b * HoWo;
-                    const int ho = r / p.Wo, wo = r - ho * p.Wo;
+                    const int ho = (int)fdiv((unsigned)r, p.fd_wo), wo = r - ho * p.Wo;
                     const int hi = ho * p.stride - p.pad_t + kh0, wi = wo * p.stride - p.pad_l + kw0;
                     if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
                         vb = *reinterpret_cast<const f32x4*>(p.x + (((size_t)b * p.H + hi) * p.W + wi) * p.Cin + ci0);
@@ -107,9 +108,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                 const int m = mb + (tid >> 6) + 4 * i;
                 float v = 0.f;
                 if (m < m_end && b1_col_ok) {
-                    const int b = m / HoWo;
+                    const int b = (int)fdiv((unsigned)m, p.fd_howo);
                     const int r = m - b * HoWo;
-                    const int ho = r / p.Wo, wo = r - ho * p.Wo;
+                    const int ho = (int)fdiv((unsigned)r, p.fd_wo), wo = r - ho * p.Wo;
                     const int hi = ho * p.stride - p.pad_t + kh1, wi = wo * p.stride - p.pad_l + kw1;
                     if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
                         v = p.x[((size_t)b * p.Cin + ci1) * plane + (size_t)hi * p.W + wi];
@@ -222,6 +223,7 @@ int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oih
     p.B = B, p.H = H, p.W = W, p.Cin = Cin, p.Cout = Cout, p.KH = KH, p.KW = KW, p.stride = stride;
     p.pad_t = pad_t, p.pad_l = pad_l, p.Ho = Ho, p.Wo = Wo;
     p.M = B * Ho * Wo, p.NC = KH * KW * Cin;
+    p.fd_howo = make_fastdiv((unsigned)(Ho * Wo)), p.fd_wo = make_fastdiv((unsigned)Wo);
     wgrad_geometry(p.M, Cout, p.NC, p.co_tiles, p.n_tiles, p.splits, p.steps_per_split);
     const int grid = p.co_tiles * p.n_tiles * p.splits;
     // algorithmic work: 2*M*Cout*K flops; bytes = input + output gradient once, filter gradient once
