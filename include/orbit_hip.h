@@ -140,6 +140,11 @@ int orbit_extractor_load(orbit_extractor_t* fe, const char* key, const float* da
  * parameters follow optimizer steps during meta-training. */
 int orbit_extractor_load_async(orbit_extractor_t* fe, const char* key, const float* device_data, size_t numel,
                                orbit_stream_t stream);
+/* All parameters in one launch: device_ptrs[i] = device pointer of parameter i (orbit_extractor_param_name order, fp32,
+ * contiguous, orbit_extractor_param_numel(i) elements). The pointer table is cached; one gather kernel copies every
+ * tensor into the plan, stream-ordered (what optimizer.step() -> next forward needs every training step: one launch
+ * instead of one hipMemcpyAsync per tensor). */
+int orbit_extractor_load_all_async(orbit_extractor_t* fe, const float* const* device_ptrs, int n, orbit_stream_t stream);
 /* repack conv weights for the kernels, precompute folded BN for the non-FiLM case. Call after loads. */
 int orbit_extractor_finalize(orbit_extractor_t* fe, orbit_stream_t stream);
 

@@ -34,6 +34,7 @@ _SIGNATURES = {
     "orbit_extractor_param_numel": (c_size_t, [P, c_int]),
     "orbit_extractor_load": (c_int, [P, c_char_p, P, c_size_t]),
     "orbit_extractor_load_async": (c_int, [P, c_char_p, P, c_size_t, P]),
+    "orbit_extractor_load_all_async": (c_int, [P, P, c_int, P]),
     "orbit_extractor_finalize": (c_int, [P, P]),
     "orbit_extractor_output_size": (c_int, [P]),
     "orbit_extractor_film_slots": (c_int, [P]),

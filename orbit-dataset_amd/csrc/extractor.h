@@ -98,6 +98,11 @@ struct orbit_extractor {
     size_t max_partial = 0;  // floats per frame of the SE pooling-partial buffer
     double macs = 0;
     float* d_pool = nullptr;
+    // batched upload (orbit_extractor_load_all_async): device table of source pointers + its host shadow, and the static
+    // table of (pool offset, numel) per parameter
+    const float** d_src = nullptr;
+    std::vector<const float*> h_src;
+    size_t* d_dst_meta = nullptr;  // [n][2] = offset, numel
     float* d_packed = nullptr;
     float* d_fold = nullptr;  // static (non-FiLM) scale | shift
     BNDev* d_bn = nullptr;

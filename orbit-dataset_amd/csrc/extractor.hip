@@ -321,6 +321,8 @@ void orbit_extractor_destroy(orbit_extractor_t* fe) {
     fe->clear_graphs();
     if (fe->cap_stream) (void)hipStreamDestroy(fe->cap_stream);
     (void)hipFree(fe->d_pool);
+    (void)hipFree(fe->d_src);
+    (void)hipFree(fe->d_dst_meta);
     (void)hipFree(fe->d_packed);
     (void)hipFree(fe->d_fold);
     (void)hipFree(fe->d_bn);
@@ -360,6 +362,44 @@ int orbit_extractor_load_async(orbit_extractor_t* fe, const char* key, const flo
     ORBIT_HIP_CHECK(hipMemcpyAsync(fe->d_pool + p.off, device_data, numel * sizeof(float), hipMemcpyDeviceToDevice,
                                    (hipStream_t)stream));
     p.loaded = true;
+    fe->finalized = false;
+    extractor_train_invalidate(fe);
+    return ORBIT_OK;
+}
+
+// one kernel copies every parameter tensor into the pool: grid (chunks, parameters)
+__global__ __launch_bounds__(256) void gather_params_kernel(const float* const* __restrict__ src,
+                                                            const size_t* __restrict__ meta, float* __restrict__ pool) {
+    const float* s_ = src[blockIdx.y];
+    float* d = pool + meta[2 * blockIdx.y];
+    const size_t n = meta[2 * blockIdx.y + 1];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s_[i];
+}
+
+int orbit_extractor_load_all_async(orbit_extractor_t* fe, const float* const* device_ptrs, int n, orbit_stream_t stream) {
+    ORBIT_REQUIRE(fe && device_ptrs, "extractor_load_all_async: null pointer");
+    ORBIT_REQUIRE(n == (int)fe->params.size(), "extractor_load_all_async: %d pointers for %zu parameters", n,
+                  fe->params.size());
+    if (int rc = fe->ensure_device()) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    if (!fe->d_src) {
+        ORBIT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&fe->d_src), n * sizeof(float*)));
+        ORBIT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&fe->d_dst_meta), 2 * n * sizeof(size_t)));
+        std::vector<size_t> meta(2 * n);
+        for (int i = 0; i < n; ++i) meta[2 * i] = fe->params[i].off, meta[2 * i + 1] = fe->params[i].numel;
+        ORBIT_HIP_CHECK(hipMemcpy(fe->d_dst_meta, meta.data(), meta.size() * sizeof(size_t), hipMemcpyHostToDevice));
+    }
+    bool same = (int)fe->h_src.size() == n;
+    for (int i = 0; same && i < n; ++i) same = fe->h_src[i] == device_ptrs[i];
+    if (!same) {  // the tensors moved (first call, load_state_dict with new storage): refresh the pointer table
+        for (int i = 0; i < n; ++i) ORBIT_REQUIRE(device_ptrs[i], "extractor_load_all_async: null tensor %d", i);
+        fe->h_src.assign(device_ptrs, device_ptrs + n);
+        ORBIT_HIP_CHECK(hipStreamSynchronize(s));  // the table may still be read by an earlier gather on this stream
+        ORBIT_HIP_CHECK(hipMemcpy(fe->d_src, fe->h_src.data(), n * sizeof(float*), hipMemcpyHostToDevice));
+    }
+    gather_params_kernel<<<dim3(32, n), 256, 0, s>>>(fe->d_src, fe->d_dst_meta, fe->d_pool);
+    ORBIT_LAUNCH_CHECK();
+    for (Param& p : fe->params) p.loaded = true;
     fe->finalized = false;
     extractor_train_invalidate(fe);
     return ORBIT_OK;

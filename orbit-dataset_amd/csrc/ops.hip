@@ -587,12 +587,9 @@ __global__ __launch_bounds__(256) void maxpool_kernel(const float* __restrict__ 
     const int C4 = C >> 2;
     const size_t total = (size_t)B * Ho * Wo * C4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int c = (int)(i % C4) * 4;
-        size_t r = i / C4;
-        const int wo = (int)(r % Wo);
-        r /= Wo;
-        const int ho = (int)(r % Ho);
-        const int b = (int)(r / Ho);
+        // 32-bit index arithmetic (the launcher checks total < 2^32): 64-bit div / mod are ~100 instructions each
+        const unsigned iu = (unsigned)i, r1 = iu / (unsigned)C4, r2 = r1 / (unsigned)Wo, bu = r2 / (unsigned)Ho;
+        const int c = (int)(iu - r1 * C4) * 4, wo = (int)(r1 - r2 * Wo), ho = (int)(r2 - bu * Ho), b = (int)bu;
         const float* xb = x + (size_t)b * H * W * C + c;
         float4 m = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
         for (int kh = 0; kh < K; ++kh) {
@@ -807,6 +804,7 @@ int launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int K, 
     ORBIT_REQUIRE(x && y, "maxpool: null pointer");
     ORBIT_REQUIRE(C % 4 == 0, "maxpool: C %% 4 != 0 (C=%d)", C);
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
+    ORBIT_REQUIRE(total < (1ull << 32), "maxpool: tensor too large for 32-bit index arithmetic");
     maxpool_kernel<<<grid_for(total), 256, 0, s>>>(x, y, B, H, W, C, K, stride, pad, Ho, Wo);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;

@@ -26,8 +26,9 @@ static int grid_for(size_t total) {
 __global__ __launch_bounds__(256) void gate_mul_kernel(const float* __restrict__ x, const float* __restrict__ gate,
                                                        float* __restrict__ xg, int HW, int C4, size_t total4) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const size_t b = i / ((size_t)HW * C4);
+        const unsigned iu = (unsigned)i;  // 32-bit index arithmetic (launcher: total < 2^32)
+        const int q = (int)(iu % (unsigned)C4);
+        const size_t b = iu / ((unsigned)HW * (unsigned)C4);
         reinterpret_cast<f32x4*>(xg)[i] = reinterpret_cast<const f32x4*>(x)[i] *
                                           reinterpret_cast<const f32x4*>(gate)[b * C4 + q];
     }
@@ -83,8 +84,9 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __rest
                                                              float* __restrict__ dx, int HW, int C4, size_t total4) {
     const float inv = 1.0f / (float)HW;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const size_t b = i / ((size_t)HW * C4);
+        const unsigned iu = (unsigned)i;  // 32-bit index arithmetic (launcher: total < 2^32)
+        const int q = (int)(iu % (unsigned)C4);
+        const size_t b = iu / ((unsigned)HW * (unsigned)C4);
         reinterpret_cast<f32x4*>(dx)[i] =
             reinterpret_cast<const f32x4*>(dxg)[i] * reinterpret_cast<const f32x4*>(gate)[b * C4 + q] +
             reinterpret_cast<const f32x4*>(dpooled)[b * C4 + q] * inv;
@@ -194,12 +196,9 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restri
                                                            int stride, int pad_t, int pad_l, int Ho, int Wo) {
     const size_t total = (size_t)B * H * W * C4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        size_t r = i / C4;
-        const int wx = (int)(r % W);
-        r /= W;
-        const int h = (int)(r % H);
-        const int b = (int)(r / H);
+        // 32-bit index arithmetic (the launcher checks total < 2^32): 64-bit div / mod are ~100 instructions each
+        const unsigned iu = (unsigned)i, r1 = iu / (unsigned)C4, r2 = r1 / (unsigned)W, bu = r2 / (unsigned)H;
+        const int q = (int)(iu - r1 * C4), wx = (int)(r1 - r2 * W), h = (int)(r2 - bu * H), b = (int)bu;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kh = 0; kh < K; ++kh) {
@@ -315,6 +314,7 @@ int launch_colmean(const float* x, float* pooled, int B, int HW, int C, hipStrea
 int launch_gate_mul(const float* x, const float* gate, float* xg, int B, int HW, int C, hipStream_t s) {
     ORBIT_REQUIRE(C % 4 == 0, "gate_mul: C %% 4 != 0");
     const size_t total4 = (size_t)B * HW * (C / 4);
+    ORBIT_REQUIRE((unsigned long long)(total4) < (1ull << 32), "tensor too large for the 32-bit index arithmetic of this kernel");
     gate_mul_kernel<<<grid_for(total4), 256, 0, s>>>(x, gate, xg, HW, C / 4, total4);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
@@ -344,6 +344,7 @@ int launch_se_gate_backward(const float* dxg, const float* x, const float* poole
         ORBIT_LAUNCH_CHECK();
     }
     const size_t total4 = (size_t)B * HW * (C / 4);
+    ORBIT_REQUIRE((unsigned long long)(total4) < (1ull << 32), "tensor too large for the 32-bit index arithmetic of this kernel");
     gate_bwd_apply_kernel<<<grid_for(total4), 256, 0, s>>>(dxg, gate, dp, dx, HW, C / 4, total4);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
@@ -353,6 +354,7 @@ int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, 
                         int pad_t, int pad_l, int Ho, int Wo, hipStream_t s) {
     ORBIT_REQUIRE(C % 4 == 0 && (K == 3 || K == 5), "dwconv_dgrad: C %% 4 != 0 or K not in {3,5}");
     const int grid = grid_for((size_t)B * H * W * (C / 4));
+    ORBIT_REQUIRE((unsigned long long)((size_t)B * H * W * (C / 4)) < (1ull << 32), "tensor too large for the 32-bit index arithmetic of this kernel");
     if (K == 3) dwconv_dgrad_kernel<3><<<grid, 256, 0, s>>>(dy, w_khwc, dx, B, H, W, C / 4, stride, pad_t, pad_l, Ho, Wo);
     else dwconv_dgrad_kernel<5><<<grid, 256, 0, s>>>(dy, w_khwc, dx, B, H, W, C / 4, stride, pad_t, pad_l, Ho, Wo);
     ORBIT_LAUNCH_CHECK();

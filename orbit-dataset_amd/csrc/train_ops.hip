@@ -129,8 +129,12 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
                                                               const float* __restrict__ shift,
                                                               const float* __restrict__ residual, int act,
                                                               size_t total4, int C4, float* __restrict__ out) {
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const int q = (int)(i % C4);
+    // channel quad of element i = i mod C4, walked incrementally: a 64-bit modulo per 16-byte element is ~100 instructions
+    // and made these streaming kernels instruction-bound
+    const unsigned stride = gridDim.x * 256u, stride_mod = stride % (unsigned)C4;
+    unsigned q = (blockIdx.x * 256u + threadIdx.x) % (unsigned)C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4;
+         i += stride, q = q + stride_mod >= (unsigned)C4 ? q + stride_mod - C4 : q + stride_mod) {
         f32x4 v = reinterpret_cast<const f32x4*>(y)[i];
         if (scale) v = v * reinterpret_cast<const f32x4*>(scale)[q] + reinterpret_cast<const f32x4*>(shift)[q];
         if (residual) v += reinterpret_cast<const f32x4*>(residual)[i];
@@ -236,8 +240,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            int C4, float* __restrict__ dy, float* __restrict__ dres,
                                                            int dres_accumulate) {
     const int C = C4 * 4;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (size_t)gridDim.x * 256) {
-        const int q = (int)(i % C4);
+    const unsigned stride = gridDim.x * 256u, stride_mod = stride % (unsigned)C4;  // see scale_shift_act_kernel
+    unsigned q = (blockIdx.x * 256u + threadIdx.x) % (unsigned)C4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total4;
+         i += stride, q = q + stride_mod >= (unsigned)C4 ? q + stride_mod - C4 : q + stride_mod) {
         f32x4 g = reinterpret_cast<const f32x4*>(dout)[i];
         const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
         if (act == ORBIT_ACT_RELU) g = relu_mask(g, reinterpret_cast<const f32x4*>(out)[i]);
@@ -261,12 +267,9 @@ __global__ __launch_bounds__(256) void maxpool_idx_kernel(const float* __restric
                                                           int K, int stride, int pad, int Ho, int Wo) {
     const size_t total = (size_t)B * Ho * Wo * C4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        size_t r = i / C4;
-        const int wo = (int)(r % Wo);
-        r /= Wo;
-        const int ho = (int)(r % Ho);
-        const int b = (int)(r / Ho);
+        // 32-bit index arithmetic (the launcher checks total < 2^32): 64-bit div / mod are ~100 instructions each
+        const unsigned iu = (unsigned)i, r1 = iu / (unsigned)C4, r2 = r1 / (unsigned)Wo, bu = r2 / (unsigned)Ho;
+        const int q = (int)(iu - r1 * C4), wo = (int)(r1 - r2 * Wo), ho = (int)(r2 - bu * Ho), b = (int)bu;
         f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
         int bi[4] = {-1, -1, -1, -1};
         for (int kh = 0; kh < K; ++kh) {
@@ -293,12 +296,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
                                                           int Ho, int Wo) {
     const size_t total = (size_t)B * H * W * C4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        size_t r = i / C4;
-        const int w = (int)(r % W);
-        r /= W;
-        const int h = (int)(r % H);
-        const int b = (int)(r / H);
+        // 32-bit index arithmetic (the launcher checks total < 2^32): 64-bit div / mod are ~100 instructions each
+        const unsigned iu = (unsigned)i, r1 = iu / (unsigned)C4, r2 = r1 / (unsigned)W, bu = r2 / (unsigned)H;
+        const int q = (int)(iu - r1 * C4), w = (int)(r1 - r2 * W), h = (int)(r2 - bu * H), b = (int)bu;
         f32x4 g = {0.f, 0.f, 0.f, 0.f};
         for (int kh = 0; kh < K; ++kh) {
             const int t = h + pad - kh;
@@ -329,8 +329,9 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* __restric
     const size_t total = (size_t)B * HW * C4;
     const float inv = 1.0f / (float)HW;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        const int b = (int)(i / ((size_t)HW * C4));
+        const unsigned iu = (unsigned)i;  // 32-bit index arithmetic (launcher: total < 2^32)
+        const int q = (int)(iu % (unsigned)C4);
+        const int b = (int)(iu / ((unsigned)HW * (unsigned)C4));
         reinterpret_cast<f32x4*>(dx)[i] = reinterpret_cast<const f32x4*>(dy)[(size_t)b * C4 + q] * inv;
     }
 }
@@ -340,12 +341,9 @@ __global__ __launch_bounds__(256) void upsample_zero_kernel(const float* __restr
                                                             int B, int H, int W, int C4, int s, int Hs, int Ws) {
     const size_t total = (size_t)B * H * W * C4;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
-        const int q = (int)(i % C4);
-        size_t r = i / C4;
-        const int w = (int)(r % W);
-        r /= W;
-        const int h = (int)(r % H);
-        const int b = (int)(r / H);
+        // 32-bit index arithmetic (the launcher checks total < 2^32): 64-bit div / mod are ~100 instructions each
+        const unsigned iu = (unsigned)i, r1 = iu / (unsigned)C4, r2 = r1 / (unsigned)W, bu = r2 / (unsigned)H;
+        const int q = (int)(iu - r1 * C4), w = (int)(r1 - r2 * W), h = (int)(r2 - bu * H), b = (int)bu;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (h % s == 0 && w % s == 0 && h / s < Hs && w / s < Ws)
             v = reinterpret_cast<const f32x4*>(src)[(((size_t)b * Hs + h / s) * Ws + w / s) * C4 + q];
@@ -415,6 +413,7 @@ int launch_bn_backward(const float* dout, const float* out, const float* y, cons
 int launch_maxpool_idx(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, int K, int stride, int pad,
                        int Ho, int Wo, hipStream_t s) {
     ORBIT_REQUIRE(C % 4 == 0 && K * K <= 255, "maxpool: C %% 4 != 0 or window too large");
+    ORBIT_REQUIRE((unsigned long long)((size_t)B * Ho * Wo * (C / 4)) < (1ull << 32), "tensor too large for the 32-bit index arithmetic of this kernel");
     maxpool_idx_kernel<<<grid_for((size_t)B * Ho * Wo * (C / 4)), 256, 0, s>>>(x, y, idx, B, H, W, C / 4, K, stride, pad,
                                                                                Ho, Wo);
     ORBIT_LAUNCH_CHECK();
@@ -424,6 +423,7 @@ int launch_maxpool_idx(const float* x, float* y, uint8_t* idx, int B, int H, int
 int launch_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int B, int H, int W, int C, int K, int stride,
                        int pad, int Ho, int Wo, hipStream_t s) {
     ORBIT_REQUIRE(C % 4 == 0, "maxpool_backward: C %% 4 != 0");
+    ORBIT_REQUIRE((unsigned long long)((size_t)B * H * W * (C / 4)) < (1ull << 32), "tensor too large for the 32-bit index arithmetic of this kernel");
     maxpool_bwd_kernel<<<grid_for((size_t)B * H * W * (C / 4)), 256, 0, s>>>(dy, idx, dx, B, H, W, C / 4, K, stride, pad,
                                                                              Ho, Wo);
     ORBIT_LAUNCH_CHECK();
@@ -432,6 +432,7 @@ int launch_maxpool_bwd(const float* dy, const uint8_t* idx, float* dx, int B, in
 
 int launch_avgpool_bwd(const float* dy, float* dx, int B, int HW, int C, hipStream_t s) {
     ORBIT_REQUIRE(C % 4 == 0, "avgpool_backward: C %% 4 != 0");
+    ORBIT_REQUIRE((unsigned long long)((size_t)B * HW * (C / 4)) < (1ull << 32), "tensor too large for the 32-bit index arithmetic of this kernel");
     avgpool_bwd_kernel<<<grid_for((size_t)B * HW * (C / 4)), 256, 0, s>>>(dy, dx, B, HW, C / 4);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
@@ -440,6 +441,7 @@ int launch_avgpool_bwd(const float* dy, float* dx, int B, int HW, int C, hipStre
 int launch_upsample_zero(const float* src, float* dst, int B, int H, int W, int C, int stride, int Hs, int Ws,
                          hipStream_t s) {
     ORBIT_REQUIRE(C % 4 == 0 && stride >= 1, "upsample_zero: C %% 4 != 0");
+    ORBIT_REQUIRE((unsigned long long)((size_t)B * H * W * (C / 4)) < (1ull << 32), "tensor too large for the 32-bit index arithmetic of this kernel");
     upsample_zero_kernel<<<grid_for((size_t)B * H * W * (C / 4)), 256, 0, s>>>(src, dst, B, H, W, C / 4, stride, Hs, Ws);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;

@@ -173,18 +173,28 @@ class HipNetwork(nn.Module):
         for pl in plans:
             if pl.stamp == stamp:
                 continue
+            tensors = []
             for node, attr, key, own in self._leaves:
                 t = self._tensor(node, attr)
                 if own is not None and not isinstance(t, nn.Parameter):
                     t = own
-                t = t.detach().contiguous().float()
-                if t.is_cuda:  # stream-ordered copy: no host sync while parameters follow optimizer steps
-                    _lib.check(lib.orbit_extractor_load_async(pl.handle, key.encode(), ctypes.c_void_p(t.data_ptr()),
-                                                              t.numel(), _lib.stream_handle()),
-                               "orbit_extractor_load_async(%s)" % key)
-                else:
-                    _lib.check(lib.orbit_extractor_load(pl.handle, key.encode(), ctypes.c_void_p(t.data_ptr()),
-                                                        t.numel()), "orbit_extractor_load(%s)" % key)
+                tensors.append(t.detach())
+            if all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors):
+                # every tensor already lives on the device: ONE gather kernel (the pointer table is cached inside the plan)
+                # instead of one stream-ordered copy per tensor - after every optimizer step this was ~360 ctypes calls
+                ptrs = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+                _lib.check(lib.orbit_extractor_load_all_async(pl.handle, ptrs, len(tensors), _lib.stream_handle()),
+                           "orbit_extractor_load_all_async")
+            else:
+                for (node, attr, key, own), t in zip(self._leaves, tensors):
+                    t = t.contiguous().float()
+                    if t.is_cuda:  # stream-ordered copy: no host sync while parameters follow optimizer steps
+                        _lib.check(lib.orbit_extractor_load_async(pl.handle, key.encode(), ctypes.c_void_p(t.data_ptr()),
+                                                                  t.numel(), _lib.stream_handle()),
+                                   "orbit_extractor_load_async(%s)" % key)
+                    else:
+                        _lib.check(lib.orbit_extractor_load(pl.handle, key.encode(), ctypes.c_void_p(t.data_ptr()),
+                                                            t.numel()), "orbit_extractor_load(%s)" % key)
             _lib.check(lib.orbit_extractor_finalize(pl.handle, _lib.stream_handle()), "orbit_extractor_finalize")
             pl.stamp = stamp
 
