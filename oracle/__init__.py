@@ -8,9 +8,14 @@ Pinning:
   * head, pooler, set encoder, FiLM generator, batching helpers, FiLM injection, personalise()/predict() and
     LITE call order are PINNED against golden vectors produced by importing the reference's own modules
     (tests/golden/make_golden.py, run once in the build container; fixtures committed under tests/golden/).
-  * the feature extractors' layer arithmetic is "PARITY UNPINNED": efficientnet_b0 lives in timm==0.6.12
-    (un-vendored, absent offline) and resnet18/84x84 were removed from the reference snapshot. The
-    restatements in oracle/extractors.py follow the published architectures (torchvision ResNet-18;
-    timm 0.6.12 `tf_efficientnet_b0`) and are cross-checked structurally against
-    transformers.models.efficientnet where available.
+  * the feature extractors' layer arithmetic: efficientnet_b0 lives in timm==0.6.12 (un-vendored, absent
+    offline) and resnet18/84x84 were removed from the reference snapshot, so the reference itself cannot produce
+    vectors for them here. The restatements in oracle/extractors.py follow the published architectures
+    (torchvision ResNet-18; timm 0.6.12 `tf_efficientnet_b0`) and are PINNED against an independent
+    implementation: Hugging Face transformers' EfficientNetModel (B0 configuration) and
+    ResNetModel(layer_type="basic"), with the same state_dict re-keyed into them (tests/hf_pin.py) -
+    tests/test_oracle_extractors_hf.py (live, eval- and train-mode BatchNorm incl. running statistics, 224 / 96 /
+    84 / 97 / 231 pixel frames, <= 1e-5) and the committed fixture tests/golden/G12_extractors_hf.npz
+    (tests/golden/make_golden_hf.py), which the HIP path is checked against too (tests/test_gpu_extractors_hf.py).
+    What remains unpinned is only the identity "timm 0.6.12 == the published EfficientNet-B0" itself.
 """

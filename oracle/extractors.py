@@ -1,7 +1,8 @@
 """ORACLE (test infrastructure) — PyTorch-CPU restatements of the two feature extractors.
 
-PARITY UNPINNED for the layer arithmetic (see oracle/__init__.py): the reference obtains these networks from
-timm==0.6.12 (`model/feature_extractors.py:31-33,39-43`), which is not vendored. Module/parameter names follow
+The reference obtains these networks from timm==0.6.12 (`model/feature_extractors.py:31-33,39-43`), which is not
+vendored; the layer arithmetic here is pinned against Hugging Face transformers' independent implementations of
+both architectures (tests/test_oracle_extractors_hf.py, fixture G12). Module/parameter names follow
 torchvision's `resnet18` and timm's `tf_efficientnet_b0` so that state_dicts interchange and the reference's
 FiLM mechanism (functional_call with `<bn>.weight/.bias`, `model/few_shot_recognisers.py:114-115`) applies.
 """
