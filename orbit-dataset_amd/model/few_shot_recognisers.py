@@ -247,6 +247,13 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
                 hidden_size=self.set_encoder.output_size,
                 slot_names=[n for n, _ in self.feature_extractor.film_slot_modules()],
             )
+            # The reference snapshots the FiLM layers' BatchNorm weights / biases of the PRETRAINED timm network at
+            # construction (`get_film_parameters` clones them, model/film.py:81-87) and keeps the snapshot outside the
+            # state_dict (model/feature_adapters.py:55-58); FiLM-replaced BatchNorm parameters never receive a gradient,
+            # so in every checkpoint the reference writes they still equal that snapshot. Here nothing is downloaded at
+            # construction - the "pretrained" values ARE whatever load_state_dict brings - so the snapshot is re-taken
+            # from the extractor after every load (it stays out of the state_dict, as in the reference).
+            self.register_load_state_dict_post_hook(SingleStepFewShotRecogniser._refresh_film_snapshot_hook)
         else:
             self.set_encoder = NullSetEncoder()
             self.film_generator = NullGenerator()
@@ -262,6 +269,18 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         # (host-resident clips are always safe: their upload is issued on the second stream).
         self.overlap_query = False
         self._film_ready = None
+
+    def refresh_initial_film_parameters(self):
+        """Re-take the generator's snapshot of the FiLM layers' BatchNorm weights / biases from the extractor's current
+        values (what the reference's constructor does once, on the pretrained network). Called automatically after
+        load_state_dict; call it by hand after writing extractor parameters in any other way."""
+        if self.adapt_features:
+            self.film_generator.initial_film_parameters = get_film_parameters(self.film_parameter_names,
+                                                                              self.feature_extractor)
+
+    @staticmethod
+    def _refresh_film_snapshot_hook(module, incompatible_keys):
+        module.refresh_initial_film_parameters()
 
     def _reset(self):
         self.film_dict = None

@@ -127,6 +127,9 @@ def init_parameters_(module, seed=DEFAULT_SEED, prefix="", film_strength=0.1, us
     with torch.no_grad():
         for k, v in module.state_dict().items():
             v.copy_(sd[k].to(v.device))
+    refresh = getattr(module, "refresh_initial_film_parameters", None)
+    if refresh is not None:  # a recogniser with a FiLM generator: its snapshot of the extractor's BatchNorm follows
+        refresh()
     return module
 
 
