@@ -58,11 +58,7 @@ def build_model(workload, device, batch_size=256, train=False):
     learn_extractor = bool(train and not adapt)
     model = SingleStepFewShotRecogniser(fe_name, adapt, HEADS.get(workload, "proto"), 1, batch_size, learn_extractor,
                                         NUM_LITE, 1.0)
-    synthetic.init_parameters_(model)
-    if adapt:
-        from orbit_dataset_amd.model.film import get_film_parameters
-        model.film_generator.initial_film_parameters = get_film_parameters(model.film_parameter_names,
-                                                                           model.feature_extractor)
+    synthetic.init_parameters_(model)  # (also re-takes the FiLM generator's snapshot of the extractor's BatchNorm)
     model._set_device(device)
     model._send_to_device()
     model.set_test_mode(not train)
@@ -73,12 +69,17 @@ def build_model(workload, device, batch_size=256, train=False):
 
 
 class LiteTrainStep:
-    """One optimizer step of Learner.train_task_with_lite (reference single-step-learner.py:212-243) with
-    tasks_per_batch = 1 per rank; N > 1 ranks form a batch of N tasks whose gradients are summed by ONE all-reduce."""
+    """Learner.train_task_with_lite (reference single-step-learner.py:212-243) for ONE task per call, and the optimizer
+    step of the reference's outer loop (:162-166) after every `tasks_per_rank` calls: an optimizer step covers
+    tasks_per_batch = tasks_per_rank x world tasks (BASELINE config 5: 8 x 8 = 64), every task's loss carries
+    1/tasks_per_batch (:231), and with N > 1 ranks the gradients are summed by ONE all-reduce of the persistent flat
+    bucket (dist.GradientBucket) right before the step."""
 
-    def __init__(self, model, world, batch_size):
+    def __init__(self, model, world, batch_size, tasks_per_rank=1):
+        from orbit_dataset_amd import dist as odist
         from orbit_dataset_amd.learner import init_optimizer
         self.model, self.world, self.batch_size = model, world, batch_size
+        self.tasks_per_rank, self.calls = int(tasks_per_rank), 0
         from argparse import Namespace
         # torch's fused multi-tensor Adam (same update formula, one kernel per group instead of ~10 foreach launches over
         # every parameter tensor: the LITE step is host-bound, measured 44.8 -> 42.2 ms on efficientnet_b0, 10.2 -> 9.5 ms on
@@ -86,29 +87,34 @@ class LiteTrainStep:
         # bump parameter versions. ORBIT_BENCH_FUSED_ADAM=0 selects the plain (foreach) optimizer of the reference.
         opt_args = Namespace(fused_optimizer=os.environ.get("ORBIT_BENCH_FUSED_ADAM", "1") == "1")
         self.optimizer = init_optimizer(model, 5e-6, "adam", opt_args, 1.0)
+        self.bucket = odist.GradientBucket(model.parameters()) if world > 1 else None
         import numpy as np
         np.random.seed(1991)
 
     def __call__(self, model, task):
         import torch.nn.functional as F
-        from orbit_dataset_amd import dist as odist
         ctx, lab, tgt, tlab = task["context_clips"], task["context_labels"], task["target_clips"], task["target_labels"]
         model._clear_caches()
         out = []
+        tasks_per_batch = self.tasks_per_rank * self.world
         with torch.enable_grad():
             for lo in range(0, len(tgt), self.batch_size):
                 model.personalise_with_lite(ctx, lab)
                 logits = model.predict_a_batch(tgt[lo:lo + self.batch_size])
-                loss = len(lab) / (NUM_LITE * self.world) * F.cross_entropy(logits, tlab[lo:lo + self.batch_size])
+                loss = len(lab) / (NUM_LITE * tasks_per_batch) * F.cross_entropy(logits, tlab[lo:lo + self.batch_size])
                 loss = loss + 0.001 * model.film_generator.regularization_term()
                 loss.backward()
                 out.append(logits.detach())
                 model._reset()
-        if self.world > 1:
-            grads = [p.grad for p in model.parameters() if p.grad is not None]
-            odist.allreduce_tensors(grads, average=False)
-        self.optimizer.step()
-        self.optimizer.zero_grad()
+        self.calls += 1
+        if self.calls % self.tasks_per_rank == 0:
+            if self.bucket is not None:
+                self.bucket.sync()
+            self.optimizer.step()
+            if self.bucket is not None:
+                self.bucket.zero_()
+            else:
+                self.optimizer.zero_grad()
         return torch.cat(out)
 
 
@@ -255,6 +261,9 @@ def main():
     ap.add_argument("--mode", default="inference", choices=["inference", "lite_train"])
     ap.add_argument("--way", type=int, default=5, help="classes per task (BASELINE config 5 is 10-way: 20 support frames "
                                                        "per class instead of 40, same 200 + 200 frames)")
+    ap.add_argument("--tasks-per-rank", type=int, default=1,
+                    help="lite_train: tasks accumulated per rank and optimizer step (reference --tasks_per_batch = this x "
+                         "--gpus; BASELINE config 5 = 8 x 8 GPUs = 64 tasks/step). One bench step = one optimizer step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--distinct-tasks", type=int, default=4, help="tasks resident in HBM, cycled through")
     ap.add_argument("--batch-size", type=int, default=256, help="clips per extractor call (reference --batch_size)")
@@ -284,7 +293,8 @@ def main():
     fe_name, adapt, size = WORKLOADS[args.workload]
     train = args.mode == "lite_train"
     model = build_model(args.workload, device, args.batch_size, train=train)
-    run_step = LiteTrainStep(model, world, args.batch_size) if train else run_task
+    run_step = LiteTrainStep(model, world, args.batch_size, args.tasks_per_rank) if train else run_task
+    per_step = args.tasks_per_rank if train else 1  # run_step calls (= tasks) per bench step on this rank
     # each rank owns its own tasks (task index = rank + world * i): weak scaling, independent units
     way = args.way
     if (WAY * SHOTS * FRAMES_PER_SHOT) % way:
@@ -314,7 +324,7 @@ def main():
         barrier()
         t0 = time.perf_counter()
         outs = []
-        for i in range(steps):
+        for i in range(steps * per_step):
             outs.append(run_step(model, tasks[i % len(tasks)]))  # logits stay on the device; scored after the clock stops
         issued = time.perf_counter() - t0  # host time to enqueue everything (diagnostic: host- vs device-bound)
         barrier()
@@ -337,7 +347,7 @@ def main():
         for _ in range(20):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(10):
+            for i in range(10 * per_step):
                 run_step(model, tasks[i % len(tasks)])
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
@@ -352,7 +362,7 @@ def main():
             if done:
                 break
             prev = dt
-    for i in range(args.warmup):
+    for i in range(args.warmup * per_step):
         run_step(model, tasks[i % len(tasks)])
     elapsed, correct, issued = loop(args.steps)  # the timed region behind `value`
     # roofline leg: the SAME K steps again with one HIP-event pair recorded per conv_igemm launch on its stream
@@ -407,7 +417,7 @@ def main():
     macs = model.feature_extractor.macs_per_frame(size, size)
     out = {
         "metric": "query frames/sec per task (224x224, 5-way ProtoNet) + frame accuracy vs ref",
-        "value": NUM_QUERY * args.steps * world / elapsed,
+        "value": NUM_QUERY * args.steps * per_step * world / elapsed,
         "unit": "query frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
@@ -421,7 +431,10 @@ def main():
                                    fe_name, " + CNAPs FiLM adaptation" if adapt else "", size, size, way,
                                    WAY * SHOTS * FRAMES_PER_SHOT, SHOTS if way == WAY else 1,
                                    FRAMES_PER_SHOT if way == WAY else frames_per_class, NUM_QUERY),
-                   "tasks_per_step": 1, "parallelism": "task-parallel x%d (independent tasks per rank)" % world},
+                   "tasks_per_step": per_step * world,
+                   "parallelism": "task-parallel x%d (independent tasks per rank%s)" % (
+                       world, "; one all-reduce of the flat gradient bucket per optimizer step" if train and world > 1
+                       else "")},
         "frame_accuracy": float(correct[0].item() / max(correct[1].item(), 1)),
         "host_enqueue_ms_per_step": 1e3 * issued / args.steps,
         "graph_option": os.environ.get("ORBIT_GRAPH", "2 (adaptive)"),

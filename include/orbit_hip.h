@@ -176,6 +176,10 @@ int orbit_filmgen_create(int n_gen, int z_dim, int hidden, const int* out_size, 
 void orbit_filmgen_destroy(orbit_filmgen_t* g);
 /* tensor: "w1"[hid][z] "b1"[hid] "ln_w"[hid] "ln_b"[hid] "w2"[out][hid] "b2"[out] "reg"[out] "init"[out] */
 int orbit_filmgen_load(orbit_filmgen_t* g, int gen, const char* tensor, const float* data, size_t numel);
+/* Stream-ordered form for parameters that already live on the device (they follow optimizer steps): ONE gather kernel on
+ * `stream` copies all 8 tensors of every generator; device_ptrs[8*gen + t], t in the order listed above. No host sync
+ * unless the pointer table changed since the previous call. */
+int orbit_filmgen_load_all_async(orbit_filmgen_t* g, const float* const* device_ptrs, int n, orbit_stream_t stream);
 /* z [z_dim] -> film_gamma, film_beta (each film_size floats), l2[1] = Σ_i Σ reg_i^2 */
 int orbit_filmgen_forward(orbit_filmgen_t* g, const float* z, float* film_gamma, float* film_beta,
                           float* l2, orbit_stream_t stream);

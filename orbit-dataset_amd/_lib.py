@@ -48,6 +48,7 @@ _SIGNATURES = {
                                      POINTER(c_void_p)]),
     "orbit_filmgen_destroy": (None, [P]),
     "orbit_filmgen_load": (c_int, [P, c_int, c_char_p, P, c_size_t]),
+    "orbit_filmgen_load_all_async": (c_int, [P, P, c_int, P]),
     "orbit_filmgen_forward": (c_int, [P, P, P, P, P, P]),
     "orbit_op_conv2d": (c_int, [P, c_int, P, P, P, P, P, P] + [c_int] * 14 + [P]),
     "orbit_op_dwconv2d": (c_int, [P, P, P, P, P] + [c_int] * 11 + [P]),

@@ -201,7 +201,20 @@ struct orbit_filmgen {
     size_t pool_floats = 0;
     float* d_pool = nullptr;
     GenDesc* d_gens = nullptr;
+    // orbit_filmgen_load_all_async: device table of source pointers + (offset, numel) of each destination
+    const float** d_src = nullptr;
+    size_t* d_dst_meta = nullptr;
+    std::vector<const float*> h_src;
 };
+
+// one kernel copies every generator tensor into the pool: grid (chunks, tensors)
+__global__ __launch_bounds__(256) void filmgen_gather_kernel(const float* const* __restrict__ src,
+                                                             const size_t* __restrict__ meta, float* __restrict__ pool) {
+    const float* s_ = src[blockIdx.y];
+    float* d = pool + meta[2 * blockIdx.y];
+    const size_t n = meta[2 * blockIdx.y + 1];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) d[i] = s_[i];
+}
 
 extern "C" {
 
@@ -245,6 +258,8 @@ void orbit_filmgen_destroy(orbit_filmgen_t* g) {
     if (!g) return;
     (void)hipFree(g->d_pool);
     (void)hipFree(g->d_gens);
+    (void)hipFree(g->d_src);
+    (void)hipFree(g->d_dst_meta);
     delete g;
 }
 
@@ -266,6 +281,36 @@ int orbit_filmgen_load(orbit_filmgen_t* g, int gen, const char* tensor, const fl
     ORBIT_REQUIRE(numel == expect, "filmgen_load: %s of generator %d has %zu elements, expected %zu", tensor,
                   gen, numel, expect);
     ORBIT_HIP_CHECK(hipMemcpy(g->d_pool + off, data, numel * sizeof(float), hipMemcpyDefault));
+    return ORBIT_OK;
+}
+
+int orbit_filmgen_load_all_async(orbit_filmgen_t* g, const float* const* device_ptrs, int n, orbit_stream_t stream) {
+    ORBIT_REQUIRE(g && device_ptrs, "filmgen_load_all_async: null pointer");
+    ORBIT_REQUIRE(n == 8 * g->n_gen, "filmgen_load_all_async: %d pointers for %d generators x 8 tensors", n, g->n_gen);
+    hipStream_t s = (hipStream_t)stream;
+    if (!g->d_src) {
+        ORBIT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->d_src), n * sizeof(float*)));
+        ORBIT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&g->d_dst_meta), 2 * n * sizeof(size_t)));
+        std::vector<size_t> meta(2 * n);
+        for (int i = 0; i < g->n_gen; ++i) {
+            const GenDesc& d = g->gens[i];
+            const size_t off[8] = {d.w1, d.b1, d.ln_w, d.ln_b, d.w2, d.b2, d.reg, d.init};
+            const size_t num[8] = {(size_t)g->hid * g->z_dim, (size_t)g->hid, (size_t)g->hid, (size_t)g->hid,
+                                   (size_t)d.out * g->hid, (size_t)d.out, (size_t)d.out, (size_t)d.out};
+            for (int t = 0; t < 8; ++t) meta[2 * (8 * i + t)] = off[t], meta[2 * (8 * i + t) + 1] = num[t];
+        }
+        ORBIT_HIP_CHECK(hipMemcpy(g->d_dst_meta, meta.data(), meta.size() * sizeof(size_t), hipMemcpyHostToDevice));
+    }
+    bool same = (int)g->h_src.size() == n;
+    for (int i = 0; same && i < n; ++i) same = g->h_src[i] == device_ptrs[i];
+    if (!same) {  // the tensors moved: refresh the pointer table (an earlier gather on this stream may still read it)
+        for (int i = 0; i < n; ++i) ORBIT_REQUIRE(device_ptrs[i], "filmgen_load_all_async: null tensor %d", i);
+        g->h_src.assign(device_ptrs, device_ptrs + n);
+        ORBIT_HIP_CHECK(hipStreamSynchronize(s));
+        ORBIT_HIP_CHECK(hipMemcpy(g->d_src, g->h_src.data(), n * sizeof(float*), hipMemcpyHostToDevice));
+    }
+    filmgen_gather_kernel<<<dim3(4, n), 256, 0, s>>>(g->d_src, g->d_dst_meta, g->d_pool);
+    ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
 

@@ -26,8 +26,8 @@ def init_from_env(backend=None):
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # ORBIT_DIST_BACKEND=gloo lets several ranks share one GPU (RCCL refuses that)
+            backend = os.environ.get("ORBIT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         kwargs = {}
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
@@ -113,6 +113,86 @@ def predict_query_sharded(model, target_clips, sharding, gather=True):
     full[lo:hi] = local
     sharding.reduce_(full)  # disjoint slices: a SUM all-reduce is an all-gather for ragged shards
     return full
+
+
+class GradientBucket:
+    """Persistent flat gradient bucket of the task-parallel training step (X3 of SURVEY §8e): ONE all-reduce(SUM) per
+    optimizer step on ONE contiguous buffer the gradients already live in - no per-step torch.cat and no copy-back.
+
+    Which parameters receive a gradient is a property of the configuration, not of the data (FiLM-replaced BatchNorm
+    weights, the detached Versa hyper-networks, ... never do). The first `sync()` therefore all-reduces (MAX) a presence
+    mask: parameters that have a gradient on NO rank keep `grad = None` - the optimizer skips them exactly as the
+    single-process run and the reference do (zero-filling them would let Adam's L2 weight decay move them); parameters
+    with a gradient on at least one rank get a view into the flat bucket as their `.grad` (zero where this rank had
+    none), and autograd accumulates into those views in place from then on. Call `zero_()` instead of
+    `optimizer.zero_grad()`: one memset, views stay attached.
+    """
+
+    def __init__(self, params, group=None):
+        self.params = [p for p in params if p.requires_grad]
+        self.group = group
+        self.flat = None
+        self.views = None      # per parameter: view into `flat`, or None (no gradient on any rank)
+        self.nbytes = 0
+
+    def _active(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _build(self):
+        dev = self.params[0].device
+        mask = torch.tensor([0.0 if p.grad is None else 1.0 for p in self.params], device=dev)
+        if self._active():
+            dist.all_reduce(mask, op=dist.ReduceOp.MAX, group=self.group)
+        present = [m > 0.5 for m in mask.tolist()]  # one host sync, first optimizer step only
+        total = sum(-(-p.numel() // 64) * 64 for p, keep in zip(self.params, present) if keep)  # 256-byte aligned slots
+        self.flat = torch.zeros(max(total, 1), device=dev, dtype=torch.float32)
+        self.nbytes = 4 * total
+        self.views, off = [], 0
+        for p, keep in zip(self.params, present):
+            if not keep:
+                self.views.append(None)
+                continue
+            v = self.flat[off:off + p.numel()].view_as(p)
+            off += -(-p.numel() // 64) * 64
+            if p.grad is not None:
+                v.copy_(p.grad)
+            p.grad = v
+            self.views.append(v)
+
+    def _attached(self):
+        """Make every present parameter's .grad the bucket view again (after an optimizer.zero_grad() dropped them):
+        a detached view takes the freshly allocated gradient's value, or zero if this rank produced none."""
+        for p, v in zip(self.params, self.views):
+            if v is None:
+                if p.grad is not None:
+                    return False  # a parameter started to receive gradients: the layout is stale, rebuild
+            elif p.grad is not v:
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                else:
+                    v.zero_()
+                p.grad = v
+        return True
+
+    def sync(self):
+        """All-reduce(SUM) the bucket. Afterwards every rank holds identical gradients; parameters without a gradient on
+        any rank still have grad None."""
+        if not self.params:
+            return
+        if self.flat is None or not self._attached():
+            self._build()
+        if self._active():
+            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+
+    def zero_(self):
+        """Start the next accumulation window (replaces optimizer.zero_grad())."""
+        if self.flat is None:
+            for p in self.params:
+                p.grad = None
+            return
+        self.flat.zero_()
+        for p, v in zip(self.params, self.views):
+            p.grad = v  # None stays None
 
 
 def allreduce_tensors(tensors, average=False):

@@ -55,6 +55,9 @@ def build_parser():
     p.add_argument("--seed", type=int, default=synthetic.DEFAULT_SEED)
     p.add_argument("--mode", default="test", choices=["train", "test", "train_test"])
     p.add_argument("--model_path", default=None)
+    p.add_argument("--save_model_path", default=None,
+                   help="where --mode train / train_test writes model.state_dict() after training (the reference saves "
+                        "checkpoint_dir/final.pt, single-step-learner.py:185)")
     # synthetic-task shape (the dataset-side flags of the reference have no meaning here)
     p.add_argument("--way", type=int, default=5)
     p.add_argument("--shots", type=int, default=5)
@@ -118,14 +121,12 @@ class Learner:
         self.model = SingleStepFewShotRecogniser(a.feature_extractor, a.adapt_features, a.classifier, a.clip_length,
                                                  a.batch_size, a.learn_extractor, a.num_lite_samples, a.logit_scale)
         if a.model_path:
+            # reference single-step-learner.py:300-302. The FiLM generator's gamma0/beta0 snapshot is not part of the file
+            # (feature_adapters.py:55-58); the recogniser re-takes it from the loaded extractor (load_state_dict hook)
             self.model.load_state_dict(torch.load(a.model_path, map_location="cpu"))
         else:
             synthetic.init_parameters_(self.model, seed=a.seed,
                                        film_strength=0.02 if a.feature_extractor == "efficientnet_b0" else 0.1)
-            if a.adapt_features:
-                from .model.film import get_film_parameters
-                self.model.film_generator.initial_film_parameters = get_film_parameters(
-                    self.model.film_parameter_names, self.model.feature_extractor)
         self.model._set_device(self.device)
         self.model._send_to_device()
 
@@ -193,25 +194,21 @@ class Learner:
         return task_loss, torch.cat(target_logits)
 
     def _sync_gradients(self):
-        """X3 of SURVEY.md §8e: one all-reduce(SUM) of the flat gradient bucket per optimizer step (+ the running
-        statistics, averaged)."""
+        """X3 of SURVEY.md §8e: one all-reduce(SUM) of the persistent flat gradient bucket per optimizer step (+ the
+        running statistics, averaged). Parameters that receive no gradient on any rank keep grad None, so the optimizer
+        skips them as the single-GPU run and the reference do (dist.GradientBucket)."""
         if self.world == 1:
             return
-        import torch.distributed as dist
-        params = [p for p in self.model.parameters() if p.requires_grad]
-        for p in params:
-            if p.grad is None:
-                p.grad = torch.zeros_like(p)
-        odist.allreduce_tensors([p.grad for p in params], average=False)
+        self.grad_bucket.sync()
         stats = [b for n, b in self.model.named_buffers() if n.endswith("running_mean") or n.endswith("running_var")]
         if stats and self.model.learn_extractor:
             odist.allreduce_tensors(stats, average=True)
-        del dist
 
     def train(self):
         a = self.args
         self.optimizer = init_optimizer(self.model, a.learning_rate, a.optimizer, a, a.extractor_lr_scale)
         apply_lr_scale(self.optimizer, a.learning_rate)  # constant schedule (the reference's timm scheduler applies it)
+        self.grad_bucket = odist.GradientBucket(self.model.parameters()) if self.world > 1 else None
         train_task_fn = self.train_task_with_lite if a.with_lite else self.train_task
         losses, accs, times = [], [], []
         prev = torch.is_grad_enabled()
@@ -231,6 +228,9 @@ class Learner:
                 for step in range(total_steps):
                     if step % self.world == self.rank:
                         task = pregen.pop(step, None) or self.make_train_task(epoch * total_steps + step)
+                        # LITE draws its subsets from np.random (few_shot_recognisers.py:330); seeding per TASK (the
+                        # reference leaves numpy unseeded) makes a run independent of how tasks are dealt to ranks
+                        np.random.seed((a.seed + 7919 * (epoch * total_steps + step + 1)) % (2 ** 32))
                         torch.cuda.synchronize()
                         t0 = time.perf_counter()
                         task_loss, logits = train_task_fn(task)
@@ -243,10 +243,18 @@ class Learner:
                                   % (epoch + 1, a.epochs, step + 1, total_steps, self.rank, losses[-1], accs[-1], times[-1]))
                     if (step + 1) % a.tasks_per_batch == 0 or step == total_steps - 1:
                         self._sync_gradients()
+                        if not hasattr(self, "gradless_parameters"):  # diagnostic, first optimizer step only
+                            self.gradless_parameters = sorted(n for n, p in self.model.named_parameters()
+                                                              if p.requires_grad and p.grad is None)
                         self.optimizer.step()
-                        self.optimizer.zero_grad()
+                        if self.grad_bucket is not None:
+                            self.grad_bucket.zero_()  # one memset; gradients keep living inside the flat bucket
+                        else:
+                            self.optimizer.zero_grad()
         finally:
             torch.set_grad_enabled(prev)
+        if a.save_model_path and self.rank == 0:  # every rank holds the same parameters after the last step
+            torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()}, a.save_model_path)
         stats = {"loss": mean_ci(losses) if losses else (0.0, 0.0), "frame_acc": mean_ci(accs) if accs else (0.0, 0.0),
                  "ms_per_task": mean_ci(times) if times else (0.0, 0.0), "num_tasks": len(losses),
                  "world_size": self.world}

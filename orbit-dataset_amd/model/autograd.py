@@ -42,7 +42,7 @@ class ExtractorFunction(torch.autograd.Function):
         ctx.net, ctx.plan, ctx.tape, ctx.bn_train, ctx.param_index = net, plan, tape, int(bn_train), param_index
         ctx.save_for_backward(frames, gamma, beta)
         ctx.film_needs = (gamma is not None and gamma.requires_grad) or (beta is not None and beta.requires_grad)
-        ctx.param_stamp = plan.stamp
+        ctx.generation = plan.generation
         return feats
 
     @staticmethod
@@ -50,6 +50,12 @@ class ExtractorFunction(torch.autograd.Function):
         lib = _lib.load()
         frames, gamma, beta = ctx.saved_tensors
         net, plan = ctx.net, ctx.plan
+        if plan.generation != ctx.generation:
+            # the backward kernels read filters / BatchNorm weights from the native plan, not from the tape: a parameter
+            # upload between forward and backward (optimizer step, load_state_dict, mark_parameters_changed + another
+            # forward) would silently differentiate a different network than the one that ran forward
+            raise RuntimeError("the extractor's parameters were modified (re-uploaded into the native plan) between the "
+                               "forward that recorded this tape and its backward; run backward before changing them")
         B, dev = frames.shape[0], frames.device
         n_fixed = 8
         need_params = any(ctx.needs_input_grad[n_fixed:])

@@ -77,12 +77,20 @@ class FilmParameterGenerator(nn.Module):
             self._handle = h
         stamp = tuple((t.data_ptr(), t._version) for i in range(n) for _, t in self._tensors(i))
         if stamp != self._stamp:
-            for i in range(n):
-                for tname, t in self._tensors(i):
-                    t = t.detach().contiguous().float()
-                    _lib.check(lib.orbit_filmgen_load(self._handle, i, tname.encode(),
-                                                      ctypes.c_void_p(t.data_ptr()), t.numel()),
-                               "orbit_filmgen_load")
+            tensors = [t.detach() for i in range(n) for _, t in self._tensors(i)]
+            if all(t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() for t in tensors):
+                # parameters resident on the device (they follow optimizer steps): one stream-ordered gather kernel on
+                # the caller's stream instead of 8 x n blocking copies on the null stream
+                ptrs = (ctypes.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+                _lib.check(lib.orbit_filmgen_load_all_async(self._handle, ptrs, len(tensors), _lib.stream_handle()),
+                           "orbit_filmgen_load_all_async")
+            else:
+                for i in range(n):
+                    for tname, t in self._tensors(i):
+                        t = t.detach().contiguous().float()
+                        _lib.check(lib.orbit_filmgen_load(self._handle, i, tname.encode(),
+                                                          ctypes.c_void_p(t.data_ptr()), t.numel()),
+                                   "orbit_filmgen_load")
             self._stamp = stamp
 
     def forward(self, x):

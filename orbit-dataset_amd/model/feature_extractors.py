@@ -59,6 +59,7 @@ class _Plan:
                 lib.orbit_set_option(b"mbconv_fusion", prev)
         self.handle = h
         self.stamp = None
+        self.generation = 0  # bumped by every parameter upload: a tape recorded under generation g can only be replayed under g
         self.workspaces = {}
 
     def destroy(self):
@@ -197,6 +198,7 @@ class HipNetwork(nn.Module):
                                                             t.numel()), "orbit_extractor_load(%s)" % key)
             _lib.check(lib.orbit_extractor_finalize(pl.handle, _lib.stream_handle()), "orbit_extractor_finalize")
             pl.stamp = stamp
+            pl.generation += 1
 
     def _workspace(self, plan, B, device):
         # one workspace per (batch size, stream): forwards issued on different streams (the query pass overlapped with the

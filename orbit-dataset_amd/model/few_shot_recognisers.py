@@ -300,7 +300,14 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         class_ids = self.classifier.unique_labels(context_labels, self.device)
         task_embedding = self._get_task_embedding_in_batches(context_clips, ops_counter)
         self.film_dict = self._generate_film_params(task_embedding, ops_counter)
-        if self.overlap_query and self.film_dict:
+        if self.overlap_query:
+            # everything the query pass needs from this stream: the FiLM vectors AND the extractor's parameters inside
+            # the native plan. The upload / repack / BatchNorm fold is queued HERE, explicitly, before the event — the
+            # first forward below would otherwise queue it after the event, and a query pass on the side stream (whose
+            # own sync() sees an up-to-date stamp) could run against half-packed filters on the first task after any
+            # parameter change.
+            fe = self.feature_extractor
+            fe.sync(fe._plan(int(context_clips.shape[-2]), int(context_clips.shape[-1])))
             self._film_ready = torch.cuda.Event()
             self._film_ready.record(torch.cuda.current_stream(self.device))
         context_features = self._get_features_in_batches(context_clips, self.film_dict, ops_counter)
@@ -410,8 +417,10 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
             if side is None:
                 side = self.__dict__["_query_stream"] = torch.cuda.Stream(device=self.device)
             main = torch.cuda.current_stream(self.device)
-            if self.film_dict and self._film_ready is not None:
-                side.wait_event(self._film_ready)  # the only thing the query pass needs from personalise()
+            if self._film_ready is not None:
+                side.wait_event(self._film_ready)  # FiLM vectors + uploaded parameters: all the query pass needs
+            else:  # personalised through another route (sharded / LITE): order after everything queued so far
+                side.wait_stream(main)
             with torch.cuda.stream(side):
                 target_features = self._get_features_in_batches(target_clips, self.film_dict)
             main.wait_stream(side)

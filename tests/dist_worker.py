@@ -1,0 +1,59 @@
+"""Worker of tests/test_gpu_dist.py: one rank of a 2-rank job in which BOTH ranks share GPU 0 (gloo backend: RCCL refuses
+two ranks on one device). Runs the PRODUCT's multi-GPU forms - dist.personalise_support_sharded, dist.predict_query_sharded,
+learner.py --mode train with dist.GradientBucket - and writes what it computed to <out>.rank<r>.pt."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+import orbit_dataset_amd  # noqa: E402,F401
+from orbit_dataset_amd import dist as odist  # noqa: E402
+from orbit_dataset_amd import synthetic  # noqa: E402
+
+
+def sharded(out, adapt):
+    from orbit_dataset_amd.model.few_shot_recognisers import SingleStepFewShotRecogniser
+    rank, world, _ = odist.init_from_env("gloo")
+    torch.cuda.set_device(0)
+    model = SingleStepFewShotRecogniser("resnet18", adapt, "proto", 1, 8, False, 16, 1.0)
+    synthetic.init_parameters_(model)
+    model._set_device("cuda:0")
+    model._send_to_device()
+    model.set_test_mode(True)
+    task = synthetic.make_task(9, way=4, shots=1, frames_per_shot=5, num_query=11, frame_size=64, label_values=(2, 5, 6, 9))
+    ctx, lab, tgt = task["context_clips"].cuda(), task["context_labels"].cuda(), task["target_clips"].cuda()
+    sh = odist.SupportSharding(rank, world)
+    lo, hi = sh.bounds(len(lab))
+    # this rank only holds ITS slice of the support clips (plus the full, tiny label vector)
+    odist.personalise_support_sharded(model, ctx[lo:hi].clone(), lab, sh)
+    logits = odist.predict_query_sharded(model, tgt, sh)
+    torch.save({"W": model.classifier.weight.detach().cpu(), "b": model.classifier.bias.detach().cpu(),
+                "logits": logits.cpu(), "bounds": (lo, hi)}, "%s.rank%d.pt" % (out, rank))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def train(out, argv):
+    from orbit_dataset_amd import learner
+    args = learner.build_parser().parse_args(argv + ["--save_model_path", out + ".model.pt"])
+    L = learner.Learner(args)
+    stats = L.run()
+    grads_none = L.gradless_parameters  # parameters whose grad was None at the first optimizer step
+    torch.save({"stats": stats, "bucket_bytes": getattr(L.grad_bucket, "nbytes", 0) if L.world > 1 else 0,
+                "grads_none": grads_none}, "%s.rank%d.pt" % (out, L.rank))
+    if L.world > 1:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    mode, out = sys.argv[1], sys.argv[2]
+    if mode == "sharded":
+        sharded(out, adapt=sys.argv[3] == "1")
+    elif mode == "train":
+        train(out, sys.argv[3:])
+    else:
+        raise SystemExit("unknown mode " + mode)

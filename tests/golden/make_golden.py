@@ -7,8 +7,8 @@ Run once in the build container (the reference is mounted read-only there and ne
 The reference's modules are imported as they are (`model.classifier_heads`, `model.poolers`,
 `model.set_encoders`, `model.feature_adapters`, `data.utils`), and `model.few_shot_recognisers` is imported
 with the absent third-party `timm` package stubbed in sys.modules and `create_feature_extractor` replaced by a
-factory returning this build's PyTorch-CPU extractor (the extractor arithmetic itself is "parity unpinned",
-see oracle/__init__.py). Inputs come from the deterministic synthetic generators; inputs and the reference's
+factory returning this build's PyTorch-CPU extractor (the extractor's layer arithmetic is pinned separately,
+against Hugging Face transformers: make_golden_hf.py / G12). Inputs come from the deterministic synthetic generators; inputs and the reference's
 outputs are written to small .npz files next to this script. Only data is stored — no reference source.
 """
 import os
@@ -404,6 +404,46 @@ def g11_finetuner(fsr):
     save("G11_finetuner", **out)
 
 
+def g13_checkpoint(fsr):
+    """§8(f3) checkpoint compatibility (single-step-learner.py:300-305,377-390): what the REFERENCE's model writes
+    with state_dict() and what it computes after `load_state_dict(torch.load(path))`.
+
+    The reference model is constructed on "pretrained" extractor values A (the factory initialises the extractor before
+    FilmParameterGenerator snapshots gamma0/beta0, as timm's pretrained download does), then loads a checkpoint whose
+    extractor equals A (FiLM-replaced BatchNorm parameters never get a gradient) and whose set encoder / FiLM generator
+    hold other values. The fixture stores the key list, shapes and dtypes of the reference's state_dict, whether the
+    snapshot is part of it, and the logits after the load; checkpoint values are regenerated from (seed, key) by
+    synthetic.synth_tensor, so no weights are stored."""
+    import tempfile
+    out = {}
+    task = synthetic.make_task(71, way=3, shots=1, frames_per_shot=3, num_query=7, frame_size=64)
+    out["context_clips"], out["context_labels"], out["target_clips"] = (task["context_clips"], task["context_labels"],
+                                                                        task["target_clips"])
+    for tag, fe_name, adapt in (("effnet_film", "efficientnet_b0", True), ("resnet_proto", "resnet18", False)):
+        model = make_reference_recogniser(fsr, fe_name, adapt, "proto", 1, 4, 16,
+                                          film_strength=0.02 if fe_name == "efficientnet_b0" else 0.1)
+        sd = model.state_dict()
+        out[tag + "_keys"] = np.array(list(sd.keys()))
+        out[tag + "_shapes"] = np.array([",".join(map(str, v.shape)) for v in sd.values()])
+        out[tag + "_dtypes"] = np.array([str(v.dtype) for v in sd.values()])
+        out[tag + "_snapshot_in_state_dict"] = np.array(any("initial_film_parameters" in k for k in sd))
+        # a checkpoint "trained elsewhere": everything outside the extractor re-drawn with another seed
+        ckpt = {k: (v.clone() if k.startswith("feature_extractor.") else
+                    synthetic.synth_tensor(k, tuple(v.shape), seed=7, film_strength=0.02)) for k, v in sd.items()}
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "checkpoint.pt")
+            torch.save(ckpt, path)
+            fresh = make_reference_recogniser(fsr, fe_name, adapt, "proto", 1, 4, 16)
+            fresh.load_state_dict(torch.load(path))
+        fresh.set_test_mode(True)
+        with torch.no_grad():
+            fresh.personalise(task["context_clips"], task["context_labels"])
+            out[tag + "_logits"] = fresh.predict(task["target_clips"])
+            if adapt:
+                out[tag + "_film_bn1_weight"] = fresh.film_dict["bn1.weight"]
+    save("G13_checkpoint", **out)
+
+
 def g7_utils():
     from data.utils import attach_frame_history, get_batch_indices
     frames = torch.arange(6 * 3 * 2 * 2, dtype=torch.float32).reshape(6, 3, 2, 2)
@@ -416,6 +456,13 @@ def main():
     torch.manual_seed(0)
     torch.set_num_threads(4)
     stub_timm()
+    only = [a for a in sys.argv[2:]]
+    if only:  # e.g. `make_golden.py /root/reference g13_checkpoint`: regenerate selected fixtures only
+        import model.few_shot_recognisers as fsr
+        for name in only:
+            fn = globals()[name]
+            fn(fsr) if fn.__code__.co_argcount else fn()
+        return
     g1_head()
     g2_pooler()
     g3_set_encoder()
@@ -428,6 +475,7 @@ def main():
     g8_lite_learn_extractor(fsr)
     g9_lite_efficientnet(fsr)
     g11_finetuner(fsr)
+    g13_checkpoint(fsr)
 
 
 if __name__ == "__main__":

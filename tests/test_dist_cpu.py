@@ -135,3 +135,72 @@ def test_gradient_allreduce_matches_single_process_accumulation():
             assert np.abs(got - ref).max() <= 2e-5 * max(np.abs(ref).max(), 1e-12)
     for a, b in zip(result[0], result[1]):
         assert np.array_equal(a, b)  # identical gradients on both ranks -> identical optimizer steps
+
+
+# ---- persistent flat gradient bucket (dist.GradientBucket): presence mask, None grads stay None ------------------------
+def _toy():
+    torch.manual_seed(5)
+    m = torch.nn.Module()
+    m.a = torch.nn.Parameter(torch.randn(7, 3))    # gradient on every rank
+    m.b = torch.nn.Parameter(torch.randn(5))       # gradient on rank 0's tasks only
+    m.c = torch.nn.Parameter(torch.randn(4, 2))    # never receives a gradient (like a FiLM-replaced BatchNorm weight)
+    return m
+
+
+def _toy_loss(m, task, tasks_per_batch):
+    x = torch.full((3,), float(task + 1))
+    loss = (m.a @ x).pow(2).sum()
+    if task % 2 == 0:
+        loss = loss + (m.b * (task + 1)).sum()
+    return loss / tasks_per_batch
+
+
+def _toy_train(rank, world, steps=3, tasks_per_batch=4):
+    m = _toy()
+    opt = torch.optim.Adam(m.parameters(), lr=0.05, weight_decay=0.2)
+    bucket = odist.GradientBucket(m.parameters()) if world > 1 else None
+    for step in range(steps):
+        for t in range(tasks_per_batch):
+            if t % world == rank:
+                _toy_loss(m, step * tasks_per_batch + t, tasks_per_batch).backward()
+        if bucket is not None:
+            bucket.sync()
+            assert m.c.grad is None  # no gradient anywhere -> stays None -> Adam's weight decay must not touch it
+            assert m.a.grad.data_ptr() == bucket.flat.data_ptr()  # gradients live inside the flat bucket
+        opt.step()
+        if bucket is not None:
+            if step == 1:
+                opt.zero_grad()  # a caller that drops the views: the bucket must re-attach them
+            else:
+                bucket.zero_()
+        else:
+            opt.zero_grad()
+    return [p.detach().clone() for p in (m.a, m.b, m.c)]
+
+
+def _bucket_worker(rank, world, port, result):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = odist.init_from_env("gloo")
+    result[rank] = [t.numpy() for t in _toy_train(r, w)]
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_matches_single_process_and_skips_gradless_parameters():
+    """zero-filling None gradients before the all-reduce let Adam's L2 weight decay move parameters
+    that never receive a gradient (Versa hyper-networks, FiLM-replaced BatchNorm). With the presence mask they keep
+    grad None on every rank; the task-parallel run equals single-process accumulation over the same tasks."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_bucket_worker, args=(2, port, result), nprocs=2, join=True)
+    want = _toy_train(0, 1)
+    init = _toy()
+    for r in range(2):
+        a, b, c = result[r]
+        assert np.allclose(a, want[0].numpy(), atol=1e-6) and np.allclose(b, want[1].numpy(), atol=1e-6)
+        assert np.array_equal(c, init.c.detach().numpy()) and np.array_equal(c, want[2].numpy())
+    assert all(np.array_equal(x, y) for x, y in zip(result[0], result[1]))  # bit-identical replicas

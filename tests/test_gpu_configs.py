@@ -1,0 +1,140 @@
+"""Every BASELINE.json config end-to-end on the GPU at its real frame size (configs 4 and 5 were not).
+
+  config 3  ProtoNet + efficientnet_b0, 224x224 LITE, 5-way      -> inference vs oracle + one LITE step vs oracle/training.py
+  config 4  CNAPs (FiLM + set encoder) + resnet18, 224x224, 5-way -> inference vs oracle (and one frozen-extractor LITE step)
+  config 5  ProtoNet + efficientnet_b0, 224x224 LITE, 10-way      -> inference vs oracle + one LITE step (H = 16), loss scaled
+            for 64 tasks/step (tasks_per_batch 64, reference single-step-learner.py:162-166,231)
+Counts are reduced where the CPU oracle has to follow (it runs ~20 frames/s at 224x224); the FULL 200 + 200 frame tasks
+are covered by size-independent properties: finite logits, per-frame argmax invariant under a permutation of the support
+set (prototypes are means), the two-stream overlap bit-equal to the single-stream run, the batched run (batch_size 64)
+equal to the one-launch run."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import orbit_dataset_amd  # noqa: E402,F401
+from oracle.recogniser import OracleRecogniser  # noqa: E402
+from oracle.training import LiteTrainer  # noqa: E402
+from orbit_dataset_amd import synthetic  # noqa: E402
+from orbit_dataset_amd.model.few_shot_recognisers import SingleStepFewShotRecogniser  # noqa: E402
+
+CONFIGS = {
+    # name: (extractor, adapt_features, way, learn_extractor when meta-training)
+    "config3_protonet_efficientnet_b0_224_5way": ("efficientnet_b0", False, 5, True),
+    "config4_cnaps_resnet18_224_5way": ("resnet18", True, 5, False),
+    "config5_protonet_efficientnet_b0_224_10way": ("efficientnet_b0", False, 10, True),
+}
+SIZE = 224
+
+
+def _native(fe_name, adapt, learn, batch_size, num_lite=16, test_mode=True):
+    m = SingleStepFewShotRecogniser(fe_name, adapt, "proto", 1, batch_size, learn, num_lite, 1.0)
+    synthetic.init_parameters_(m, film_strength=0.02 if fe_name == "efficientnet_b0" else 0.1)
+    m._set_device("cuda:0")
+    m._send_to_device()
+    m.set_test_mode(test_mode)
+    return m
+
+
+def _oracle_of(model, fe_name, adapt, batch_size, num_lite=16):
+    ref = OracleRecogniser(fe_name, adapt, "proto", 1, batch_size, num_lite)
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    ref.fe.load_state_dict({k[len("feature_extractor."):]: v for k, v in sd.items() if k.startswith("feature_extractor.")})
+    if adapt:
+        ref.set_encoder.load_state_dict({k[len("set_encoder."):]: v for k, v in sd.items() if k.startswith("set_encoder.")})
+        ref.build_film_generator().load_state_dict(
+            {k[len("film_generator."):]: v for k, v in sd.items() if k.startswith("film_generator.")})
+    return ref
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_inference_matches_oracle_at_224(device, name):
+    fe_name, adapt, way, _ = CONFIGS[name]
+    model = _native(fe_name, adapt, False, 16)
+    ref = _oracle_of(model, fe_name, adapt, 16)
+    task = synthetic.make_task(40 + way, way=way, shots=1, frames_per_shot=20 // way, num_query=12, frame_size=SIZE)
+    with torch.no_grad():
+        model.personalise(task["context_clips"].cuda(), task["context_labels"].cuda())
+        got = model.predict(task["target_clips"].cuda()).cpu()
+    ref.personalise(task["context_clips"], task["context_labels"])
+    want = ref.predict(task["target_clips"])
+    assert got.shape == want.shape == (12, way)
+    assert (got - want).abs().max().item() < 1e-3
+    assert torch.equal(got.argmax(1), want.argmax(1))
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_one_lite_step_matches_oracle_at_224(device, name):
+    """One query batch of Learner.train_task_with_lite at 224x224 with H = 16 LITE samples; the loss carries the
+    config's 1/tasks_per_batch (16, resp. 64 for config 5). Logits, loss and parameter gradients against autograd on the
+    CPU oracle."""
+    fe_name, adapt, way, learn = CONFIGS[name]
+    tasks_per_batch = 64 if way == 10 else 16
+    H = 16
+    model = _native(fe_name, adapt, learn, 16, num_lite=H, test_mode=False)
+    ref = _oracle_of(model, fe_name, adapt, 16, num_lite=H)
+    trainer = LiteTrainer(ref, learn, tasks_per_batch)
+    task = synthetic.make_task(60 + way, way=way, shots=1, frames_per_shot=40 // way, num_query=10, frame_size=SIZE)
+    ctx, lab, tgt, tlab = task["context_clips"], task["context_labels"], task["target_clips"], task["target_labels"]
+    model._clear_caches()
+    np.random.seed(4242)
+    model.personalise_with_lite(ctx.cuda(), lab.cuda())
+    logits = model.predict_a_batch(tgt.cuda())
+    loss = len(lab) / (H * tasks_per_batch) * F.cross_entropy(logits, tlab.cuda())
+    loss = loss + 0.001 * model.film_generator.regularization_term()
+    loss.backward()
+    ref.clear_caches()
+    np.random.seed(4242)
+    (want_logits, want_loss), = trainer.train_task_with_lite(ctx, lab, tgt, tlab)
+    assert (logits.detach().cpu() - want_logits).abs().max().item() < 1e-3
+    assert torch.equal(logits.detach().cpu().argmax(1), want_logits.argmax(1))
+    assert abs(loss.item() - want_loss.item()) < 1e-3 * max(1.0, abs(want_loss.item()))
+    got = {n: p.grad for n, p in model.named_parameters() if p.grad is not None}
+    want = {}
+    for prefix, mod in (("feature_extractor.", ref.fe), ("set_encoder.", ref.set_encoder),
+                        ("film_generator.", ref.film_generator)):
+        if mod is not None:
+            want.update({prefix + n: p.grad for n, p in mod.named_parameters() if p.grad is not None})
+    assert sorted(got) == sorted(want) and len(want) > 10
+    worst = 0.0
+    for n, g in want.items():
+        scale = max(float(g.abs().max()), 1e-12)
+        worst = max(worst, float((got[n].cpu() - g).abs().max()) / scale)
+    # smooth activations (efficientnet) are fp32-exact; ReLU networks can flip a mask bit (tests/test_gpu_train.py)
+    assert worst < (2e-3 if fe_name == "efficientnet_b0" else 3e-2), "worst relative gradient error %g" % worst
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS))
+def test_full_size_task_properties(device, name):
+    """The configs' real sizes: 200 support + 200 query frames of 224x224."""
+    fe_name, adapt, way, _ = CONFIGS[name]
+    model = _native(fe_name, adapt, False, 256)
+    task = synthetic.make_task_on_device(3, way, 1, 200 // way, 200, SIZE, 1, device)
+    ctx, lab, tgt = task["context_clips"], task["context_labels"], task["target_clips"]
+
+    def run(ctx_, lab_, overlap=False, batch_size=256):
+        model.overlap_query, model.batch_size = overlap, batch_size
+        with torch.no_grad():
+            model.personalise(ctx_, lab_)
+            out = model.predict(tgt).clone()
+        model._reset()
+        model.overlap_query, model.batch_size = False, 256
+        return out
+
+    base = run(ctx, lab)
+    assert base.shape == (200, way) and torch.isfinite(base).all()
+    assert torch.equal(run(ctx, lab), base)  # deterministic
+    assert torch.equal(run(ctx, lab, overlap=True), base)  # two-stream overlap: same kernels, same inputs
+    perm = torch.randperm(len(ctx), device=device, generator=torch.Generator(device=device).manual_seed(1))
+    shuffled = run(ctx[perm], lab[perm])
+    if adapt:  # the task embedding is a mean over the (permuted) set: summation order moves the last bits
+        assert (shuffled - base).abs().max().item() < 1e-3
+    else:  # features are per-frame; only the per-class mean's summation order changes
+        assert (shuffled - base).abs().max().item() < 1e-3 * max(1.0, base.abs().max().item())
+    assert (shuffled.argmax(1) == base.argmax(1)).float().mean().item() >= 0.99
+    batched = run(ctx, lab, batch_size=64)  # 4 extractor launches per set instead of 1 (reference --batch_size)
+    assert (batched - base).abs().max().item() < 1e-4 * max(1.0, base.abs().max().item())
+    assert torch.equal(batched.argmax(1), base.argmax(1))

@@ -1,0 +1,112 @@
+"""The product's multi-rank forms executed by TWO processes on hardware (both ranks on GPU 0, gloo backend - the GPU box
+has one device and RCCL refuses two ranks on it; the exchange steps are the same torch.distributed calls the nccl backend
+serves on a multi-GPU node):
+  * dist.personalise_support_sharded + dist.predict_query_sharded: each rank extracts features for ITS slice of the
+    support clips, ONE all-reduce of the [C*D + C] prototype payload, bit-identical prototypes on both ranks, equal to
+    the single-process personalise()/predict();
+  * learner.py --mode train (LITE, tasks dealt round-robin, dist.GradientBucket all-reduce per optimizer step): the
+    parameters after the step equal single-process accumulation over the same tasks (reference tasks_per_batch
+    semantics, single-step-learner.py:162-166,231), parameters without a gradient stay untouched."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import orbit_dataset_amd  # noqa: E402,F401
+from orbit_dataset_amd import synthetic  # noqa: E402
+from orbit_dataset_amd.model.few_shot_recognisers import SingleStepFewShotRecogniser  # noqa: E402
+
+WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "dist_worker.py")
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _launch(world, args, timeout=600):
+    port = _free_port()
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0", ORBIT_DIST_BACKEND="gloo")
+        procs.append(subprocess.Popen([sys.executable, WORKER] + args, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(o)
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    return outs
+
+
+@pytest.mark.parametrize("adapt", [False, True])
+def test_support_and_query_sharded_on_two_ranks(device, adapt, tmp_path):
+    out = str(tmp_path / "sh")
+    _launch(2, ["sharded", out, "1" if adapt else "0"])
+    r0, r1 = torch.load(out + ".rank0.pt"), torch.load(out + ".rank1.pt")
+    assert r0["bounds"] == (0, 10) and r1["bounds"] == (10, 20)
+    assert torch.equal(r0["W"], r1["W"]) and torch.equal(r0["b"], r1["b"])  # bit-identical prototypes on both ranks
+    assert torch.equal(r0["logits"], r1["logits"])
+    model = SingleStepFewShotRecogniser("resnet18", adapt, "proto", 1, 8, False, 16, 1.0)
+    synthetic.init_parameters_(model)
+    model._set_device(device)
+    model._send_to_device()
+    model.set_test_mode(True)
+    task = synthetic.make_task(9, way=4, shots=1, frames_per_shot=5, num_query=11, frame_size=64, label_values=(2, 5, 6, 9))
+    with torch.no_grad():
+        model.personalise(task["context_clips"].cuda(), task["context_labels"].cuda())
+        want = model.predict(task["target_clips"].cuda()).cpu()
+    W = model.classifier.weight.detach().cpu()
+    assert (r0["W"] - W).abs().max().item() < 1e-5 * max(1.0, W.abs().max().item())
+    assert (r0["logits"] - want).abs().max().item() < 1e-3
+    assert torch.equal(r0["logits"].argmax(1), want.argmax(1))
+
+
+TRAIN = ["--mode", "train", "--with_lite", "--num_lite_samples", "4", "--frame_size", "64", "--way", "3", "--shots", "1",
+         "--frames_per_shot", "4", "--num_query_videos", "2", "--frames_per_video", "5", "--batch_size", "8",
+         "--num_train_tasks", "4", "--tasks_per_batch", "4", "--optimizer", "sgd", "--learning_rate", "0.05",
+         "--weight_decay", "0.1"]
+
+
+@pytest.mark.parametrize("recipe", [["--feature_extractor", "resnet18", "--learn_extractor"],
+                                    ["--feature_extractor", "resnet18", "--adapt_features", "--classifier", "versa"],
+                                    ["--feature_extractor", "efficientnet_b0", "--learn_extractor"]],
+                         ids=["protonet_resnet18", "cnaps_versa_resnet18", "protonet_efficientnet_b0"])
+def test_task_parallel_training_step_equals_single_process(device, recipe, tmp_path):
+    one, two = str(tmp_path / "w1"), str(tmp_path / "w2")
+    _launch(1, ["train", one] + TRAIN + recipe)
+    _launch(2, ["train", two] + TRAIN + recipe)
+    a, b = torch.load(one + ".model.pt"), torch.load(two + ".model.pt")
+    init = SingleStepFewShotRecogniser(recipe[1], "--adapt_features" in recipe,
+                                       recipe[recipe.index("--classifier") + 1] if "--classifier" in recipe else "proto",
+                                       1, 8, "--learn_extractor" in recipe, 4, 1.0)
+    synthetic.init_parameters_(init, film_strength=0.02 if recipe[1] == "efficientnet_b0" else 0.1)
+    init_sd = init.state_dict()
+    moved = 0
+    for k in a:
+        if k.endswith(("running_mean", "running_var", "num_batches_tracked")):
+            continue  # train-mode statistics are AVERAGED over ranks (a documented difference from sequential updates)
+        d = (a[k].float() - b[k].float()).abs().max().item()
+        step = (a[k].float() - init_sd[k].float()).abs().max().item()
+        assert d <= 2e-6 + 2e-3 * step, "%s differs between 1 and 2 ranks by %g (step size %g)" % (k, d, step)
+        moved += step > 0
+    assert moved > 10
+    info1, info2 = torch.load(one + ".rank0.pt"), torch.load(two + ".rank0.pt")
+    assert info2["bucket_bytes"] > 0
+    # parameters that get no gradient in the single-process run get none in the 2-rank run either
+    assert info1["grads_none"] == info2["grads_none"]
+    for k in info2["grads_none"]:
+        assert torch.equal(b[k], init_sd[k].to(b[k].dtype)), k
