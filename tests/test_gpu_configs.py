@@ -99,12 +99,23 @@ def test_one_lite_step_matches_oracle_at_224(device, name):
         if mod is not None:
             want.update({prefix + n: p.grad for n, p in mod.named_parameters() if p.grad is not None})
     assert sorted(got) == sorted(want) and len(want) > 10
-    worst = 0.0
+    # per-parameter error relative to that parameter's largest gradient entry. Parameters whose gradient is
+    # mathematically zero (a BatchNorm bias followed, through a linear conv, by a batch-statistics BatchNorm: the shift
+    # is absorbed) show up as ~1e-7 rounding noise on both sides: those must be noise on the GPU too
+    top = max(float(g.abs().max()) for g in want.values())
+    worst, worst_name, zero_grad = 0.0, None, 0
     for n, g in want.items():
-        scale = max(float(g.abs().max()), 1e-12)
-        worst = max(worst, float((got[n].cpu() - g).abs().max()) / scale)
+        if float(g.abs().max()) < 1e-5 * top:
+            zero_grad += 1
+            assert float(got[n].abs().max()) < 1e-5 * top, n
+            continue
+        err = float((got[n].cpu() - g).abs().max()) / float(g.abs().max())
+        if err > worst:
+            worst, worst_name = err, "%s (max |g| %.3g, network max %.3g)" % (n, float(g.abs().max()), top)
+    assert zero_grad < len(want) // 4
     # smooth activations (efficientnet) are fp32-exact; ReLU networks can flip a mask bit (tests/test_gpu_train.py)
-    assert worst < (2e-3 if fe_name == "efficientnet_b0" else 3e-2), "worst relative gradient error %g" % worst
+    assert worst < (2e-3 if fe_name == "efficientnet_b0" else 3e-2), "worst relative gradient error %g at %s" % (
+        worst, worst_name)
 
 
 @pytest.mark.parametrize("name", sorted(CONFIGS))
