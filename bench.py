@@ -118,6 +118,42 @@ class LiteTrainStep:
         return torch.cat(out)
 
 
+def parity_gate(model, fe_name, device):
+    """Cheap gate that runs on EVERY rank before the clock starts: the extractor on the committed frames of
+    tests/golden/G12_extractors_hf.npz must reproduce the features Hugging Face transformers computed for them (an
+    implementation independent of this repository, tests/hf_pin.py) to 2e-5. The full logits-vs-oracle gate follows at
+    N = 1 (cpu_baseline leg); either failing means no timing line is printed."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "G12_extractors_hf.npz")
+    if not os.path.exists(path):
+        return {"fixture": None}
+    g = dict(np.load(path))
+    case = {"efficientnet_b0": "efficientnet_b0_224", "resnet18": "resnet18_224"}[fe_name]
+    x = torch.from_numpy(g["x231"].astype("float32")[:, :, :224, :224].copy()).to(device)
+    fe = model.feature_extractor
+    was_training = fe.training
+    fe.eval()
+    with torch.no_grad():
+        got = fe(x).cpu()
+    fe.train(was_training)
+    err = float((got - torch.from_numpy(g[case + "_feats"])).abs().max())
+    if not err < 2e-5:
+        print("PARITY GATE FAILED (extractor vs transformers fixture %s): max |d feature| %g" % (case, err), file=sys.stderr)
+        raise SystemExit(3)
+    return {"fixture": "tests/golden/G12_extractors_hf.npz:" + case, "max_abs_dfeature_vs_transformers": err, "tol": 2e-5}
+
+
+def kernel_sources_sha16():
+    """Fingerprint of the HIP sources: a PMC traffic figure measured in another process is only quoted for these."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "orbit-dataset_amd", "csrc")
+    for name in sorted(n for n in os.listdir(d) if n.endswith((".hip", ".h"))):
+        with open(os.path.join(d, name), "rb") as f:
+            h.update(name.encode()), h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def run_task(model, task):
     with torch.no_grad():  # as every test-time caller of the reference does (single-step-learner.py:311)
         model.personalise(task["context_clips"], task["context_labels"])
@@ -213,19 +249,22 @@ def cpu_baseline(workload, model, train=False, way=WAY):
         ref.build_film_generator().load_state_dict(
             {k[len("film_generator."):]: v for k, v in sd.items() if k.startswith("film_generator.")})
     task = synthetic.make_task(0, way, 1, WAY * SHOTS * FRAMES_PER_SHOT // way, NUM_QUERY, size)
-    # pick the intra-op thread count that is fastest on this host (more threads than the small convolutions
-    # can use slows PyTorch-CPU down badly on many-core hosts); `cores` reports the count actually used
-    warm = synthetic.make_task(1, WAY, 1, 4, 12, size)
-    best, cores = None, 1
-    for nt in sorted({min(c, os.cpu_count() or 1) for c in (8, 16, 32, 64, 128)}):
+    # Thread count: BASELINE.md asks for os.cpu_count(); PyTorch-CPU gets SLOWER past the point where the small
+    # convolutions stop scaling, so every candidate up to and including os.cpu_count() is timed on a probe with the batch
+    # shape of the real task (one 64-frame extractor batch + one 64-frame query batch; the round-1 probe used 32 frames,
+    # which under-fed the wide settings) and the fastest is used; `cores` reports the count actually used.
+    ncpu = os.cpu_count() or 1
+    warm = synthetic.make_task(1, WAY, 1, 12, 64, size)
+    probe = {}
+    for nt in sorted({min(c, ncpu) for c in (8, 16, 32, 64, 128, ncpu)}):
         torch.set_num_threads(nt)
-        ref.personalise(warm["context_clips"], warm["context_labels"])
+        if not probe:
+            ref.personalise(warm["context_clips"][:8], warm["context_labels"][:8])  # first-call set-up, untimed
         t0 = time.perf_counter()
         ref.personalise(warm["context_clips"], warm["context_labels"])
         ref.predict(warm["target_clips"])
-        dt = time.perf_counter() - t0
-        if best is None or dt < best:
-            best, cores = dt, nt
+        probe[nt] = time.perf_counter() - t0
+    cores = min(probe, key=probe.get)
     torch.set_num_threads(cores)
     if train:
         import numpy as np
@@ -247,8 +286,9 @@ def cpu_baseline(workload, model, train=False, way=WAY):
         what += ")"
     return {"value": NUM_QUERY / dt, "unit": "query frames/s", "cores": cores, "kind": "port",
             "host_cpus": os.cpu_count(),
-            "sample": "%s, %dx%d, PyTorch-CPU oracle, %d threads (fastest of 8/16/32/64/128 on a 32-frame probe), "
-                      "%.1f s" % (what, size, size, cores, dt)
+            "sample": "%s, %dx%d, PyTorch-CPU oracle, %d threads (fastest of %s on a 60+64-frame probe), "
+                      "%.1f s" % (what, size, size, cores, "/".join(str(k) for k in sorted(probe)), dt),
+            "thread_probe_frames_per_s": {str(k): round(124 / v, 1) for k, v in sorted(probe.items())},
             }, task, logits
 
 
@@ -293,6 +333,7 @@ def main():
     fe_name, adapt, size = WORKLOADS[args.workload]
     train = args.mode == "lite_train"
     model = build_model(args.workload, device, args.batch_size, train=train)
+    gate = parity_gate(model, fe_name, device)  # every rank, before anything is timed
     run_step = LiteTrainStep(model, world, args.batch_size, args.tasks_per_rank) if train else run_task
     per_step = args.tasks_per_rank if train else 1  # run_step calls (= tasks) per bench step on this rank
     # each rank owns its own tasks (task index = rank + world * i): weak scaling, independent units
@@ -365,6 +406,30 @@ def main():
     for i in range(args.warmup * per_step):
         run_step(model, tasks[i % len(tasks)])
     elapsed, correct, issued = loop(args.steps)  # the timed region behind `value`
+
+    def per_task_events(steps):
+        """SURVEY §8(d): per-task HIP-event time (events on the caller's stream before personalise() and after predict();
+        the query stream joins it before the head kernel), median over the tasks of a repeat of the timed steps."""
+        barrier()
+        evs = []
+        for i in range(steps * per_step):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            run_step(model, tasks[i % len(tasks)])
+            e1.record()
+            evs.append((e0, e1))
+        barrier()
+        ms = sorted(a.elapsed_time(b) for a, b in evs)
+        return ms[len(ms) // 2]
+
+    median_task_ms = per_task_events(args.steps)
+    value_overlap_off = None
+    if bool(getattr(model, "overlap_query", False)):
+        model.overlap_query = False
+        loop(2)
+        off_elapsed, _, _ = loop(args.steps)
+        model.overlap_query = True
+        value_overlap_off = NUM_QUERY * args.steps * per_step * world / off_elapsed
     # roofline leg: the SAME K steps again with one HIP-event pair recorded per conv_igemm launch on its stream
     # (kept out of the timed region above: recording ~80 events per task costs host time and serialises the queue)
     overlap = bool(getattr(model, "overlap_query", False))
@@ -407,13 +472,21 @@ def main():
     achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process; the value is
     # the one tools/collect_profiles.sh measured with rocprofv3 on this same command (committed under profiles/)
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "r01_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
+    traffic, traffic_source = None, "none (no PMC pass recorded for this workload)"
+    for tname in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_traffic.json")),
+                        reverse=True):
+        with open(os.path.join(ROOT, "profiles", tname)) as f:
             tj = json.load(f)
-        if tj.get("workload") == args.workload:
+        if tj.get("workload") != args.workload:
+            continue
+        if tj.get("kernel_sources_sha16") == kernel_sources_sha16():
             traffic = tj.get("traffic_bytes_per_launch")
+            traffic_source = "file profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command on these " \
+                             "kernel sources, %s)" % (tname, tj.get("kernel_sources_sha16"))
+        else:
+            traffic_source = "refused: profiles/%s was measured on other kernel sources (%s, now %s)" % (
+                tname, tj.get("kernel_sources_sha16"), kernel_sources_sha16())
+        break
     macs = model.feature_extractor.macs_per_frame(size, size)
     out = {
         "metric": "query frames/sec per task (224x224, 5-way ProtoNet) + frame accuracy vs ref",
@@ -436,13 +509,15 @@ def main():
                        world, "; one all-reduce of the flat gradient bucket per optimizer step" if train and world > 1
                        else "")},
         "frame_accuracy": float(correct[0].item() / max(correct[1].item(), 1)),
+        "median_task_ms": median_task_ms,
+        "value_overlap_off": value_overlap_off,
         "host_enqueue_ms_per_step": 1e3 * issued / args.steps,
         "graph_option": os.environ.get("ORBIT_GRAPH", "2 (adaptive)"),
         "settling_steps_before_warmup": settling,
         "overlap_query_stream": bool(getattr(model, "overlap_query", False)),
         "extractor_gflop_per_task": 2 * macs * (WAY * SHOTS * FRAMES_PER_SHOT + NUM_QUERY) / 1e9,
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                     "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                      "algorithmic_bytes_per_launch": total_bytes / max(n_main, 1),
                      "kernel": "orbit::conv_igemm_kernel (all instantiations, incl. the reduce pass of split-K launches)" + (
                          " + orbit::conv_wgrad_kernel" if train else ""),
@@ -468,8 +543,13 @@ def main():
         base["max_abs_dlogit_vs_gpu"] = float((got - want).abs().max().item())
         base["argmax_identical"] = bool(torch.equal(got.argmax(1), want.argmax(1)))
         out["cpu_baseline"] = base
+        # parity gate (no timing is reported for a path that does not reproduce the reference's logits)
+        if not (base["max_abs_dlogit_vs_gpu"] <= 1e-3 and base["argmax_identical"]):
+            print("PARITY GATE FAILED, no timing reported: " + json.dumps(base), file=sys.stderr)
+            raise SystemExit(3)
     else:
         out["cpu_baseline"] = None
+    out["parity_gate"] = gate
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -106,6 +106,12 @@ int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_
 // fused expand(1x1, MFMA) + BN + SiLU + depthwise + BN + SiLU (+ SE pooling partials [B][tiles][mid]); csrc/mbconv.hip
 bool mbconv_front_supported(int Cin, int mid, int K, int stride);
 int mbconv_front_tiles(int Ho, int Wo, int stride);
+// whole-map form for the 14x14 / 7x7 stages (csrc/mbconv_map.hip): pool sums are complete per (frame, channel), i.e. the
+// squeeze-excite gate kernel sees ONE partial per frame
+bool mbconv_map_supported(int H, int W, int Cin, int mid, int K, int stride);
+int launch_mbconv_map(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
+                      const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
+                      int K, int stride, hipStream_t s);
 // stem form of the fused front kernel: conv_stem (NCHW frames, 3x3 stride 2) + BN + SiLU + depthwise 3x3/1 + BN + SiLU
 bool stem_dw_front_supported(int mid, int K, int stride);
 int stem_pack_weights(const float* w_oihw, float* w_packed, int mid, hipStream_t s);  // [mid][27] -> [mid][32]

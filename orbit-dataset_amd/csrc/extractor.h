@@ -50,6 +50,7 @@ struct Op {
     int se_chunks = 0, se_hw = 0;  // squeeze-excite pooling partials produced by the preceding depthwise conv
     int pool_partial = 0;          // depthwise: also emit the pooling partials
     int weight2 = -1, bn2 = -1;    // OP_MBFRONT: depthwise weight (packed at packed_off) and its BatchNorm
+    bool whole_map = false;        // OP_MBFRONT served by the whole-map kernel (csrc/mbconv_map.hip)
     int pool_k = 0, pool_pad = 0;
 };
 

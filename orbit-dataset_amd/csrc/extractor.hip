@@ -85,7 +85,14 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
     // 3x3/1 at 56x56: 281-306 vs 338-347 us; the 5x5 blocks and 40 -> 240 3x3/2 tie or lose: 282 vs 282, 305 vs 166,
     // 143 vs 104 us - fusing the 5x5/2 block as well left the whole-task time unchanged), 0 = never
     const int fuse_opt = get_option("mbconv_fusion");
-    auto fuse_front_ok = [&](int cin, int mid, int K, int stride) {
+    // whole-map form (csrc/mbconv_map.hip) for the 14x14 / 7x7 stages: opt-in (mbconv_map = 1). Measured on MI355X it ties
+    // the conv + depthwise pair (tools/mb_bench.py, profiles/r02_mbconv_map.txt), so the pair stays the default
+    const int map_opt = get_option("mbconv_map");
+    auto fuse_map_ok = [&](int hh, int ww, int cin, int mid, int K, int stride) {
+        return fuse_opt != 0 && map_opt != 0 && mbconv_map_supported(hh, ww, cin, mid, K, stride);
+    };
+    auto fuse_front_ok = [&](int hh, int ww, int cin, int mid, int K, int stride) {
+        if (fuse_map_ok(hh, ww, cin, mid, K, stride)) return true;
         if (fuse_opt == 0 || !mbconv_front_supported(cin, mid, K, stride)) return false;
         return fuse_opt == 1 || (cin <= 24 && K == 3);
     };
@@ -188,7 +195,7 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
             int ho, wo;
             const int bn1 = fe->add_bn(p + ".bn1", mid, eps, false);
             int se_chunks;
-            if (fuse_front_ok(cin, mid, K, stride)) {
+            if (fuse_front_ok(h, w, cin, mid, K, stride)) {
                 // expand + depthwise in one kernel: the 6x-expanded tensor never leaves LDS (csrc/mbconv.hip)
                 Op o;
                 o.kind = OP_MBFRONT, o.in = cur, o.out = t2, o.H = h, o.W = w, o.Cin = cin, o.Cout = mid;
@@ -201,7 +208,8 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
                 o.packed_off = fe->packed_floats;
                 fe->packed_floats += (size_t)(mid * K * K + 3) / 4 * 4;
                 ho = o.Ho, wo = o.Wo;
-                se_chunks = mbconv_front_tiles(ho, wo, stride);
+                o.whole_map = fuse_map_ok(h, w, cin, mid, K, stride);
+                se_chunks = o.whole_map ? 1 : mbconv_front_tiles(ho, wo, stride);
                 fe->max_partial = std::max(fe->max_partial, (size_t)se_chunks * mid);
                 fe->note_buf(t2, (size_t)ho * wo * mid);
                 fe->macs += (double)h * w * cin * mid + (double)ho * wo * mid * K * K;
@@ -592,6 +600,14 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
                                               scale + fe->bns[o.bn2].fold_off, shift + fe->bns[o.bn2].fold_off, buf(o.out),
                                               buf(101), B, o.stem_h, o.stem_w, o.stem_pt, o.stem_pl, o.H, o.W, o.Cout, o.KH,
                                               o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+                    break;
+                }
+                if (o.whole_map) {
+                    rc = launch_mbconv_map(buf(o.in), fe->d_pool + fe->params[o.weight].off,
+                                           scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off,
+                                           fe->d_packed + o.packed_off, scale + fe->bns[o.bn2].fold_off,
+                                           shift + fe->bns[o.bn2].fold_off, buf(o.out), buf(101), B, o.H, o.W, o.Cin, o.Cout,
+                                           o.KH, o.stride, s);
                     break;
                 }
                 rc = launch_mbconv_front(buf(o.in), fe->d_pool + fe->params[o.weight].off,

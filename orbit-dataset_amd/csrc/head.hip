@@ -34,6 +34,8 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"dw_lds", "ORBIT_DW_LDS", 1, false},
                              {"dw_pipe", "ORBIT_DW_PIPE", 1, false},
                              {"mbconv_fusion", "ORBIT_MBCONV_FUSION", 2, false},
+                             {"mbconv_map", "ORBIT_MBCONV_MAP", 0, false},
+                             {"mbmap_groups", "ORBIT_MBMAP_GROUPS", 0, false},
                              {"graph", "ORBIT_GRAPH", 2, false},
                              {"conv_tile", "ORBIT_CONV_TILE", 0, false},
                              {"conv_bk", "ORBIT_CONV_BK", 0, false},

@@ -415,9 +415,15 @@ extern "C" int orbit_op_mbconv_front(const float* x, const float* w1, const floa
     float* wp = nullptr;
     ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&wp), (size_t)mid * K * K * sizeof(float), s));
     int rc = dwconv_pack_weights(wdw, wp, mid, K, s);
-    if (rc == ORBIT_OK)
-        rc = launch_mbconv_front(x, w1, scale1, shift1, wp, scale2, shift2, y, pool_partial, B, H, W, Cin, mid, K, stride,
-                                 pad_top, pad_left, Ho, Wo, s);
+    if (rc == ORBIT_OK) {
+        // the whole-map kernel (csrc/mbconv_map.hip) where it applies - as the extractor plans choose; its pool_partial is
+        // [B][1][mid] instead of [B][tiles][mid] (mbconv_map option 0 = tiled kernel everywhere it is supported)
+        if (get_option("mbconv_map") && mbconv_map_supported(H, W, Cin, mid, K, stride))
+            rc = launch_mbconv_map(x, w1, scale1, shift1, wp, scale2, shift2, y, pool_partial, B, H, W, Cin, mid, K, stride, s);
+        else
+            rc = launch_mbconv_front(x, w1, scale1, shift1, wp, scale2, shift2, y, pool_partial, B, H, W, Cin, mid, K,
+                                     stride, pad_top, pad_left, Ho, Wo, s);
+    }
     (void)hipFreeAsync(wp, s);
     return rc;
 }

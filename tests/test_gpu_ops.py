@@ -272,6 +272,47 @@ def test_mbconv_front_fused(lib, device, Cin, mid, K, stride, H, W):
     assert (pool.cpu().sum(1) - want.sum((2, 3))).abs().max().item() < 2e-3 * max(1.0, want.sum((2, 3)).abs().max().item())
 
 
+MBMAP_CASES = [  # Cin, K, stride, HW : every whole-map shape of efficientnet_b0 @224 (blocks 3.1 .. 6.0)
+    (80, 3, 1, 14), (80, 5, 1, 14), (112, 5, 1, 14), (112, 5, 2, 14), (192, 5, 1, 7), (192, 3, 1, 7)]
+
+
+@pytest.mark.parametrize("Cin,K,stride,HW", MBMAP_CASES)
+@pytest.mark.parametrize("B,groups", [(3, 0), (5, 1), (4, 100)])
+def test_mbconv_front_whole_map(lib, device, Cin, K, stride, HW, B, groups):
+    """csrc/mbconv_map.hip: a block owns the whole 14x14 / 7x7 map of one (two) frame(s); input fragments in registers,
+    expanded chunk in a zero-bordered LDS tile. Against the unfused PyTorch-CPU sequence: odd frame counts (the 7x7 form
+    pairs frames), one chunk group per frame / one chunk per block / the automatic grouping; pool sums are complete."""
+    mid = 6 * Cin
+    g = torch.Generator().manual_seed(Cin * 100 + K * 10 + stride + B)
+    x = torch.randn(B, Cin, HW, HW, generator=g)
+    w1 = torch.randn(mid, Cin, 1, 1, generator=g) / Cin ** 0.5
+    wd = torch.randn(mid, 1, K, K, generator=g) / K
+    s1, h1 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.3
+    s2, h2 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.1
+    Ho = -(-HW // stride)
+    pt = max((Ho - 1) * stride + K - HW, 0)
+    e = F.silu(F.conv2d(x, w1) * s1[None, :, None, None] + h1[None, :, None, None])
+    ep = F.pad(e, [pt // 2, pt - pt // 2, pt // 2, pt - pt // 2])
+    want = F.silu(F.conv2d(ep, wd, None, stride, 0, 1, mid) * s2[None, :, None, None] + h2[None, :, None, None])
+    y = torch.full((B, Ho, Ho, mid), float("nan"), device=device)
+    pool = torch.full((B, 1, mid), float("nan"), device=device)
+    dev = [t.to(device).contiguous() for t in (nhwc(x), w1, s1, h1, wd, s2, h2)]
+    prev = lib.orbit_get_option(b"mbconv_map")
+    lib.orbit_set_option(b"mbconv_map", 1)  # opt-in kernel (it ties the conv + depthwise pair, which stays the default)
+    lib.orbit_set_option(b"mbmap_groups", groups)
+    try:
+        _lib.check(lib.orbit_op_mbconv_front(*[_lib.dptr(t) for t in dev], _lib.dptr(y), _lib.dptr(pool), B, HW, HW, Cin,
+                                             mid, K, stride, pt // 2, pt // 2, Ho, Ho, _st()), "mbconv_front (whole map)")
+        torch.cuda.synchronize()
+    finally:
+        lib.orbit_set_option(b"mbmap_groups", 0)
+        lib.orbit_set_option(b"mbconv_map", prev)
+    got = nchw(y.cpu())
+    assert not torch.isnan(got).any() and not torch.isnan(pool).any()
+    assert (got - want).abs().max().item() < 5e-5
+    assert (pool.cpu()[:, 0] - want.sum((2, 3))).abs().max().item() < 2e-3 * max(1.0, want.sum((2, 3)).abs().max().item())
+
+
 @pytest.mark.parametrize("FH,FW,mid", [(64, 64, 32), (37, 45, 32), (30, 30, 32), (21, 52, 16)])
 def test_stem_dw_front_fused(lib, device, FH, FW, mid):
     """stem conv (NCHW frames, 3x3 stride 2, TF-SAME) + BN + SiLU + depthwise 3x3 (SAME) + BN + SiLU in one kernel, the
