@@ -7,13 +7,13 @@
   the CPU oracle modules at other sizes and batch shapes.
 
 Tolerances. The kernels themselves are fp32-exact: against the fp64 oracle every parameter gradient of resnet18 is
-within ~3e-6 of its largest magnitude (tools/train_diag3.py). What is NOT stable across implementations is the
-ReLU mask: a pre-activation within rounding distance of zero (a handful per few-hundred-thousand elements) takes the
-other branch on the GPU than on the CPU, which perturbs every upstream gradient by 1e-3..3e-2 (measured: the error is
-~1e-6 downstream of one layer and jumps to that level upstream of it; which layer depends on the input seed). So:
-  * oracle comparisons run several input seeds; most seeds must be fp32-exact (< 2e-5) and every seed < 0.1;
-  * the reference-recorded goldens (fixed inputs) are checked at 3e-2 on sampled gradients + 2e-2 on their norms;
-    logits keep the 1e-3 absolute bar, running statistics 1e-4.
+within ~3e-6 of its largest magnitude. What is NOT stable across implementations is the ReLU mask: a pre-activation
+within rounding distance of zero takes the other branch on the GPU than on the CPU, which perturbs every upstream
+gradient by 1e-3..3e-2. Round 1 tolerated that with loose bounds; now the masks are ALIGNED (tests/relu_align.py): when the
+plain comparison misses the exact bound, the oracle's ReLU units with |pre-activation| < 2e-5 are flipped (at most three,
+chosen greedily) and the oracle must then reproduce the GPU's gradients to the exact bound - 2e-5 against the fp64
+oracle for EVERY seed, 1e-3 for the LITE flows against the fp32 oracle (itself within 1e-3 of the gradients the
+reference recorded, tests/test_oracle_golden.py). Logits keep the 1e-3 absolute bar, running statistics 1e-4.
 """
 import os
 
@@ -23,8 +23,11 @@ import torch
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
+import sys  # noqa: E402
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 import orbit_dataset_amd  # noqa: E402,F401
+from relu_align import ReluTap, aligned_error  # noqa: E402
 from oracle import blocks as oracle_blocks  # noqa: E402
 from oracle import extractors as oracle_extractors  # noqa: E402
 from orbit_dataset_amd import synthetic  # noqa: E402
@@ -77,17 +80,69 @@ def lite_steps(m, g, seed0, prefix="", batches=2):
         m._reset()
 
 
+def _oracle_lite(g, adapt, learn_extractor, seeds):
+    """The same LITE steps on the fp32 CPU oracle (oracle/training.py, pinned to the reference's recorded gradients at
+    1e-3 by tests/test_oracle_golden.py) with its ReLUs instrumented. Returns (run, tap); run() restores the initial
+    parameters / running statistics first (train-mode BatchNorm mutates them) and returns {name: gradient}."""
+    from oracle.recogniser import OracleRecogniser
+    from oracle.training import LiteTrainer
+    nl, tpb, bs = int(g["num_lite_samples"]), int(g["tasks_per_batch"]), int(g["batch_size"])
+    ref = OracleRecogniser("resnet18", adapt, "proto", 1, bs, nl)
+    synthetic.init_parameters_(ref.fe)
+    mods = {"feature_extractor.": ref.fe}
+    if adapt:
+        synthetic.init_parameters_(ref.set_encoder)
+        synthetic.init_parameters_(ref.build_film_generator(), prefix="film_generator.")
+        mods.update({"set_encoder.": ref.set_encoder, "film_generator.": ref.film_generator})
+    tr = LiteTrainer(ref, learn_extractor, tpb)
+    init = {pre: {k: v.clone() for k, v in mod.state_dict().items()} for pre, mod in mods.items()}
+    tap = ReluTap(ref.fe, ref.set_encoder)
+
+    def run():
+        for pre, mod in mods.items():
+            mod.load_state_dict(init[pre])
+            for prm in mod.parameters():
+                prm.grad = None
+        n = 2 * bs
+        tr.train_task_with_lite(g["context_clips"], g["context_labels"], g["target_clips"][:n], g["target_labels"][:n],
+                                seeds=seeds)
+        return {pre + k: prm.grad for pre, mod in mods.items() for k, prm in mod.named_parameters()
+                if prm.grad is not None}
+    return run, tap
+
+
+def _check_lite_gradients(m, g, adapt, learn_extractor, seeds, tag=""):
+    """GPU gradients of ALL parameters against the fp32 oracle at 1e-3 (ReLU masks aligned if needed), and the sampled
+    gradients the reference recorded: directly at 1e-3 when no mask flipped."""
+    run, tap = _oracle_lite(g, adapt, learn_extractor, seeds)
+    got = {n: p.grad.detach().cpu() for n, p in m.named_parameters() if p.grad is not None}
+
+    def error_of(grads):
+        assert sorted(grads) == sorted(got)
+        return max(rel(got[n], grads[n]) for n in grads)
+
+    err, flipped, plain = aligned_error(run, error_of, tap, exact=1e-3)
+    assert err < 1e-3, "GPU vs oracle gradients %g (plain %g, flipped %s)" % (err, plain, flipped)
+    prefix = tag + "_grad__" if tag else "grad__"
+    checked = 0
+    for key in g:
+        if not key.startswith(prefix):
+            continue
+        name = key[len(prefix):]
+        flat = got[name].flatten()
+        sample = flat[::max(1, flat.numel() // 4096)][:4096] if tag else flat
+        if not flipped:  # same masks as the reference's run: the recorded gradients must match directly
+            assert rel(sample, g[key]) < 1e-3, (name, rel(sample, g[key]))
+        checked += 1
+    return checked, flipped
+
+
 def test_G6_lite_backward_frozen_extractor(device):
     g = gold("G6_lite")
     m = native(True, int(g["batch_size"]), int(g["num_lite_samples"]), False)
     lite_steps(m, g, 500)
-    params = dict(m.named_parameters())
-    for key in g:
-        if not key.startswith("grad__"):
-            continue
-        name = key[len("grad__"):]
-        assert params[name].grad is not None, name
-        assert rel(params[name].grad, g[key]) < 3e-2, (name, rel(params[name].grad, g[key]))
+    checked, _ = _check_lite_gradients(m, g, True, False, (500, 501))
+    assert checked >= 4
     assert not bool(g["extractor_has_grad"])
     assert all(p.grad is None for p in m.feature_extractor.parameters())
 
@@ -98,20 +153,14 @@ def test_G8_lite_unfrozen_extractor(device, tag, adapt):
     m = native(adapt, int(g["batch_size"]), int(g["num_lite_samples"]), True)
     lite_steps(m, g, 800, prefix=tag + "_")
     params = dict(m.named_parameters())
-    checked = 0
-    for key in g:
-        if not key.startswith(tag + "_grad__"):
-            continue
-        name = key[len(tag + "_grad__"):]
-        grad = params[name].grad
-        assert grad is not None, name
-        flat = grad.flatten()
-        sample = flat[::max(1, flat.numel() // 4096)][:4096]
-        assert rel(sample, g[key]) < 3e-2, (name, rel(sample, g[key]))
-        gn = float(g[tag + "_gnorm__" + name])
-        assert abs(float(flat.double().norm()) - gn) < 2e-2 * gn, name
-        checked += 1
+    checked, flipped = _check_lite_gradients(m, g, adapt, True, (800, 801), tag=tag)
     assert checked >= 6
+    if not flipped:
+        for key in g:
+            if key.startswith(tag + "_gnorm__"):
+                name = key[len(tag + "_gnorm__"):]
+                gn = float(g[key])
+                assert abs(float(params[name].grad.flatten().double().norm()) - gn) < 1e-3 * gn, name
     sd = m.state_dict()
     for key in g:
         if key.startswith(tag + "_stat__"):
@@ -194,11 +243,16 @@ def _oracle_and_native(name, device, requires_grad=True):
     return ref, nat.to(device)
 
 
-def _seeded_check(run, seeds=5, exact=2e-5, bound=0.1, need_exact=3):
-    """run(seed) -> worst relative gradient error. Most seeds must be fp32-exact; none may exceed `bound`."""
-    errs = [run(seed) for seed in range(seeds)]
-    assert max(errs) < bound, errs
-    assert sum(e < exact for e in errs) >= need_exact, errs
+def _seeded_check(run, tap, seeds=5, exact=2e-5):
+    """run(seed) -> (run_oracle, error_of): EVERY seed must reach the fp32-exact bound, directly or - when a ReLU mask
+    flipped between CPU and GPU - after flipping at most three fragile units of the oracle (tests/relu_align.py)."""
+    report = []
+    for seed in range(seeds):
+        run_oracle, error_of = run(seed)
+        err, flipped, plain = aligned_error(run_oracle, error_of, tap, exact)
+        report.append((seed, plain, err, flipped))
+        assert err < exact, "seed %d: %g after aligning %s (plain %g)" % (seed, err, flipped, plain)
+    return report
 
 
 @pytest.mark.parametrize("bn_train", [True, False])
@@ -206,20 +260,33 @@ def _seeded_check(run, seeds=5, exact=2e-5, bound=0.1, need_exact=3):
 def test_resnet18_backward_matches_autograd(device, bn_train, size, B):
     ref, nat = _oracle_and_native("resnet18", device)
     ref = ref.double()
+    tap = ReluTap(ref)
     sd, rsd = {k: v.clone() for k, v in nat.state_dict().items()}, {k: v.clone() for k, v in ref.state_dict().items()}
 
     def run(seed):
-        nat.load_state_dict(sd), ref.load_state_dict(rsd)
-        nat.zero_grad(), ref.zero_grad()
-        ref.train(bn_train), nat.train(bn_train)
+        nat.load_state_dict(sd)
+        nat.zero_grad()
+        nat.train(bn_train)
         x = torch.randn(B, 3, size, size, generator=torch.Generator().manual_seed(100 * size + seed))
         dfeat = torch.randn(B, 512, generator=torch.Generator().manual_seed(seed))
-        out_ref = ref(x.double())
-        out_ref.backward(dfeat.double())
         out = nat(x.to(device))
-        assert rel(out.detach(), out_ref.detach()) < 2e-5
         out.backward(dfeat.to(device))
-        ref_grads = dict(ref.named_parameters())
+        got = {name: p.grad.detach().cpu() for name, p in nat.named_parameters()}
+        state = {}
+
+        def run_oracle():
+            ref.load_state_dict(rsd)
+            ref.zero_grad()
+            ref.train(bn_train)
+            state["out"] = ref(x.double())
+            state["out"].backward(dfeat.double())
+            return {name: p.grad for name, p in ref.named_parameters()}
+
+        def error_of(grads):
+            return max(rel(got[name], grads[name]) for name in got)
+
+        run_oracle()
+        assert rel(out.detach(), state["out"].detach()) < 2e-5
         if bn_train:
             ref_sd = ref.state_dict()
             for name, buf in nat.state_dict().items():
@@ -227,9 +294,9 @@ def test_resnet18_backward_matches_autograd(device, bn_train, size, B):
                     assert rel(buf, ref_sd[name]) < 1e-5, name
                 elif "num_batches_tracked" in name:
                     assert int(buf) == int(ref_sd[name]) == 1
-        return max(rel(p.grad, ref_grads[name].grad) for name, p in nat.named_parameters())
+        return run_oracle, error_of
 
-    _seeded_check(run)
+    _seeded_check(run, tap)
 
 
 def test_resnet18_film_gradients_frozen_extractor(device):
@@ -243,27 +310,37 @@ def test_resnet18_film_gradients_frozen_extractor(device):
     slots = [n for n, _ in nat.film_slot_modules()]
     params = dict(ref.named_parameters())
 
+    tap = ReluTap(ref)
+
     def run(seed):
         gen = torch.Generator().manual_seed(11 + seed)
-        film_ref, gam, bet = {}, [], []
+        film_vals, gam, bet = {}, [], []
         for n in slots:
             w0, b0 = params[n + ".weight"].detach(), params[n + ".bias"].detach()
             gvec = w0 * (1 + 0.1 * torch.randn(w0.shape, generator=gen, dtype=torch.float64))
             bvec = b0 + 0.1 * torch.randn(b0.shape, generator=gen, dtype=torch.float64)
-            film_ref[n + ".weight"], film_ref[n + ".bias"] = gvec.requires_grad_(True), bvec.requires_grad_(True)
-            gam.append(gvec.detach().float()), bet.append(bvec.detach().float())
+            film_vals[n + ".weight"], film_vals[n + ".bias"] = gvec, bvec
+            gam.append(gvec.float()), bet.append(bvec.float())
         x = torch.randn(5, 3, 64, 64, generator=gen)
         dfeat = torch.randn(5, 512, generator=gen)
-        functional_call(ref, film_ref, (x.double(),)).backward(dfeat.double())
         gamma = torch.cat(gam).to(device).requires_grad_(True)
         beta = torch.cat(bet).to(device).requires_grad_(True)
         nat(x.to(device), film=(gamma, beta)).backward(dfeat.to(device))
-        dg_ref = torch.cat([film_ref[n + ".weight"].grad for n in slots])
-        db_ref = torch.cat([film_ref[n + ".bias"].grad for n in slots])
         assert all(p.grad is None for p in nat.parameters())
-        return max(rel(gamma.grad, dg_ref), rel(beta.grad, db_ref))
+        got = (gamma.grad.cpu(), beta.grad.cpu())
 
-    _seeded_check(run)
+        def run_oracle():
+            film_ref = {k: v.clone().requires_grad_(True) for k, v in film_vals.items()}
+            functional_call(ref, film_ref, (x.double(),)).backward(dfeat.double())
+            return (torch.cat([film_ref[n + ".weight"].grad for n in slots]),
+                    torch.cat([film_ref[n + ".bias"].grad for n in slots]))
+
+        def error_of(grads):
+            return max(rel(got[0], grads[0]), rel(got[1], grads[1]))
+
+        return run_oracle, error_of
+
+    _seeded_check(run, tap)
 
 
 @pytest.mark.parametrize("size,B", [(32, 3), (84, 5), (50, 2)])
@@ -272,19 +349,31 @@ def test_set_encoder_backward_matches_autograd(device, size, B):
     ref = ref.double().eval()
     nat.eval()  # the set encoder always normalises with running statistics (few_shot_recognisers.py:176-183)
 
+    tap = ReluTap(ref)
+
     def run(seed):
-        nat.zero_grad(), ref.zero_grad()
+        nat.zero_grad()
         x = torch.randn(B, 3, size, size, generator=torch.Generator().manual_seed(size + seed))
         dfeat = torch.randn(B, 64, generator=torch.Generator().manual_seed(2 + seed))
-        out_ref = ref(x.double())
-        out_ref.backward(dfeat.double())
         out = nat(x.to(device))
-        assert rel(out.detach(), out_ref.detach()) < 2e-5
         out.backward(dfeat.to(device))
-        ref_grads = dict(ref.named_parameters())
-        return max(rel(p.grad, ref_grads[name].grad) for name, p in nat.named_parameters())
+        got = {name: p.grad.detach().cpu() for name, p in nat.named_parameters()}
+        state = {}
 
-    _seeded_check(run)
+        def run_oracle():
+            ref.zero_grad()
+            state["out"] = ref(x.double())
+            state["out"].backward(dfeat.double())
+            return {name: p.grad for name, p in ref.named_parameters()}
+
+        def error_of(grads):
+            return max(rel(got[name], grads[name]) for name in got)
+
+        run_oracle()
+        assert rel(out.detach(), state["out"].detach()) < 2e-5
+        return run_oracle, error_of
+
+    _seeded_check(run, tap)
 
 
 def test_backward_is_deterministic(device):
