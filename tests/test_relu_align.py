@@ -34,6 +34,8 @@ def _err(a, b):
 
 def test_flipped_unit_is_found_and_explains_the_difference():
     _, tap, run = _setup()
+    tap.begin()
+    run()  # records the pre-activation shapes
     tap.set_flips([(0, (2, 3))])
     tap.begin()
     other = run()  # the "other implementation": same network, unit (call 0, [2, 3]) on the other side of zero
