@@ -44,7 +44,8 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"conv_stem_fast", "ORBIT_CONV_STEM_FAST", 1, false},
                              {"conv_early_sc", "ORBIT_CONV_EARLY_SC", 1, false},
                              {"conv_epi_batch", "ORBIT_CONV_EPI_BATCH", 1, false},
-                             {"head_lds", "ORBIT_HEAD_LDS", 1, false}};
+                             {"head_lds", "ORBIT_HEAD_LDS", 1, false},
+                             {"head_stream", "ORBIT_HEAD_STREAM", 2, false}};
 static Option* find_option(const char* name) {
     for (Option& o : g_options)
         if (strcmp(o.name, name) == 0) {
@@ -349,6 +350,97 @@ __global__ __launch_bounds__(256) void proto_predict_lds_kernel(
     }
 }
 
+// Streaming form of the LDS-staged kernel for T = 1 and D = 256 * NI (D = 1280: NI 5, D = 512: NI 2, the two extractors):
+// every wave REQUESTS all of its query rows (R rows x NI float4 per lane = its whole share of the HBM stream) before the
+// block stages the task's weights into LDS, so the two memory latencies overlap instead of adding, and the dot products run
+// from registers against LDS after the barrier. The 64-task launch (67 MB) is ~8 us of HBM time: what it can lose is
+// exactly such serialised latencies (round 1: W staging -> barrier -> first row load, 2.7 TB/s). Same per-lane accumulation
+// order as proto_predict_lds_kernel (d ascending), hence bit-identical logits.
+template <int NW, int R, int NI>
+__global__ __launch_bounds__(NW * 64) void proto_predict_stream_kernel(
+    const float* __restrict__ Q, const float* __restrict__ W, const float* __restrict__ bias, int M, int D, int C,
+    float logit_scale, int cosine, float* __restrict__ logits, int32_t* __restrict__ argmax) {
+    extern __shared__ __attribute__((aligned(16))) float Ws[];  // [C][D] weights, then [C] norms
+    const int task = blockIdx.y;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int m0 = (blockIdx.x * NW + wave) * R;
+    const bool wave_ok = m0 < M;
+    float4 x[R][NI];
+    bool row_ok[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+        row_ok[r] = m0 + r < M;
+        const float* q = Q + ((size_t)task * M + (row_ok[r] ? m0 + r : (wave_ok ? m0 : 0))) * D + lane * 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) x[r][i] = *reinterpret_cast<const float4*>(q + i * 256);  // all in flight at once
+    }
+    const float* Wt = W + (size_t)task * C * D;
+    for (int i = tid * 4; i < C * D; i += NW * 256) *reinterpret_cast<float4*>(Ws + i) = *reinterpret_cast<const float4*>(Wt + i);
+    __syncthreads();
+    float* wn = Ws + (size_t)C * D;
+    if (cosine) {
+        for (int c = wave; c < C; c += NW) {
+            float s = 0.f;
+            for (int d = lane * 4; d < D; d += 256) {
+                const float4 w = *reinterpret_cast<const float4*>(Ws + (size_t)c * D + d);
+                s += w.x * w.x + w.y * w.y + w.z * w.z + w.w * w.w;
+            }
+            s = wave_sum(s);
+            if (lane == 0) wn[c] = sqrtf(s);
+        }
+        __syncthreads();
+    }
+    if (!wave_ok) return;
+    float best[R], qn2[R];
+    int best_c[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) best[r] = -INFINITY, best_c[r] = 0, qn2[r] = 0.f;
+    if (cosine) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float qq = 0.f;
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                qq += x[r][i].x * x[r][i].x + x[r][i].y * x[r][i].y + x[r][i].z * x[r][i].z + x[r][i].w * x[r][i].w;
+            qn2[r] = wave_sum(qq);
+        }
+    }
+    // one class at a time (rolled): only NI weight quads are live beside the R x NI query quads. Unrolled over the classes
+    // hipcc hoists all C x NI LDS reads - 190-256 VGPRs, one or two waves per SIMD - and a block that computes with
+    // nothing in flight then leaves HBM idle (standalone probe tools/head_probe.hip: the same row stream reaches 4.5 TB/s
+    // without the weights, 2.5 with them at that occupancy)
+#pragma unroll 1
+    for (int c = 0; c < C; ++c) {
+        float acc[R];
+#pragma unroll
+        for (int r = 0; r < R; ++r) acc[r] = 0.f;
+        const float* wrow = Ws + (size_t)c * D + lane * 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const float4 w = *reinterpret_cast<const float4*>(wrow + i * 256);
+#pragma unroll
+            for (int r = 0; r < R; ++r) acc[r] += x[r][i].x * w.x + x[r][i].y * w.y + x[r][i].z * w.z + x[r][i].w * w.w;
+        }
+        const float bj = cosine ? 0.f : bias[(size_t)task * C + c];
+        const float wnj = cosine ? wn[c] : 0.f;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            float v = wave_sum(acc[r]);
+            if (cosine)
+                v = logit_scale * (v / (fmaxf(sqrtf(qn2[r]), 1e-8f) * fmaxf(wnj, 1e-8f)));
+            else
+                v = logit_scale * (v + bj);
+            if (lane == 0 && row_ok[r]) logits[((size_t)task * M + m0 + r) * C + c] = v;
+            if (v > best[r]) best[r] = v, best_c[r] = c;
+        }
+    }
+    if (argmax != nullptr && lane == 0) {
+#pragma unroll
+        for (int r = 0; r < R; ++r)
+            if (row_ok[r]) argmax[(size_t)task * M + m0 + r] = best_c[r];
+    }
+}
+
 // ---- MeanPooler --------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void mean_pool_kernel(const float* __restrict__ x, int N, int T, int D,
                                                         float* __restrict__ out) {
@@ -459,6 +551,20 @@ int orbit_proto_predict(const float* Q, const float* W, const float* b, int n_ta
     const size_t lds = ((size_t)C * D + C) * sizeof(float);
     if ((D & 3) == 0 && lds <= 60 * 1024 && (long)M * n_tasks >= 64 && get_option("head_lds")) {
         const int opt = get_option("head_lds");  // 1: 4 rows per wave (16 per block), 2: 8 rows per wave (32 per block)
+        // head_stream (default 2): rows requested before the weight staging, one class at a time (T = 1, D = 1280 / 512).
+        // 1 = 4 waves x 4 rows per block, 2 = 8 waves x 2 rows (79 VGPRs: 6 waves per SIMD), 3 = 4 waves x 2 rows
+        const int stream_opt = get_option("head_stream");
+        if (stream_opt && T == 1 && (D == 1280 || D == 512)) {
+#define ORBIT_HEAD_STREAM(NW_, R_, NI_)                                                                                  \
+    proto_predict_stream_kernel<NW_, R_, NI_><<<dim3(cdiv(M, NW_ * R_), n_tasks), NW_ * 64, lds, s>>>(Q, W, b, M, D, C,  \
+                                                                                                 logit_scale, cosine, logits, argmax)
+            if (stream_opt == 1) { if (D == 1280) ORBIT_HEAD_STREAM(4, 4, 5); else ORBIT_HEAD_STREAM(4, 4, 2); }
+            else if (stream_opt == 3) { if (D == 1280) ORBIT_HEAD_STREAM(4, 2, 5); else ORBIT_HEAD_STREAM(4, 2, 2); }
+            else { if (D == 1280) ORBIT_HEAD_STREAM(8, 2, 5); else ORBIT_HEAD_STREAM(8, 2, 2); }
+#undef ORBIT_HEAD_STREAM
+            ORBIT_LAUNCH_CHECK();
+            return ORBIT_OK;
+        }
         if (opt == 2) {
             const dim3 grid(cdiv(M, 32), n_tasks);
             if (C <= 5)
