@@ -533,6 +533,7 @@ def main():
                        world, "; one all-reduce of the flat gradient bucket per optimizer step" if train and world > 1
                        else "")},
         "frame_accuracy": float(correct[0].item() / max(correct[1].item(), 1)),
+        "train_graph_calls_replayed_eager": list(model.feature_extractor.train_graph_stats()) if train else None,
         "median_task_ms": median_task_ms,
         "value_overlap_off": value_overlap_off,
         "host_enqueue_ms_per_step": 1e3 * issued / args.steps,

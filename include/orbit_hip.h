@@ -288,6 +288,9 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
                              const float* film_beta, int bn_train, const float* dfeats, const void* tape,
                              size_t tape_bytes, float* param_grads, int filter_grads, float* dfilm_gamma,
                              float* dfilm_beta, void* workspace, size_t workspace_bytes, orbit_stream_t stream);
+/* Training entry points replay captured HIP graphs when a call repeats an earlier call's pointers and scalars exactly
+ * (option train_graph = 1, off by default: it frees the host but the step is GPU-bound; the plan's own buffers never move). Diagnostics: calls that replayed / ran eagerly. */
+int orbit_extractor_train_graph_stats(const orbit_extractor_t* fe, long* replays, long* eager);
 /* Backward of orbit_filmgen_forward: given d(film_gamma), d(film_beta) (film_size floats each) and d(l2) ([1], NULL = 0)
  * writes the gradients of every generator parameter into `grads` (orbit_filmgen_grad_floats floats; tensor t of
  * generator i at orbit_filmgen_param_offset(g, i, t), same tensor names as orbit_filmgen_load except "init") and

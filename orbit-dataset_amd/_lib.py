@@ -97,6 +97,7 @@ _SIGNATURES = {
     "orbit_comm_world": (c_int, []),
     "orbit_comm_rank": (c_int, []),
     "orbit_allreduce_sum": (c_int, [P, c_size_t, P]),
+    "orbit_extractor_train_graph_stats": (c_int, [P, P, P]),
     "orbit_comm_destroy": (None, []),
 }
 

@@ -327,6 +327,7 @@ void orbit_extractor_destroy(orbit_extractor_t* fe) {
     if (!fe) return;
     extractor_train_release(fe);
     fe->clear_graphs();
+    fe->clear_train_graphs();
     if (fe->cap_stream) (void)hipStreamDestroy(fe->cap_stream);
     (void)hipFree(fe->d_pool);
     (void)hipFree(fe->d_src);

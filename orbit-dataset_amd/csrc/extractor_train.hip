@@ -209,6 +209,13 @@ static int ensure_dgrad_filters(orbit_extractor* fe, orbit_train_state** out, hi
     return ORBIT_OK;
 }
 
+static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
+                             const float* film_beta, int bn_train, float momentum, float* feats, void* tape,
+                             hipStream_t s);
+static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const float* frames, int B, const float* film_gamma,
+                        const float* film_beta, int bn_train, const float* dfeats, const void* tape, float* param_grads,
+                        int filter_grads, float* dfilm_gamma, float* dfilm_beta, void* workspace, hipStream_t s);
+
 extern "C" {
 
 int orbit_extractor_supports_training(const orbit_extractor_t* fe) { return fe && plan_trainable(fe) ? 1 : 0; }
@@ -251,7 +258,22 @@ int orbit_extractor_train_forward(orbit_extractor_t* fe, const float* frames, in
     const TapeLayout L = tape_layout(fe, B);
     ORBIT_REQUIRE(tape_bytes >= L.total, "extractor_train_forward: tape too small (%zu < %zu bytes)", tape_bytes, L.total);
     ORBIT_REQUIRE(((uintptr_t)tape & 255) == 0, "extractor_train_forward: tape must be 256-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
+    orbit_extractor::TrainGraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.p[0] = frames, key.p[1] = film_gamma, key.p[2] = film_beta, key.p[3] = feats, key.p[4] = tape;
+    key.v[0] = 1 /* forward */, key.v[1] = B, key.v[2] = bn_train;
+    memcpy(&key.v[3], &momentum, sizeof(float));
+    return fe->run_train_graphed(key, (hipStream_t)stream, [&](hipStream_t s) {
+        return train_forward_run(fe, frames, B, film_gamma, film_beta, bn_train, momentum, feats, tape, s);
+    });
+}
+
+}  // extern "C"
+
+static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
+                             const float* film_beta, int bn_train, float momentum, float* feats, void* tape,
+                             hipStream_t s) {
+    const TapeLayout L = tape_layout(fe, B);
     char* tp = static_cast<char*>(tape);
     auto fl = [&](size_t off) { return reinterpret_cast<float*>(tp + off); };
     float *mean = fl(L.mean), *invstd = fl(L.invstd), *scale = fl(L.scale), *shift = fl(L.shift);
@@ -359,6 +381,8 @@ int orbit_extractor_train_forward(orbit_extractor_t* fe, const float* frames, in
     return ORBIT_OK;
 }
 
+extern "C" {
+
 int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
                              const float* film_beta, int bn_train, const float* dfeats, const void* tape,
                              size_t tape_bytes, float* param_grads, int filter_grads, float* dfilm_gamma,
@@ -373,9 +397,6 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
     const bool film = film_gamma && film_beta && fe->film_size > 0;
     ORBIT_REQUIRE(!dfilm_gamma || film, "extractor_backward: FiLM gradients requested without FiLM inputs");
     if (!param_grads && !dfilm_gamma) return ORBIT_OK;  // nothing to compute
-    // filter_grads == 0: only the BatchNorm weight / bias gradients are wanted (FiLM fine-tuning of a frozen extractor,
-    // few_shot_recognisers.py:196-199): skip every filter / squeeze-excite / bias gradient
-    const bool wg = param_grads != nullptr && filter_grads != 0;
     const TapeLayout L = tape_layout(fe, B);
     const BwdLayout W = bwd_layout(fe, B);
     ORBIT_REQUIRE(tape_bytes >= L.total, "extractor_backward: tape too small");
@@ -383,10 +404,31 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
                   W.total);
     ORBIT_REQUIRE(((uintptr_t)workspace & 255) == 0 && ((uintptr_t)tape & 255) == 0,
                   "extractor_backward: tape and workspace must be 256-byte aligned");
-    hipStream_t s = (hipStream_t)stream;
+    // the dgrad-packed filters follow the parameters: repacked OUTSIDE any captured graph whenever they changed
     orbit_train_state* st = nullptr;
-    if (int rc = ensure_dgrad_filters(fe, &st, s)) return rc;
+    if (int rc = ensure_dgrad_filters(fe, &st, (hipStream_t)stream)) return rc;
+    orbit_extractor::TrainGraphKey key;
+    memset(&key, 0, sizeof(key));
+    key.p[0] = frames, key.p[1] = film_gamma, key.p[2] = film_beta, key.p[3] = dfeats, key.p[4] = tape;
+    key.p[5] = param_grads, key.p[6] = dfilm_gamma, key.p[7] = dfilm_beta, key.p[8] = workspace;
+    key.v[0] = 2 /* backward */, key.v[1] = B, key.v[2] = bn_train, key.v[3] = filter_grads;
+    return fe->run_train_graphed(key, (hipStream_t)stream, [&](hipStream_t s) {
+        return backward_run(fe, st, frames, B, film_gamma, film_beta, bn_train, dfeats, tape, param_grads, filter_grads,
+                            dfilm_gamma, dfilm_beta, workspace, s);
+    });
+}
 
+}  // extern "C"
+
+static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const float* frames, int B, const float* film_gamma,
+                        const float* film_beta, int bn_train, const float* dfeats, const void* tape, float* param_grads,
+                        int filter_grads, float* dfilm_gamma, float* dfilm_beta, void* workspace, hipStream_t s) {
+    const bool film = film_gamma && film_beta && fe->film_size > 0;
+    // filter_grads == 0: only the BatchNorm weight / bias gradients are wanted (FiLM fine-tuning of a frozen extractor,
+    // few_shot_recognisers.py:196-199): skip every filter / squeeze-excite / bias gradient
+    const bool wg = param_grads != nullptr && filter_grads != 0;
+    const TapeLayout L = tape_layout(fe, B);
+    const BwdLayout W = bwd_layout(fe, B);
     const char* tp = static_cast<const char*>(tape);
     auto tf = [&](size_t off) { return reinterpret_cast<const float*>(tp + off); };
     char* ws = static_cast<char*>(workspace);
@@ -592,6 +634,16 @@ int orbit_extractor_backward(orbit_extractor_t* fe, const float* frames, int B, 
         if (rc != ORBIT_OK) return rc;
     }
 #undef SLOT_OR_FAIL
+    return ORBIT_OK;
+}
+
+extern "C" {
+
+// diagnostics: how many training-entry calls of this plan replayed a captured graph / ran eagerly
+int orbit_extractor_train_graph_stats(const orbit_extractor_t* fe, long* replays, long* eager) {
+    ORBIT_REQUIRE(fe, "extractor_train_graph_stats: null pointer");
+    if (replays) *replays = fe->train_graph_replays;
+    if (eager) *eager = fe->train_graph_eager;
     return ORBIT_OK;
 }
 

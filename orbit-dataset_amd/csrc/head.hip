@@ -37,6 +37,7 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"mbconv_map", "ORBIT_MBCONV_MAP", 0, false},
                              {"mbmap_groups", "ORBIT_MBMAP_GROUPS", 0, false},
                              {"graph", "ORBIT_GRAPH", 2, false},
+                             {"train_graph", "ORBIT_TRAIN_GRAPH", 0, false},
                              {"conv_tile", "ORBIT_CONV_TILE", 0, false},
                              {"conv_bk", "ORBIT_CONV_BK", 0, false},
                              {"conv_uncond", "ORBIT_CONV_UNCOND", 1, false},

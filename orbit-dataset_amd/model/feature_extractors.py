@@ -213,6 +213,18 @@ class HipNetwork(nn.Module):
             plan.workspaces[key] = ws
         return ws
 
+    def train_graph_stats(self):
+        """(replayed, eager) calls of the native training entry points over this network's plans: the tape / gradient
+        buffers come from torch's caching allocator, which hands back the same addresses step after step in a steady
+        training loop - such calls replay a captured HIP graph instead of ~1 300 launches (option train_graph)."""
+        lib = _lib.load()
+        rep = eag = 0
+        for pl in self._plans.values():
+            a, b = ctypes.c_long(0), ctypes.c_long(0)
+            lib.orbit_extractor_train_graph_stats(pl.handle, ctypes.byref(a), ctypes.byref(b))
+            rep, eag = rep + a.value, eag + b.value
+        return rep, eag
+
     def macs_per_frame(self, H, W):
         return _lib.load().orbit_extractor_macs_per_frame(self._plan(H, W).handle)
 

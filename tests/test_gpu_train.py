@@ -461,3 +461,42 @@ def test_efficientnet_film_gradients_frozen_extractor(device):
     db_ref = torch.cat([film_ref[n + ".bias"].grad for n in slots])
     assert rel(gamma.grad, dg_ref) < 2e-4 and rel(beta.grad, db_ref) < 2e-4
     assert all(p.grad is None for p in nat.parameters())
+
+
+def test_training_graph_replay_is_bit_identical(device, lib):
+    """Option train_graph = 1: orbit_extractor_train_forward / _backward replay captured HIP graphs once a call repeats an
+    earlier call's pointers (same tensors here). Gradients, features and running statistics must equal the eager run bit
+    for bit, also after the parameters changed in between (the graph reads the plan's current parameter pool)."""
+    _, nat = _oracle_and_native("resnet18", device)
+    nat.train()
+    x = torch.randn(6, 3, 64, 64, generator=torch.Generator().manual_seed(4)).to(device)
+    dfeat = torch.randn(6, 512, generator=torch.Generator().manual_seed(5)).to(device)
+    sd0 = {k: v.clone() for k, v in nat.state_dict().items()}
+
+    def run(scale):
+        nat.load_state_dict(sd0)
+        with torch.no_grad():
+            dict(nat.named_parameters())["layer3.0.conv1.weight"].mul_(scale)
+        nat.zero_grad()
+        out = nat(x)
+        out.backward(dfeat)
+        return (out.detach().clone(), {n: p.grad.clone() for n, p in nat.named_parameters()},
+                {k: v.clone() for k, v in nat.state_dict().items() if "running" in k})
+
+    prev = lib.orbit_get_option(b"train_graph")
+    try:
+        lib.orbit_set_option(b"train_graph", 0)
+        want = {s_: run(s_) for s_ in (1.0, 1.25)}
+        lib.orbit_set_option(b"train_graph", 1)
+        before = nat.train_graph_stats()
+        for rep in range(4):  # sight 1 eager, sight 2 captures, then replays; parameters alternate between the runs
+            for s_ in (1.0, 1.25):
+                out, grads, stats = run(s_)
+                assert torch.equal(out, want[s_][0])
+                assert all(torch.equal(grads[n], want[s_][1][n]) for n in grads), (rep, s_)
+                assert all(torch.equal(stats[k], want[s_][2][k]) for k in stats)
+        after = nat.train_graph_stats()
+    finally:
+        lib.orbit_set_option(b"train_graph", prev)
+    # torch's caching allocator returns the tape / gradient buffers at the same addresses in this steady loop
+    assert after[0] - before[0] >= 4, (before, after)
