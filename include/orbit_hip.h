@@ -371,6 +371,21 @@ int orbit_comm_rank(void);
 int orbit_allreduce_sum(float* buf, size_t n, orbit_stream_t stream);  /* in place */
 void orbit_comm_destroy(void);
 
+/* ---- one-shot peer-to-peer all-reduce(SUM) over xGMI for the SMALL exchange steps (csrc/comm.hip) -----------------
+ * The prototype payload of a support-sharded task is 25.6 KB: a latency-bound message. Every rank pushes its payload
+ * into a slot of every peer's inbox (IPC-mapped device memory, all xGMI links in parallel), raises a flag and sums the
+ * world slots of its own inbox in rank order: one hop, bit-identical result on every rank. orbit_allreduce_sum (RCCL)
+ * stays the baseline and the path for large buffers.
+ *   create (every rank) -> export 64-byte IPC handle -> exchange handles (host side) -> connect -> allreduce ... */
+#define ORBIT_P2P_HANDLE_BYTES 64
+typedef struct orbit_p2p orbit_p2p_t;
+int orbit_p2p_create(int rank, int world, size_t max_floats, orbit_p2p_t** out);
+int orbit_p2p_export(orbit_p2p_t* c, void* handle64);
+int orbit_p2p_connect(orbit_p2p_t* c, const void* handles /* [world][64], own entry ignored */);
+int orbit_p2p_allreduce_sum(orbit_p2p_t* c, float* buf, size_t n, orbit_stream_t stream); /* in place, n <= max_floats */
+int orbit_p2p_error(orbit_p2p_t* c);   /* 0 ok; k > 0: waiting for rank k-1 timed out (synchronises the device) */
+void orbit_p2p_destroy(orbit_p2p_t* c);
+
 #ifdef __cplusplus
 }
 #endif

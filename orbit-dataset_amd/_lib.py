@@ -99,6 +99,12 @@ _SIGNATURES = {
     "orbit_allreduce_sum": (c_int, [P, c_size_t, P]),
     "orbit_extractor_train_graph_stats": (c_int, [P, P, P]),
     "orbit_comm_destroy": (None, []),
+    "orbit_p2p_create": (c_int, [c_int, c_int, c_size_t, POINTER(c_void_p)]),
+    "orbit_p2p_export": (c_int, [P, P]),
+    "orbit_p2p_connect": (c_int, [P, P]),
+    "orbit_p2p_allreduce_sum": (c_int, [P, P, c_size_t, P]),
+    "orbit_p2p_error": (c_int, [P]),
+    "orbit_p2p_destroy": (None, [P]),
 }
 
 EXPORTS = tuple(_SIGNATURES)

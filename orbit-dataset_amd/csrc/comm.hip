@@ -3,6 +3,8 @@
 // when ONE task's support frames are sharded over ranks is the sum of the per-class prototype partials
 // ([C][D] sums + [C] counts, ~25 KB) produced by orbit_proto_configure — a latency-bound all-reduce.
 #include <rccl/rccl.h>
+#include <cstring>
+#include <vector>
 #include "common.h"
 
 using namespace orbit;
@@ -50,6 +52,165 @@ int orbit_allreduce_sum(float* buf, size_t n, orbit_stream_t stream) {
 void orbit_comm_destroy(void) {
     if (g_comm) ncclCommDestroy(g_comm);
     g_comm = nullptr, g_world = 0, g_rank = -1;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------------------------------------------
+// One-shot peer-to-peer all-reduce(SUM) for the SMALL exchange steps of the sharded episodic path:
+// the prototype payload of a support-sharded task ([C][D] sums + [C] counts = 25.6 KB at C = 5, D = 1280) and the
+// set-encoder embedding sums (65 floats). A ring / tree all-reduce of such a message is pure latency (RCCL: a kernel launch
+// plus 2 (N-1) dependent xGMI hops); xGMI is a full point-to-point mesh inside a node, so every rank instead PUSHES its
+// payload straight into a slot of every peer's inbox (posted remote stores, all links in parallel), raises a flag, waits for
+// its own N flags and sums the N slots in RANK ORDER - one hop of latency, and the identical summation order on every rank
+// makes the result bit-identical everywhere (what personalise_support_sharded promises: identical prototypes on all ranks).
+//
+// Memory: each rank owns an inbox  data[2][world][max_floats] + flag[world]  in device memory, exported to its peers with
+// hipIpcGetMemHandle (the host side exchanges the 64-byte handles through whatever rendezvous it has: torch.distributed,
+// MPI, files) and mapped by them with hipIpcOpenMemHandle. Epochs alternate the two data halves: a rank can start epoch
+// e+1 while a slower peer still sums epoch e, and cannot reach e+2 before that peer has pushed e+1, i.e. finished e.
+// Flags and payload cross the fabric with system-scope release / acquire; a spin that does not complete within
+// ~4 s of GPU clock gives up and reports an error instead of hanging the device.
+struct orbit_p2p {
+    int rank = 0, world = 0;
+    size_t max_floats = 0;
+    float* inbox = nullptr;                 // this rank's inbox (device)
+    unsigned* flags = nullptr;              // = inbox + 2 * world * max_floats
+    std::vector<float*> peer_inbox;         // mapped inbox of every rank (own entry = inbox)
+    float** d_peer_inbox = nullptr;         // device copy of the table
+    int* d_error = nullptr;
+    unsigned epoch = 0;
+    bool connected = false;
+};
+
+namespace orbit {
+
+__global__ __launch_bounds__(1024) void p2p_allreduce_kernel(float* const* __restrict__ peer_inbox, float* __restrict__ buf,
+                                                             int n, int rank, int world, size_t max_floats,
+                                                             unsigned epoch, int* __restrict__ error) {
+    const int tid = threadIdx.x;
+    const size_t half = (size_t)(epoch & 1u) * world * max_floats;
+    // ---- push: my payload into slot [rank] of every inbox (own included), 16-byte stores where aligned
+    for (int p = 0; p < world; ++p) {
+        float* dst = peer_inbox[p] + half + (size_t)rank * max_floats;
+        for (int i = tid; i < n; i += blockDim.x) __hip_atomic_store(dst + i, buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < world) {
+        unsigned* f = reinterpret_cast<unsigned*>(peer_inbox[tid] + 2 * (size_t)world * max_floats) + rank;
+        __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    // ---- wait for the world flags of my inbox
+    if (tid < world) {
+        const unsigned* f = reinterpret_cast<const unsigned*>(peer_inbox[rank] + 2 * (size_t)world * max_floats) + tid;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
+            if (wall_clock64() - t0 > 400000000LL) {  // ~4 s at the 100 MHz constant clock
+                atomicExch(error, 1 + tid);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+    // ---- sum the slots in rank order
+    const float* mine = peer_inbox[rank] + half;
+    for (int i = tid; i < n; i += blockDim.x) {
+        float s = __hip_atomic_load(mine + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        for (int p = 1; p < world; ++p)
+            s += __hip_atomic_load(mine + (size_t)p * max_floats + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        buf[i] = s;
+    }
+}
+
+}  // namespace orbit
+
+extern "C" {
+
+int orbit_p2p_create(int rank, int world, size_t max_floats, orbit_p2p_t** out) {
+    ORBIT_REQUIRE(out && world > 0 && world <= 64 && rank >= 0 && rank < world && max_floats > 0 && max_floats <= (1u << 22),
+                  "p2p_create: bad arguments (rank %d, world %d, max_floats %zu)", rank, world, max_floats);
+    orbit_p2p* c = new orbit_p2p();
+    c->rank = rank, c->world = world, c->max_floats = (max_floats + 3) & ~(size_t)3;
+    const size_t bytes = 2 * (size_t)world * c->max_floats * sizeof(float) + (size_t)world * sizeof(unsigned);
+    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->inbox), bytes);
+    if (e == hipSuccess) e = hipMemset(c->inbox, 0, bytes);
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_peer_inbox), world * sizeof(float*));
+    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_error), sizeof(int));
+    if (e == hipSuccess) e = hipMemset(c->d_error, 0, sizeof(int));
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) {
+        (void)hipFree(c->inbox), (void)hipFree(c->d_peer_inbox), (void)hipFree(c->d_error);
+        delete c;
+        (void)hipGetLastError();
+        return set_err(ORBIT_ERR_HIP, "p2p_create: %s", hipGetErrorString(e));
+    }
+    c->flags = reinterpret_cast<unsigned*>(c->inbox + 2 * (size_t)world * c->max_floats);
+    c->peer_inbox.assign(world, nullptr);
+    c->peer_inbox[rank] = c->inbox;
+    *out = c;
+    return ORBIT_OK;
+}
+
+int orbit_p2p_export(orbit_p2p_t* c, void* handle64) {
+    ORBIT_REQUIRE(c && handle64, "p2p_export: null pointer");
+    static_assert(sizeof(hipIpcMemHandle_t) == ORBIT_P2P_HANDLE_BYTES, "hipIpcMemHandle_t size");
+    hipIpcMemHandle_t h;
+    ORBIT_HIP_CHECK(hipIpcGetMemHandle(&h, c->inbox));
+    memcpy(handle64, &h, sizeof(h));
+    return ORBIT_OK;
+}
+
+int orbit_p2p_connect(orbit_p2p_t* c, const void* handles) {
+    ORBIT_REQUIRE(c && handles, "p2p_connect: null pointer");
+    if (c->connected) return set_err(ORBIT_ERR_STATE, "p2p_connect: already connected");
+    const char* hs = static_cast<const char*>(handles);
+    for (int p = 0; p < c->world; ++p) {
+        if (p == c->rank) continue;
+        hipIpcMemHandle_t h;
+        memcpy(&h, hs + (size_t)p * ORBIT_P2P_HANDLE_BYTES, sizeof(h));
+        void* ptr = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            return set_err(ORBIT_ERR_HIP, "p2p_connect: hipIpcOpenMemHandle(rank %d): %s", p, hipGetErrorString(e));
+        }
+        c->peer_inbox[p] = static_cast<float*>(ptr);
+    }
+    ORBIT_HIP_CHECK(hipMemcpy(c->d_peer_inbox, c->peer_inbox.data(), c->world * sizeof(float*), hipMemcpyHostToDevice));
+    c->connected = true;
+    return ORBIT_OK;
+}
+
+int orbit_p2p_allreduce_sum(orbit_p2p_t* c, float* buf, size_t n, orbit_stream_t stream) {
+    ORBIT_REQUIRE(c && buf && n > 0, "p2p_allreduce_sum: bad arguments");
+    ORBIT_REQUIRE(c->connected, "p2p_allreduce_sum: call orbit_p2p_connect first");
+    ORBIT_REQUIRE(n <= c->max_floats, "p2p_allreduce_sum: %zu floats exceed the inbox slot (%zu)", n, c->max_floats);
+    ++c->epoch;
+    if (c->epoch == 0) ++c->epoch;  // 0 is the "never written" value of the flags
+    const int threads = n >= 4096 ? 1024 : 256;
+    orbit::p2p_allreduce_kernel<<<1, threads, 0, (hipStream_t)stream>>>(c->d_peer_inbox, buf, (int)n, c->rank, c->world,
+                                                                       c->max_floats, c->epoch, c->d_error);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+/* 0 = every all-reduce so far completed; k > 0 = a wait for rank k-1's flag timed out (synchronises the device) */
+int orbit_p2p_error(orbit_p2p_t* c) {
+    ORBIT_REQUIRE(c, "p2p_error: null pointer");
+    int e = 0;
+    ORBIT_HIP_CHECK(hipMemcpy(&e, c->d_error, sizeof(int), hipMemcpyDeviceToHost));
+    return e;
+}
+
+void orbit_p2p_destroy(orbit_p2p_t* c) {
+    if (!c) return;
+    for (int p = 0; p < c->world; ++p)
+        if (p != c->rank && c->peer_inbox[p]) (void)hipIpcCloseMemHandle(c->peer_inbox[p]);
+    (void)hipFree(c->inbox), (void)hipFree(c->d_peer_inbox), (void)hipFree(c->d_error);
+    delete c;
 }
 
 }  // extern "C"

@@ -49,10 +49,61 @@ def train(out, argv):
         torch.distributed.destroy_process_group()
 
 
+def p2p(out):
+    """One-shot P2P all-reduce between two processes that share GPU 0: IPC-mapped inboxes, flags, rank-order sums."""
+    import time
+    rank, world, _ = odist.init_from_env("gloo")
+    torch.cuda.set_device(0)
+    ar = odist.P2PAllReduce(rank, world, max_floats=16384)
+    res = {}
+    g = torch.Generator().manual_seed(100 + rank)
+    for n in (6405, 65, 1, 16384, 6405):  # prototype payload (5 x 1280 + 5), embedding sums, a scalar, a full slot
+        x = torch.randn(n, generator=g)
+        want = x.clone()
+        torch.distributed.all_reduce(want)  # gloo on the host: the reference sum
+        dev = x.cuda()
+        ar(dev)
+        torch.cuda.synchronize()
+        res.setdefault("got", []).append(dev.cpu())
+        res.setdefault("want", []).append(want)
+    # the sharded product path through the P2P exchange
+    from orbit_dataset_amd.model.few_shot_recognisers import SingleStepFewShotRecogniser
+    model = SingleStepFewShotRecogniser("resnet18", True, "proto", 1, 8, False, 16, 1.0)
+    synthetic.init_parameters_(model)
+    model._set_device("cuda:0")
+    model._send_to_device()
+    model.set_test_mode(True)
+    task = synthetic.make_task(9, way=4, shots=1, frames_per_shot=5, num_query=11, frame_size=64, label_values=(2, 5, 6, 9))
+    ctx, lab, tgt = task["context_clips"].cuda(), task["context_labels"].cuda(), task["target_clips"].cuda()
+    sh = odist.SupportSharding(rank, world, p2p=ar)
+    lo, hi = sh.bounds(len(lab))
+    odist.personalise_support_sharded(model, ctx[lo:hi].clone(), lab, sh)
+    res["W"] = model.classifier.weight.detach().cpu()
+    res["logits"] = model.predict(tgt).cpu()
+    # latency of the 25.6 KB exchange (per-call, host-synchronised: an upper bound)
+    dev = torch.randn(6405).cuda()
+    for _ in range(5):
+        ar(dev)
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(50):
+        ar(dev)
+    torch.cuda.synchronize()
+    res["us_per_allreduce"] = 1e6 * (time.perf_counter() - t0) / 50
+    res["error"] = ar.error()
+    torch.save(res, "%s.rank%d.pt" % (out, rank))
+    torch.distributed.barrier()
+    ar.close()
+    torch.distributed.destroy_process_group()
+
+
 if __name__ == "__main__":
     mode, out = sys.argv[1], sys.argv[2]
     if mode == "sharded":
         sharded(out, adapt=sys.argv[3] == "1")
+    elif mode == "p2p":
+        p2p(out)
     elif mode == "train":
         train(out, sys.argv[3:])
     else:

@@ -39,7 +39,7 @@ done
 # HBM traffic of the dominant kernel family per launch, from the two PMC passes (rocprofv3 reports KiB; on gfx950
 # FETCH_SIZE counts wide 16-B/lane streaming reads at exactly half their bytes -> x2, see MI355X_MICROARCH.md §HBM)
 python - "$O" "$TAG" > $O/${TAG}_traffic.json <<'PY'
-import csv, glob, json, sys
+import csv, glob, json, os, sys
 out, tag = sys.argv[1], sys.argv[2]
 tot = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
@@ -53,10 +53,40 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 launches = tot["FETCH_SIZE"][0]
 fetch = 2.0 * tot["FETCH_SIZE"][1] * 1024 / max(launches, 1)
 write = tot["WRITE_SIZE"][1] * 1024 / max(tot["WRITE_SIZE"][0], 1)
+import subprocess
+sha = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; print(bench.kernel_sources_sha16())" % os.environ.get("GRAFT_REPO_ROOT", ".")],
+                     capture_output=True, text=True).stdout.strip().splitlines()[-1]
 print(json.dumps({"workload": "efficientnet_b0_224", "kernel": "orbit::conv_igemm_kernel (all instantiations)",
+                  "kernel_sources_sha16": sha,
                   "launches_profiled": launches, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                   "traffic_bytes_per_launch": fetch + write,
                   "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of bench.py; FETCH_SIZE x2 "
                             "(gfx950 wide-load correction), WRITE_SIZE as reported"}))
 PY
-ls -la $O | head -40
+# ---- distance kernel (64-task batched launch): kernel-trace stats + FETCH_SIZE / WRITE_SIZE in their own passes ----------
+cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_head -- python $R/tools/head_roofline.py quick > $O/${TAG}_head_roofline.log 2>&1
+cp $(ls $O/stats_head/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_head.csv
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 600 rocprofv3 --pmc $C --output-format csv -d $O/pmc_head_$C -- python $R/tools/head_roofline.py quick > /dev/null 2> $O/${TAG}_pmc_head_$C.err
+done
+python - "$O" "$TAG" > $O/${TAG}_head_traffic.json <<'PY'
+import csv, glob, json, os, subprocess, sys
+out, tag = sys.argv[1], sys.argv[2]
+tot = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob("%s/pmc_head_%s/*/*counter_collection.csv" % (out, c))[0]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+            if r.get("Counter_Name") == c and "proto_predict_stream_kernel<8" in r["Kernel_Name"] and int(r["Grid_Size"]) >= 64 * 13 * 512]
+    tot[c] = vals
+fetch = 2.0 * 1024 * sum(tot["FETCH_SIZE"]) / max(len(tot["FETCH_SIZE"]), 1)
+write = 1024 * sum(tot["WRITE_SIZE"]) / max(len(tot["WRITE_SIZE"]), 1)
+sha = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; print(bench.kernel_sources_sha16())" % os.environ.get("GRAFT_REPO_ROOT", ".")],
+                     capture_output=True, text=True).stdout.strip().splitlines()[-1]
+print(json.dumps({"kernel": "orbit::proto_predict_stream_kernel<8, 2, 5> (64 tasks x 200 x 1280, 5-way)", "kernel_sources_sha16": sha,
+                  "launches_profiled": len(tot["FETCH_SIZE"]), "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
+                  "traffic_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": 4.0 * (200 * 1280 + 5 * 1280 + 5 + 200 * 5) * 64,
+                  "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of tools/head_roofline.py quick; "
+                            "FETCH_SIZE x2 (gfx950 wide-load correction), WRITE_SIZE as reported"}))
+PY
+ls -la $O | head -60
