@@ -472,11 +472,20 @@ def main():
     ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
     _lib.check(lib.orbit_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "orbit_prof_collect")
     variants, total_bytes, n_main = [], 0.0, 0
+    conv_ms = conv_fl = 0.0  # the roofline is the conv kernels' (conv_igemm / split-K reduce / conv_wgrad); other profiled
+    other = []               # kernels (the stem's direct kernel, the opt-in fused MBConv map kernel) are listed on their own
     for i in range(lib.orbit_prof_num_variants()):
         name = ctypes.create_string_buffer(48)
         ln, vms, vfl, vby = ctypes.c_long(), ctypes.c_double(), ctypes.c_double(), ctypes.c_double()
         lib.orbit_prof_variant(i, name, ctypes.byref(ln), ctypes.byref(vms), ctypes.byref(vfl), ctypes.byref(vby))
+        if ln.value and vms.value > 0 and not name.value.decode().startswith("conv"):
+            sec = vms.value * 1e-3
+            other.append({"kernel": name.value.decode(), "launches": ln.value, "avg_us": round(1e3 * vms.value / ln.value, 2),
+                          "tflops": round(vfl.value / sec / 1e12, 2), "algorithmic_gbs": round(vby.value / sec / 1e9, 1)})
+            continue
         if ln.value and vms.value > 0:
+            conv_ms += vms.value
+            conv_fl += vfl.value
             # the split-K reduce pass of a conv is part of that conv's time and bytes, not a launch of its own
             n_main += 0 if name.value.decode().startswith("conv_splitk_reduce") else ln.value
             sec = vms.value * 1e-3
@@ -493,6 +502,7 @@ def main():
             dist.destroy_process_group()
         return
 
+    ms.value, fl.value = conv_ms, conv_fl
     achieved = fl.value / (ms.value * 1e-3) / 1e12 if ms.value > 0 else 0.0
     # HBM traffic per launch of the dominant kernel: PMC counters cannot be read from inside this process; the value is
     # the one tools/collect_profiles.sh measured with rocprofv3 on this same command (committed under profiles/)
@@ -552,7 +562,7 @@ def main():
                      "measured": "per-launch HIP events on the launch stream over a repeat of the %d timed steps with the "
                                  "support/query overlap switched off, so every kernel runs alone (instrumented repeat took "
                                  "%.1f ms/step)" % (args.steps, 1e3 * elapsed_prof / args.steps),
-                     "variants": variants},
+                     "variants": variants, "other_profiled_kernels": other},
     }
     out["head_roofline"] = head_roofline(device)
     if not train and world == 1:

@@ -106,6 +106,10 @@ int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_
 // fused expand(1x1, MFMA) + BN + SiLU + depthwise + BN + SiLU (+ SE pooling partials [B][tiles][mid]); csrc/mbconv.hip
 bool mbconv_front_supported(int Cin, int mid, int K, int stride);
 int mbconv_front_tiles(int Ho, int Wo, int stride);
+// EfficientNet stem as a direct VALU kernel with LDS-staged input rows (csrc/stem.hip); w = raw OIHW filter [32][3][3][3]
+bool stem_direct_supported(int Cin, int Cout, int K, int stride, int W, int act);
+int launch_stem_direct(const float* frames, const float* w_oihw, const float* scale, const float* shift, float* y, int B,
+                       int H, int W, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s);
 // whole-map form for the 14x14 / 7x7 stages (csrc/mbconv_map.hip): pool sums are complete per (frame, channel), i.e. the
 // squeeze-excite gate kernel sees ONE partial per frame
 bool mbconv_map_supported(int H, int W, int Cin, int mid, int K, int stride);

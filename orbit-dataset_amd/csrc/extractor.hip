@@ -575,6 +575,14 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
         int rc = ORBIT_OK;
         switch (o.kind) {
             case OP_CONV: {
+                if (o.x_nchw && !o.pool2 && o.res < 0 && o.bn >= 0 && get_option("stem_direct") &&
+                    stem_direct_supported(o.Cin, o.Cout, o.KH, o.stride, o.W, o.act) && o.KH == o.KW) {
+                    // EfficientNet stem: LDS-staged input rows + VALU (csrc/stem.hip) instead of the element-wise gather
+                    rc = launch_stem_direct(buf(o.in), fe->d_pool + fe->params[o.weight].off, scale + fe->bns[o.bn].fold_off,
+                                            shift + fe->bns[o.bn].fold_off, buf(o.out), B, o.H, o.W, o.pad_t, o.pad_l, o.Ho,
+                                            o.Wo, s);
+                    break;
+                }
                 ConvDesc d;
                 d.x = buf(o.in), d.w_packed = fe->d_packed + o.packed_off, d.y = buf(o.out);
                 d.scale = o.bn >= 0 ? scale + fe->bns[o.bn].fold_off : nullptr;
