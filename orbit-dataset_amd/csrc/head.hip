@@ -39,6 +39,7 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"graph", "ORBIT_GRAPH", 2, false},
                              {"train_graph", "ORBIT_TRAIN_GRAPH", 0, false},
                              {"stem_direct", "ORBIT_STEM_DIRECT", 1, false},
+                             {"se_wide", "ORBIT_SE_WIDE", 1, false},
                              {"conv_tile", "ORBIT_CONV_TILE", 0, false},
                              {"conv_bk", "ORBIT_CONV_BK", 0, false},
                              {"conv_uncond", "ORBIT_CONV_UNCOND", 1, false},

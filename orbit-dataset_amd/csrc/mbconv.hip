@@ -130,6 +130,9 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
         }
         valid[px] = ok ? 1 : 0;
     }
+    // block-uniform: the whole patch lies inside the image (51-61 % of the tiles at 56x56). The expand epilogue then needs
+    // no validity flags at all - rows beyond P of the last row tile are never read by the depthwise phase
+    const bool interior = hi0 >= 0 && wi0 >= 0 && hi0 + IH <= p.H && wi0 + IW <= p.W;
 
     // depthwise thread mapping: channel quad lc (8 per chunk), column segment seg (32 per tile)
     const int lc = tid & 7, seg = tid >> 3;
@@ -212,14 +215,23 @@ __global__ __launch_bounds__(256) void mbconv_front_kernel(const MbParams p) {
             // C/D layout: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (patch pixel)
             // branch-free: SiLU on every element, zeroed through a select (a per-element branch on valid[] costs an exec-mask
             // branch and a wait each); the four flags of four consecutive patch pixels are one 32-bit LDS read
+            if (interior) {
 #pragma unroll
-            for (int rq = 0; rq < 4; ++rq) {
-                const int px0 = t * 32 + 8 * rq + 4 * lh;
-                const unsigned vb = *reinterpret_cast<const unsigned*>(valid + px0);
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int px0 = t * 32 + 8 * rq + 4 * lh;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float e = silu_f(acc[rq * 4 + j] * s1 + h1);
-                    Es[(px0 + j) * ES + l31] = ((vb >> (8 * j)) & 0xffu) ? e : 0.f;
+                    for (int j = 0; j < 4; ++j) Es[(px0 + j) * ES + l31] = silu_f(acc[rq * 4 + j] * s1 + h1);
+                }
+            } else {
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const int px0 = t * 32 + 8 * rq + 4 * lh;
+                    const unsigned vb = *reinterpret_cast<const unsigned*>(valid + px0);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float e = silu_f(acc[rq * 4 + j] * s1 + h1);
+                        Es[(px0 + j) * ES + l31] = ((vb >> (8 * j)) & 0xffu) ? e : 0.f;
+                    }
                 }
             }
         }

@@ -477,7 +477,8 @@ __device__ __forceinline__ float se_wave_sum(float v) {  // lane 63 holds the su
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
 }
 
-__global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__ partial, int chunks, float inv_hw,
+template <int NT>
+__global__ __launch_bounds__(NT) void se_gate2_kernel(const float* __restrict__ partial, int chunks, float inv_hw,
                                                        const float* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ w2t, const float* __restrict__ b2,
                                                        float* __restrict__ gate, int C, int R) {
@@ -487,7 +488,7 @@ __global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__
     const int b = blockIdx.x, tid = threadIdx.x;
     const int C4 = C >> 2;
     const v4f* part4 = reinterpret_cast<const v4f*>(partial) + (size_t)b * chunks * C4;
-    const int parts = C4 <= 128 ? 256 / C4 : 1;  // thread groups sharing the chunk list of a channel quad
+    const int parts = C4 <= NT / 2 ? NT / C4 : 1;  // thread groups sharing the chunk list of a channel quad
     if (parts > 1 && chunks > 8) {
         // many partials (the fused MBConv front writes one per 8x8 / 4x8 tile: up to 98) and few channels: 256 / C4 threads
         // per quad take every parts-th chunk, the groups' sums are added in group order (fixed order, deterministic)
@@ -506,7 +507,7 @@ __global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__
             sp4[tid] = s * inv_hw;
         }
     } else {
-        for (int c4 = tid; c4 < C4; c4 += 256) {
+        for (int c4 = tid; c4 < C4; c4 += NT) {
             v4f s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 8
             for (int k = 0; k < chunks; ++k) s += part4[(size_t)k * C4 + c4];  // loads batched, adds in chunk order
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__
     // layer 1: wave w takes hidden units w, w + 4, ...; four units at a time, lanes stride the channel quads
     const int lane = tid & 63, wave = tid >> 6;
     const v4f* w14 = reinterpret_cast<const v4f*>(w1);
-    for (int r0 = wave; r0 < R; r0 += 16) {
+    for (int r0 = wave; r0 < R; r0 += 4 * (NT / 64)) {  // each wave takes units r0, r0 + NW, r0 + 2 NW, r0 + 3 NW
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (int cb = 0; cb < C4; cb += 320) {  // 5 quads per lane per pass: C <= 1280 is a single pass
             v4f wv[4][5], pv[5];
@@ -528,7 +529,7 @@ __global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__
                 pv[j] = ok ? sp4[c4] : (v4f){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int r = r0 + 4 * u;
+                    const int r = r0 + (NT / 64) * u;
                     wv[u][j] = (ok && r < R) ? w14[(size_t)r * C4 + c4] : (v4f){0.f, 0.f, 0.f, 0.f};
                 }
             }
@@ -542,7 +543,7 @@ __global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int r = r0 + 4 * u;
+            const int r = r0 + (NT / 64) * u;
             const float sum = se_wave_sum(acc[u]);
             if (r < R && lane == 0) {
                 const float t = sum + b1[r];
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(256) void se_gate2_kernel(const float* __restrict__
     __syncthreads();
     // layer 2: thread = channel quad, eight hidden units (eight independent 16-byte loads) per step
     const v4f* w24 = reinterpret_cast<const v4f*>(w2t);
-    for (int c4 = tid; c4 < C4; c4 += 256) {
+    for (int c4 = tid; c4 < C4; c4 += NT) {
         v4f a = *reinterpret_cast<const v4f*>(b2 + 4 * c4);
         int r = 0;
         for (; r + 8 <= R; r += 8) {
@@ -781,8 +782,14 @@ int launch_se_gate2(const float* partial, int chunks, int HW, const float* w1, c
                     const float* b2, float* gate, int B, int C, int R, hipStream_t s) {
     ORBIT_REQUIRE(partial && w1 && b1 && w2t && b2 && gate, "se_gate2: null pointer");
     ORBIT_REQUIRE(C % 4 == 0, "se_gate2: C %% 4 != 0 (C=%d)", C);
-    se_gate2_kernel<<<B, 256, (size_t)(((C + R + 3) & ~3) + 4 * 256) * sizeof(float), s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2,
-                                                                     gate, C, R);
+    // wide blocks for the wide layers: the gate of a frame is a chain of L2 latencies through ONE CU (up to 2 x 221 KB of
+    // weights); 1024 threads take all 48 hidden units of the 1152-channel blocks in one round and every channel quad in one
+    // pass (19-20 us -> measured below), 256 stay best for the narrow early blocks
+    const size_t lds = (size_t)(((C + R + 3) & ~3) + 4 * 1024) * sizeof(float);
+    if (C >= 1024 && get_option("se_wide"))  // measured per 200 frames: C = 1152: 19-20 -> 14.2-14.8 us; C = 672: 11.0-11.3 -> 11.3-13.1 (worse)
+        se_gate2_kernel<1024><<<B, 1024, lds, s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2, gate, C, R);
+    else
+        se_gate2_kernel<256><<<B, 256, lds, s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2, gate, C, R);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
