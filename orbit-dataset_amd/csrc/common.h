@@ -113,6 +113,7 @@ int launch_stem_direct(const float* frames, const float* w_oihw, const float* sc
 // whole-map form for the 14x14 / 7x7 stages (csrc/mbconv_map.hip): pool sums are complete per (frame, channel), i.e. the
 // squeeze-excite gate kernel sees ONE partial per frame
 bool mbconv_map_supported(int H, int W, int Cin, int mid, int K, int stride);
+bool mbconv_map_preferred(int H, int W, int Cin, int mid, int K, int stride);  // where it measured faster than the pair
 int launch_mbconv_map(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
                       const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
                       int K, int stride, hipStream_t s);

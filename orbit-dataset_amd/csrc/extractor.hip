@@ -85,11 +85,14 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
     // 3x3/1 at 56x56: 281-306 vs 338-347 us; the 5x5 blocks and 40 -> 240 3x3/2 tie or lose: 282 vs 282, 305 vs 166,
     // 143 vs 104 us - fusing the 5x5/2 block as well left the whole-task time unchanged), 0 = never
     const int fuse_opt = get_option("mbconv_fusion");
-    // whole-map form (csrc/mbconv_map.hip) for the 14x14 / 7x7 stages: opt-in (mbconv_map = 1). Measured on MI355X it ties
-    // the conv + depthwise pair (tools/mb_bench.py, profiles/r02_mbconv_map.txt), so the pair stays the default
+    // whole-map form (csrc/mbconv_map.hip) for the 14x14 / 7x7 stages: mbconv_map = 0 (default) never, 1 = where it measured
+    // faster than the conv + depthwise pair, 2 = every supported shape. Opt-in: per block it is 6-20 % faster on 7 of the 9
+    // shapes, but the whole task only moves from 6.63 to 6.58 ms (the blocks it replaces are the best-running convs)
     const int map_opt = get_option("mbconv_map");
     auto fuse_map_ok = [&](int hh, int ww, int cin, int mid, int K, int stride) {
-        return fuse_opt != 0 && map_opt != 0 && mbconv_map_supported(hh, ww, cin, mid, K, stride);
+        if (fuse_opt == 0 || map_opt == 0) return false;
+        return map_opt >= 2 ? mbconv_map_supported(hh, ww, cin, mid, K, stride)
+                            : mbconv_map_preferred(hh, ww, cin, mid, K, stride);
     };
     auto fuse_front_ok = [&](int hh, int ww, int cin, int mid, int K, int stride) {
         if (fuse_map_ok(hh, ww, cin, mid, K, stride)) return true;

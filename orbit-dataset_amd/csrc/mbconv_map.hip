@@ -12,12 +12,10 @@
 //   * the block input never touches LDS: wave w keeps the A-operand fragments of its 32-pixel row tiles (w, w+4) in
 //     REGISTERS for the whole block (CIN/2 floats per lane and tile), loaded once from HBM/L2 in MFMA operand order
 //     (lane (i, h) holds channels 8g+4h..+3 of pixel i) - the expand GEMM re-uses them for every chunk;
-//   * 8 waves, role-split: waves 0-3 expand chunk i (MFMA straight from the register fragments against the chunk's W1
-//     rows in LDS, BN1 + SiLU, scatter into the padded map tile Es[i & 1]) while waves 4-7 run the depthwise taps of chunk
-//     i-1 from Es[(i-1) & 1] (ds_read_b128, NOUT outputs along a row per thread) + BN2 + SiLU -> HBM + pool sums, and
-//     stage chunk i+1's weights; ONE barrier per chunk. Every SIMD hosts one wave of each role, so the matrix pipe and
-//     the VALU / LDS pipes overlap by construction (a first version with two co-resident 4-wave blocks, each alternating
-//     the two phases, left the MFMA pipe 26 % busy: measured, rocprofv3 SQ counters).
+//   * per chunk: W1 rows of the chunk -> LDS (prefetched through registers one chunk ahead), MFMA expand straight from
+//     the register fragments, BN1 + SiLU, scatter into the padded map tile Es; barrier; depthwise from Es (ds_read_b128,
+//     NOUT outputs along a row per thread) + BN2 + SiLU -> HBM, pool sums; barrier.
+//   * two blocks per CU (<= 78 KB of LDS, <= 256 VGPRs): one block's MFMA phase can run beside the other's VALU phase.
 // The expand uses the same k order as conv_igemm (groups of 8, kk ascending) and the depthwise the same tap order as the
 // unfused kernels; pool sums are complete per (frame, channel) (pool_partial [B][1][mid]).
 #include "common.h"
@@ -52,244 +50,233 @@ struct MbMapGeom {
     static constexpr int NPIX = HW * HW;
     static constexpr int P = FB * NPIX;
     static constexpr int TILES = (P + 31) / 32;
-    static constexpr int TPW = (TILES + 3) / 4;          // row tiles per producer wave
+    static constexpr int TPW = (TILES + 3) / 4;          // row tiles per wave
     static constexpr int NG = CIN / 8;
+    static constexpr int ES = 36;
     static constexpr int XS = CIN + 4;
-    // consumer side: 8 units of 32 threads (one per channel of the chunk) = FB frames x NH column parts x NB row bands
-    static constexpr int NH = 2;
-    static constexpr int NB = 4 / FB;
-    static constexpr int NOUT = (HO + NH - 1) / NH;      // output columns per thread
-    static constexpr int R = (HO + NB - 1) / NB;         // output rows per thread
-    static constexpr int NCOL = (NOUT - 1) * S + K;      // input columns a thread reads per input row
-    static constexpr int NROW = (R - 1) * S + K;         // input rows a thread walks
-    // channel-major padded map: E[channel][PLANE]; PLANE odd -> the 32 channels of a wave instruction hit 32 banks.
-    // The slack after the last frame keeps the (discarded) reads of rows / columns beyond the map inside the plane.
-    static constexpr int MAXIDX = (((FB - 1) * EH + ((NB - 1) * HO / NB) * S) * EH + (NH - 1) * NOUT * S) + (NROW - 1) * EH +
-                                  NCOL - 1;                               // last element any consumer thread reads
-    static constexpr int PLANE_MIN = (FB * EH * EH + 1) > (MAXIDX + 1) ? (FB * EH * EH + 1) : (MAXIDX + 1);
-    static constexpr int PLANE = PLANE_MIN | 1;
-    static constexpr int DUMP = FB * EH * EH;            // where the pixels that pad the last row tile are written
-    static constexpr int WR = (8 * CIN + 255) / 256;     // expand-weight quads per consumer thread and chunk
-    static constexpr int ES_FLOATS = 32 * PLANE;
+    static constexpr int RO = HO > 8 ? 16 : 8;           // output rows rounded up to a power of two
+    static constexpr int SPR = 32 / (FB * RO);           // thread segments per output row
+    static constexpr int NOUT = (HO + SPR - 1) / SPR;    // outputs per thread along a row
+    static constexpr int NCOL = (NOUT - 1) * S + K;
+    static constexpr int WR = (8 * CIN + 255) / 256;     // expand-weight quads per thread and chunk
+    static constexpr int ES_ROWS = FB * EH * EH + 1;     // + one dump row for the pixels that pad the last row tile
     static size_t lds_bytes(int G) {
-        return ((size_t)2 * ES_FLOATS + 2 * 32 * XS + (size_t)G * 256) * sizeof(float) + (size_t)TILES * 32 * sizeof(int);
+        return ((size_t)ES_ROWS * ES + 32 * XS) * sizeof(float) + (size_t)(2 * K * K * 8 + 256 + G * 32) * sizeof(v4f) +
+               (size_t)TILES * 32 * sizeof(int);
     }
 };
 
-// 512 threads: waves 0-3 PRODUCE (expand chunk i on the matrix cores from their register-resident input fragments, BN1 +
-// SiLU, scatter into the channel-major map Es[i & 1]); waves 4-7 CONSUME (depthwise + BN2 + SiLU + pool sums of chunk
-// i-1 from Es[(i-1) & 1], and fetch chunk i+1's weights). One barrier per chunk. Hardware places wave w on SIMD w % 4, so
-// every SIMD hosts one producer (MFMA pipe) and one consumer (VALU + LDS pipes).
-//
-// Consumer thread = (channel of the chunk, column part, row band): it walks the NROW input rows of its band ONCE, reads
-// NCOL floats of each (ds_read_b32: adjacent lanes = adjacent channels = distinct banks) and scatters them into the R
-// output rows they feed (taps in 25 registers). Every map element is read ~2.5x instead of the ~8x of a gather over tap
-// rows with float4 channel quads - that gather form was LDS-bound (12 k cycles per chunk against the producers' 10 k;
-// measured with s_memtime stamps) - and the tap weights never pass through LDS.
+// 256 threads, two blocks per CU (<= 78 KB of LDS, <= 256 VGPRs). Per chunk: every wave expands its row tiles on the
+// matrix cores from its register-resident input fragments (B operand = the chunk's W1 rows in LDS), BN1 + SiLU, scatter
+// into the padded map tile Es; barrier; depthwise from Es (ds_read_b128 gather over the tap rows, NOUT outputs along a
+// row per thread) + BN2 + SiLU -> HBM, pool sums; barrier. This is the fastest of the three structures that were built
+// (profiles/r02_mbconv_map.txt): 8-wave producer / consumer blocks - with the same float4 gather, or with a
+// channel-major map walked row by row (3.6x fewer LDS bytes) - measured 5-15 % slower, because one 8-wave block per CU
+// pays its prologue and a pipeline-fill iteration per 3-7 chunks and the period is set by the slower role anyway.
 template <int CIN, int K, int S, int HW, int FB>
-__global__ __launch_bounds__(512, 2) void mbconv_map_kernel(const MbMapParams p) {
+__global__ __launch_bounds__(256, 2) void mbconv_map_kernel(const MbMapParams p) {
     using Gm = MbMapGeom<CIN, K, S, HW, FB>;
     constexpr int HO = Gm::HO, EH = Gm::EH, NPIX = Gm::NPIX, P = Gm::P, TILES = Gm::TILES, TPW = Gm::TPW, NG = Gm::NG;
-    constexpr int XS = Gm::XS, NH = Gm::NH, NB = Gm::NB, NOUT = Gm::NOUT, R = Gm::R, NCOL = Gm::NCOL, NROW = Gm::NROW;
-    constexpr int WR = Gm::WR, PAD = Gm::PT_, ESF = Gm::ES_FLOATS, PLANE = Gm::PLANE;
-    static_assert(CIN % 8 == 0 && TPW <= 2 && FB * NH * NB == 8, "geometry");
+    constexpr int ES = Gm::ES, XS = Gm::XS, SPR = Gm::SPR, NOUT = Gm::NOUT, NCOL = Gm::NCOL, WR = Gm::WR;
+    constexpr int PAD = Gm::PT_;
+    static_assert(CIN % 8 == 0 && TPW <= 2 && 32 % (FB * Gm::RO) == 0 && SPR >= 1, "geometry");
 
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Es = smem;                                              // [2][32][PLANE] padded expanded map(s), per chunk parity
-    float* Ws = Es + 2 * ESF;                                      // [2][32][XS] expand weights
-    float* pool_all = Ws + 2 * 32 * XS;                            // [G][8 units][32 channels]
-    int* estab = reinterpret_cast<int*>(pool_all + p.G * 256);     // [TILES*32] pixel -> offset inside a channel plane
+    float* Es = smem;                                              // [ES_ROWS][ES] padded expanded map(s) of one chunk
+    float* Ws = Es + Gm::ES_ROWS * ES;                             // [32][XS] expand weights of the chunk
+    v4f* Ds = reinterpret_cast<v4f*>(Ws + 32 * XS);                // [2][K*K][8] depthwise taps (double-buffered)
+    v4f* redw = Ds + 2 * K * K * 8;                                // [4 waves][64] pooling scratch
+    v4f* pool_all = redw + 256;                                    // [G][4 waves][8 quads]
+    int* estab = reinterpret_cast<int*>(pool_all + p.G * 32);      // [TILES*32] pixel -> Es float offset
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, lh = lane >> 5;
-    const bool producer = wave < 4;                                // wave-uniform role
-    const int ctid = tid & 255, cw = wave & 3;                     // index inside the role's 256 threads / 4 waves
     const int b0 = blockIdx.y * FB;
     const int nchunks = p.mid >> 5;
     const int cfirst = (int)((long)blockIdx.x * nchunks / gridDim.x);        // balanced partition: group sizes differ by
     const int cend = (int)((long)(blockIdx.x + 1) * nchunks / gridDim.x);    // at most one chunk
-    const int n = cend - cfirst;
-    if (n <= 0) return;
+    if (cfirst >= cend) return;
 
-    // ---- zero both padded maps (their borders stay zero), build the pixel -> plane offset table -----------------------
-    for (int i = tid; i < 2 * ESF / 4; i += 512) reinterpret_cast<v4f*>(Es)[i] = (v4f){0.f, 0.f, 0.f, 0.f};
-    for (int px = tid; px < TILES * 32; px += 512) {
-        int off = Gm::DUMP;
+    // ---- A-operand fragments of this wave's row tiles: registers for the whole block --------------------------------
+    v4f xr[TPW][NG];
+#pragma unroll
+    for (int i = 0; i < TPW; ++i) {
+        const int px = (wave + 4 * i) * 32 + l31;
+        const int f = px / NPIX, pp = px - f * NPIX;
+        const bool ok = (wave + 4 * i) < TILES && px < P && b0 + f < p.B;
+        const float* src = p.x + ((size_t)(b0 + (ok ? f : 0)) * NPIX + (ok ? pp : 0)) * CIN + lh * 4;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const v4f v = *reinterpret_cast<const v4f*>(src + g * 8);  // unconditional load from a safe address
+            xr[i][g] = ok ? v : (v4f){0.f, 0.f, 0.f, 0.f};
+        }
+    }
+
+    // ---- zero the padded map (the border stays zero for every chunk), build the pixel -> Es offset table --------------
+    for (int i = tid; i < Gm::ES_ROWS * ES / 4; i += 256) reinterpret_cast<v4f*>(Es)[i] = (v4f){0.f, 0.f, 0.f, 0.f};
+    for (int px = tid; px < TILES * 32; px += 256) {
+        int row = FB * EH * EH;  // dump row
         if (px < P) {
             const int f = px / NPIX, pp = px - f * NPIX;
             const int yy = pp / HW, xx = pp - yy * HW;
-            off = (f * EH + yy + PAD) * EH + xx + PAD;
+            row = (f * EH + yy + PAD) * EH + xx + PAD;
         }
-        estab[px] = off;
+        estab[px] = row * ES;
     }
 
-    if (producer) {
-        // ---- A-operand fragments of this wave's row tiles: registers for the whole block -----------------------------
-        v4f xr[TPW][NG];
-#pragma unroll
-        for (int i = 0; i < TPW; ++i) {
-            const int px = (cw + 4 * i) * 32 + l31;
-            const int f = px / NPIX, pp = px - f * NPIX;
-            const bool ok = (cw + 4 * i) < TILES && px < P && b0 + f < p.B;
-            const float* src = p.x + ((size_t)(b0 + (ok ? f : 0)) * NPIX + (ok ? pp : 0)) * CIN + lh * 4;
-#pragma unroll
-            for (int g = 0; g < NG; ++g) {
-                const v4f v = *reinterpret_cast<const v4f*>(src + g * 8);  // unconditional load from a safe address
-                xr[i][g] = ok ? v : (v4f){0.f, 0.f, 0.f, 0.f};
-            }
-        }
-        const bool two = TPW == 2 && cw + 4 < TILES;  // wave-uniform: this wave owns a second row tile
-        float s1n = p.sc1[cfirst * 32 + l31], h1n = p.sh1[cfirst * 32 + l31];
-        __syncthreads();  // P0: maps zeroed, table built, chunk 0's weights in Ws[0] (consumers)
-        for (int i = 0; i <= n; ++i) {
-            if (i < n) {
-                const float s1 = s1n, h1 = h1n;
-                if (i + 1 < n) s1n = p.sc1[(cfirst + i + 1) * 32 + l31], h1n = p.sh1[(cfirst + i + 1) * 32 + l31];
-                float* E = Es + (i & 1) * ESF + l31 * PLANE;
-                const float* Bq = Ws + (i & 1) * 32 * XS + l31 * XS + lh * 4;
-                f32x16 acc[TPW];
-#pragma unroll
-                for (int t = 0; t < TPW; ++t)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
-                if (two) {
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        const v4f bf = *reinterpret_cast<const v4f*>(Bq + g * 8);
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[0][g][kk], bf[kk], acc[0], 0, 0, 0);
-                            acc[TPW - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[TPW - 1][g][kk], bf[kk], acc[TPW - 1], 0, 0, 0);
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int g = 0; g < NG; ++g) {
-                        const v4f bf = *reinterpret_cast<const v4f*>(Bq + g * 8);
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk)
-                            acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[0][g][kk], bf[kk], acc[0], 0, 0, 0);
-                    }
-                }
-                // C/D layout: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (pixel of the tile)
-#pragma unroll
-                for (int t = 0; t < TPW; ++t) {
-                    if (t == 1 && !two) break;
-                    const int tile = cw + 4 * t;
-#pragma unroll
-                    for (int rq = 0; rq < 4; ++rq) {
-                        const v4i er = *reinterpret_cast<const v4i*>(estab + tile * 32 + 8 * rq + 4 * lh);
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) E[er[j]] = silu_m(acc[t][rq * 4 + j] * s1 + h1);
-                    }
-                }
-            }
-            __syncthreads();  // chunk i expanded; consumers finished chunk i-1 and staged chunk i+1's weights
-        }
-    } else {
-        // ---- consumer thread = (channel ch, frame f, column part, row band) --------------------------------------------
-        const int ch = ctid & 31, unit = ctid >> 5;
-        const int f = unit / (NH * NB), hb = unit % (NH * NB);
-        const int oy0 = (hb / NH) * HO / NB, oy1 = (hb / NH + 1) * HO / NB;   // output rows [oy0, oy1) of this band
-        const int ox0 = (hb % NH) * NOUT;                                     // output columns [ox0, min(ox0 + NOUT, HO))
-        const bool frame_ok = b0 + f < p.B;
-        const int ebase = (f * EH + oy0 * S) * EH + ox0 * S;                  // first input element of the band
+    // ---- depthwise thread mapping: channel quad lc, segment seg = (frame, output row, row part) -----------------------
+    const int lc = tid & 7, seg = tid >> 3;
+    const int fseg = seg / (32 / FB), sl = seg % (32 / FB);
+    const int oy = sl / SPR, ox0 = (sl % SPR) * NOUT;
+    const bool seg_ok = oy < HO && b0 + fseg < p.B;
+    const int oyc = oy < HO ? oy : HO - 1;  // rows beyond the map compute on a valid address, nothing is stored
 
-        v4f wreg[WR];
-        float tapn[K * K], s2n = 0.f, h2n = 0.f;
-        auto load_weights = [&](int c0) {  // expand rows (for the producers) + this channel's taps -> registers
+    // chunk parameters travel through registers one chunk ahead (no global load inside a phase that consumes it)
+    v4f wreg[WR], dreg = {0.f, 0.f, 0.f, 0.f};
+    float s1n = 0.f, h1n = 0.f;
+    v4f s2n = {0.f, 0.f, 0.f, 0.f}, h2n = {0.f, 0.f, 0.f, 0.f};
+    auto load_weights = [&](int c0) {
+        s1n = p.sc1[c0 + l31], h1n = p.sh1[c0 + l31];
+        s2n = *reinterpret_cast<const v4f*>(p.sc2 + c0 + lc * 4), h2n = *reinterpret_cast<const v4f*>(p.sh2 + c0 + lc * 4);
 #pragma unroll
-            for (int u = 0; u < WR; ++u) {
-                const int i = ctid + u * 256;
-                const int r = i / (CIN / 4), c4 = i - r * (CIN / 4);
-                wreg[u] = (v4f){0.f, 0.f, 0.f, 0.f};
-                if (i < 8 * CIN) wreg[u] = *reinterpret_cast<const v4f*>(p.w1 + (size_t)(c0 + r) * CIN + c4 * 4);
-            }
-        };
-        auto load_taps = [&](int c0) {
+        for (int u = 0; u < WR; ++u) {
+            const int i = tid + u * 256;
+            const int r = i / (CIN / 4), c4 = i - r * (CIN / 4);
+            wreg[u] = (v4f){0.f, 0.f, 0.f, 0.f};
+            if (i < 8 * CIN) wreg[u] = *reinterpret_cast<const v4f*>(p.w1 + (size_t)(c0 + r) * CIN + c4 * 4);
+        }
+        if (tid < K * K * 8) dreg = *reinterpret_cast<const v4f*>(p.wdw + (size_t)(tid >> 3) * p.mid + c0 + (tid & 7) * 4);
+    };
+    auto store_w = [&]() {
 #pragma unroll
-            for (int t = 0; t < K * K; ++t) tapn[t] = p.wdw[(size_t)t * p.mid + c0 + ch];
-            s2n = p.sc2[c0 + ch], h2n = p.sh2[c0 + ch];
-        };
-        auto store_weights = [&](int ci) {  // registers -> Ws[ci & 1]
-            float* W = Ws + (ci & 1) * 32 * XS;
+        for (int u = 0; u < WR; ++u) {
+            const int i = tid + u * 256;
+            const int r = i / (CIN / 4), c4 = i - r * (CIN / 4);
+            if (i < 8 * CIN) *reinterpret_cast<v4f*>(Ws + r * XS + c4 * 4) = wreg[u];
+        }
+    };
+    load_weights(cfirst * 32);
+    store_w();
+
+    for (int c = cfirst; c < cend; ++c) {
+        const int ci = c - cfirst, c0 = c * 32;
+        v4f* Dc = Ds + (ci & 1) * K * K * 8;
+        if (tid < K * K * 8) Dc[tid] = dreg;
+        const float s1 = s1n, h1 = h1n;
+        const v4f s2 = s2n, h2 = h2n;
+        __syncthreads();  // B1: Ws / Ds of this chunk visible, Es zeroed (first chunk), previous chunk's readers of Es done
+        if (c + 1 < cend) load_weights(c0 + 32);
+
+        // ---- expand: E[pixels][32 channels] = X . W1^T, A from registers, B from LDS; BN1 + SiLU -> Es ----------------
+        {
+            f32x16 acc[TPW];
 #pragma unroll
-            for (int u = 0; u < WR; ++u) {
-                const int i = ctid + u * 256;
-                const int r = i / (CIN / 4), c4 = i - r * (CIN / 4);
-                if (i < 8 * CIN) *reinterpret_cast<v4f*>(W + r * XS + c4 * 4) = wreg[u];
-            }
-        };
-        load_weights(cfirst * 32);
-        store_weights(0);
-        load_taps(cfirst * 32);
-        __syncthreads();  // P0
-        for (int i = 0; i <= n; ++i) {
-            // Ws[(i+1) & 1] was last read by the producers in iteration i-1: chunk i+1's expand rows are requested now
-            // and written at the end of the iteration, so their latency hides under the depthwise work below
-            if (i + 1 < n) load_weights((cfirst + i + 1) * 32);
-            if (i >= 1) {
-                const int ci = i - 1, c0 = (cfirst + ci) * 32;
-                float tap[K * K];
+            for (int i = 0; i < TPW; ++i)
 #pragma unroll
-                for (int t = 0; t < K * K; ++t) tap[t] = tapn[t];
-                const float s2 = s2n, h2 = h2n;
-                if (i < n) load_taps((cfirst + i) * 32);  // next chunk's taps / BN2: in flight during this chunk's walk
-                const float* E = Es + (ci & 1) * ESF + ch * PLANE + ebase;
-                float acc2[R][NOUT];
+                for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+            const float* Bq = Ws + l31 * XS + lh * 4;
+            const bool two = TPW == 2 && wave + 4 < TILES;  // wave-uniform
+            if (two) {
 #pragma unroll
-                for (int ry = 0; ry < R; ++ry)
+                for (int g = 0; g < NG; ++g) {
+                    const v4f bf = *reinterpret_cast<const v4f*>(Bq + g * 8);
 #pragma unroll
-                    for (int j = 0; j < NOUT; ++j) acc2[ry][j] = 0.f;
-#pragma unroll
-                for (int yy = 0; yy < NROW; ++yy) {
-                    float col[NCOL];
-#pragma unroll
-                    for (int q = 0; q < NCOL; ++q) col[q] = E[yy * EH + q];
-#pragma unroll
-                    for (int ry = 0; ry < R; ++ry) {
-                        constexpr int dummy = 0;
-                        (void)dummy;
-                        const int kh = yy - ry * S;  // compile-time after unrolling
-                        if (kh >= 0 && kh < K) {
-#pragma unroll
-                            for (int kw = 0; kw < K; ++kw)
-#pragma unroll
-                                for (int j = 0; j < NOUT; ++j) acc2[ry][j] = fmaf(col[j * S + kw], tap[kh * K + kw], acc2[ry][j]);
-                        }
+                    for (int kk = 0; kk < 4; ++kk) {
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[0][g][kk], bf[kk], acc[0], 0, 0, 0);
+                        acc[TPW - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[TPW - 1][g][kk], bf[kk], acc[TPW - 1], 0, 0, 0);
                     }
                 }
-                float psum = 0.f;
+            } else {
 #pragma unroll
-                for (int ry = 0; ry < R; ++ry) {
-                    const int oy = oy0 + ry;
+                for (int g = 0; g < NG; ++g) {
+                    const v4f bf = *reinterpret_cast<const v4f*>(Bq + g * 8);
 #pragma unroll
-                    for (int j = 0; j < NOUT; ++j) {
-                        if (frame_ok && oy < oy1 && ox0 + j < HO) {
-                            const float o = silu_m(acc2[ry][j] * s2 + h2);
-                            p.y[(((size_t)(b0 + f) * HO + oy) * HO + ox0 + j) * p.mid + c0 + ch] = o;
-                            psum += o;
-                        }
-                    }
+                    for (int kk = 0; kk < 4; ++kk)
+                        acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xr[0][g][kk], bf[kk], acc[0], 0, 0, 0);
                 }
-                if (p.pool) pool_all[(ci * 8 + unit) * 32 + ch] = psum;
             }
-            if (i + 1 < n) store_weights(i + 1);
-            __syncthreads();
+            // C/D layout: col = lane & 31 (channel), row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5) (pixel of the tile)
+#pragma unroll
+            for (int i = 0; i < TPW; ++i) {
+                if (i == 1 && !two) break;
+                const int t = wave + 4 * i;
+#pragma unroll
+                for (int rq = 0; rq < 4; ++rq) {
+                    const v4i er = *reinterpret_cast<const v4i*>(estab + t * 32 + 8 * rq + 4 * lh);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) Es[er[j] + l31] = silu_m(acc[i][rq * 4 + j] * s1 + h1);
+                }
+            }
+        }
+        __syncthreads();  // B2: Es complete; nobody reads Ws any more
+        if (c + 1 < cend) store_w();  // next chunk's expand weights (made visible by B1 of the next iteration)
+
+        // ---- depthwise from LDS + BN2 + SiLU -> HBM; pool sums --------------------------------------------------------
+        v4f acc2[NOUT];
+#pragma unroll
+        for (int j = 0; j < NOUT; ++j) acc2[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+        {
+            const float* erow = Es + ((fseg * EH + oyc * S) * EH + ox0 * S) * ES + lc * 4;
+            const v4f* dk = Dc + lc;
+#pragma unroll 1
+            for (int kh = 0; kh < K; ++kh) {
+                v4f col[NCOL];
+#pragma unroll
+                for (int q = 0; q < NCOL; ++q) col[q] = *reinterpret_cast<const v4f*>(erow + q * ES);
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) {
+                    const v4f f = dk[kw * 8];
+#pragma unroll
+                    for (int j = 0; j < NOUT; ++j) acc2[j] += col[j * S + kw] * f;
+                }
+                erow += EH * ES;
+                dk += K * 8;
+            }
+        }
+        v4f psum = {0.f, 0.f, 0.f, 0.f};
+        if (seg_ok) {
+            float* yrow = p.y + (((size_t)(b0 + fseg) * HO + oy) * HO + ox0) * p.mid + c0 + lc * 4;
+#pragma unroll
+            for (int j = 0; j < NOUT; ++j) {
+                if (ox0 + j < HO) {
+                    v4f o = acc2[j] * s2 + h2;
+                    o[0] = silu_m(o[0]), o[1] = silu_m(o[1]), o[2] = silu_m(o[2]), o[3] = silu_m(o[3]);
+                    *reinterpret_cast<v4f*>(yrow + (size_t)j * p.mid) = o;
+                    psum += o;
+                }
+            }
+        }
+        if (p.pool) {  // this wave's 8 segments per channel quad, summed in segment order by lanes 0-7
+            redw[wave * 64 + lane] = psum;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // LDS is in-order per wave: the stores above are visible
+            if (lane < 8) {
+                v4f t = redw[wave * 64 + lane];
+#pragma unroll
+                for (int sg = 1; sg < 8; ++sg) t += redw[wave * 64 + sg * 8 + lane];
+                pool_all[(ci * 4 + wave) * 8 + lane] = t;
+            }
         }
     }
-    if (p.pool) {  // (the loop's last barrier made pool_all complete) sum the units of a frame in fixed order
-        constexpr int UPF = NH * NB;
-        for (int i = tid; i < n * 32 * FB; i += 512) {
-            const int c = i & 31, ci = (i >> 5) % n, f = (i >> 5) / n;
+    if (p.pool) {
+        __syncthreads();
+        constexpr int WPF = 4 / FB;  // waves per frame
+        const int nloc = cend - cfirst;
+        for (int i = tid; i < nloc * 8 * FB; i += 256) {
+            const int q = i & 7, ci = (i >> 3) % nloc, f = (i >> 3) / nloc;
             if (b0 + f < p.B) {
-                float t = pool_all[(ci * 8 + f * UPF) * 32 + c];
+                v4f t = pool_all[(ci * 4 + f * WPF) * 8 + q];
 #pragma unroll
-                for (int u = 1; u < UPF; ++u) t += pool_all[(ci * 8 + f * UPF + u) * 32 + c];
-                p.pool[(size_t)(b0 + f) * p.mid + (cfirst + ci) * 32 + c] = t;
+                for (int w2 = 1; w2 < WPF; ++w2) t += pool_all[(ci * 4 + f * WPF + w2) * 8 + q];
+                *reinterpret_cast<v4f*>(p.pool + (size_t)(b0 + f) * p.mid + (cfirst + ci) * 32 + q * 4) = t;
             }
         }
     }
+}
+
+// the shapes where the whole-map kernel measured FASTER than the conv + depthwise pair (tools/mb_bench.py, 200 frames:
+// -20 % 80->480 3x3, -16 % 80->480 5x5, -17 % 112->672 5x5/2, -6..-7 % at 7x7; 112->672 5x5/1 ties): mbconv_map = 1
+bool mbconv_map_preferred(int H, int W, int Cin, int mid, int K, int stride) {
+    return mbconv_map_supported(H, W, Cin, mid, K, stride) && !(Cin == 112 && stride == 1);
 }
 
 // shapes served by the whole-map kernel: square 14x14 / 7x7 inputs of EfficientNet-B0's stages 3-6
@@ -307,34 +294,33 @@ static int launch_map(MbMapParams& p, hipStream_t s) {
     const int nchunks = p.mid / 32;
     const int frames = cdiv(p.B, FB);
     // Chunk groups per frame (pair): blocks = frames x groups. A block pays a prologue (register-resident input, zeroed map
-    // tiles) and one pipeline-fill iteration, and the chip runs 256 blocks at a time (one 8-wave block per CU), so the
-    // cost of a grouping is rounds(blocks / 256) x (1.5 + chunks per block); the cheapest wins (ties: fewer groups).
-    // mbmap_groups overrides.
+    // tile: about half a chunk's time) and the chip runs 512 blocks at a time (2 per CU), so the cost of a grouping is
+    // rounds(blocks / 512) x (0.5 + chunks per block); the cheapest wins (ties: fewer groups). mbmap_groups overrides.
     int groups = get_option("mbmap_groups");
     if (groups <= 0) {
         double best = 1e30;
         for (int g = 1; g <= nchunks; ++g) {
-            if (cdiv(nchunks, g) > 8) continue;  // pool scratch holds 8 chunks per block (8 KB)
-            const double rounds = (double)cdiv(frames * g, 256);
-            const double cost = rounds * (1.5 + cdiv(nchunks, g));
+            if (cdiv(nchunks, g) > 16) continue;  // pool scratch holds 16 chunks per block
+            const double rounds = (double)cdiv(frames * g, 512);
+            const double cost = rounds * (0.5 + cdiv(nchunks, g));
             if (cost < best - 1e-9) best = cost, groups = g;
         }
     }
     if (groups > nchunks) groups = nchunks;
-    if (cdiv(nchunks, groups) > 8) groups = cdiv(nchunks, 8);
+    if (cdiv(nchunks, groups) > 16) groups = cdiv(nchunks, 16);
     p.G = cdiv(nchunks, groups);
     const size_t lds = Gm::lds_bytes(p.G);
     auto kern = mbconv_map_kernel<CIN, K, S, HW, FB>;
     static bool attr_set = false;
     if (!attr_set) {
         ORBIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                            (int)Gm::lds_bytes(8)));
+                                            (int)Gm::lds_bytes(16)));
         attr_set = true;
     }
-    ORBIT_REQUIRE(p.G <= 8, "mbconv_map: at most 8 chunks per block (G=%d)", p.G);
+    ORBIT_REQUIRE(p.G <= 16, "mbconv_map: at most 16 chunks per block (G=%d)", p.G);
     const double pix = (double)p.B * HW * HW, opix = (double)p.B * Gm::HO * Gm::HO;
     const int rec = prof_start("mbconv_map", 2.0 * pix * p.mid * CIN, 4.0 * (pix * CIN + opix * p.mid), s);
-    kern<<<dim3(groups, frames), 512, lds, s>>>(p);
+    kern<<<dim3(groups, frames), 256, lds, s>>>(p);
     prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
