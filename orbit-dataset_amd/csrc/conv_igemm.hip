@@ -740,7 +740,8 @@ int conv_splitk(const ConvDesc& d) {
     const long tiles = (long)cdiv(d.B * d.Ho * d.Wo, 64) * cdiv(d.Cout, 64);
     // measured with the reduce pass included (tools/conv_bench.py <net> ab conv_splitk): -11..-18 % time at 232 tiles
     // (resnet18 @84 layer4), break-even at ~450 tiles (layer3, EfficientNet's 7x7 projections)
-    if (tiles >= 320 || nk < 16) return 1;
+    const int tile_cap = get_option("conv_splitk_tiles");  // tuning: split-K below this many 64x64 tiles (default 320)
+    if (tiles >= (tile_cap > 0 ? tile_cap : 320) || nk < 16) return 1;
     int S = (int)(1280 / tiles);
     S = S < 2 ? 2 : (S > 4 ? 4 : S);
     while (S > 1 && cdiv(nk, S) < 6) --S;

@@ -44,6 +44,7 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"conv_bk", "ORBIT_CONV_BK", 0, false},
                              {"conv_uncond", "ORBIT_CONV_UNCOND", 1, false},
                              {"conv_splitk", "ORBIT_CONV_SPLITK", 1, false},
+                             {"conv_splitk_tiles", "ORBIT_CONV_SPLITK_TILES", 0, false},
                              {"conv_stem_fast", "ORBIT_CONV_STEM_FAST", 1, false},
                              {"conv_early_sc", "ORBIT_CONV_EARLY_SC", 1, false},
                              {"conv_epi_batch", "ORBIT_CONV_EPI_BATCH", 1, false},
