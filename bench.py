@@ -87,12 +87,18 @@ class LiteTrainStep:
         # bump parameter versions. ORBIT_BENCH_FUSED_ADAM=0 selects the plain (foreach) optimizer of the reference.
         opt_args = Namespace(fused_optimizer=os.environ.get("ORBIT_BENCH_FUSED_ADAM", "1") == "1")
         self.optimizer = init_optimizer(model, 5e-6, "adam", opt_args, 1.0)
-        self.bucket = odist.GradientBucket(model.parameters()) if world > 1 else None
+        self.bucket = None
+        if world > 1:
+            p2p = None
+            if os.environ.get("ORBIT_BENCH_P2P_GRADIENTS", "0") == "1":  # direct RS + AG instead of the backend's ring
+                cap = sum(-(-q.numel() // 64) * 64 for q in model.parameters() if q.requires_grad)
+                p2p = odist.P2PAllReduce(int(os.environ.get("RANK", 0)), world, odist.P2PAllReduce.floats_for_bucket(cap, world))
+            self.bucket = odist.GradientBucket(model.parameters(), p2p=p2p)
         import numpy as np
         np.random.seed(1991)
 
     def __call__(self, model, task):
-        import torch.nn.functional as F
+        from orbit_dataset_amd.optim import cross_entropy
         ctx, lab, tgt, tlab = task["context_clips"], task["context_labels"], task["target_clips"], task["target_labels"]
         model._clear_caches()
         out = []
@@ -101,7 +107,7 @@ class LiteTrainStep:
             for lo in range(0, len(tgt), self.batch_size):
                 model.personalise_with_lite(ctx, lab)
                 logits = model.predict_a_batch(tgt[lo:lo + self.batch_size])
-                loss = len(lab) / (NUM_LITE * tasks_per_batch) * F.cross_entropy(logits, tlab[lo:lo + self.batch_size])
+                loss = len(lab) / (NUM_LITE * tasks_per_batch) * cross_entropy(logits, tlab[lo:lo + self.batch_size])
                 loss = loss + 0.001 * model.film_generator.regularization_term()
                 loss.backward()
                 out.append(logits.detach())

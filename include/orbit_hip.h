@@ -54,6 +54,10 @@ typedef void* orbit_stream_t; /* hipStream_t */
 #define ORBIT_ACT_SILU 2
 #define ORBIT_ACT_ELU 3   /* alpha = 1; only orbit_dense_rows */
 
+#define ORBIT_REDUCE_NONE 0
+#define ORBIT_REDUCE_MEAN 1
+#define ORBIT_REDUCE_SUM 2
+
 /* ---- library ---------------------------------------------------------------------------------- */
 int orbit_version(void);
 const char* orbit_last_error(void);
@@ -311,6 +315,18 @@ int orbit_proto_predict_backward(const float* dlogits, const float* features, co
 int orbit_linear_head_backward(const float* dlogits, const float* features, int M, int D, int C, float logit_scale,
                                float* dweight, float* dbias, orbit_stream_t stream);
 
+/* Cross-entropy of logits [N][C] against int64 labels [N]: reference utils/optim.py:8-9 (F.cross_entropy, the `loss` of
+ * single-step-learner.py:77,225-232 and of the FineTuner, few_shot_recognisers.py:231-236).
+ * row_loss [N] = logsumexp(logits[i]) - logits[i][labels[i]] (NaN for a label outside [0, C)); softmax [N][C] is kept for
+ * the backward (NULL to skip); loss [1] = mean / sum of the rows in one fixed order (ORBIT_REDUCE_MEAN / _SUM; unused for
+ * ORBIT_REDUCE_NONE). N = 0 is allowed (mean = NaN, sum = 0, like torch). */
+int orbit_cross_entropy_forward(const float* logits, const int64_t* labels, int N, int C, int reduction, float* row_loss,
+                                float* softmax, float* loss, orbit_stream_t stream);
+/* dlogits [N][C] = g_i * (softmax - onehot(labels)); g_i = grad[0] / N (mean), grad[0] (sum), grad[i] (none). `grad` is a
+ * DEVICE pointer (the upstream gradient): nothing is read back to the host. */
+int orbit_cross_entropy_backward(const float* softmax, const int64_t* labels, const float* grad, int N, int C,
+                                 int reduction, float* dlogits, orbit_stream_t stream);
+
 /* single training operators (NHWC, [M][C] = [B*H*W][C]), exposed for parity tests against torch autograd */
 /* out = act(BN_train(y) + residual): batch mean / biased variance, saves mean and 1/sqrt(var+eps), updates the running
  * statistics in place when given (unbiased variance, momentum). gamma/beta NULL = 1/0. act: NONE or RELU. */
@@ -383,7 +399,11 @@ int orbit_p2p_create(int rank, int world, size_t max_floats, orbit_p2p_t** out);
 int orbit_p2p_export(orbit_p2p_t* c, void* handle64);
 int orbit_p2p_connect(orbit_p2p_t* c, const void* handles /* [world][64], own entry ignored */);
 int orbit_p2p_allreduce_sum(orbit_p2p_t* c, float* buf, size_t n, orbit_stream_t stream); /* in place, n <= max_floats */
-int orbit_p2p_error(orbit_p2p_t* c);   /* 0 ok; k > 0: waiting for rank k-1 timed out (synchronises the device) */
+/* Large payloads (the flat gradient bucket of the task-parallel LITE step, reference single-step-learner.py:162-166,231
+ * under data parallelism): direct reduce-scatter + all-gather over the point-to-point mesh, every element
+ * summed once in rank order (bit-identical on all ranks). In place; n <= world * max_floats / 2. */
+int orbit_p2p_allreduce_sum_sharded(orbit_p2p_t* c, float* buf, size_t n, orbit_stream_t stream);
+int orbit_p2p_error(orbit_p2p_t* c);   /* 0 ok; k > 0: waiting for rank (k-1) % 100 timed out (synchronises the device) */
 void orbit_p2p_destroy(orbit_p2p_t* c);
 
 #ifdef __cplusplus

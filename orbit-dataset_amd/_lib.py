@@ -77,6 +77,8 @@ _SIGNATURES = {
     "orbit_filmgen_backward": (c_int, [P, P, P, P, P, P, P, P]),
     "orbit_proto_predict_backward": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_float, c_int, P, P]),
     "orbit_linear_head_backward": (c_int, [P, P, c_int, c_int, c_int, c_float, P, P, P]),
+    "orbit_cross_entropy_forward": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P]),
+    "orbit_cross_entropy_backward": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     "orbit_op_bn_train_forward": (c_int, [P, c_int, c_int, P, P, c_float, c_float, P, P, P, c_int, P, P, P, P]),
     "orbit_op_bn_backward": (c_int, [P, P, P, c_int, c_int, P, P, P, c_int, c_int, P, P, P, P, P]),
     "orbit_op_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 12 + [P]),
@@ -103,6 +105,7 @@ _SIGNATURES = {
     "orbit_p2p_export": (c_int, [P, P]),
     "orbit_p2p_connect": (c_int, [P, P]),
     "orbit_p2p_allreduce_sum": (c_int, [P, P, c_size_t, P]),
+    "orbit_p2p_allreduce_sum_sharded": (c_int, [P, P, c_size_t, P]),
     "orbit_p2p_error": (c_int, [P]),
     "orbit_p2p_destroy": (None, [P]),
 }

@@ -71,6 +71,17 @@ void orbit_comm_destroy(void) {
 // e+1 while a slower peer still sums epoch e, and cannot reach e+2 before that peer has pushed e+1, i.e. finished e.
 // Flags and payload cross the fabric with system-scope release / acquire; a spin that does not complete within
 // ~4 s of GPU clock gives up and reports an error instead of hanging the device.
+//
+// LARGE payloads - the flat gradient bucket of the LITE step (16-45 MB) - take the sharded form
+// (orbit_p2p_allreduce_sum_sharded): a direct reduce-scatter + all-gather over the mesh. The vector is cut into `world`
+// shards; rank r pushes shard p of its vector into peer p's inbox (7 links busy at once, each carrying 1/world of the
+// vector), peer p sums the world copies of ITS shard in rank order and pushes the sum to every peer, which copy it home:
+// 2 (N-1)/N of the vector crosses each rank's links exactly as in a ring, but in 2 hops instead of 2 (N-1), and every
+// element is summed once, by one rank, in one order (bit-identical on all ranks). The kernel runs P2P_GRID blocks; block b
+// owns the same slice of every shard on every rank and synchronises only with block b of the peers (per-block flags), so no
+// grid-wide barrier exists and a block's reduce overlaps the other blocks' pushes. The inbox is the same memory as the
+// one-shot form's (per half: world shards in + world shards out = 2 * ceil(n / world) <= max_floats per slot).
+constexpr int P2P_GRID = 64;      // blocks of the sharded form (all co-resident: no block waits on an unscheduled one)
 struct orbit_p2p {
     int rank = 0, world = 0;
     size_t max_floats = 0;
@@ -125,16 +136,106 @@ __global__ __launch_bounds__(1024) void p2p_allreduce_kernel(float* const* __res
     }
 }
 
+// 8-byte system-scope accesses: coherent across agents without an L2 write-back / invalidate of the whole cache
+__device__ __forceinline__ void store_sys2(float* p, float a, float b) {
+    unsigned long long v = (unsigned long long)__float_as_uint(a) | ((unsigned long long)__float_as_uint(b) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(p), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ __forceinline__ float2 load_sys2(const float* p) {
+    const unsigned long long v =
+        __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
+}
+
+// wait until the `world` flags f[q * stride] all read `epoch`; error code base + q on a timeout
+__device__ __forceinline__ void wait_flags(const unsigned* f, int stride, int world, unsigned epoch, int* error, int base) {
+    if ((int)threadIdx.x < world) {
+        const unsigned* fq = f + (size_t)threadIdx.x * stride;
+        const long long t0 = wall_clock64();
+        while (__hip_atomic_load(fq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
+            if (wall_clock64() - t0 > 400000000LL) {
+                atomicExch(error, base + (int)threadIdx.x);
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    __threadfence_system();
+}
+
+// n floats in `buf`, shard length s (even), per-block slice length c (even): block b covers [b*c, min((b+1)*c, s)) of
+// every shard. Inbox half: in[q][s] (rank q's copy of MY shard) then out[q][s] (rank q's reduced shard).
+__global__ __launch_bounds__(512) void p2p_allreduce_sharded_kernel(float* const* __restrict__ peer_inbox,
+                                                                    float* __restrict__ buf, size_t n, size_t s, size_t c,
+                                                                    int rank, int world, size_t max_floats, unsigned epoch,
+                                                                    int* __restrict__ error) {
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const size_t half = (size_t)(epoch & 1u) * world * max_floats;
+    const size_t flag_off = 2 * (size_t)world * max_floats;  // floats; one-shot flags [world] come first
+    const size_t lo = (size_t)b * c, hi = lo + c < s ? lo + c : s;
+    auto flag_in = [&](int owner, int sender) {   // raised in `owner`'s inbox by `sender`: its copy of slice b arrived
+        return reinterpret_cast<unsigned*>(peer_inbox[owner] + flag_off) + world + ((size_t)sender * P2P_GRID + b);
+    };
+    auto flag_out = [&](int owner, int sender) {  // `sender`'s reduced slice b arrived in `owner`'s inbox
+        return reinterpret_cast<unsigned*>(peer_inbox[owner] + flag_off) + world + (size_t)world * P2P_GRID +
+               ((size_t)sender * P2P_GRID + b);
+    };
+    // ---- reduce-scatter push: slice b of shard p goes to rank p (starting with my right neighbour: all links busy)
+    for (int k = 0; k < world; ++k) {
+        const int p = (rank + 1 + k) % world;
+        float* dst = peer_inbox[p] + half + (size_t)rank * s;
+        const size_t g0 = (size_t)p * s;
+        for (size_t i = lo + 2 * (size_t)tid; i < hi; i += 2 * blockDim.x) {
+            const size_t g = g0 + i;
+            store_sys2(dst + i, g < n ? buf[g] : 0.f, g + 1 < n ? buf[g + 1] : 0.f);
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < world) __hip_atomic_store(flag_in(tid, rank), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- my shard: sum the world copies of slice b in rank order, push the sum to every rank (own inbox included)
+    wait_flags(flag_in(rank, 0), P2P_GRID, world, epoch, error, 1);
+    const float* in = peer_inbox[rank] + half;
+    for (size_t i = lo + 2 * (size_t)tid; i < hi; i += 2 * blockDim.x) {
+        float2 acc = load_sys2(in + i);
+        for (int q = 1; q < world; ++q) {
+            const float2 v = load_sys2(in + (size_t)q * s + i);
+            acc.x += v.x, acc.y += v.y;
+        }
+        for (int k = 0; k < world; ++k) {
+            const int p = (rank + 1 + k) % world;
+            store_sys2(peer_inbox[p] + half + (size_t)(world + rank) * s + i, acc.x, acc.y);
+        }
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid < world) __hip_atomic_store(flag_out(tid, rank), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    // ---- all-gather: copy slice b of every reduced shard home
+    wait_flags(flag_out(rank, 0), P2P_GRID, world, epoch, error, 101);
+    const float* out = peer_inbox[rank] + half + (size_t)world * s;
+    for (int q = 0; q < world; ++q) {
+        const size_t g0 = (size_t)q * s;
+        for (size_t i = lo + 2 * (size_t)tid; i < hi; i += 2 * blockDim.x) {
+            const float2 v = load_sys2(out + (size_t)q * s + i);
+            const size_t g = g0 + i;
+            if (g < n) buf[g] = v.x;
+            if (g + 1 < n) buf[g + 1] = v.y;
+        }
+    }
+}
+
 }  // namespace orbit
 
 extern "C" {
 
 int orbit_p2p_create(int rank, int world, size_t max_floats, orbit_p2p_t** out) {
-    ORBIT_REQUIRE(out && world > 0 && world <= 64 && rank >= 0 && rank < world && max_floats > 0 && max_floats <= (1u << 22),
+    ORBIT_REQUIRE(out && world > 0 && world <= 64 && rank >= 0 && rank < world && max_floats > 0 && max_floats <= (1u << 26),
                   "p2p_create: bad arguments (rank %d, world %d, max_floats %zu)", rank, world, max_floats);
     orbit_p2p* c = new orbit_p2p();
     c->rank = rank, c->world = world, c->max_floats = (max_floats + 3) & ~(size_t)3;
-    const size_t bytes = 2 * (size_t)world * c->max_floats * sizeof(float) + (size_t)world * sizeof(unsigned);
+    const size_t bytes = 2 * (size_t)world * c->max_floats * sizeof(float) +
+                         (size_t)world * (1 + 2 * P2P_GRID) * sizeof(unsigned);  // one-shot flags, then the sharded form's
     hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->inbox), bytes);
     if (e == hipSuccess) e = hipMemset(c->inbox, 0, bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_peer_inbox), world * sizeof(float*));
@@ -197,7 +298,26 @@ int orbit_p2p_allreduce_sum(orbit_p2p_t* c, float* buf, size_t n, orbit_stream_t
     return ORBIT_OK;
 }
 
-/* 0 = every all-reduce so far completed; k > 0 = a wait for rank k-1's flag timed out (synchronises the device) */
+/* Large payloads: direct reduce-scatter + all-gather over the mesh (see the header of this section). n <= world * max_floats / 2. */
+int orbit_p2p_allreduce_sum_sharded(orbit_p2p_t* c, float* buf, size_t n, orbit_stream_t stream) {
+    ORBIT_REQUIRE(c && buf && n > 0, "p2p_allreduce_sum_sharded: bad arguments");
+    ORBIT_REQUIRE(c->connected, "p2p_allreduce_sum_sharded: call orbit_p2p_connect first");
+    ORBIT_REQUIRE((reinterpret_cast<uintptr_t>(buf) & 3) == 0, "p2p_allreduce_sum_sharded: unaligned buffer");
+    size_t s = (n + c->world - 1) / c->world;
+    s = (s + 1) & ~(size_t)1;  // 8-byte accesses
+    ORBIT_REQUIRE(2 * s <= c->max_floats, "p2p_allreduce_sum_sharded: %zu floats need inbox slots of %zu floats (have %zu)", n,
+                  2 * s, c->max_floats);
+    size_t slice = (s + P2P_GRID - 1) / P2P_GRID;
+    slice = (slice + 1) & ~(size_t)1;
+    ++c->epoch;
+    if (c->epoch == 0) ++c->epoch;
+    orbit::p2p_allreduce_sharded_kernel<<<P2P_GRID, 512, 0, (hipStream_t)stream>>>(
+        c->d_peer_inbox, buf, n, s, slice, c->rank, c->world, c->max_floats, c->epoch, c->d_error);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+/* 0 = every all-reduce so far completed; k > 0 = a wait for rank (k-1) % 100's flag timed out (synchronises the device) */
 int orbit_p2p_error(orbit_p2p_t* c) {
     ORBIT_REQUIRE(c, "p2p_error: null pointer");
     int e = 0;

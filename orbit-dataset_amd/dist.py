@@ -56,11 +56,17 @@ def allreduce_sum_(tensor, group=None):
 
 
 class P2PAllReduce:
-    """One-shot peer-to-peer all-reduce(SUM) for small device tensors (csrc/comm.hip): every rank
-    pushes its payload into an IPC-mapped inbox slot on every peer over xGMI, raises a flag, and sums the world slots of
-    its own inbox in rank order - one hop of latency instead of a ring's 2 (N-1), and bit-identical results on all ranks.
+    """Peer-to-peer all-reduce(SUM) of device tensors over IPC-mapped inboxes (csrc/comm.hip).
+
+    Small tensors (<= ONE_SHOT_FLOATS; X1/X2: prototype sums, embedding sums): every rank pushes its payload into a slot of
+    every peer's inbox over xGMI, raises a flag, and sums the world slots of its own inbox in rank order - one hop of
+    latency instead of a ring's 2 (N-1). Large tensors (X3: the flat gradient bucket; pass max_floats >= 2 * numel / world):
+    direct reduce-scatter + all-gather - rank p sums shard p of all ranks and pushes the sum back, two hops with all links
+    busy. Either way every element is summed once in rank order: bit-identical results on all ranks.
     The 64-byte IPC handles are exchanged once through the torch.distributed group (any backend). Tensors that do not fit
     (or are not contiguous fp32 on the device) fall back to torch.distributed.all_reduce."""
+
+    ONE_SHOT_FLOATS = 32768
 
     def __init__(self, rank, world, max_floats=16384, group=None):
         import ctypes
@@ -82,11 +88,24 @@ class P2PAllReduce:
 
     def __call__(self, tensor):
         t = tensor
-        if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and 0 < t.numel() <= self.max_floats):
+        n = t.numel()
+        ok = t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and n > 0
+        lib = self._lib.load()
+        if ok and n <= min(self.max_floats, self.ONE_SHOT_FLOATS):
+            self._lib.check(lib.orbit_p2p_allreduce_sum(self.handle, self._ct.c_void_p(t.data_ptr()), n,
+                                                        self._lib.stream_handle()), "orbit_p2p_allreduce_sum")
+        elif ok and 2 * (-(-n // self.world) + 1) <= self.max_floats:
+            self._lib.check(lib.orbit_p2p_allreduce_sum_sharded(self.handle, self._ct.c_void_p(t.data_ptr()), n,
+                                                                self._lib.stream_handle()),
+                            "orbit_p2p_allreduce_sum_sharded")
+        else:
             return allreduce_sum_(tensor, self.group)
-        self._lib.check(self._lib.load().orbit_p2p_allreduce_sum(self.handle, self._ct.c_void_p(t.data_ptr()), t.numel(),
-                                                                 self._lib.stream_handle()), "orbit_p2p_allreduce_sum")
         return tensor
+
+    @staticmethod
+    def floats_for_bucket(numel, world):
+        """max_floats that lets a bucket of `numel` floats take the sharded form"""
+        return 2 * (-(-int(numel) // world) + 2)
 
     def error(self):
         """0 = all all-reduces completed; k > 0 = waiting for rank k-1 timed out (synchronises the device)."""
@@ -175,9 +194,10 @@ class GradientBucket:
     `optimizer.zero_grad()`: one memset, views stay attached.
     """
 
-    def __init__(self, params, group=None):
+    def __init__(self, params, group=None, p2p=None):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
+        self.p2p = p2p         # a P2PAllReduce sized with floats_for_bucket(): direct RS + AG instead of the backend's ring
         self.flat = None
         self.views = None      # per parameter: view into `flat`, or None (no gradient on any rank)
         self.nbytes = 0
@@ -229,7 +249,10 @@ class GradientBucket:
         if self.flat is None or not self._attached():
             self._build()
         if self._active():
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.p2p is not None:
+                self.p2p(self.flat)
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def zero_(self):
         """Start the next accumulation window (replaces optimizer.zero_grad())."""

@@ -11,6 +11,7 @@ C-ABI call; torch only routes the gradients between the nodes and into `param.gr
   MahalanobisPredictFunction  orbit_mahalanobis_predict / orbit_mahalanobis_predict_backward (w.r.t. query features)
   FilmGeneratorFunction  orbit_filmgen_forward / orbit_filmgen_backward
   MeanPoolFunction       orbit_mean_pool (+ broadcast backward)
+  CrossEntropyFunction   orbit_cross_entropy_forward / orbit_cross_entropy_backward  (the learners' loss, utils/optim.py:8-9)
   SetMeanFunction        orbit_set_mean  (+ broadcast backward)
 """
 import ctypes
@@ -270,3 +271,38 @@ class SetMeanFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         return (g / ctx.n).expand(ctx.n, -1).contiguous()
+
+
+_REDUCTIONS = {"none": 0, "mean": 1, "sum": 2}
+
+
+class CrossEntropyFunction(torch.autograd.Function):
+    """loss = F.cross_entropy(logits, labels, reduction) (reference utils/optim.py:8-9) as two native launches; the
+    backward reads the upstream gradient on the device (no host synchronisation inside the training step)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels, reduction):
+        red = _REDUCTIONS[reduction]
+        z = logits.contiguous().float()
+        lab = labels.contiguous().long()
+        N, C = z.shape
+        row_loss = torch.empty(N, device=z.device, dtype=torch.float32)
+        softmax = torch.empty(N, C, device=z.device, dtype=torch.float32)
+        loss = torch.empty((), device=z.device, dtype=torch.float32)
+        _lib.check(_lib.load().orbit_cross_entropy_forward(
+            _lib.dptr(z), _lib.dptr(lab, torch.int64), N, C, red, _lib.dptr(row_loss), _lib.dptr(softmax),
+            _lib.dptr(loss), _lib.stream_handle()), "orbit_cross_entropy_forward")
+        ctx.save_for_backward(softmax, lab)
+        ctx.args = (N, C, red)
+        return row_loss if red == 0 else loss
+
+    @staticmethod
+    def backward(ctx, grad):
+        softmax, lab = ctx.saved_tensors
+        N, C, red = ctx.args
+        dz = torch.empty_like(softmax)
+        g = grad.contiguous().float()
+        _lib.check(_lib.load().orbit_cross_entropy_backward(
+            _lib.dptr(softmax), _lib.dptr(lab, torch.int64), _lib.dptr(g), N, C, red, _lib.dptr(dz),
+            _lib.stream_handle()), "orbit_cross_entropy_backward")
+        return dz, None, None

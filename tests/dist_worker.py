@@ -98,12 +98,57 @@ def p2p(out):
     torch.distributed.destroy_process_group()
 
 
+def p2p_bucket(out):
+    """Sharded P2P all-reduce (direct reduce-scatter + all-gather) of gradient-bucket-sized vectors, two processes on GPU 0."""
+    import time
+    rank, world, _ = odist.init_from_env("gloo")
+    torch.cuda.set_device(0)
+    big = 5_288_548 + 64 * 213  # efficientnet_b0's parameters in 256-byte slots
+    ar = odist.P2PAllReduce(rank, world, max_floats=odist.P2PAllReduce.floats_for_bucket(big, world))
+    res = {"got": [], "want": []}
+    g = torch.Generator().manual_seed(200 + rank)
+    for n in (big, 32769, 100001, 1_000_003, big, 40000):  # odd lengths: ragged last shard / last slice
+        x = torch.randn(n, generator=g)
+        want = x.clone()
+        torch.distributed.all_reduce(want)
+        dev = x.cuda()
+        ar(dev)
+        torch.cuda.synchronize()
+        res["got"].append(dev.cpu())
+        res["want"].append(want)
+    # interleaved with the one-shot form on the same inbox (epochs are shared)
+    small = torch.full((6405,), float(rank + 1)).cuda()
+    ar(small)
+    dev = torch.ones(big).cuda() * (rank + 1)
+    ar(dev)
+    torch.cuda.synchronize()
+    res["mixed_small"], res["mixed_big"] = small.cpu(), dev.cpu()
+    dev = torch.randn(big).cuda()
+    for _ in range(3):
+        ar(dev)
+    torch.cuda.synchronize()
+    torch.distributed.barrier()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        ar(dev)
+    torch.cuda.synchronize()
+    res["us_per_allreduce"] = 1e6 * (time.perf_counter() - t0) / 20
+    res["bytes"] = 4 * big
+    res["error"] = ar.error()
+    torch.save(res, "%s.rank%d.pt" % (out, rank))
+    torch.distributed.barrier()
+    ar.close()
+    torch.distributed.destroy_process_group()
+
+
 if __name__ == "__main__":
     mode, out = sys.argv[1], sys.argv[2]
     if mode == "sharded":
         sharded(out, adapt=sys.argv[3] == "1")
     elif mode == "p2p":
         p2p(out)
+    elif mode == "p2p_bucket":
+        p2p_bucket(out)
     elif mode == "train":
         train(out, sys.argv[3:])
     else:
