@@ -214,8 +214,10 @@ int orbit_op_se_gate(const float* pooled, const float* w1, const float* b1, cons
 
 /* fused MBConv front half (EfficientNet InvertedResidual, Cin <= 40): y = silu(bn2(dw_KxK(silu(bn1(x . w1^T))))) with the
  * expanded tensor kept in LDS. x NHWC [B][H][W][Cin]; w1 torch [mid][Cin][1][1]; wdw torch [mid][1][K][K];
- * scale/shift = folded BatchNorms [mid]; y NHWC [B][Ho][Wo][mid]; pool_partial [B][tiles][mid] or NULL
- * (tiles = ceil(Ho/TH)*ceil(Wo/8), TH = 8 at stride 1, 4 at stride 2): per-tile sums of y for the SE average pool. */
+ * scale/shift = folded BatchNorms [mid]; y NHWC [B][Ho][Wo][mid]; pool_partial [B][tiles][mid] or NULL: partial sums
+ * of y for the SE average pool, tiles = orbit_op_mbconv_front_partials(...) (the kernel form - tiled, whole-map or
+ * row-streaming, options mbconv_map / mbconv_rows - decides how many partial sums a frame has). */
+int orbit_op_mbconv_front_partials(int H, int W, int Cin, int mid, int K, int stride);
 int orbit_op_mbconv_front(const float* x, const float* w1, const float* scale1, const float* shift1,
                           const float* wdw, const float* scale2, const float* shift2, float* y, float* pool_partial,
                           int B, int H, int W, int Cin, int mid, int K, int stride, int pad_top, int pad_left,

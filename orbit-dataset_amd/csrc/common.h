@@ -117,6 +117,13 @@ bool mbconv_map_preferred(int H, int W, int Cin, int mid, int K, int stride);  /
 int launch_mbconv_map(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
                       const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
                       int K, int stride, hipStream_t s);
+// row-streaming form for the 112x112 .. 28x28 stages (csrc/mbconv_rows.hip): a block walks down a strip of the map with the
+// expanded rows in an LDS ring - no tile halo; pool partials [B][mbconv_rows_tiles][mid]
+bool mbconv_rows_supported(int H, int W, int Cin, int mid, int K, int stride);
+int mbconv_rows_tiles(int H, int W, int Cin, int mid, int K, int stride);
+int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
+                       const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
+                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s);
 // stem form of the fused front kernel: conv_stem (NCHW frames, 3x3 stride 2) + BN + SiLU + depthwise 3x3/1 + BN + SiLU
 bool stem_dw_front_supported(int mid, int K, int stride);
 int stem_pack_weights(const float* w_oihw, float* w_packed, int mid, hipStream_t s);  // [mid][27] -> [mid][32]

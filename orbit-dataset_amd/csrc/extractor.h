@@ -52,6 +52,7 @@ struct Op {
     int pool_partial = 0;          // depthwise: also emit the pooling partials
     int weight2 = -1, bn2 = -1;    // OP_MBFRONT: depthwise weight (packed at packed_off) and its BatchNorm
     bool whole_map = false;        // OP_MBFRONT served by the whole-map kernel (csrc/mbconv_map.hip)
+    bool rows = false;             // OP_MBFRONT served by the row-streaming kernel (csrc/mbconv_rows.hip)
     int pool_k = 0, pool_pad = 0;
 };
 

@@ -94,8 +94,13 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
         return map_opt >= 2 ? mbconv_map_supported(hh, ww, cin, mid, K, stride)
                             : mbconv_map_preferred(hh, ww, cin, mid, K, stride);
     };
+    // row-streaming form (csrc/mbconv_rows.hip) for the 112x112 .. 28x28 stages: mbconv_rows = 1 wherever it applies
+    const int rows_opt = get_option("mbconv_rows");
+    auto fuse_rows_ok = [&](int hh, int ww, int cin, int mid, int K, int stride) {
+        return fuse_opt != 0 && rows_opt != 0 && mbconv_rows_supported(hh, ww, cin, mid, K, stride);
+    };
     auto fuse_front_ok = [&](int hh, int ww, int cin, int mid, int K, int stride) {
-        if (fuse_map_ok(hh, ww, cin, mid, K, stride)) return true;
+        if (fuse_map_ok(hh, ww, cin, mid, K, stride) || fuse_rows_ok(hh, ww, cin, mid, K, stride)) return true;
         if (fuse_opt == 0 || !mbconv_front_supported(cin, mid, K, stride)) return false;
         return fuse_opt == 1 || (cin <= 24 && K == 3);
     };
@@ -212,7 +217,9 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
                 fe->packed_floats += (size_t)(mid * K * K + 3) / 4 * 4;
                 ho = o.Ho, wo = o.Wo;
                 o.whole_map = fuse_map_ok(h, w, cin, mid, K, stride);
-                se_chunks = o.whole_map ? 1 : mbconv_front_tiles(ho, wo, stride);
+                o.rows = !o.whole_map && fuse_rows_ok(h, w, cin, mid, K, stride);
+                se_chunks = o.whole_map ? 1 : o.rows ? mbconv_rows_tiles(h, w, cin, mid, K, stride)
+                                                     : mbconv_front_tiles(ho, wo, stride);
                 fe->max_partial = std::max(fe->max_partial, (size_t)se_chunks * mid);
                 fe->note_buf(t2, (size_t)ho * wo * mid);
                 fe->macs += (double)h * w * cin * mid + (double)ho * wo * mid * K * K;
@@ -620,6 +627,14 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
                                            fe->d_packed + o.packed_off, scale + fe->bns[o.bn2].fold_off,
                                            shift + fe->bns[o.bn2].fold_off, buf(o.out), buf(101), B, o.H, o.W, o.Cin, o.Cout,
                                            o.KH, o.stride, s);
+                    break;
+                }
+                if (o.rows) {
+                    rc = launch_mbconv_rows(buf(o.in), fe->d_pool + fe->params[o.weight].off,
+                                            scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off,
+                                            fe->d_packed + o.packed_off, scale + fe->bns[o.bn2].fold_off,
+                                            shift + fe->bns[o.bn2].fold_off, buf(o.out), buf(101), B, o.H, o.W, o.Cin,
+                                            o.Cout, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
                     break;
                 }
                 rc = launch_mbconv_front(buf(o.in), fe->d_pool + fe->params[o.weight].off,

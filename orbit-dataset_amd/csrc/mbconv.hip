@@ -417,6 +417,14 @@ extern "C" int orbit_op_stem_dw_front(const float* frames, const float* w_stem, 
     return rc;
 }
 
+// pooling partials per frame of orbit_op_mbconv_front under the current options (the kernel selection below)
+extern "C" int orbit_op_mbconv_front_partials(int H, int W, int Cin, int mid, int K, int stride) {
+    if (get_option("mbconv_map") && mbconv_map_supported(H, W, Cin, mid, K, stride)) return 1;
+    if (get_option("mbconv_rows") && mbconv_rows_supported(H, W, Cin, mid, K, stride))
+        return mbconv_rows_tiles(H, W, Cin, mid, K, stride);
+    return mbconv_front_tiles(cdiv(H, stride), cdiv(W, stride), stride);
+}
+
 // single-operator entry for the parity tests: w1 torch [mid][Cin][1][1], wdw torch [mid][1][K][K]
 extern "C" int orbit_op_mbconv_front(const float* x, const float* w1, const float* scale1, const float* shift1,
                                      const float* wdw, const float* scale2, const float* shift2, float* y,
@@ -432,6 +440,9 @@ extern "C" int orbit_op_mbconv_front(const float* x, const float* w1, const floa
         // [B][1][mid] instead of [B][tiles][mid] (mbconv_map option 0 = tiled kernel everywhere it is supported)
         if (get_option("mbconv_map") && mbconv_map_supported(H, W, Cin, mid, K, stride))
             rc = launch_mbconv_map(x, w1, scale1, shift1, wp, scale2, shift2, y, pool_partial, B, H, W, Cin, mid, K, stride, s);
+        else if (get_option("mbconv_rows") && mbconv_rows_supported(H, W, Cin, mid, K, stride))  // pool: [B][rows tiles][mid]
+            rc = launch_mbconv_rows(x, w1, scale1, shift1, wp, scale2, shift2, y, pool_partial, B, H, W, Cin, mid, K, stride,
+                                    pad_top, pad_left, Ho, Wo, s);
         else
             rc = launch_mbconv_front(x, w1, scale1, shift1, wp, scale2, shift2, y, pool_partial, B, H, W, Cin, mid, K,
                                      stride, pad_top, pad_left, Ho, Wo, s);

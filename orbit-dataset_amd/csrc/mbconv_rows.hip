@@ -1,0 +1,351 @@
+// Row-streaming fused MBConv front half for the HIGH-RESOLUTION EfficientNet-B0 stages (112x112 .. 28x28 maps):
+// expand 1x1 conv (fp32 MFMA) -> BN1 -> SiLU -> depthwise KxK (TF-SAME) -> BN2 -> SiLU -> squeeze-excite pooling partials,
+// with the 6x-expanded tensor in an LDS ring of rows. Same arithmetic as csrc/mbconv.hip (timm InvertedResidual.forward's
+// conv_pw -> bn1 -> act -> conv_dw -> bn2 -> act -> se.mean, reached from the reference's model/feature_extractors.py:39-43).
+//
+// Why another form. mbconv.hip tiles the output 8x8 / 4x8 and re-expands the (K-1)-pixel halo of every tile: 20-60 % more
+// expand-GEMM rows, BN1/SiLU evaluations (the kernel's bound: two transcendentals per expanded element) and LDS
+// scatter than the layer has, and five MFMA row tiles for four waves. The 5x5 blocks lose to the unfused pair for that
+// reason and stayed unfused: their expanded tensor (361 / 150 MB per 200 frames) makes an HBM round trip.
+// Here a block owns ONE 32-channel chunk of a full-width strip of the map and walks DOWN it: every step expands the next
+// TO*S input rows (4 MFMA row tiles = one per wave, no halo: vertical neighbours are already in the ring; the only
+// recomputed rows are the K-S rows at a band's top) and the depthwise stage consumes the rows in the ring:
+//
+//   ring  Es [3 windows][TO*S rows][SWi px][36]   window w = input rows r_first + w*TO*S ..; BN1+SiLU applied, ZERO
+//                                                  outside the image (the depthwise conv zero-pads the EXPANDED tensor)
+//   step i: expand(window i+2)  ||  depthwise(output rows i*TO .. from windows i, i+1)  -> ONE barrier
+//
+// The block input never touches LDS: a lane's MFMA A-fragments are 16-byte loads straight from the NHWC tensor (pixel
+// = l31, channels 8g + 4*lh ..+3 - the k-order conv_igemm uses, so sums are bit-identical to the unfused conv), requested
+// one window ahead; the chunk's B-fragments (expand weights) and BN1 vectors stay in registers for the whole walk.
+// Pixels of a window are enumerated in ring-memory order (pad columns included and forced to zero), so an accumulator
+// row's LDS address is linear in the tile row; the last tile is shifted back to end at the window's end (a few pixels are
+// computed by two waves - same values) instead of guarding its tail.
+#include "common.h"
+
+namespace orbit {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using v4f = __attribute__((ext_vector_type(4))) float;
+
+using v2f = __attribute__((ext_vector_type(2))) float;
+
+// SiLU of two values: v * rcp(1 + exp2(-log2(e) * v)), the arithmetic of mbconv.hip's silu_f (bit-identical), with the
+// multiplies and the add as packed-fp32 instructions - the kernel is bound by VALU issue (two transcendentals + four
+// ordinary instructions per expanded element), so v_pk_* halves the ordinary part
+__device__ __forceinline__ v2f silu2(v2f x) {
+    const v2f t = x * (v2f){-1.44269502f, -1.44269502f};
+    const v2f e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
+    const v2f d = e + (v2f){1.0f, 1.0f};
+    const v2f r = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    return x * r;
+}
+__device__ __forceinline__ v2f fma2(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+
+struct MbRowsParams {
+    const float* x;    // [B][H][W][Cin] NHWC
+    const float* w1;   // [mid][Cin]
+    const float* sc1;  // [mid] folded BN1
+    const float* sh1;
+    const float* wdw;  // [K][K][mid]
+    const float* sc2;  // [mid] folded BN2
+    const float* sh2;
+    float* y;          // [B][Ho][Wo][mid]
+    float* pool;       // [B][tiles][mid] or nullptr
+    int H, W, Cin, mid, pad_t, pad_l, Ho, Wo;
+    int SWo, SWi, strips, band_rows, bands, nchunk, total;
+};
+
+constexpr int ROWS_ES = 36;  // ring pixel stride (floats): 32 channels + 4 (conflict-free ds_read_b128 across pixels)
+
+template <int K, int S, int TO, int NOUT, int NG>
+__global__ __launch_bounds__(256) void mbconv_rows_kernel(const MbRowsParams p) {
+    constexpr int NEW = TO * S;                  // input rows per window
+    constexpr int NCOL = (NOUT - 1) * S + K;
+    constexpr int ES = ROWS_ES;
+    static_assert((TO - 1) * S + K <= 2 * NEW, "an output step reads two windows");
+    static_assert(NEW <= 4, "row-in-window index is packed in 2 bits");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n_new = NEW * p.SWi;               // ring pixels per window (32 < n_new <= 128)
+    float* ring = smem;                          // [3][n_new][ES]
+    v4f* Ds = reinterpret_cast<v4f*>(ring + 3 * n_new * ES);  // [K*K][8] depthwise taps of the chunk
+
+    // block -> (chunk, strip, band, frame). Consecutive ids go round-robin over the 8 XCDs: remap so that the chunk-blocks
+    // of one strip (which read the same input rows) run on the same XCD at about the same time (one L2 fetch of the input)
+    const int per = gridDim.x >> 3;
+    const int v = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (v >= p.total) return;
+    const int chunk = v % p.nchunk;
+    int t = v / p.nchunk;
+    const int tiles = p.strips * p.bands;
+    const int tile = t % tiles, b = t / tiles;
+    const int strip = tile % p.strips, band = tile / p.strips;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int c0 = chunk * 32;
+    const int x0 = strip * p.SWo, y0 = band * p.band_rows;
+    const int y1 = y0 + p.band_rows < p.Ho ? y0 + p.band_rows : p.Ho;
+    const int wi0 = x0 * S - p.pad_l;            // input column of ring column 0
+    const int r_first = y0 * S - p.pad_t;        // input row of window 0, row 0
+    const int NI = (y1 - y0 + TO - 1) / TO;      // output steps; windows 0 .. NI are needed
+
+    // ---- per-lane constants of the expand stage (the pixel pattern of a window is the same for every window)
+    const int tstart = wave * 32 < n_new - 32 ? wave * 32 : n_new - 32;  // last tile ends at the window's end
+    int a_off;       // float offset of this lane's A pixel inside the frame, relative to the window's first input row
+    bool a_colok;
+    int a_rl;
+    {
+        const int f = tstart + l31;
+        a_rl = f / p.SWi;
+        const int col = f - a_rl * p.SWi, wi = wi0 + col;
+        a_colok = (unsigned)wi < (unsigned)p.W;
+        a_off = (a_rl * p.W + wi) * p.Cin + 4 * lh;
+    }
+    // accumulator element e = rq*4 + j sits at tile row 8*rq + 4*lh + j: its column validity and its row inside the window
+    unsigned colmask = 0, rlpack = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int f = tstart + 8 * (e >> 2) + 4 * lh + (e & 3);
+        const int rl = f / p.SWi, col = f - rl * p.SWi;
+        if ((unsigned)(wi0 + col) < (unsigned)p.W) colmask |= 1u << e;
+        rlpack |= (unsigned)rl << (2 * e);
+    }
+    const bool cols_all = __all(colmask == 0xffffu);  // wave-uniform: no pad column in this wave's tile
+
+    // expand weights of the chunk as MFMA B-fragments (lane = channel l31, k = 8g + 4*lh ..+3), BN1 of that channel
+    v4f wb[NG];
+    float s1 = 0.f, h1 = 0.f;
+    {
+        const int ch = c0 + l31;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            wb[g] = (v4f){0.f, 0.f, 0.f, 0.f};
+            if (ch < p.mid) wb[g] = *reinterpret_cast<const v4f*>(p.w1 + (size_t)ch * p.Cin + 8 * g + 4 * lh);
+        }
+        if (ch < p.mid) s1 = p.sc1[ch], h1 = p.sh1[ch];
+    }
+    // depthwise: thread = (channel quad lc, output slot)
+    const int lc = tid & 7, slot = tid >> 3;
+    const int cq = c0 + lc * 4;
+    const bool q_ok = cq < p.mid;
+    v4f s2 = {0.f, 0.f, 0.f, 0.f}, h2 = {0.f, 0.f, 0.f, 0.f};
+    if (q_ok) s2 = *reinterpret_cast<const v4f*>(p.sc2 + cq), h2 = *reinterpret_cast<const v4f*>(p.sh2 + cq);
+    if (tid < K * K * 8) {
+        const int tap = tid >> 3;
+        Ds[tid] = q_ok ? *reinterpret_cast<const v4f*>(p.wdw + (size_t)tap * p.mid + cq) : (v4f){0.f, 0.f, 0.f, 0.f};
+    }
+
+    const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
+    v4f xa[NG];
+    // A-fragments of window w. A pixel outside the image reads the frame's first pixel instead of being zeroed: an MFMA
+    // output row depends on its own A row only, and the epilogue forces those rows to zero - a select on the loaded value
+    // would make the wave wait for the load right where it is issued, i.e. no prefetch at all
+    auto load_x = [&](int w) {
+        const int hi0 = r_first + w * NEW;
+        const bool ok = a_colok && (unsigned)(hi0 + a_rl) < (unsigned)p.H;
+        const float* src = ok ? xb + (ptrdiff_t)hi0 * p.W * p.Cin + a_off : xb + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) xa[g] = *reinterpret_cast<const v4f*>(src + 8 * g);
+    };
+    auto expand = [&](int w) {  // window w -> ring slot w % 3 (uses xa; requests window w+1's fragments under the epilogue)
+        float* Ew = ring + (w % 3) * n_new * ES + tstart * ES + l31;
+        const int hi0 = r_first + w * NEW;
+        unsigned rowmask = 0;
+#pragma unroll
+        for (int r = 0; r < NEW; ++r) rowmask |= ((unsigned)(hi0 + r) < (unsigned)p.H ? 1u : 0u) << r;
+        if (rowmask == 0) {  // window entirely above / below the image: zeros, no arithmetic
+            if (w + 1 <= NI) load_x(w + 1);
+#pragma unroll
+            for (int e = 0; e < 16; ++e) Ew[(8 * (e >> 2) + 4 * lh + (e & 3)) * ES] = 0.f;
+            return;
+        }
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[g][kk], wb[g][kk], acc, 0, 0, 0);
+        if (w + 1 <= NI) load_x(w + 1);
+        const v2f s1v = {s1, s1}, h1v = {h1, h1};
+        if (rowmask == (1u << NEW) - 1u && cols_all) {
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const v2f val = silu2(fma2((v2f){acc[e], acc[e + 1]}, s1v, h1v));
+                Ew[(8 * (e >> 2) + 4 * lh + (e & 3)) * ES] = val.x;
+                Ew[(8 * (e >> 2) + 4 * lh + (e & 3) + 1) * ES] = val.y;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const bool ok0 = ((colmask >> e) & 1u) && ((rowmask >> ((rlpack >> (2 * e)) & 3u)) & 1u);
+                const bool ok1 = ((colmask >> (e + 1)) & 1u) && ((rowmask >> ((rlpack >> (2 * e + 2)) & 3u)) & 1u);
+                const v2f val = silu2(fma2((v2f){acc[e], acc[e + 1]}, s1v, h1v));
+                Ew[(8 * (e >> 2) + 4 * lh + (e & 3)) * ES] = ok0 ? val.x : 0.f;
+                Ew[(8 * (e >> 2) + 4 * lh + (e & 3) + 1) * ES] = ok1 ? val.y : 0.f;
+            }
+        }
+    };
+
+    const int G = p.SWo / NOUT;       // output column groups per row
+    const int items = TO * G;
+    v4f psum = {0.f, 0.f, 0.f, 0.f};
+    auto depthwise = [&](int i) {
+        const float* EA = ring + (i % 3) * n_new * ES;
+        const float* EB = ring + ((i + 1) % 3) * n_new * ES;
+        for (int it = slot; it < items; it += 32) {
+            const int j = it / G, ox = (it - j * G) * NOUT;
+            const int ho = y0 + i * TO + j;
+            if (ho >= y1) break;  // rows are enumerated in order
+            v2f alo[NOUT], ahi[NOUT];  // channel pairs (0,1) / (2,3) of the quad: packed FMAs
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n) alo[n] = (v2f){0.f, 0.f}, ahi[n] = (v2f){0.f, 0.f};
+            const v4f* dk = Ds + lc;
+#pragma unroll 1
+            for (int kh = 0; kh < K; ++kh) {
+                const int rr = j * S + kh;
+                const float* erow = (rr >= NEW ? EB + (rr - NEW) * p.SWi * ES : EA + rr * p.SWi * ES) + ox * S * ES + lc * 4;
+                v4f col[NCOL];
+#pragma unroll
+                for (int q = 0; q < NCOL; ++q) col[q] = *reinterpret_cast<const v4f*>(erow + q * ES);
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) {
+                    const v4f f = dk[kw * 8];
+                    const v2f flo = {f[0], f[1]}, fhi = {f[2], f[3]};
+#pragma unroll
+                    for (int n = 0; n < NOUT; ++n) {
+                        const v4f c = col[n * S + kw];
+                        alo[n] = fma2((v2f){c[0], c[1]}, flo, alo[n]);
+                        ahi[n] = fma2((v2f){c[2], c[3]}, fhi, ahi[n]);
+                    }
+                }
+                dk += K * 8;
+            }
+            if (q_ok) {
+#pragma unroll
+                for (int n = 0; n < NOUT; ++n) {
+                    const int wo = x0 + ox + n;
+                    if (wo < p.Wo) {
+                        const v2f olo = silu2(fma2(alo[n], (v2f){s2[0], s2[1]}, (v2f){h2[0], h2[1]}));
+                        const v2f ohi = silu2(fma2(ahi[n], (v2f){s2[2], s2[3]}, (v2f){h2[2], h2[3]}));
+                        const v4f o = {olo.x, olo.y, ohi.x, ohi.y};
+                        *reinterpret_cast<v4f*>(p.y + (((size_t)b * p.Ho + ho) * p.Wo + wo) * p.mid + cq) = o;
+                        psum += o;
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- the walk: windows 0 and 1, then one window ahead of the depthwise stage
+    load_x(0);
+    expand(0);
+    expand(1);
+    __syncthreads();
+    for (int i = 0; i < NI; ++i) {
+        if (i + 2 <= NI) expand(i + 2);
+        depthwise(i);
+        __syncthreads();
+    }
+
+    // ---- pooling partial of this (frame, tile, chunk): the 32 slots summed in slot order (deterministic)
+    if (p.pool) {
+        v4f* red = reinterpret_cast<v4f*>(ring);  // the ring is free after the last barrier
+        red[slot * 8 + lc] = psum;
+        __syncthreads();
+        if (tid < 8 && q_ok) {
+            v4f t4 = red[tid];
+            for (int sl = 1; sl < 32; ++sl) t4 += red[sl * 8 + tid];
+            *reinterpret_cast<v4f*>(p.pool + ((size_t)b * tiles + tile) * p.mid + cq) = t4;
+        }
+    }
+}
+
+// ---- geometry: per (K, stride) the output strip width and the band height are fixed by the map size alone (the pooling
+// partial count is part of the network plan, which does not know the batch size)
+struct RowsGeom {
+    int SWo, SWi, strips, band_rows, bands, TO, NOUT;
+};
+static bool rows_geom(int H, int W, int Cin, int mid, int K, int stride, int Ho, int Wo, RowsGeom& g) {
+    if (Cin % 8 != 0 || mid % 4 != 0 || H < 1 || W < 1) return false;
+    const int ng = Cin / 8;
+    // (K, stride, Cin) -> rows per step, outputs per depthwise item, widest strip whose window fits 4 MFMA row tiles
+    int swo_max = 0;
+    if (K == 3 && stride == 2 && ng == 2) g.TO = 1, g.NOUT = 1, swo_max = 28;       // 16 -> 96 3x3/2 (112x112 at 224)
+    else if (K == 3 && stride == 1 && ng == 3) g.TO = 2, g.NOUT = 2, swo_max = 56;  // 24 -> 144 3x3/1 (56x56)
+    else if (K == 5 && stride == 2 && ng == 3) g.TO = 2, g.NOUT = 1, swo_max = 14;  // 24 -> 144 5x5/2 (56x56)
+    else if (K == 5 && stride == 1 && ng == 5) g.TO = 4, g.NOUT = 2, swo_max = 28;  // 40 -> 240 5x5/1 (28x28)
+    else if (K == 3 && stride == 2 && ng == 5) g.TO = 2, g.NOUT = 1, swo_max = 14;  // 40 -> 240 3x3/2 (28x28)
+    else return false;
+    // equal strips (a map that is not a multiple of the widest strip is not served by one full and one sliver)
+    g.strips = cdiv(Wo, swo_max);
+    g.SWo = cdiv(cdiv(Wo, g.strips), g.NOUT) * g.NOUT;
+    g.SWi = (g.SWo - 1) * stride + K;
+    const int n_new = g.TO * stride * g.SWi;
+    if (n_new <= 32 || n_new > 128) return false;
+    g.band_rows = 14;
+    const int forced = get_option("mbrows_band");
+    if (forced > 0) g.band_rows = forced;
+    g.band_rows = cdiv(g.band_rows, g.TO) * g.TO;
+    g.bands = cdiv(Ho, g.band_rows);
+    return true;
+}
+
+bool mbconv_rows_supported(int H, int W, int Cin, int mid, int K, int stride) {
+    RowsGeom g;
+    const int Ho = cdiv(H, stride), Wo = cdiv(W, stride);
+    return rows_geom(H, W, Cin, mid, K, stride, Ho, Wo, g);
+}
+
+int mbconv_rows_tiles(int H, int W, int Cin, int mid, int K, int stride) {
+    RowsGeom g;
+    const int Ho = cdiv(H, stride), Wo = cdiv(W, stride);
+    if (!rows_geom(H, W, Cin, mid, K, stride, Ho, Wo, g)) return 0;
+    return g.strips * g.bands;
+}
+
+int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
+                       const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
+                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s) {
+    ORBIT_REQUIRE(x && w1 && sc1 && sh1 && wdw && sc2 && sh2 && y, "mbconv_rows: null pointer");
+    RowsGeom g;
+    ORBIT_REQUIRE(Ho == cdiv(H, stride) && Wo == cdiv(W, stride) && rows_geom(H, W, Cin, mid, K, stride, Ho, Wo, g),
+                  "mbconv_rows: unsupported shape (H=%d W=%d Cin=%d mid=%d K=%d s=%d)", H, W, Cin, mid, K, stride);
+    MbRowsParams p;
+    p.x = x, p.w1 = w1, p.sc1 = sc1, p.sh1 = sh1, p.wdw = wdw, p.sc2 = sc2, p.sh2 = sh2, p.y = y, p.pool = pool;
+    p.H = H, p.W = W, p.Cin = Cin, p.mid = mid, p.pad_t = pad_t, p.pad_l = pad_l, p.Ho = Ho, p.Wo = Wo;
+    p.SWo = g.SWo, p.SWi = g.SWi, p.strips = g.strips, p.band_rows = g.band_rows, p.bands = g.bands;
+    p.nchunk = cdiv(mid, 32);
+    p.total = p.nchunk * g.strips * g.bands * B;
+    const int grid = cdiv(p.total, 8) * 8;
+    const int n_new = g.TO * stride * g.SWi;
+    const size_t lds = (size_t)3 * n_new * ROWS_ES * sizeof(float) + (size_t)K * K * 8 * 16;
+    const double pix = (double)B * H * W;
+    const int rec = prof_start("mbconv_rows", 2.0 * pix * Cin * mid + 2.0 * B * Ho * Wo * mid * K * K,
+                               4.0 * (pix * Cin + (double)B * Ho * Wo * mid), s);
+#define ORBIT_MBR(KK, SS, TO_, NOUT_, NG_)                                                              \
+    do {                                                                                                \
+        auto kern = mbconv_rows_kernel<KK, SS, TO_, NOUT_, NG_>;                                        \
+        static bool attr_set = false;                                                                   \
+        if (!attr_set) {                                                                                \
+            ORBIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                    \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+            attr_set = true;                                                                            \
+        }                                                                                               \
+        kern<<<grid, 256, lds, s>>>(p);                                                                 \
+    } while (0)
+    const int ng = Cin / 8;
+    if (K == 3 && stride == 2 && ng == 2) ORBIT_MBR(3, 2, 1, 1, 2);  // the (TO, NOUT) of rows_geom
+    else if (K == 3 && stride == 1 && ng == 3) ORBIT_MBR(3, 1, 2, 2, 3);
+    else if (K == 5 && stride == 2 && ng == 3) ORBIT_MBR(5, 2, 2, 1, 3);
+    else if (K == 5 && stride == 1 && ng == 5) ORBIT_MBR(5, 1, 4, 2, 5);
+    else ORBIT_MBR(3, 2, 2, 1, 5);
+#undef ORBIT_MBR
+    prof_stop(rec, s);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+}  // namespace orbit

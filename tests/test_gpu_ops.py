@@ -263,13 +263,75 @@ def test_mbconv_front_fused(lib, device, Cin, mid, K, stride, H, W):
     y = torch.full((B, Ho, Wo, mid), float("nan"), device=device)
     pool = torch.full((B, tiles, mid), float("nan"), device=device)
     dev = [t.to(device).contiguous() for t in (nhwc(x), w1, s1, h1, wd, s2, h2)]
-    _lib.check(lib.orbit_op_mbconv_front(*[_lib.dptr(t) for t in dev], _lib.dptr(y), _lib.dptr(pool), B, H, W, Cin, mid, K,
-                                         stride, ph // 2, pw // 2, Ho, Wo, _st()), "mbconv_front")
-    torch.cuda.synchronize()
+    prev = lib.orbit_get_option(b"mbconv_rows")
+    lib.orbit_set_option(b"mbconv_rows", 0)  # the TILED kernel (csrc/mbconv.hip); the row-streaming form has its own test
+    try:
+        assert lib.orbit_op_mbconv_front_partials(H, W, Cin, mid, K, stride) == tiles
+        _lib.check(lib.orbit_op_mbconv_front(*[_lib.dptr(t) for t in dev], _lib.dptr(y), _lib.dptr(pool), B, H, W, Cin, mid,
+                                             K, stride, ph // 2, pw // 2, Ho, Wo, _st()), "mbconv_front")
+        torch.cuda.synchronize()
+    finally:
+        lib.orbit_set_option(b"mbconv_rows", prev)
     got = nchw(y.cpu())
     assert not torch.isnan(got).any() and not torch.isnan(pool).any()
     assert (got - want).abs().max().item() < 5e-5
     assert (pool.cpu().sum(1) - want.sum((2, 3))).abs().max().item() < 2e-3 * max(1.0, want.sum((2, 3)).abs().max().item())
+
+
+MBROWS_CASES = [  # Cin, mid, K, stride, H, W: the five high-resolution block shapes of efficientnet_b0, at the 224x224
+    # map sizes (full strips, several bands) and at odd sizes (ragged strips / bands, pad columns inside a row tile)
+    (16, 96, 3, 2, 112, 112), (24, 144, 3, 1, 56, 56), (24, 144, 5, 2, 56, 56), (40, 240, 5, 1, 28, 28),
+    (40, 240, 3, 2, 28, 28), (16, 96, 3, 2, 37, 21), (16, 80, 3, 2, 116, 58), (24, 144, 3, 1, 29, 58), (24, 144, 3, 1, 15, 9),
+    (24, 100, 5, 2, 42, 31), (40, 240, 5, 1, 15, 29), (40, 240, 5, 1, 5, 8), (40, 236, 3, 2, 29, 30), (40, 240, 3, 2, 6, 3)]
+
+
+@pytest.mark.parametrize("Cin,mid,K,stride,H,W", MBROWS_CASES)
+@pytest.mark.parametrize("band", [0, 4])
+def test_mbconv_front_row_streaming(lib, device, Cin, mid, K, stride, H, W, band):
+    """csrc/mbconv_rows.hip: a block walks down a strip of the map, expanded rows in an LDS ring, input fragments straight
+    from HBM. Against the unfused PyTorch-CPU sequence AND bit for bit against the library's conv + depthwise pair (same
+    k-order, same tap order); pooling partials sum to the plane sums. band = 4: many bands (top-halo recompute, ragged
+    last band)."""
+    g = torch.Generator().manual_seed(Cin * 1000 + mid + K + stride + H)
+    B = 3
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w1 = torch.randn(mid, Cin, 1, 1, generator=g) / Cin ** 0.5
+    wd = torch.randn(mid, 1, K, K, generator=g) / K
+    s1, h1 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.3
+    s2, h2 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.1
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph, pw = max((Ho - 1) * stride + K - H, 0), max((Wo - 1) * stride + K - W, 0)
+    e = F.silu(F.conv2d(x, w1) * s1[None, :, None, None] + h1[None, :, None, None])
+    ep = F.pad(e, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
+    want = F.silu(F.conv2d(ep, wd, None, stride, 0, 1, mid) * s2[None, :, None, None] + h2[None, :, None, None])
+    dev = [t.to(device).contiguous() for t in (nhwc(x), w1, s1, h1, wd, s2, h2)]
+    prev = lib.orbit_get_option(b"mbconv_rows")
+    lib.orbit_set_option(b"mbconv_rows", 1)
+    lib.orbit_set_option(b"mbrows_band", band)
+    try:
+        tiles = lib.orbit_op_mbconv_front_partials(H, W, Cin, mid, K, stride)
+        assert tiles >= 1
+        y = torch.full((B, Ho, Wo, mid), float("nan"), device=device)
+        pool = torch.full((B, tiles, mid), float("nan"), device=device)
+        _lib.check(lib.orbit_op_mbconv_front(*[_lib.dptr(t) for t in dev], _lib.dptr(y), _lib.dptr(pool), B, H, W, Cin, mid,
+                                             K, stride, ph // 2, pw // 2, Ho, Wo, _st()), "mbconv_front (rows)")
+        torch.cuda.synchronize()
+    finally:
+        lib.orbit_set_option(b"mbrows_band", 0)
+        lib.orbit_set_option(b"mbconv_rows", prev)
+    got = nchw(y.cpu())
+    assert not torch.isnan(got).any() and not torch.isnan(pool).any()
+    assert (got - want).abs().max().item() < 5e-5
+    assert (pool.cpu().sum(1) - want.sum((2, 3))).abs().max().item() < 2e-3 * max(1.0, want.sum((2, 3)).abs().max().item())
+    # the unfused pair of the same library: identical bits
+    ex = torch.empty(B, H, W, mid, device=device)
+    y2 = torch.empty(B, Ho, Wo, mid, device=device)
+    _lib.check(lib.orbit_op_conv2d(_lib.dptr(dev[0]), 0, _lib.dptr(dev[1]), _lib.dptr(ex), _lib.dptr(dev[2]), _lib.dptr(dev[3]),
+                                   None, None, B, H, W, Cin, mid, 1, 1, 1, 0, 0, H, W, 2, 0, _st()), "conv2d")
+    _lib.check(lib.orbit_op_dwconv2d(_lib.dptr(ex), _lib.dptr(dev[4]), _lib.dptr(y2), _lib.dptr(dev[5]), _lib.dptr(dev[6]), B, H,
+                                     W, mid, K, stride, ph // 2, pw // 2, Ho, Wo, 2, _st()), "dwconv2d")
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), y2.cpu())
 
 
 MBMAP_CASES = [  # Cin, K, stride, HW : every whole-map shape of efficientnet_b0 @224 (blocks 3.1 .. 6.0)
