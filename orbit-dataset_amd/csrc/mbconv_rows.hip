@@ -59,7 +59,7 @@ struct MbRowsParams {
 constexpr int ROWS_ES = 36;  // ring pixel stride (floats): 32 channels + 4 (conflict-free ds_read_b128 across pixels)
 
 template <int K, int S, int TO, int NOUT, int NG>
-__global__ __launch_bounds__(256) void mbconv_rows_kernel(const MbRowsParams p) {
+__global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows_kernel(const MbRowsParams p) {
     constexpr int NEW = TO * S;                  // input rows per window
     constexpr int NCOL = (NOUT - 1) * S + K;
     constexpr int ES = ROWS_ES;
@@ -69,7 +69,6 @@ __global__ __launch_bounds__(256) void mbconv_rows_kernel(const MbRowsParams p) 
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int n_new = NEW * p.SWi;               // ring pixels per window (32 < n_new <= 128)
     float* ring = smem;                          // [3][n_new][ES]
-    v4f* Ds = reinterpret_cast<v4f*>(ring + 3 * n_new * ES);  // [K*K][8] depthwise taps of the chunk
 
     // block -> (chunk, strip, band, frame). Consecutive ids go round-robin over the 8 XCDs: remap so that the chunk-blocks
     // of one strip (which read the same input rows) run on the same XCD at about the same time (one L2 fetch of the input)
@@ -132,7 +131,13 @@ __global__ __launch_bounds__(256) void mbconv_rows_kernel(const MbRowsParams p) 
     const bool q_ok = cq < p.mid;
     v4f s2 = {0.f, 0.f, 0.f, 0.f}, h2 = {0.f, 0.f, 0.f, 0.f};
     if (q_ok) s2 = *reinterpret_cast<const v4f*>(p.sc2 + cq), h2 = *reinterpret_cast<const v4f*>(p.sh2 + cq);
-    if (tid < K * K * 8) {
+    v4f* Ds = reinterpret_cast<v4f*>(ring + 3 * n_new * ES);  // 5x5 only: [K*K][8] depthwise taps of the chunk
+    v4f tapr[K == 3 ? K * K : 1];  // 3x3: this thread's nine tap quads stay in registers for the whole walk
+    if constexpr (K == 3) {
+#pragma unroll
+        for (int tap = 0; tap < K * K; ++tap)
+            tapr[tap] = q_ok ? *reinterpret_cast<const v4f*>(p.wdw + (size_t)tap * p.mid + cq) : (v4f){0.f, 0.f, 0.f, 0.f};
+    } else if (tid < K * K * 8) {
         const int tap = tid >> 3;
         Ds[tid] = q_ok ? *reinterpret_cast<const v4f*>(p.wdw + (size_t)tap * p.mid + cq) : (v4f){0.f, 0.f, 0.f, 0.f};
     }
@@ -202,26 +207,56 @@ __global__ __launch_bounds__(256) void mbconv_rows_kernel(const MbRowsParams p) 
             v2f alo[NOUT], ahi[NOUT];  // channel pairs (0,1) / (2,3) of the quad: packed FMAs
 #pragma unroll
             for (int n = 0; n < NOUT; ++n) alo[n] = (v2f){0.f, 0.f}, ahi[n] = (v2f){0.f, 0.f};
-            const v4f* dk = Ds + lc;
-#pragma unroll 1
-            for (int kh = 0; kh < K; ++kh) {
+            auto row_of = [&](int kh) {
                 const int rr = j * S + kh;
-                const float* erow = (rr >= NEW ? EB + (rr - NEW) * p.SWi * ES : EA + rr * p.SWi * ES) + ox * S * ES + lc * 4;
-                v4f col[NCOL];
-#pragma unroll
-                for (int q = 0; q < NCOL; ++q) col[q] = *reinterpret_cast<const v4f*>(erow + q * ES);
+                return (rr >= NEW ? EB + (rr - NEW) * p.SWi * ES : EA + rr * p.SWi * ES) + ox * S * ES + lc * 4;
+            };
+            auto mac = [&](const v4f* c, const v4f* t) {
 #pragma unroll
                 for (int kw = 0; kw < K; ++kw) {
-                    const v4f f = dk[kw * 8];
-                    const v2f flo = {f[0], f[1]}, fhi = {f[2], f[3]};
+                    const v2f flo = {t[kw][0], t[kw][1]}, fhi = {t[kw][2], t[kw][3]};
 #pragma unroll
                     for (int n = 0; n < NOUT; ++n) {
-                        const v4f c = col[n * S + kw];
-                        alo[n] = fma2((v2f){c[0], c[1]}, flo, alo[n]);
-                        ahi[n] = fma2((v2f){c[2], c[3]}, fhi, ahi[n]);
+                        const v4f cv = c[n * S + kw];
+                        alo[n] = fma2((v2f){cv[0], cv[1]}, flo, alo[n]);
+                        ahi[n] = fma2((v2f){cv[2], cv[3]}, fhi, ahi[n]);
                     }
                 }
-                dk += K * 8;
+            };
+            // two row buffers: row kh+1 is requested before row kh is consumed
+            v4f cA[NCOL], cB[NCOL];
+            auto fetch = [&](v4f* c, int kh) {
+                const float* erow = row_of(kh);
+#pragma unroll
+                for (int q = 0; q < NCOL; ++q) c[q] = *reinterpret_cast<const v4f*>(erow + q * ES);
+            };
+            fetch(cA, 0);
+            if constexpr (K == 3) {
+                // 3x3: the thread's nine tap quads live in registers (kh unrolled: static register indices)
+#pragma unroll
+                for (int kh = 0; kh < K; ++kh) {
+                    v4f* cur = (kh & 1) ? cB : cA;
+                    v4f* nxt = (kh & 1) ? cA : cB;
+                    if (kh + 1 < K) fetch(nxt, kh + 1);
+                    mac(cur, tapr + kh * K);
+                }
+            } else {
+                // 5x5: 25 tap quads do not fit the register budget (unrolled, hipcc also hoists every row's reads and
+                // spills): taps come from LDS with their row, the loop over row pairs stays rolled
+                v4f tA[K], tB[K];
+                auto taps = [&](v4f* t, int kh) {
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw) t[kw] = Ds[(kh * K + kw) * 8 + lc];
+                };
+                taps(tA, 0);
+#pragma unroll 1
+                for (int kh = 0; kh + 1 < K; kh += 2) {
+                    fetch(cB, kh + 1), taps(tB, kh + 1);
+                    mac(cA, tA);
+                    if (kh + 2 < K) fetch(cA, kh + 2), taps(tA, kh + 2);
+                    mac(cB, tB);
+                }
+                if (K & 1) mac(cA, tA);
             }
             if (q_ok) {
 #pragma unroll
@@ -276,7 +311,7 @@ static bool rows_geom(int H, int W, int Cin, int mid, int K, int stride, int Ho,
     if (K == 3 && stride == 2 && ng == 2) g.TO = 1, g.NOUT = 1, swo_max = 28;       // 16 -> 96 3x3/2 (112x112 at 224)
     else if (K == 3 && stride == 1 && ng == 3) g.TO = 2, g.NOUT = 2, swo_max = 56;  // 24 -> 144 3x3/1 (56x56)
     else if (K == 5 && stride == 2 && ng == 3) g.TO = 2, g.NOUT = 1, swo_max = 14;  // 24 -> 144 5x5/2 (56x56)
-    else if (K == 5 && stride == 1 && ng == 5) g.TO = 4, g.NOUT = 2, swo_max = 28;  // 40 -> 240 5x5/1 (28x28)
+    else if (K == 5 && stride == 1 && ng == 5) g.TO = 4, g.NOUT = 4, swo_max = 28;  // 40 -> 240 5x5/1 (28x28)
     else if (K == 3 && stride == 2 && ng == 5) g.TO = 2, g.NOUT = 1, swo_max = 14;  // 40 -> 240 3x3/2 (28x28)
     else return false;
     // equal strips (a map that is not a multiple of the widest strip is not served by one full and one sliver)
@@ -321,7 +356,7 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
     p.total = p.nchunk * g.strips * g.bands * B;
     const int grid = cdiv(p.total, 8) * 8;
     const int n_new = g.TO * stride * g.SWi;
-    const size_t lds = (size_t)3 * n_new * ROWS_ES * sizeof(float) + (size_t)K * K * 8 * 16;
+    const size_t lds = (size_t)3 * n_new * ROWS_ES * sizeof(float) + (K == 3 ? 0 : (size_t)K * K * 8 * 16);
     const double pix = (double)B * H * W;
     const int rec = prof_start("mbconv_rows", 2.0 * pix * Cin * mid + 2.0 * B * Ho * Wo * mid * K * K,
                                4.0 * (pix * Cin + (double)B * Ho * Wo * mid), s);
@@ -340,7 +375,7 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
     if (K == 3 && stride == 2 && ng == 2) ORBIT_MBR(3, 2, 1, 1, 2);  // the (TO, NOUT) of rows_geom
     else if (K == 3 && stride == 1 && ng == 3) ORBIT_MBR(3, 1, 2, 2, 3);
     else if (K == 5 && stride == 2 && ng == 3) ORBIT_MBR(5, 2, 2, 1, 3);
-    else if (K == 5 && stride == 1 && ng == 5) ORBIT_MBR(5, 1, 4, 2, 5);
+    else if (K == 5 && stride == 1 && ng == 5) ORBIT_MBR(5, 1, 4, 4, 5);
     else ORBIT_MBR(3, 2, 2, 1, 5);
 #undef ORBIT_MBR
     prof_stop(rec, s);
