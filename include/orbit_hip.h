@@ -226,6 +226,7 @@ int orbit_op_mbconv_front(const float* x, const float* w1, const float* scale1, 
  * SiLU, reached from model/feature_extractors.py:39-43): frames NCHW [B][3][FH][FW], w_stem torch [mid][3][3][3]
  * (3x3 stride 2, padding spad_top / spad_left before, the rest after), depthwise 3x3 stride 1 on the stem's H x W output
  * grid; y NHWC [B][Ho][Wo][mid]; pool_partial [B][ceil(Ho/8)*ceil(Wo/8)][mid] or NULL. The stem output never reaches HBM. */
+int orbit_op_stem_dw_front_partials(int H, int W, int mid);  /* pool_partial rows per frame under the current options */
 int orbit_op_stem_dw_front(const float* frames, const float* w_stem, const float* scale1, const float* shift1,
                            const float* wdw, const float* scale2, const float* shift2, float* y, float* pool_partial,
                            int B, int FH, int FW, int spad_top, int spad_left, int H, int W, int mid, int pad_top,

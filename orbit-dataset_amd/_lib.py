@@ -57,6 +57,7 @@ _SIGNATURES = {
     "orbit_op_se_gate": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),
     "orbit_op_mbconv_front": (c_int, [P] * 9 + [c_int] * 11 + [P]),
     "orbit_op_mbconv_front_partials": (c_int, [c_int] * 6),
+    "orbit_op_stem_dw_front_partials": (c_int, [c_int] * 3),
     "orbit_op_stem_dw_front": (c_int, [P] * 9 + [c_int] * 12 + [P]),
     "orbit_dense_rows": (c_int, [P, c_int, c_int, P, P, c_int, c_int, P, P, P]),
     "orbit_spd_inverse": (c_int, [P, P, c_int, c_int, P]),

@@ -111,7 +111,10 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
     // stem + first depthwise in one kernel (the stem's 112x112x32 output never reaches HBM): only with mbconv_fusion = 1 -
     // measured in the whole network it is 1.3 % SLOWER than the stem conv + depthwise pair (16 scalar gathers per thread
     // to build the im2col patch, two blocks per CU)
-    const bool fuse_stem = fuse_opt == 1 && stem_dw_front_supported(32, 3, 1);
+    // row-streaming stem + depthwise (csrc/mbconv_rows.hip, option mbconv_rows): the stem's 112x112x32 output stays in LDS
+    const bool stem_rows = fuse_opt != 0 && get_option("mbconv_rows") >= 1 && get_option("stem_rows") != 0 &&
+                           stem_rows_supported(h, w, 32, 3, 1);
+    const bool fuse_stem = stem_rows || (fuse_opt == 1 && stem_dw_front_supported(32, 3, 1));
     size_t stem_weight = 0;
     if (fuse_stem) stem_weight = fe->add_param("conv_stem.weight", (size_t)32 * 27);
     else fe->add_conv("conv_stem.weight", bn, -1, 0, -1, H, W, 3, 32, 3, 2, pt, pl, h, w, ORBIT_ACT_SILU, 0, 1, 0);
@@ -175,7 +178,8 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
             o.packed_off2 = fe->packed_floats;  // stem filter [32][32]
             fe->packed_floats += (size_t)32 * 32;
             ho = o.Ho, wo = o.Wo;
-            se_chunks0 = mbconv_front_tiles(ho, wo, 1);
+            o.rows = stem_rows;
+            se_chunks0 = stem_rows ? stem_rows_tiles(h, w) : mbconv_front_tiles(ho, wo, 1);
             fe->max_partial = std::max(fe->max_partial, (size_t)se_chunks0 * 32);
             fe->note_buf(t1, (size_t)ho * wo * 32);
             fe->macs += (double)h * w * 27 * 32 + (double)ho * wo * 32 * 9;
@@ -613,6 +617,13 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
                                       o.pad_l, o.Ho, o.Wo, o.act, s);
                 break;
             case OP_MBFRONT:
+                if (o.stem && o.rows) {
+                    rc = launch_stem_rows(buf(o.in), fe->d_packed + o.packed_off2, scale + fe->bns[o.bn].fold_off,
+                                          shift + fe->bns[o.bn].fold_off, fe->d_packed + o.packed_off,
+                                          scale + fe->bns[o.bn2].fold_off, shift + fe->bns[o.bn2].fold_off, buf(o.out),
+                                          buf(101), B, o.stem_h, o.stem_w, o.stem_pt, o.stem_pl, o.H, o.W, s);
+                    break;
+                }
                 if (o.stem) {
                     rc = launch_stem_dw_front(buf(o.in), fe->d_packed + o.packed_off2, scale + fe->bns[o.bn].fold_off,
                                               shift + fe->bns[o.bn].fold_off, fe->d_packed + o.packed_off,

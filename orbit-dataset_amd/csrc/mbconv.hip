@@ -399,6 +399,12 @@ int launch_stem_dw_front(const float* frames, const float* w1_packed, const floa
 
 using namespace orbit;
 
+// pooling partials per frame of orbit_op_stem_dw_front under the current options
+extern "C" int orbit_op_stem_dw_front_partials(int H, int W, int mid) {
+    if (get_option("mbconv_rows") && get_option("stem_rows") && stem_rows_supported(H, W, mid, 3, 1)) return stem_rows_tiles(H, W);
+    return mbconv_front_tiles(H, W, 1);
+}
+
 // single-operator entry for the parity tests: frames NCHW, w_stem torch [mid][3][3][3], wdw torch [mid][1][3][3]
 extern "C" int orbit_op_stem_dw_front(const float* frames, const float* w_stem, const float* scale1, const float* shift1,
                                       const float* wdw, const float* scale2, const float* shift2, float* y,
@@ -410,7 +416,10 @@ extern "C" int orbit_op_stem_dw_front(const float* frames, const float* w_stem, 
     ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&wp), (size_t)mid * (32 + 9) * sizeof(float), s));
     int rc = stem_pack_weights(w_stem, wp, mid, s);
     if (rc == ORBIT_OK) rc = dwconv_pack_weights(wdw, wp + (size_t)mid * 32, mid, 3, s);
-    if (rc == ORBIT_OK)
+    if (rc == ORBIT_OK && get_option("mbconv_rows") && get_option("stem_rows") && stem_rows_supported(H, W, mid, 3, 1))
+        rc = launch_stem_rows(frames, wp, scale1, shift1, wp + (size_t)mid * 32, scale2, shift2, y, pool_partial, B, FH, FW,
+                              spad_top, spad_left, H, W, s);
+    else if (rc == ORBIT_OK)
         rc = launch_stem_dw_front(frames, wp, scale1, shift1, wp + (size_t)mid * 32, scale2, shift2, y, pool_partial, B, FH,
                                   FW, spad_top, spad_left, H, W, mid, 3, pad_top, pad_left, Ho, Wo, s);
     (void)hipFreeAsync(wp, s);

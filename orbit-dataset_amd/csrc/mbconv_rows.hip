@@ -320,7 +320,7 @@ static bool rows_geom(int H, int W, int Cin, int mid, int K, int stride, int Ho,
     g.SWi = (g.SWo - 1) * stride + K;
     const int n_new = g.TO * stride * g.SWi;
     if (n_new <= 32 || n_new > 128) return false;
-    g.band_rows = 14;
+    g.band_rows = 28;  // measured: 28-row bands beat 14 (fewer pipeline fills) and 56 (too few blocks) on the whole task
     const int forced = get_option("mbrows_band");
     if (forced > 0) g.band_rows = forced;
     g.band_rows = cdiv(g.band_rows, g.TO) * g.TO;
@@ -378,6 +378,264 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
     else if (K == 5 && stride == 1 && ng == 5) ORBIT_MBR(5, 1, 4, 4, 5);
     else ORBIT_MBR(3, 2, 2, 1, 5);
 #undef ORBIT_MBR
+    prof_stop(rec, s);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+
+// ---- stem form: conv_stem (NCHW frames, 3 -> 32 channels, 3x3 stride 2, TF-SAME) + BN + SiLU + blocks.0.0.conv_dw 3x3/1 +
+// BN + SiLU + squeeze-excite pooling partials with the same walk (timm tf_efficientnet_b0: conv_stem -> bn1 -> act ->
+// DepthwiseSeparableConv.conv_dw -> bn1 -> act, reached from the reference's model/feature_extractors.py:39-43). Unfused, the
+// stem's 112x112x32 output makes an HBM round trip (321 MB written + read per 200 frames, the largest tensor of the net).
+// The "expand" stage is a direct convolution on the VALU: lane = stem pixel of the window (one window = 2 rows x <= 30
+// columns <= 64 pixels), wave = 8 of the 32 output channels. A lane reads its 27 input taps once from an LDS frame patch
+// (5 frame rows x 61 columns x 3 planes, double-buffered, refilled one window ahead through registers); the filter taps of
+// the wave's channels are wave-uniform and arrive in SGPRs (scalar loads of the [32][32]-packed filter): 27 FMAs per
+// channel with a scalar operand, no LDS or VGPR traffic for weights. Summation order (ci, kh, kw).
+struct StemRowsParams {
+    const float* frames;  // [B][3][FH][FW]
+    const float* w1;      // [32][32]: channel-major, tap ci*9 + kh*3 + kw (stem_pack_weights)
+    const float* sc1;
+    const float* sh1;
+    const float* wdw;     // [3][3][32]
+    const float* sc2;
+    const float* sh2;
+    float* y;             // [B][H][W][32]
+    float* pool;          // [B][tiles][32] or nullptr
+    int FH, FW, spad_t, spad_l, H, W;  // (H, W) = stem output grid = depthwise grid
+    int SWo, SWi, strips, band_rows, bands, total;
+};
+
+constexpr int STEM_PW = 64;  // patch row stride (floats): 2 * 30 + 1 columns
+
+__global__ __launch_bounds__(256, 3) void stem_rows_kernel(const StemRowsParams p, const float* __restrict__ w1g,
+                                                           const float* __restrict__ sc1g, const float* __restrict__ sh1g) {
+    constexpr int K = 3, TO = 2, NEW = 2, NOUT = 2, NCOL = 4, ES = ROWS_ES;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n_new = NEW * p.SWi;                  // <= 64 ring pixels per window
+    float* ring = smem;                             // [3][n_new][ES]
+    float* patch = ring + 3 * n_new * ES;           // [2][3 planes][5 rows][STEM_PW]
+    constexpr int PATCH = 3 * 5 * STEM_PW;
+
+    const int per = gridDim.x >> 3;
+    const int v = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (v >= p.total) return;
+    const int tiles = p.strips * p.bands;
+    const int tile = v % tiles, b = v / tiles;
+    const int strip = tile % p.strips, band = tile / p.strips;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int x0 = strip * p.SWo, y0 = band * p.band_rows;
+    const int y1 = y0 + p.band_rows < p.H ? y0 + p.band_rows : p.H;
+    const int c_first = x0 - 1, r_first = y0 - 1;   // stem column / row of ring column 0 / window 0 row 0 (dw pad 1)
+    const int NI = (y1 - y0 + TO - 1) / TO;
+    const float* fb = p.frames + (size_t)b * 3 * p.FH * p.FW;
+
+    // ---- frame patch of window w: frame rows 2 * (r_first + 2w) - spad_t + 0..4, columns 2 * c_first - spad_l + 0 .. 2 SWi
+    const int fcol0 = 2 * c_first - p.spad_l;
+    const int pcols = 2 * p.SWi + 1;
+    constexpr int NPL = (PATCH + 255) / 256;        // patch elements per thread
+    float preg[NPL];
+    unsigned pmask = 0;  // which of preg[] lie inside the frame: applied when the patch is WRITTEN - a select on the loaded
+                         // value would make the wave wait for the load where it is issued (no prefetch at all)
+    auto patch_load = [&](int w) {
+        const int frow0 = 2 * (r_first + NEW * w) - p.spad_t;
+        pmask = 0;
+#pragma unroll
+        for (int u = 0; u < NPL; ++u) {
+            const int i = tid + u * 256;
+            const int c = i & (STEM_PW - 1), pr = i >> 6;      // pr = plane * 5 + row
+            const int plane = pr / 5, row = pr - plane * 5;
+            const int fr = frow0 + row, fc = fcol0 + c;
+            const bool ok = i < PATCH && c < pcols && (unsigned)fr < (unsigned)p.FH && (unsigned)fc < (unsigned)p.FW;
+            pmask |= (ok ? 1u : 0u) << u;
+            preg[u] = fb[ok ? ((size_t)plane * p.FH + fr) * p.FW + fc : 0];
+        }
+    };
+    auto patch_store = [&](int w) {
+        float* dst = patch + (w & 1) * PATCH;
+#pragma unroll
+        for (int u = 0; u < NPL; ++u) {
+            const int i = tid + u * 256;
+            if (i < PATCH) dst[i] = ((pmask >> u) & 1u) ? preg[u] : 0.f;
+        }
+    };
+
+    // ---- stem stage constants: lane = window pixel
+    const int f = lane < n_new ? lane : n_new - 1;
+    const int s_rl = f / p.SWi, s_col = f - s_rl * p.SWi;
+    const bool s_colok = (unsigned)(c_first + s_col) < (unsigned)p.W;
+    // wave-uniform addresses read through the CONSTANT address space (the filter is never written while the kernel runs):
+    // the eight channels' taps and BatchNorm vectors arrive as scalar loads in SGPRs
+    typedef const float __attribute__((address_space(4))) cfloat;
+    const cfloat* w_wave0 = (const cfloat*)(w1g + (size_t)(wave * 8) * 32);
+    const cfloat* s1w = (const cfloat*)(sc1g + wave * 8);
+    const cfloat* h1w = (const cfloat*)(sh1g + wave * 8);
+    auto stem = [&](int w) {
+        const cfloat* w_wave = w_wave0;
+        asm volatile("" : "+s"(w_wave));  // keep the 216 tap loads inside the step (hoisted, they become 216 live registers)
+        const float* P = patch + (w & 1) * PATCH + (2 * s_rl) * STEM_PW + 2 * s_col;
+        float xin[27];  // tap ci*9 + kh*3 + kw: the packed filter's order
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci)
+#pragma unroll
+            for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < 3; ++kw) xin[ci * 9 + kh * 3 + kw] = P[(ci * 5 + kh) * STEM_PW + kw];
+        const bool ok = s_colok && (unsigned)(r_first + NEW * w + s_rl) < (unsigned)p.H;
+        // four independent packed accumulators (channel pairs); per input plane the 8 x 9 taps of the wave's channels are
+        // 72 SGPRs - one channel at a time was one 27-long dependent FMA chain behind every scalar-load round trip
+        v2f acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] = (v2f){0.f, 0.f};
+#pragma unroll
+        for (int ci = 0; ci < 3; ++ci) {
+#pragma unroll
+            for (int t9 = 0; t9 < 9; ++t9) {
+                const int k = ci * 9 + t9;
+                const v2f xv = {xin[k], xin[k]};
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    acc[q] = fma2(xv, (v2f){w_wave[(2 * q) * 32 + k], w_wave[(2 * q + 1) * 32 + k]}, acc[q]);
+            }
+        }
+        float o[8];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) o[2 * q] = acc[q].x, o[2 * q + 1] = acc[q].y;
+        v4f r0, r1;
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) {
+            const v2f val = silu2(fma2((v2f){o[j], o[j + 1]}, (v2f){s1w[j], s1w[j + 1]}, (v2f){h1w[j], h1w[j + 1]}));
+            if (j < 4) r0[j] = ok ? val.x : 0.f, r0[j + 1] = ok ? val.y : 0.f;
+            else r1[j - 4] = ok ? val.x : 0.f, r1[j - 3] = ok ? val.y : 0.f;
+        }
+        if (lane < n_new) {
+            float* E = ring + ((w % 3) * n_new + lane) * ES + wave * 8;
+            *reinterpret_cast<v4f*>(E) = r0;
+            *reinterpret_cast<v4f*>(E + 4) = r1;
+        }
+    };
+
+    // ---- depthwise stage: thread = (channel quad, output slot), taps in registers
+    const int lc = tid & 7, slot = tid >> 3;
+    const int cq = lc * 4;
+    const v4f s2 = *reinterpret_cast<const v4f*>(p.sc2 + cq), h2 = *reinterpret_cast<const v4f*>(p.sh2 + cq);
+    v4f tapr[K * K];
+#pragma unroll
+    for (int tap = 0; tap < K * K; ++tap) tapr[tap] = *reinterpret_cast<const v4f*>(p.wdw + tap * 32 + cq);
+    const int G = p.SWo / NOUT, items = TO * G;
+    v4f psum = {0.f, 0.f, 0.f, 0.f};
+    auto depthwise = [&](int i) {
+        const float* EA = ring + (i % 3) * n_new * ES;
+        const float* EB = ring + ((i + 1) % 3) * n_new * ES;
+        for (int it = slot; it < items; it += 32) {
+            const int j = it / G, ox = (it - j * G) * NOUT;
+            const int ho = y0 + i * TO + j;
+            if (ho >= y1) break;
+            v2f alo[NOUT], ahi[NOUT];
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n) alo[n] = (v2f){0.f, 0.f}, ahi[n] = (v2f){0.f, 0.f};
+            v4f c[K][NCOL];
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) {
+                const int rr = j + kh;
+                const float* erow = (rr >= NEW ? EB + (rr - NEW) * p.SWi * ES : EA + rr * p.SWi * ES) + ox * ES + lc * 4;
+#pragma unroll
+                for (int q = 0; q < NCOL; ++q) c[kh][q] = *reinterpret_cast<const v4f*>(erow + q * ES);
+            }
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh)
+#pragma unroll
+                for (int kw = 0; kw < K; ++kw) {
+                    const v4f t = tapr[kh * K + kw];
+                    const v2f flo = {t[0], t[1]}, fhi = {t[2], t[3]};
+#pragma unroll
+                    for (int n = 0; n < NOUT; ++n) {
+                        const v4f cv = c[kh][n + kw];
+                        alo[n] = fma2((v2f){cv[0], cv[1]}, flo, alo[n]);
+                        ahi[n] = fma2((v2f){cv[2], cv[3]}, fhi, ahi[n]);
+                    }
+                }
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n) {
+                const int wo = x0 + ox + n;
+                if (wo < p.W) {
+                    const v2f olo = silu2(fma2(alo[n], (v2f){s2[0], s2[1]}, (v2f){h2[0], h2[1]}));
+                    const v2f ohi = silu2(fma2(ahi[n], (v2f){s2[2], s2[3]}, (v2f){h2[2], h2[3]}));
+                    const v4f o = {olo.x, olo.y, ohi.x, ohi.y};
+                    *reinterpret_cast<v4f*>(p.y + (((size_t)b * p.H + ho) * p.W + wo) * 32 + cq) = o;
+                    psum += o;
+                }
+            }
+        }
+    };
+
+    // ---- the walk. Step w: request patch w+1, stem window w (patch w & 1), depthwise of output step w-2, park patch w+1
+    patch_load(0);
+    patch_store(0);
+    __syncthreads();
+    for (int w = 0; w <= NI + 1; ++w) {
+        if (w + 1 <= NI) patch_load(w + 1);
+        if (w <= NI) stem(w);
+        if (w >= 2) depthwise(w - 2);
+        if (w + 1 <= NI) patch_store(w + 1);
+        __syncthreads();
+    }
+    if (p.pool) {
+        v4f* red = reinterpret_cast<v4f*>(ring);
+        red[slot * 8 + lc] = psum;
+        __syncthreads();
+        if (tid < 8) {
+            v4f t4 = red[tid];
+            for (int sl = 1; sl < 32; ++sl) t4 += red[sl * 8 + tid];
+            *reinterpret_cast<v4f*>(p.pool + ((size_t)b * tiles + tile) * 32 + tid * 4) = t4;
+        }
+    }
+}
+
+struct StemRowsGeom {
+    int SWo, SWi, strips, band_rows, bands;
+};
+static bool stem_rows_geom(int H, int W, int mid, int K, int stride, StemRowsGeom& g) {
+    if (mid != 32 || K != 3 || stride != 1 || H < 1 || W < 1) return false;
+    g.strips = cdiv(W, 28);
+    g.SWo = cdiv(cdiv(W, g.strips), 2) * 2;
+    g.SWi = g.SWo + 2;
+    if (2 * g.SWi > 64) return false;
+    g.band_rows = 28;  // measured: 28-row bands beat 14 (fewer pipeline fills) and 56 (too few blocks) on the whole task
+    const int forced = get_option("mbrows_band");
+    if (forced > 0) g.band_rows = forced;
+    g.band_rows = cdiv(g.band_rows, 2) * 2;
+    g.bands = cdiv(H, g.band_rows);
+    return true;
+}
+bool stem_rows_supported(int H, int W, int mid, int K, int stride) {
+    StemRowsGeom g;
+    return stem_rows_geom(H, W, mid, K, stride, g);
+}
+int stem_rows_tiles(int H, int W) {
+    StemRowsGeom g;
+    return stem_rows_geom(H, W, 32, 3, 1, g) ? g.strips * g.bands : 0;
+}
+
+int launch_stem_rows(const float* frames, const float* w1_packed, const float* sc1, const float* sh1, const float* wdw,
+                     const float* sc2, const float* sh2, float* y, float* pool, int B, int FH, int FW, int spad_t,
+                     int spad_l, int H, int W, hipStream_t s) {
+    ORBIT_REQUIRE(frames && w1_packed && sc1 && sh1 && wdw && sc2 && sh2 && y, "stem_rows: null pointer");
+    StemRowsGeom g;
+    ORBIT_REQUIRE(stem_rows_geom(H, W, 32, 3, 1, g), "stem_rows: unsupported shape (H=%d W=%d)", H, W);
+    StemRowsParams p;
+    p.frames = frames, p.w1 = w1_packed, p.sc1 = sc1, p.sh1 = sh1, p.wdw = wdw, p.sc2 = sc2, p.sh2 = sh2, p.y = y, p.pool = pool;
+    p.FH = FH, p.FW = FW, p.spad_t = spad_t, p.spad_l = spad_l, p.H = H, p.W = W;
+    p.SWo = g.SWo, p.SWi = g.SWi, p.strips = g.strips, p.band_rows = g.band_rows, p.bands = g.bands;
+    p.total = g.strips * g.bands * B;
+    const int grid = cdiv(p.total, 8) * 8;
+    const size_t lds = ((size_t)3 * 2 * g.SWi * ROWS_ES + 2 * 3 * 5 * STEM_PW) * sizeof(float);
+    const double pix = (double)B * H * W;
+    const int rec = prof_start("stem_rows", 2.0 * pix * 32 * 27 + 2.0 * pix * 32 * 9,
+                               4.0 * ((double)B * 3 * FH * FW + pix * 32), s);
+    stem_rows_kernel<<<grid, 256, lds, s>>>(p, w1_packed, sc1, sh1);
     prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;

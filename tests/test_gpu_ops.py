@@ -375,10 +375,16 @@ def test_mbconv_front_whole_map(lib, device, Cin, K, stride, HW, B, groups):
     assert (pool.cpu()[:, 0] - want.sum((2, 3))).abs().max().item() < 2e-3 * max(1.0, want.sum((2, 3)).abs().max().item())
 
 
-@pytest.mark.parametrize("FH,FW,mid", [(64, 64, 32), (37, 45, 32), (30, 30, 32), (21, 52, 16)])
-def test_stem_dw_front_fused(lib, device, FH, FW, mid):
+@pytest.mark.parametrize("FH,FW,mid", [(64, 64, 32), (37, 45, 32), (30, 30, 32), (21, 52, 16), (224, 224, 32), (97, 131, 32),
+                                       (6, 5, 32)])
+@pytest.mark.parametrize("rows,band", [(0, 0), (1, 0), (1, 6)])
+def test_stem_dw_front_fused(lib, device, FH, FW, mid, rows, band):
     """stem conv (NCHW frames, 3x3 stride 2, TF-SAME) + BN + SiLU + depthwise 3x3 (SAME) + BN + SiLU in one kernel, the
-    stem output only in LDS, + SE pooling partials - against the unfused PyTorch-CPU sequence (odd sizes, partial tiles)"""
+    stem output only in LDS, + SE pooling partials - against the unfused PyTorch-CPU sequence (odd sizes, partial tiles).
+    rows = 0: the tiled MFMA form (csrc/mbconv.hip); rows = 1: the row-streaming form (csrc/mbconv_rows.hip stem_rows_kernel,
+    32 channels only), which must also equal the library's stem + depthwise kernel pair bit for bit."""
+    if rows and mid != 32:
+        pytest.skip("the row-streaming stem serves the 32-channel EfficientNet stem only")
     g = torch.Generator().manual_seed(FH * 100 + FW + mid)
     B = 3
     x = torch.randn(B, 3, FH, FW, generator=g)
@@ -391,17 +397,36 @@ def test_stem_dw_front_fused(lib, device, FH, FW, mid):
     xp = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
     e = F.silu(F.conv2d(xp, ws, None, 2) * s1[None, :, None, None] + h1[None, :, None, None])
     want = F.silu(F.conv2d(e, wd, None, 1, 1, 1, mid) * s2[None, :, None, None] + h2[None, :, None, None])
-    tiles = -(-H // 8) * -(-W // 8)
-    y = torch.full((B, H, W, mid), float("nan"), device=device)
-    pool = torch.full((B, tiles, mid), float("nan"), device=device)
     dev = [t.to(device).contiguous() for t in (x, ws, s1, h1, wd, s2, h2)]
-    _lib.check(lib.orbit_op_stem_dw_front(*[_lib.dptr(t) for t in dev], _lib.dptr(y), _lib.dptr(pool), B, FH, FW, ph // 2,
-                                          pw // 2, H, W, mid, 1, 1, H, W, _st()), "stem_dw_front")
-    torch.cuda.synchronize()
+    prev = lib.orbit_get_option(b"mbconv_rows")
+    lib.orbit_set_option(b"mbconv_rows", rows)
+    lib.orbit_set_option(b"mbrows_band", band)
+    try:
+        tiles = lib.orbit_op_stem_dw_front_partials(H, W, mid)
+        if not rows:
+            assert tiles == -(-H // 8) * -(-W // 8)
+        y = torch.full((B, H, W, mid), float("nan"), device=device)
+        pool = torch.full((B, tiles, mid), float("nan"), device=device)
+        _lib.check(lib.orbit_op_stem_dw_front(*[_lib.dptr(t) for t in dev], _lib.dptr(y), _lib.dptr(pool), B, FH, FW, ph // 2,
+                                              pw // 2, H, W, mid, 1, 1, H, W, _st()), "stem_dw_front")
+        torch.cuda.synchronize()
+    finally:
+        lib.orbit_set_option(b"mbrows_band", 0)
+        lib.orbit_set_option(b"mbconv_rows", prev)
     got = nchw(y.cpu())
     assert not torch.isnan(got).any() and not torch.isnan(pool).any()
     assert (got - want).abs().max().item() < 5e-5
     assert (pool.cpu().sum(1) - want.sum((2, 3))).abs().max().item() < 2e-3 * max(1.0, want.sum((2, 3)).abs().max().item())
+    if rows and FW >= 8:  # the unfused pair of the same library (direct stem kernel + depthwise): identical bits
+        ex = torch.empty(B, H, W, mid, device=device)
+        y2 = torch.empty(B, H, W, mid, device=device)
+        _lib.check(lib.orbit_op_conv2d(_lib.dptr(dev[0]), 1, _lib.dptr(dev[1]), _lib.dptr(ex), _lib.dptr(dev[2]),
+                                       _lib.dptr(dev[3]), None, None, B, FH, FW, 3, mid, 3, 3, 2, ph // 2, pw // 2, H, W, 2, 0,
+                                       _st()), "conv2d (stem)")
+        _lib.check(lib.orbit_op_dwconv2d(_lib.dptr(ex), _lib.dptr(dev[4]), _lib.dptr(y2), _lib.dptr(dev[5]), _lib.dptr(dev[6]),
+                                         B, H, W, mid, 3, 1, 1, 1, H, W, 2, _st()), "dwconv2d")
+        torch.cuda.synchronize()
+        assert (y.cpu() - y2.cpu()).abs().max().item() < 1e-5  # same tap order; the FMA pairing differs
 
 
 @pytest.mark.parametrize("Cin,Cout,K,HW,gated", [(256, 128, 3, 15, False), (512, 512, 3, 6, False), (1152, 192, 1, 7, True),
