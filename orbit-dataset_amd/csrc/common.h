@@ -90,6 +90,10 @@ size_t conv_packed_floats(int Cin, int Cout, int KH, int KW, int x_nchw);
 int conv_pack_weights(const float* w_oihw, float* w_packed, int Cin, int Cout, int KH, int KW,
                       int x_nchw, hipStream_t s);
 int launch_conv(const ConvDesc& d, hipStream_t s);
+// narrow pointwise projections (Cout <= 32, high-resolution maps) as an HBM stream without an LDS stage for the pixels
+// (csrc/pw_narrow.hip; option pw_narrow); launch_conv routes to it
+bool pw_narrow_supported(const ConvDesc& d);
+int launch_pw_narrow(const ConvDesc& d, hipStream_t s);
 bool conv_prof_enabled();
 // per-launch HIP-event records of orbit_prof_* (no-ops returning -1 while profiling is off)
 int prof_start(const char* name, double flops, double bytes, hipStream_t s);

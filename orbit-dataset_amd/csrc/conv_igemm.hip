@@ -761,6 +761,7 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     ORBIT_REQUIRE(!(d.pool2 && d.residual), "conv: pool2 cannot be combined with a residual input");
     ORBIT_REQUIRE(d.Cout % 4 == 0, "conv: Cout %% 4 != 0 (Cout=%d): the epilogue writes float4 rows", d.Cout);
     const bool pw = !d.x_nchw && d.KH == 1 && d.KW == 1 && d.pad_t == 0 && d.pad_l == 0;
+    if (pw && pw_narrow_supported(d)) return launch_pw_narrow(d, s);
     ORBIT_REQUIRE(!d.gate || (!d.x_nchw && !d.pool2), "conv: the squeeze-excite gate needs the NHWC path without fused pooling");
     const ConvPackGeom g = conv_pack_geom(d.Cin, d.Cout, d.KH, d.KW, d.x_nchw);
     ConvParams p;

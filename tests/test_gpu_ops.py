@@ -469,6 +469,34 @@ def test_conv_random_shapes(lib, device, tile):
         lib.orbit_set_option(b"conv_tile", 0)
 
 
+@pytest.mark.parametrize("Cin,Cout,HW,gated,res,act", [(32, 16, (112, 112), True, False, 0), (96, 24, (56, 56), True, False, 0),
+                                                       (96, 24, (56, 56), False, True, 0), (32, 16, (32, 32), False, False, 2),
+                                                       (96, 32, (64, 48), True, True, 1), (32, 20, (40, 32), False, True, 0)])
+def test_conv_pointwise_narrow(lib, device, Cin, Cout, HW, gated, res, act):
+    """csrc/pw_narrow.hip: the narrow high-resolution projections as an HBM stream (pixels as the MFMA B operand, 16-byte
+    stores of 4 consecutive channels). Against the reference and BIT-IDENTICAL to the implicit-GEMM kernel it replaces."""
+    H, W = HW
+    g = torch.Generator().manual_seed(Cin + Cout + H)
+    B = 3
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    kw = dict(scale=torch.rand(Cout, generator=g) + 0.5, shift=torch.randn(Cout, generator=g) * 0.1,
+              residual=torch.randn(B, Cout, H, W, generator=g) if res else None,
+              gate=torch.rand(B, Cin, generator=g) if gated else None, act=act)
+    want = ref_conv(x, w, 1, 0, 0, H, W, **kw)
+    prev = lib.orbit_get_option(b"pw_narrow")
+    try:
+        lib.orbit_set_option(b"pw_narrow", 1)
+        got = run_conv(lib, device, x, w, 1, 0, 0, H, W, **kw)
+        lib.orbit_set_option(b"pw_narrow", 0)
+        igemm = run_conv(lib, device, x, w, 1, 0, 0, H, W, **kw)
+    finally:
+        lib.orbit_set_option(b"pw_narrow", prev)
+    assert not torch.isnan(got).any()
+    assert (got - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+    assert torch.equal(got, igemm)
+
+
 def _conv_random_cases(lib, device, rnd):
     for case in range(40):
         Cin = rnd.choice([4, 8, 12, 16, 24, 40, 48, 64, 80, 96, 144, 160])
