@@ -220,39 +220,65 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restri
     }
 }
 
-// partial[chunk][tap][c] = sum over the chunk's output pixels of dy * x(tap); block = (chunk of rows, group of G quads)
-template <int K>
+// partial[chunk][tap][c] = sum over the chunk's output pixels of dy * x(tap); block = (chunk of OUTPUT ROWS, group of G quads).
+// A thread (channel quad, row lane) walks whole output rows, NB output columns at a time: per tap row it loads the
+// (NB-1)*S + K input columns those NB outputs touch ONCE and reuses them across the K taps and the NB outputs -
+// (NB + K*((NB-1)*S + K)) / NB loads per output (11 for 5x5 / stride 1) instead of 1 + K*K (26): the first form of this
+// kernel (one output pixel per step, every tap a load behind its own bounds branch, 64-bit div / mod per pixel) was bound by
+// the vector L1 and by address arithmetic (287 us per launch on the 5x5 layers of efficientnet_b0 @224). All index math is
+// 32-bit; out-of-image taps read a clamped address and are zeroed by a select. Fixed summation order (deterministic).
+template <int K, int S, int NB>
 __global__ __launch_bounds__(256) void dwconv_wgrad_partial_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ dy,
                                                                    float* __restrict__ partial, int B, int H, int W,
-                                                                   int C4, int stride, int pad_t, int pad_l, int Ho,
-                                                                   int Wo, int rows_per_block, int G, int R) {
+                                                                   int C4, int pad_t, int pad_l, int Ho, int Wo,
+                                                                   int rows_per_block, int G, int R) {
+    constexpr int NW = (NB - 1) * S + K;
     __shared__ f32x4 red[256];
     const int tid = threadIdx.x;
     const int rl = tid / G, qi = tid - rl * G, q = blockIdx.y * G + qi;
     const bool active = rl < R && q < C4;
-    const size_t M = (size_t)B * Ho * Wo;
-    const size_t r0 = (size_t)blockIdx.x * rows_per_block;
-    const size_t r1 = r0 + rows_per_block < M ? r0 + rows_per_block : M;
+    const int total_rows = B * Ho;
+    const int row0 = blockIdx.x * rows_per_block;
+    const int row1 = row0 + rows_per_block < total_rows ? row0 + rows_per_block : total_rows;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[K * K];
 #pragma unroll
-    for (int t = 0; t < K * K; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < K * K; ++t) acc[t] = zero;
     if (active) {
-        for (size_t m = r0 + rl; m < r1; m += R) {
-            const int wo = (int)(m % Wo);
-            const size_t t2 = m / Wo;
-            const int ho = (int)(t2 % Ho);
-            const int b = (int)(t2 / Ho);
-            const f32x4 d = reinterpret_cast<const f32x4*>(dy)[m * C4 + q];
+        const f32x4* x4 = reinterpret_cast<const f32x4*>(x) + q;
+        const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy) + q;
+        for (int row = row0 + rl; row < row1; row += R) {
+            const int b = row / Ho, ho = row - b * Ho;
+            const f32x4* dyr = dy4 + (size_t)row * Wo * C4;
+            const f32x4* xb = x4 + (size_t)b * H * W * C4;
+            const int hi0 = ho * S - pad_t;
+            for (int wo0 = 0; wo0 < Wo; wo0 += NB) {
+                f32x4 d[NB];
 #pragma unroll
-            for (int kh = 0; kh < K; ++kh) {
-                const int hi = ho * stride - pad_t + kh;
-                if ((unsigned)hi >= (unsigned)H) continue;
+                for (int j = 0; j < NB; ++j) {
+                    const bool ok = wo0 + j < Wo;
+                    const f32x4 v = dyr[(size_t)(ok ? wo0 + j : 0) * C4];
+                    d[j] = ok ? v : zero;
+                }
+                const int wi0 = wo0 * S - pad_l;
 #pragma unroll
-                for (int kw = 0; kw < K; ++kw) {
-                    const int wi = wo * stride - pad_l + kw;
-                    if ((unsigned)wi >= (unsigned)W) continue;
-                    acc[kh * K + kw] += d * reinterpret_cast<const f32x4*>(x)[(((size_t)b * H + hi) * W + wi) * C4 + q];
+                for (int kh = 0; kh < K; ++kh) {
+                    const int hi = hi0 + kh;
+                    if ((unsigned)hi >= (unsigned)H) continue;   // block-divergent only at the image's top / bottom rows
+                    const f32x4* xr = xb + (size_t)hi * W * C4;
+                    f32x4 win[NW];
+#pragma unroll
+                    for (int u = 0; u < NW; ++u) {
+                        const int wi = wi0 + u;
+                        const bool ok = (unsigned)wi < (unsigned)W;
+                        const f32x4 v = xr[(size_t)(ok ? wi : 0) * C4];
+                        win[u] = ok ? v : zero;
+                    }
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                        for (int j = 0; j < NB; ++j) acc[kh * K + kw] += d[j] * win[j * S + kw];
                 }
             }
         }
@@ -370,16 +396,24 @@ int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scrat
     ORBIT_REQUIRE(C % 4 == 0 && (K == 3 || K == 5), "dwconv_wgrad: C %% 4 != 0 or K not in {3,5}");
     int G, R, yg;
     dw_layout(C, G, R, yg);
-    const int chunks = dwconv_wgrad_chunks(B, Ho, Wo, C);
-    const size_t M = (size_t)B * Ho * Wo;
-    const int rows = (int)((M + chunks - 1) / chunks);
+    ORBIT_REQUIRE(stride == 1 || stride == 2, "dwconv_wgrad: stride %d", stride);
+    ORBIT_REQUIRE((long long)B * H * W * (C / 4) < (1ll << 31), "dwconv_wgrad: tensor too large for 32-bit pixel indices");
+    // chunks of whole output rows; never more blocks than the scratch was sized for (dwconv_wgrad_chunks), and at least one
+    // row per row lane
+    const int total_rows = B * Ho;
+    int chunks = dwconv_wgrad_chunks(B, Ho, Wo, C);
+    if (chunks > cdiv(total_rows, R)) chunks = cdiv(total_rows, R);
+    const int rows = cdiv(total_rows, chunks);
+    chunks = cdiv(total_rows, rows);
     dim3 grid(chunks, yg);
-    if (K == 3)
-        dwconv_wgrad_partial_kernel<3><<<grid, 256, 0, s>>>(x, dy, scratch, B, H, W, C / 4, stride, pad_t, pad_l, Ho, Wo,
-                                                           rows, G, R);
-    else
-        dwconv_wgrad_partial_kernel<5><<<grid, 256, 0, s>>>(x, dy, scratch, B, H, W, C / 4, stride, pad_t, pad_l, Ho, Wo,
-                                                           rows, G, R);
+#define ORBIT_DWW(KK, SS, NBB)                                                                                          \
+    dwconv_wgrad_partial_kernel<KK, SS, NBB><<<grid, 256, 0, s>>>(x, dy, scratch, B, H, W, C / 4, pad_t, pad_l, Ho, Wo, \
+                                                                  rows, G, R)
+    if (K == 3 && stride == 1) ORBIT_DWW(3, 1, 4);
+    else if (K == 3) ORBIT_DWW(3, 2, 4);
+    else if (stride == 1) ORBIT_DWW(5, 1, 4);
+    else ORBIT_DWW(5, 2, 2);
+#undef ORBIT_DWW
     ORBIT_LAUNCH_CHECK();
     dwconv_wgrad_reduce_kernel<<<cdiv(K * K * C, 16), 256, 0, s>>>(scratch, chunks, K * K, C, dw);
     ORBIT_LAUNCH_CHECK();
