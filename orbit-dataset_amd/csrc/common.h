@@ -184,8 +184,10 @@ size_t se_bwd_scratch_floats(int B, int C, int R);
 int launch_se_gate_backward(const float* dxg, const float* x, const float* pooled, const float* gate, const float* w1,
                             const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1,
                             float* dw2, float* db2, float* scratch, int B, int HW, int C, int R, hipStream_t s);
+// flip_scratch (K*K*C floats, optional): stride-1 layers then run as a FORWARD depthwise convolution of dy with the flipped
+// taps through the LDS-patch kernels of csrc/ops.hip instead of the per-pixel gather
 int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, int H, int W, int C, int K, int stride,
-                        int pad_t, int pad_l, int Ho, int Wo, hipStream_t s);
+                        int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, float* flip_scratch = nullptr);
 size_t dwconv_wgrad_scratch_floats(int B, int Ho, int Wo, int C, int K);
 int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int C, int K,
                         int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s);

@@ -533,8 +533,9 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                 ORBIT_REQUIRE(grad_slot[src] < 0, "extractor_backward: unexpected fan-out into a depthwise convolution");
                 SLOT_OR_FAIL(k);
                 grad_slot[src] = k;
+                // wgrad_scratch is free again here (the weight-gradient launches above are earlier on the stream)
                 rc = launch_dwconv_dgrad(slot_ptr(kdy), fe->d_packed + o.packed_off, slot_ptr(k), B, o.H, o.W, o.Cin, o.KH,
-                                         o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+                                         o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s, wgrad_scratch);
             }
             release(kdy);
         } else {  // OP_CONV

@@ -40,6 +40,7 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"mbrows_band", "ORBIT_MBROWS_BAND", 0, false},
                              {"stem_rows", "ORBIT_STEM_ROWS", 1, false},
                              {"pw_narrow", "ORBIT_PW_NARROW", 0, false},
+                             {"dw_dgrad_forward", "ORBIT_DW_DGRAD_FORWARD", 1, false},
                              {"graph", "ORBIT_GRAPH", 2, false},
                              {"train_graph", "ORBIT_TRAIN_GRAPH", 0, false},
                              {"stem_direct", "ORBIT_STEM_DIRECT", 1, false},

@@ -376,8 +376,27 @@ int launch_se_gate_backward(const float* dxg, const float* x, const float* poole
     return ORBIT_OK;
 }
 
+// [K][K][C] taps -> taps rotated by 180 degrees
+__global__ __launch_bounds__(256) void dwconv_flip_kernel(const float* __restrict__ w, float* __restrict__ wf, int KK, int C) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < KK * C) {
+        const int tap = i / C, c = i - tap * C;
+        wf[(KK - 1 - tap) * C + c] = w[i];
+    }
+}
+
 int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, int H, int W, int C, int K, int stride,
-                        int pad_t, int pad_l, int Ho, int Wo, hipStream_t s) {
+                        int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, float* flip_scratch) {
+    if (stride == 1 && flip_scratch != nullptr && get_option("dw_dgrad_forward")) {
+        // dx[h][w] = sum dy[h + pad_t - kh][w + pad_l - kw] w[kh][kw] = a forward depthwise conv of dy with the rotated
+        // taps and padding K-1-pad: the LDS-patch forward kernels (35-60 us on these layers) replace the gather below
+        // (180-200 us: K*K loads of dy and K*K loads of w per pixel, each behind its bounds branch)
+        dwconv_flip_kernel<<<cdiv(K * K * C, 256), 256, 0, s>>>(w_khwc, flip_scratch, K * K, C);
+        ORBIT_LAUNCH_CHECK();
+        return launch_dwconv_se(dy, flip_scratch, dx, nullptr, nullptr, nullptr, B, Ho, Wo, C, K, 1, K - 1 - pad_t,
+                                K - 1 - pad_l, H, W, ORBIT_ACT_NONE, s);
+    }
+
     ORBIT_REQUIRE(C % 4 == 0 && (K == 3 || K == 5), "dwconv_dgrad: C %% 4 != 0 or K not in {3,5}");
     const int grid = grid_for((size_t)B * H * W * (C / 4));
     ORBIT_REQUIRE((unsigned long long)((size_t)B * H * W * (C / 4)) < (1ull << 32), "tensor too large for the 32-bit index arithmetic of this kernel");
@@ -437,7 +456,7 @@ int orbit_op_dwconv2d_backward(const float* x, const float* w, const float* dy, 
     ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), (npack + nscr) * sizeof(float), s));
     int rc = dwconv_pack_weights(w, tmp, C, K, s);
     if (rc == ORBIT_OK && dx)
-        rc = launch_dwconv_dgrad(dy, tmp, dx, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, s);
+        rc = launch_dwconv_dgrad(dy, tmp, dx, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, s, tmp + npack);
     if (rc == ORBIT_OK && dw)
         rc = launch_dwconv_wgrad(x, dy, dw, tmp + npack, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, s);
     (void)hipFreeAsync(tmp, s);
