@@ -48,7 +48,8 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     const int r1 = min(M, r0 + rows_per_block);
     f32x4 s = {0.f, 0.f, 0.f, 0.f}, ss = {0.f, 0.f, 0.f, 0.f};
     if (active) {
-        for (int r = r0 + rl; r < r1; r += R) {
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += R) {  // 4 rows' loads in flight (rolled: one HBM round trip per row and thread)
             const f32x4 v = *reinterpret_cast<const f32x4*>(y + (size_t)r * C + q * 4);
             s += v;
             ss += v * v;
@@ -189,7 +190,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __rest
         if (act == ORBIT_ACT_SILU) {
             sc = *reinterpret_cast<const f32x4*>(scale + q * 4), sh = *reinterpret_cast<const f32x4*>(shift + q * 4);
         }
-        for (int r = r0 + rl; r < r1; r += R) {
+#pragma unroll 2
+        for (int r = r0 + rl; r < r1; r += R) {  // two rows' loads in flight
             const size_t o = (size_t)r * C + q * 4;
             f32x4 g = *reinterpret_cast<const f32x4*>(dout + o);
             const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
