@@ -1,0 +1,50 @@
+"""bench.py's output contract on a real GPU: ONE JSON line with BASELINE.json's metric on the headline workload, the
+`roofline` block of the dominant kernel and the `cpu_baseline` block of the oracle, behind the parity gates."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, timeout=900):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, "bench.py must print exactly one line on stdout, got %d" % len(lines)
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract():
+    d = _run(["--steps", "3", "--warmup", "1"])
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert d["metric"] == base["metric"] and d["unit"] == "query frames/s"
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f32" and d["data"] == "synthetic"
+    assert "efficientnet_b0" in d["config"]["workload"] and "224x224" in d["config"]["workload"]
+    assert "model" not in d["config"]
+    # 200 query frames per task: value and ms_per_step describe the same measurement
+    assert abs(d["value"] - 200.0 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert r["peak"] > 0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.0 < r["frac"] < 1.0
+    assert "traffic" in r and (r["traffic"] is None or r["traffic"] > 0) and r["traffic_source"]
+    assert d["parity_gate"]["max_abs_dfeature_vs_transformers"] <= d["parity_gate"]["tol"]
+    cb = d["cpu_baseline"]
+    assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
+    assert cb["max_abs_dlogit_vs_gpu"] <= 1e-3 and cb["argmax_identical"] is True
+    assert d["median_task_ms"] > 0 and d["value_overlap_off"] > 0
+
+
+def test_bench_other_modes_run():
+    d = _run(["--workload", "resnet18_84", "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
+    assert "resnet18" in d["config"]["workload"] and d["value"] > 0 and "cpu_baseline" not in d or d["cpu_baseline"] is None
+    t = _run(["--mode", "lite_train", "--workload", "resnet18_84", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
+    assert "LITE" in t["config"]["workload"] and t["ms_per_step"] > 0
