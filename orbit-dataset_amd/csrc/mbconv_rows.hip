@@ -388,11 +388,13 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
 // BN + SiLU + squeeze-excite pooling partials with the same walk (timm tf_efficientnet_b0: conv_stem -> bn1 -> act ->
 // DepthwiseSeparableConv.conv_dw -> bn1 -> act, reached from the reference's model/feature_extractors.py:39-43). Unfused, the
 // stem's 112x112x32 output makes an HBM round trip (321 MB written + read per 200 frames, the largest tensor of the net).
-// The "expand" stage is a direct convolution on the VALU: lane = stem pixel of the window (one window = 2 rows x <= 30
-// columns <= 64 pixels), wave = 8 of the 32 output channels. A lane reads its 27 input taps once from an LDS frame patch
-// (5 frame rows x 61 columns x 3 planes, double-buffered, refilled one window ahead through registers); the filter taps of
-// the wave's channels are wave-uniform and arrive in SGPRs (scalar loads of the [32][32]-packed filter): 27 FMAs per
-// channel with a scalar operand, no LDS or VGPR traffic for weights. Summation order (ci, kh, kw).
+// The "expand" stage is an im2col GEMM on the matrix cores (one window = 2 stem rows x <= 30 columns <= 64 pixels, 28
+// taps, 32 channels: v_mfma_f32_16x16x4_f32), its A operand gathered from an LDS frame patch (5 frame rows x 61 columns x
+// 3 planes, double-buffered, refilled one window ahead through registers), its B operand (the [32][32]-packed filter) in LDS
+// in lane order. (First form: a direct VALU convolution, lane = pixel, wave = 8 channels whose 27 taps arrived as scalar
+// loads in SGPRs - 108 packed FMAs with scalar operands per wave and step were 5 k of a step's 8 k cycles: 245 us per 200
+// frames against 225 us for this form. With the filter in registers the MFMA form needs 182 VGPRs = two blocks per CU and
+// loses its advantage; at 168 it runs three.)
 struct StemRowsParams {
     const float* frames;  // [B][3][FH][FW]
     const float* w1;      // [32][32]: channel-major, tap ci*9 + kh*3 + kw (stem_pack_weights)
@@ -462,58 +464,64 @@ __global__ __launch_bounds__(256, 3) void stem_rows_kernel(const StemRowsParams 
         }
     };
 
-    // ---- stem stage constants: lane = window pixel
-    const int f = lane < n_new ? lane : n_new - 1;
-    const int s_rl = f / p.SWi, s_col = f - s_rl * p.SWi;
-    const bool s_colok = (unsigned)(c_first + s_col) < (unsigned)p.W;
-    // wave-uniform addresses read through the CONSTANT address space (the filter is never written while the kernel runs):
-    // the eight channels' taps and BatchNorm vectors arrive as scalar loads in SGPRs
-    typedef const float __attribute__((address_space(4))) cfloat;
-    const cfloat* w_wave0 = (const cfloat*)(w1g + (size_t)(wave * 8) * 32);
-    const cfloat* s1w = (const cfloat*)(sc1g + wave * 8);
-    const cfloat* h1w = (const cfloat*)(sh1g + wave * 8);
+    // ---- stem stage on the matrix cores: per window an im2col GEMM [<= 64 pixels][28 taps] x [28][32 channels] with
+    // v_mfma_f32_16x16x4_f32. Wave w owns pixels 16w .. 16w+15 and both 16-channel halves: 7 k-steps x 2 MFMAs. A lane's
+    // A element of step s is ONE patch read (pixel l % 16, tap 4s + l / 16; tap 27 is padding with a zero weight); its B
+    // elements (the filter) sit in LDS in lane order ([14][64] floats) - registers decide the blocks per CU here.
+    using f32x4 = __attribute__((ext_vector_type(4))) float;
+    const int l15 = lane & 15, lq = lane >> 4;
+    float* Wl = patch + 2 * PATCH;                   // [2 halves][7 steps][64 lanes]
+    for (int i = tid; i < 14 * 64; i += 256) {
+        const int ln = i & 63, hs = i >> 6, h = hs / 7, st = hs - h * 7;
+        const int k = 4 * st + (ln >> 4);
+        Wl[i] = k < 27 ? w1g[(16 * h + (ln & 15)) * 32 + k] : 0.f;
+    }
+    int a_base;          // patch offset of this lane's A pixel
+    {
+        const int fa = wave * 16 + l15 < n_new ? wave * 16 + l15 : n_new - 1;
+        const int rl = fa / p.SWi, col = fa - rl * p.SWi;
+        a_base = (2 * rl) * STEM_PW + 2 * col;
+    }
+    float s1c[2], h1c[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) s1c[h] = sc1g[16 * h + l15], h1c[h] = sh1g[16 * h + l15];
+    // output element r of a lane: pixel 16w + 4 lq + r (C/D layout of the 16x16 MFMA: column = l15, row = 4 lq + r)
+    unsigned o_colok = 0, o_rl = 0, o_inwin = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int fo = wave * 16 + 4 * lq + r;
+        const int rl = fo / p.SWi, col = fo - rl * p.SWi;
+        if (fo < n_new) o_inwin |= 1u << r;
+        if ((unsigned)(c_first + col) < (unsigned)p.W) o_colok |= 1u << r;
+        o_rl |= (unsigned)(rl & 1) << r;
+    }
     auto stem = [&](int w) {
-        const cfloat* w_wave = w_wave0;
-        asm volatile("" : "+s"(w_wave));  // keep the 216 tap loads inside the step (hoisted, they become 216 live registers)
-        const float* P = patch + (w & 1) * PATCH + (2 * s_rl) * STEM_PW + 2 * s_col;
-        float xin[27];  // tap ci*9 + kh*3 + kw: the packed filter's order
+        const float* P = patch + (w & 1) * PATCH + a_base;
+        f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int ci = 0; ci < 3; ++ci)
+        for (int st = 0; st < 7; ++st) {
+            const int k = 4 * st + lq < 27 ? 4 * st + lq : 0;          // tap of this lane in step st
+            const int ci = k / 9, kh = (k - ci * 9) / 3, kw = k - ci * 9 - kh * 3;
+            const float av = P[(ci * 5 + kh) * STEM_PW + kw];
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wl[st * 64 + lane], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wl[(7 + st) * 64 + lane], acc1, 0, 0, 0);
+        }
+        const int hi0 = r_first + NEW * w;
+        const unsigned rowok = ((unsigned)hi0 < (unsigned)p.H ? 1u : 0u) | ((unsigned)(hi0 + 1) < (unsigned)p.H ? 2u : 0u);
+        float* E = ring + ((w % 3) * n_new + wave * 16 + 4 * lq) * ES + l15;
 #pragma unroll
-            for (int kh = 0; kh < 3; ++kh)
+        for (int r = 0; r < 4; r += 2) {
+            const v2f v0 = silu2(fma2((v2f){acc0[r], acc0[r + 1]}, (v2f){s1c[0], s1c[0]}, (v2f){h1c[0], h1c[0]}));
+            const v2f v1 = silu2(fma2((v2f){acc1[r], acc1[r + 1]}, (v2f){s1c[1], s1c[1]}, (v2f){h1c[1], h1c[1]}));
 #pragma unroll
-                for (int kw = 0; kw < 3; ++kw) xin[ci * 9 + kh * 3 + kw] = P[(ci * 5 + kh) * STEM_PW + kw];
-        const bool ok = s_colok && (unsigned)(r_first + NEW * w + s_rl) < (unsigned)p.H;
-        // four independent packed accumulators (channel pairs); per input plane the 8 x 9 taps of the wave's channels are
-        // 72 SGPRs - one channel at a time was one 27-long dependent FMA chain behind every scalar-load round trip
-        v2f acc[4];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] = (v2f){0.f, 0.f};
-#pragma unroll
-        for (int ci = 0; ci < 3; ++ci) {
-#pragma unroll
-            for (int t9 = 0; t9 < 9; ++t9) {
-                const int k = ci * 9 + t9;
-                const v2f xv = {xin[k], xin[k]};
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    acc[q] = fma2(xv, (v2f){w_wave[(2 * q) * 32 + k], w_wave[(2 * q + 1) * 32 + k]}, acc[q]);
+            for (int u = 0; u < 2; ++u) {
+                const int rr = r + u;
+                const bool ok = ((o_colok >> rr) & 1u) && ((rowok >> ((o_rl >> rr) & 1u)) & 1u);
+                if ((o_inwin >> rr) & 1u) {
+                    E[rr * ES] = ok ? (u ? v0.y : v0.x) : 0.f;
+                    E[rr * ES + 16] = ok ? (u ? v1.y : v1.x) : 0.f;
+                }
             }
-        }
-        float o[8];
-#pragma unroll
-        for (int q = 0; q < 4; ++q) o[2 * q] = acc[q].x, o[2 * q + 1] = acc[q].y;
-        v4f r0, r1;
-#pragma unroll
-        for (int j = 0; j < 8; j += 2) {
-            const v2f val = silu2(fma2((v2f){o[j], o[j + 1]}, (v2f){s1w[j], s1w[j + 1]}, (v2f){h1w[j], h1w[j + 1]}));
-            if (j < 4) r0[j] = ok ? val.x : 0.f, r0[j + 1] = ok ? val.y : 0.f;
-            else r1[j - 4] = ok ? val.x : 0.f, r1[j - 3] = ok ? val.y : 0.f;
-        }
-        if (lane < n_new) {
-            float* E = ring + ((w % 3) * n_new + lane) * ES + wave * 8;
-            *reinterpret_cast<v4f*>(E) = r0;
-            *reinterpret_cast<v4f*>(E + 4) = r1;
         }
     };
 
@@ -631,7 +639,7 @@ int launch_stem_rows(const float* frames, const float* w1_packed, const float* s
     p.SWo = g.SWo, p.SWi = g.SWi, p.strips = g.strips, p.band_rows = g.band_rows, p.bands = g.bands;
     p.total = g.strips * g.bands * B;
     const int grid = cdiv(p.total, 8) * 8;
-    const size_t lds = ((size_t)3 * 2 * g.SWi * ROWS_ES + 2 * 3 * 5 * STEM_PW) * sizeof(float);
+    const size_t lds = ((size_t)3 * 2 * g.SWi * ROWS_ES + 2 * 3 * 5 * STEM_PW + 14 * 64) * sizeof(float);
     const double pix = (double)B * H * W;
     const int rec = prof_start("stem_rows", 2.0 * pix * 32 * 27 + 2.0 * pix * 32 * 9,
                                4.0 * ((double)B * 3 * FH * FW + pix * 32), s);
