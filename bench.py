@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """Throughput of the episodic few-shot hot path on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run, one rank/GPU)
+    python bench.py --gpus N --steps K --warmup W        (N>1: one rank per GPU. Launched by torch.distributed.run it reads
+                                                          RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*; launched plainly it
+                                                          re-executes itself under torch.distributed.run with N ranks. A
+                                                          line is only ever printed with n_gpus == --gpus)
 
 One step = one synthetic ORBIT-shaped task through SingleStepFewShotRecogniser.personalise() + predict() with
 the support/query frames already resident in HBM (5-way, 5 shots x 8 frames = 200 support frames, 200 query
@@ -331,6 +334,30 @@ def cpu_baseline(workload, model, train=False, way=WAY):
             }, task, logits
 
 
+def rccl_check(lib, rank, world, backend, dist, device):
+    """The C-ABI's own RCCL communicator (csrc/comm.hip orbit_comm_init / orbit_allreduce_sum - the carrier a non-PyTorch
+    host uses for the prototype / gradient exchange) all-reduces a ones vector over all ranks: the result must be `world`
+    in every element. Returns that sum (None when ranks share a GPU under the gloo self-test: RCCL refuses that)."""
+    if backend != "nccl":
+        return None
+    uid = ctypes.create_string_buffer(128)
+    if rank == 0:
+        _lib.check(lib.orbit_comm_unique_id(uid), "orbit_comm_unique_id")
+    if world > 1:
+        box = [bytes(uid.raw)]
+        dist.broadcast_object_list(box, src=0)
+        uid = ctypes.create_string_buffer(box[0], 128)
+    _lib.check(lib.orbit_comm_init(rank, world, uid), "orbit_comm_init")
+    ones = torch.ones(6405, device=device)  # the prototype payload of a 5-way, D = 1280 task
+    _lib.check(lib.orbit_allreduce_sum(_lib.dptr(ones), ones.numel(), _lib.stream_handle()), "orbit_allreduce_sum")
+    torch.cuda.synchronize()
+    lo, hi = float(ones.min().item()), float(ones.max().item())
+    lib.orbit_comm_destroy()
+    if lo != hi or lo != float(world):
+        raise SystemExit("bench.py: orbit_allreduce_sum over %d ranks returned [%g, %g], expected %d" % (world, lo, hi, world))
+    return int(lo)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -348,15 +375,29 @@ def main():
     ap.add_argument("--batch-size", type=int, default=256, help="clips per extractor call (reference --batch_size)")
     args = ap.parse_args()
 
+    backend = os.environ.get("ORBIT_BENCH_BACKEND", "nccl")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (this form used to run ONE rank
+        # and print an N = 1 line). Same command line the driver uses for N > 1.
+        import socket
+        import subprocess
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if args.gpus != world:  # never a line whose n_gpus differs from what was asked for
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d; no line printed" % (args.gpus, world))
     _lib.require_gpu()
     # one rank per GPU; ORBIT_BENCH_BACKEND=gloo lets several ranks share a GPU (self-test of the N>1 path on a
-    # one-GPU box — RCCL refuses two ranks on one device)
-    backend = os.environ.get("ORBIT_BENCH_BACKEND", "nccl")
+    # one-GPU box — RCCL refuses two ranks on one device); the line then says so (`ranks_share_gpus`)
+    if backend == "nccl" and world > torch.cuda.device_count():
+        raise SystemExit("bench.py: --gpus %d but only %d GPU(s) visible (one rank per GPU over RCCL); no line printed"
+                         % (world, torch.cuda.device_count()))
     dev_index = local_rank if backend == "nccl" else local_rank % torch.cuda.device_count()
     torch.cuda.set_device(dev_index)
     device = torch.device("cuda", dev_index)
@@ -445,6 +486,8 @@ def main():
     for i in range(args.warmup * per_step):
         run_step(model, tasks[i % len(tasks)])
     elapsed, correct, issued = loop(args.steps)  # the timed region behind `value`
+    if train and getattr(run_step.bucket, "p2p", None) is not None:
+        run_step.bucket.p2p.raise_on_error()  # (the loop ended on a barrier + synchronize: every exchange has completed)
 
     def per_task_events(steps):
         """SURVEY §8(d): per-task HIP-event time (events on the caller's stream before personalise() and after predict();
@@ -483,6 +526,8 @@ def main():
         elapsed = float(t.item())
         dist.all_reduce(correct)  # frame-accuracy counts: the only exchange of the task-parallel form
         torch.cuda.synchronize()
+
+    rccl_ranks = rccl_check(lib, rank, world, backend, dist, device)  # every rank: it is a collective
 
     ms, fl, n = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
     _lib.check(lib.orbit_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n)), "orbit_prof_collect")
@@ -542,6 +587,7 @@ def main():
         "value": NUM_QUERY * args.steps * per_step * world / elapsed,
         "unit": "query frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "rccl_ranks": rccl_ranks, "ranks_share_gpus": bool(world > torch.cuda.device_count()),
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",

@@ -406,7 +406,16 @@ int orbit_p2p_allreduce_sum(orbit_p2p_t* c, float* buf, size_t n, orbit_stream_t
  * under data parallelism): direct reduce-scatter + all-gather over the point-to-point mesh, every element
  * summed once in rank order (bit-identical on all ranks). In place; n <= world * max_floats / 2. */
 int orbit_p2p_allreduce_sum_sharded(orbit_p2p_t* c, float* buf, size_t n, orbit_stream_t stream);
-int orbit_p2p_error(orbit_p2p_t* c);   /* 0 ok; k > 0: waiting for rank (k-1) % 100 timed out (synchronises the device) */
+/* 0 ok; k > 0: a wait for rank (k-1) % 100's flag timed out (~4 s) and that all-reduce's buffer was filled with NaN instead
+ * of a partial sum. Reads a host-mapped word, does not synchronise the device: it covers the all-reduces that have completed. */
+int orbit_p2p_error(orbit_p2p_t* c);
+/* How the inbox was allocated. Peers write it and the owner polls it while kernels run, so it must be uncached or
+ * fine-grained device memory (coarse-grained memory is only coherent at kernel boundaries); orbit_p2p_create fails rather
+ * than fall back to coarse-grained memory unless ORBIT_P2P_ALLOW_COARSE=1. */
+#define ORBIT_P2P_MEM_UNCACHED 1
+#define ORBIT_P2P_MEM_FINEGRAINED 2
+#define ORBIT_P2P_MEM_COARSE 3
+int orbit_p2p_memory_kind(orbit_p2p_t* c);
 void orbit_p2p_destroy(orbit_p2p_t* c);
 
 #ifdef __cplusplus

@@ -109,6 +109,7 @@ _SIGNATURES = {
     "orbit_p2p_allreduce_sum": (c_int, [P, P, c_size_t, P]),
     "orbit_p2p_allreduce_sum_sharded": (c_int, [P, P, c_size_t, P]),
     "orbit_p2p_error": (c_int, [P]),
+    "orbit_p2p_memory_kind": (c_int, [P]),
     "orbit_p2p_destroy": (None, [P]),
 }
 

@@ -49,12 +49,15 @@ LINK = ["-shared", "-fPIC", "--offload-arch=gfx950", "-no-hip-rt", "-L" + RTLIB,
 
 
 def _digest(paths):
+    """Fingerprint of the sources and flags. Paths enter RELATIVE to the repository (and the flags with the checkout
+    prefix removed), so the stamp that travels with a built .so matches on whatever path the tree is unpacked to."""
+    root = os.path.dirname(HERE)
     h = hashlib.sha256()
     for p in sorted(paths):
         with open(p, "rb") as f:
-            h.update(p.encode())
+            h.update(os.path.relpath(p, root).encode())
             h.update(f.read())
-    h.update(" ".join(FLAGS + LINK).encode())
+    h.update(" ".join(x.replace(root, "<repo>") for x in FLAGS + LINK).encode())
     return h.hexdigest()
 
 

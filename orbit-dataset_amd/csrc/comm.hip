@@ -3,6 +3,7 @@
 // when ONE task's support frames are sharded over ranks is the sum of the per-class prototype partials
 // ([C][D] sums + [C] counts, ~25 KB) produced by orbit_proto_configure — a latency-bound all-reduce.
 #include <rccl/rccl.h>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 #include "common.h"
@@ -89,19 +90,30 @@ struct orbit_p2p {
     unsigned* flags = nullptr;              // = inbox + 2 * world * max_floats
     std::vector<float*> peer_inbox;         // mapped inbox of every rank (own entry = inbox)
     float** d_peer_inbox = nullptr;         // device copy of the table
-    int* d_error = nullptr;
+    int* h_error = nullptr;                 // pinned, host-mapped error word (the host reads it without a device sync)
+    int* d_error = nullptr;                 // its device address
+    int memory_kind = 0;                    // ORBIT_P2P_MEM_*: how the inbox was allocated
     unsigned epoch = 0;
     bool connected = false;
 };
 
 namespace orbit {
 
+// A flag holds the epoch of the sender's LATEST push. The waiter accepts any value at or past its own epoch (wrap-safe
+// signed distance): a waiter that is descheduled while the sender already posts epoch e+1 must not miss e -
+// the data of epoch e is still intact then, because e+1 goes to the other half and e+2 cannot start before this rank has
+// pushed e+1, i.e. finished e.
+__device__ __forceinline__ bool flag_reached(const unsigned* f, unsigned epoch) {
+    return (int)(__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - epoch) >= 0;
+}
+constexpr long long P2P_TIMEOUT_TICKS = 400000000LL;  // ~4 s at the 100 MHz constant clock
+
 __global__ __launch_bounds__(1024) void p2p_allreduce_kernel(float* const* __restrict__ peer_inbox, float* __restrict__ buf,
                                                              int n, int rank, int world, size_t max_floats,
                                                              unsigned epoch, int* __restrict__ error) {
     const int tid = threadIdx.x;
     const size_t half = (size_t)(epoch & 1u) * world * max_floats;
-    // ---- push: my payload into slot [rank] of every inbox (own included), 16-byte stores where aligned
+    // ---- push: my payload into slot [rank] of every inbox (own included)
     for (int p = 0; p < world; ++p) {
         float* dst = peer_inbox[p] + half + (size_t)rank * max_floats;
         for (int i = tid; i < n; i += blockDim.x) __hip_atomic_store(dst + i, buf[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -113,19 +125,25 @@ __global__ __launch_bounds__(1024) void p2p_allreduce_kernel(float* const* __res
         __hip_atomic_store(f, epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     // ---- wait for the world flags of my inbox
+    int timed_out = 0;
     if (tid < world) {
         const unsigned* f = reinterpret_cast<const unsigned*>(peer_inbox[rank] + 2 * (size_t)world * max_floats) + tid;
         const long long t0 = wall_clock64();
-        while (__hip_atomic_load(f, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
-            if (wall_clock64() - t0 > 400000000LL) {  // ~4 s at the 100 MHz constant clock
-                atomicExch(error, 1 + tid);
+        while (!flag_reached(f, epoch)) {
+            if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) {
+                __hip_atomic_exchange(error, 1 + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                timed_out = 1;
                 break;
             }
             __builtin_amdgcn_s_sleep(8);
         }
     }
-    __syncthreads();
+    timed_out = __syncthreads_or(timed_out);
     __threadfence_system();
+    if (timed_out) {  // a peer never arrived: the result must not look like a sum - poison it
+        for (int i = tid; i < n; i += blockDim.x) buf[i] = __builtin_nanf("");
+        return;
+    }
     // ---- sum the slots in rank order
     const float* mine = peer_inbox[rank] + half;
     for (int i = tid; i < n; i += blockDim.x) {
@@ -147,21 +165,25 @@ __device__ __forceinline__ float2 load_sys2(const float* p) {
     return make_float2(__uint_as_float((unsigned)v), __uint_as_float((unsigned)(v >> 32)));
 }
 
-// wait until the `world` flags f[q * stride] all read `epoch`; error code base + q on a timeout
-__device__ __forceinline__ void wait_flags(const unsigned* f, int stride, int world, unsigned epoch, int* error, int base) {
+// wait until the `world` flags f[q * stride] have all reached `epoch`; on a timeout: error code base + q, returns true
+// (block-uniform)
+__device__ __forceinline__ bool wait_flags(const unsigned* f, int stride, int world, unsigned epoch, int* error, int base) {
+    int timed_out = 0;
     if ((int)threadIdx.x < world) {
         const unsigned* fq = f + (size_t)threadIdx.x * stride;
         const long long t0 = wall_clock64();
-        while (__hip_atomic_load(fq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != epoch) {
-            if (wall_clock64() - t0 > 400000000LL) {
-                atomicExch(error, base + (int)threadIdx.x);
+        while (!flag_reached(fq, epoch)) {
+            if (wall_clock64() - t0 > P2P_TIMEOUT_TICKS) {
+                __hip_atomic_exchange(error, base + (int)threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                timed_out = 1;
                 break;
             }
             __builtin_amdgcn_s_sleep(8);
         }
     }
-    __syncthreads();
+    timed_out = __syncthreads_or(timed_out);
     __threadfence_system();
+    return timed_out != 0;
 }
 
 // n floats in `buf`, shard length s (even), per-block slice length c (even): block b covers [b*c, min((b+1)*c, s)) of
@@ -195,7 +217,15 @@ __global__ __launch_bounds__(512) void p2p_allreduce_sharded_kernel(float* const
     __syncthreads();
     if (tid < world) __hip_atomic_store(flag_in(tid, rank), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // ---- my shard: sum the world copies of slice b in rank order, push the sum to every rank (own inbox included)
-    wait_flags(flag_in(rank, 0), P2P_GRID, world, epoch, error, 1);
+    auto poison = [&]() {  // slice b of every shard of buf: a timed-out exchange must not look like a sum
+        for (int q = 0; q < world; ++q)
+            for (size_t i = lo + tid; i < hi; i += blockDim.x)
+                if ((size_t)q * s + i < n) buf[(size_t)q * s + i] = __builtin_nanf("");
+    };
+    if (wait_flags(flag_in(rank, 0), P2P_GRID, world, epoch, error, 1)) {
+        poison();
+        return;
+    }
     const float* in = peer_inbox[rank] + half;
     for (size_t i = lo + 2 * (size_t)tid; i < hi; i += 2 * blockDim.x) {
         float2 acc = load_sys2(in + i);
@@ -212,7 +242,10 @@ __global__ __launch_bounds__(512) void p2p_allreduce_sharded_kernel(float* const
     __syncthreads();
     if (tid < world) __hip_atomic_store(flag_out(tid, rank), epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     // ---- all-gather: copy slice b of every reduced shard home
-    wait_flags(flag_out(rank, 0), P2P_GRID, world, epoch, error, 101);
+    if (wait_flags(flag_out(rank, 0), P2P_GRID, world, epoch, error, 101)) {
+        poison();
+        return;
+    }
     const float* out = peer_inbox[rank] + half + (size_t)world * s;
     for (int q = 0; q < world; ++q) {
         const size_t g0 = (size_t)q * s;
@@ -236,17 +269,40 @@ int orbit_p2p_create(int rank, int world, size_t max_floats, orbit_p2p_t** out) 
     c->rank = rank, c->world = world, c->max_floats = (max_floats + 3) & ~(size_t)3;
     const size_t bytes = 2 * (size_t)world * c->max_floats * sizeof(float) +
                          (size_t)world * (1 + 2 * P2P_GRID) * sizeof(unsigned);  // one-shot flags, then the sharded form's
-    hipError_t e = hipMalloc(reinterpret_cast<void**>(&c->inbox), bytes);
+    // The inbox is written by peers and polled by this rank WHILE a kernel runs: it must not be ordinary (coarse-grained)
+    // device memory, which is only coherent across agents at kernel boundaries - over xGMI the owner's L2 may keep serving
+    // stale flag / payload lines. Uncached device memory (MTYPE_UC, what RCCL uses for its signal buffers on
+    // gfx942 / gfx950), else fine-grained; coarse-grained only when ORBIT_P2P_ALLOW_COARSE=1 (single-GPU experiments).
+    hipError_t e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->inbox), bytes, hipDeviceMallocUncached);
+    c->memory_kind = ORBIT_P2P_MEM_UNCACHED;
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        e = hipExtMallocWithFlags(reinterpret_cast<void**>(&c->inbox), bytes, hipDeviceMallocFinegrained);
+        c->memory_kind = ORBIT_P2P_MEM_FINEGRAINED;
+    }
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        const char* allow = getenv("ORBIT_P2P_ALLOW_COARSE");
+        if (allow && allow[0] == '1') {
+            e = hipMalloc(reinterpret_cast<void**>(&c->inbox), bytes);
+            c->memory_kind = ORBIT_P2P_MEM_COARSE;
+        }
+    }
     if (e == hipSuccess) e = hipMemset(c->inbox, 0, bytes);
     if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_peer_inbox), world * sizeof(float*));
-    if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&c->d_error), sizeof(int));
-    if (e == hipSuccess) e = hipMemset(c->d_error, 0, sizeof(int));
+    if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&c->h_error), sizeof(int), hipHostMallocMapped);
+    if (e == hipSuccess) {
+        *c->h_error = 0;
+        e = hipHostGetDevicePointer(reinterpret_cast<void**>(&c->d_error), c->h_error, 0);
+    }
     if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) {
-        (void)hipFree(c->inbox), (void)hipFree(c->d_peer_inbox), (void)hipFree(c->d_error);
+        (void)hipFree(c->inbox), (void)hipFree(c->d_peer_inbox);
+        if (c->h_error) (void)hipHostFree(c->h_error);
         delete c;
         (void)hipGetLastError();
-        return set_err(ORBIT_ERR_HIP, "p2p_create: %s", hipGetErrorString(e));
+        return set_err(ORBIT_ERR_HIP, "p2p_create: %s (inbox of %zu bytes, uncached / fine-grained device memory)",
+                       hipGetErrorString(e), bytes);
     }
     c->flags = reinterpret_cast<unsigned*>(c->inbox + 2 * (size_t)world * c->max_floats);
     c->peer_inbox.assign(world, nullptr);
@@ -289,8 +345,7 @@ int orbit_p2p_allreduce_sum(orbit_p2p_t* c, float* buf, size_t n, orbit_stream_t
     ORBIT_REQUIRE(c && buf && n > 0, "p2p_allreduce_sum: bad arguments");
     ORBIT_REQUIRE(c->connected, "p2p_allreduce_sum: call orbit_p2p_connect first");
     ORBIT_REQUIRE(n <= c->max_floats, "p2p_allreduce_sum: %zu floats exceed the inbox slot (%zu)", n, c->max_floats);
-    ++c->epoch;
-    if (c->epoch == 0) ++c->epoch;  // 0 is the "never written" value of the flags
+    ++c->epoch;  // flags start at 0 = "epoch 0 reached"; the wait is a wrap-safe signed distance, so any sequence works
     const int threads = n >= 4096 ? 1024 : 256;
     orbit::p2p_allreduce_kernel<<<1, threads, 0, (hipStream_t)stream>>>(c->d_peer_inbox, buf, (int)n, c->rank, c->world,
                                                                        c->max_floats, c->epoch, c->d_error);
@@ -310,26 +365,28 @@ int orbit_p2p_allreduce_sum_sharded(orbit_p2p_t* c, float* buf, size_t n, orbit_
     size_t slice = (s + P2P_GRID - 1) / P2P_GRID;
     slice = (slice + 1) & ~(size_t)1;
     ++c->epoch;
-    if (c->epoch == 0) ++c->epoch;
     orbit::p2p_allreduce_sharded_kernel<<<P2P_GRID, 512, 0, (hipStream_t)stream>>>(
         c->d_peer_inbox, buf, n, s, slice, c->rank, c->world, c->max_floats, c->epoch, c->d_error);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
 
-/* 0 = every all-reduce so far completed; k > 0 = a wait for rank (k-1) % 100's flag timed out (synchronises the device) */
+/* 0 = no flag wait has timed out so far; k > 0 = a wait for rank (k-1) % 100's flag timed out and that all-reduce's buffer
+ * was filled with NaN. Reads a host-mapped word: does NOT synchronise the device, so it reports the all-reduces that have
+ * COMPLETED by now (call it after a sync point, or once per optimizer step about the step before). */
 int orbit_p2p_error(orbit_p2p_t* c) {
     ORBIT_REQUIRE(c, "p2p_error: null pointer");
-    int e = 0;
-    ORBIT_HIP_CHECK(hipMemcpy(&e, c->d_error, sizeof(int), hipMemcpyDeviceToHost));
-    return e;
+    return __atomic_load_n(c->h_error, __ATOMIC_ACQUIRE);
 }
+
+int orbit_p2p_memory_kind(orbit_p2p_t* c) { return c ? c->memory_kind : 0; }
 
 void orbit_p2p_destroy(orbit_p2p_t* c) {
     if (!c) return;
     for (int p = 0; p < c->world; ++p)
         if (p != c->rank && c->peer_inbox[p]) (void)hipIpcCloseMemHandle(c->peer_inbox[p]);
-    (void)hipFree(c->inbox), (void)hipFree(c->d_peer_inbox), (void)hipFree(c->d_error);
+    (void)hipFree(c->inbox), (void)hipFree(c->d_peer_inbox);
+    if (c->h_error) (void)hipHostFree(c->h_error);
     delete c;
 }
 

@@ -127,13 +127,14 @@ bool mbconv_rows_supported(int H, int W, int Cin, int mid, int K, int stride);
 int mbconv_rows_tiles(int H, int W, int Cin, int mid, int K, int stride);
 int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
                        const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
-                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s);
+                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, int plan_tiles = 0);
+// (plan_tiles > 0: the tile count the caller sized `pool` and its consumer for; the launch fails if the options now differ)
 // row-streaming stem + first depthwise (csrc/mbconv_rows.hip): w1_packed = stem_pack_weights' [32][32]; pool [B][stem_rows_tiles][32]
 bool stem_rows_supported(int H, int W, int mid, int K, int stride);
 int stem_rows_tiles(int H, int W);
 int launch_stem_rows(const float* frames, const float* w1_packed, const float* sc1, const float* sh1, const float* wdw,
                      const float* sc2, const float* sh2, float* y, float* pool, int B, int FH, int FW, int spad_t,
-                     int spad_l, int H, int W, hipStream_t s);
+                     int spad_l, int H, int W, hipStream_t s, int plan_tiles = 0);
 // stem form of the fused front kernel: conv_stem (NCHW frames, 3x3 stride 2) + BN + SiLU + depthwise 3x3/1 + BN + SiLU
 bool stem_dw_front_supported(int mid, int K, int stride);
 int stem_pack_weights(const float* w_oihw, float* w_packed, int mid, hipStream_t s);  // [mid][27] -> [mid][32]

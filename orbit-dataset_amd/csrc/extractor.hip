@@ -180,6 +180,7 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
             ho = o.Ho, wo = o.Wo;
             o.rows = stem_rows;
             se_chunks0 = stem_rows ? stem_rows_tiles(h, w) : mbconv_front_tiles(ho, wo, 1);
+            o.se_chunks = se_chunks0;  // what the pooling buffer and the gate were sized for (checked at launch)
             fe->max_partial = std::max(fe->max_partial, (size_t)se_chunks0 * 32);
             fe->note_buf(t1, (size_t)ho * wo * 32);
             fe->macs += (double)h * w * 27 * 32 + (double)ho * wo * 32 * 9;
@@ -224,6 +225,7 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
                 o.rows = !o.whole_map && fuse_rows_ok(h, w, cin, mid, K, stride);
                 se_chunks = o.whole_map ? 1 : o.rows ? mbconv_rows_tiles(h, w, cin, mid, K, stride)
                                                      : mbconv_front_tiles(ho, wo, stride);
+                o.se_chunks = se_chunks;  // what the pooling buffer and the gate were sized for (checked at launch)
                 fe->max_partial = std::max(fe->max_partial, (size_t)se_chunks * mid);
                 fe->note_buf(t2, (size_t)ho * wo * mid);
                 fe->macs += (double)h * w * cin * mid + (double)ho * wo * mid * K * K;
@@ -621,7 +623,7 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
                     rc = launch_stem_rows(buf(o.in), fe->d_packed + o.packed_off2, scale + fe->bns[o.bn].fold_off,
                                           shift + fe->bns[o.bn].fold_off, fe->d_packed + o.packed_off,
                                           scale + fe->bns[o.bn2].fold_off, shift + fe->bns[o.bn2].fold_off, buf(o.out),
-                                          buf(101), B, o.stem_h, o.stem_w, o.stem_pt, o.stem_pl, o.H, o.W, s);
+                                          buf(101), B, o.stem_h, o.stem_w, o.stem_pt, o.stem_pl, o.H, o.W, s, o.se_chunks);
                     break;
                 }
                 if (o.stem) {
@@ -645,7 +647,7 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
                                             scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off,
                                             fe->d_packed + o.packed_off, scale + fe->bns[o.bn2].fold_off,
                                             shift + fe->bns[o.bn2].fold_off, buf(o.out), buf(101), B, o.H, o.W, o.Cin,
-                                            o.Cout, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+                                            o.Cout, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s, o.se_chunks);
                     break;
                 }
                 rc = launch_mbconv_front(buf(o.in), fe->d_pool + fe->params[o.weight].off,

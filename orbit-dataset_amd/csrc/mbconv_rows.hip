@@ -343,11 +343,16 @@ int mbconv_rows_tiles(int H, int W, int Cin, int mid, int K, int stride) {
 
 int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
                        const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
-                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s) {
+                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, int plan_tiles) {
     ORBIT_REQUIRE(x && w1 && sc1 && sh1 && wdw && sc2 && sh2 && y, "mbconv_rows: null pointer");
     RowsGeom g;
     ORBIT_REQUIRE(Ho == cdiv(H, stride) && Wo == cdiv(W, stride) && rows_geom(H, W, Cin, mid, K, stride, Ho, Wo, g),
                   "mbconv_rows: unsupported shape (H=%d W=%d Cin=%d mid=%d K=%d s=%d)", H, W, Cin, mid, K, stride);
+    // the band height is a runtime option: a plan sized its pooling partials (and the SE gate sums them) for the tile count
+    // it saw when it was built - refuse to write a different number of partials than the consumer reads
+    ORBIT_REQUIRE(plan_tiles <= 0 || plan_tiles == g.strips * g.bands,
+                  "mbconv_rows: the plan was built for %d pooling tiles per frame, the current options give %d "
+                  "(mbrows_band changed after the plan was created: rebuild the plan)", plan_tiles, g.strips * g.bands);
     MbRowsParams p;
     p.x = x, p.w1 = w1, p.sc1 = sc1, p.sh1 = sh1, p.wdw = wdw, p.sc2 = sc2, p.sh2 = sh2, p.y = y, p.pool = pool;
     p.H = H, p.W = W, p.Cin = Cin, p.mid = mid, p.pad_t = pad_t, p.pad_l = pad_l, p.Ho = Ho, p.Wo = Wo;
@@ -629,10 +634,13 @@ int stem_rows_tiles(int H, int W) {
 
 int launch_stem_rows(const float* frames, const float* w1_packed, const float* sc1, const float* sh1, const float* wdw,
                      const float* sc2, const float* sh2, float* y, float* pool, int B, int FH, int FW, int spad_t,
-                     int spad_l, int H, int W, hipStream_t s) {
+                     int spad_l, int H, int W, hipStream_t s, int plan_tiles) {
     ORBIT_REQUIRE(frames && w1_packed && sc1 && sh1 && wdw && sc2 && sh2 && y, "stem_rows: null pointer");
     StemRowsGeom g;
     ORBIT_REQUIRE(stem_rows_geom(H, W, 32, 3, 1, g), "stem_rows: unsupported shape (H=%d W=%d)", H, W);
+    ORBIT_REQUIRE(plan_tiles <= 0 || plan_tiles == g.strips * g.bands,
+                  "stem_rows: the plan was built for %d pooling tiles per frame, the current options give %d "
+                  "(mbrows_band changed after the plan was created: rebuild the plan)", plan_tiles, g.strips * g.bands);
     StemRowsParams p;
     p.frames = frames, p.w1 = w1_packed, p.sc1 = sc1, p.sh1 = sh1, p.wdw = wdw, p.sc2 = sc2, p.sh2 = sh2, p.y = y, p.pool = pool;
     p.FH = FH, p.FW = FW, p.spad_t = spad_t, p.spad_l = spad_l, p.H = H, p.W = W;

@@ -78,6 +78,9 @@ class P2PAllReduce:
         h = ctypes.c_void_p()
         _lib.check(lib.orbit_p2p_create(rank, world, self.max_floats, ctypes.byref(h)), "orbit_p2p_create")
         self.handle = h
+        # 1 uncached / 2 fine-grained device memory (coherent while kernels run); 3 = coarse-grained, only with
+        # ORBIT_P2P_ALLOW_COARSE=1 and only safe when all ranks share one GPU's L2
+        self.memory_kind = int(lib.orbit_p2p_memory_kind(h))
         mine = ctypes.create_string_buffer(64)
         _lib.check(lib.orbit_p2p_export(h, mine), "orbit_p2p_export")
         gathered = [None] * world
@@ -108,8 +111,17 @@ class P2PAllReduce:
         return 2 * (-(-int(numel) // world) + 2)
 
     def error(self):
-        """0 = all all-reduces completed; k > 0 = waiting for rank k-1 timed out (synchronises the device)."""
+        """0 = no flag wait has timed out among the all-reduces that have completed; k > 0 = waiting for rank (k-1) % 100
+        timed out, and that call's tensor was filled with NaN instead of a partial sum. Does not synchronise the device."""
         return int(self._lib.load().orbit_p2p_error(self.handle))
+
+    def raise_on_error(self):
+        """Called once per optimizer step (GradientBucket.sync) / per sharded personalise: a stalled peer becomes an
+        exception on the host instead of NaN gradients feeding optimizer.step()."""
+        e = self.error()
+        if e:
+            raise RuntimeError("P2P all-reduce: rank %d timed out waiting for rank %d's flag (%s phase); the affected buffer "
+                               "was poisoned with NaN" % (self.rank, (e - 1) % 100, "all-gather" if e > 100 else "reduce"))
 
     def close(self):
         if getattr(self, "handle", None):
@@ -130,6 +142,7 @@ class SupportSharding:
 
     def reduce_(self, tensor):
         if self.p2p is not None:
+            self.p2p.raise_on_error()  # exchanges completed so far (host-mapped word, no device sync)
             return self.p2p(tensor)
         return allreduce_sum_(tensor, self.group)
 
@@ -194,10 +207,15 @@ class GradientBucket:
     `optimizer.zero_grad()`: one memset, views stay attached.
     """
 
-    def __init__(self, params, group=None, p2p=None):
+    def __init__(self, params, group=None, p2p=None, collective_layout_check=True):
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.p2p = p2p         # a P2PAllReduce sized with floats_for_bucket(): direct RS + AG instead of the backend's ring
+        # The decision to (re)build the layout must be the SAME on every rank: _build() issues a collective of its own, so a
+        # rank that rebuilds alone would pair its mask all-reduce with its peers' bucket all-reduce (ADVICE r2). Every
+        # sync() therefore first all-reduces (MAX) a one-element "my layout is stale" flag - one tiny collective and one
+        # host read per OPTIMIZER step (the learner already synchronises once per task).
+        self.collective_layout_check = collective_layout_check
         self.flat = None
         self.views = None      # per parameter: view into `flat`, or None (no gradient on any rank)
         self.nbytes = 0
@@ -246,10 +264,16 @@ class GradientBucket:
         any rank still have grad None."""
         if not self.params:
             return
-        if self.flat is None or not self._attached():
+        stale = self.flat is None or not self._attached()
+        if self._active() and self.collective_layout_check:
+            flag = torch.tensor([1.0 if stale else 0.0], device=self.params[0].device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.group)
+            stale = bool(flag.item() > 0.5)  # every rank rebuilds, or none does
+        if stale:
             self._build()
         if self._active():
             if self.p2p is not None:
+                self.p2p.raise_on_error()  # covers the previous step's exchange (non-blocking read of a host-mapped word)
                 self.p2p(self.flat)
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)

@@ -262,6 +262,11 @@ class Learner:
                             self.optimizer.zero_grad()
         finally:
             torch.set_grad_enabled(prev)
+        if self.grad_bucket is not None and self.grad_bucket.p2p is not None:
+            # every optimizer step checked the exchange before it (GradientBucket.sync); this covers the last one: a peer
+            # that stalled makes this rank raise instead of saving parameters updated from NaN-poisoned gradients
+            torch.cuda.synchronize()
+            self.grad_bucket.p2p.raise_on_error()
         if a.save_model_path and self.rank == 0:  # every rank holds the same parameters after the last step
             torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()}, a.save_model_path)
         stats = {"loss": mean_ci(losses) if losses else (0.0, 0.0), "frame_acc": mean_ci(accs) if accs else (0.0, 0.0),

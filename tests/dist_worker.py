@@ -1,4 +1,4 @@
-"""Worker of tests/test_gpu_dist.py: one rank of a 2-rank job in which BOTH ranks share GPU 0 (gloo backend: RCCL refuses
+"""Worker of tests/test_gpu_dist.py: one rank of a 2- / 4- / 8-rank job in which ALL ranks share GPU 0 (gloo backend: RCCL refuses
 two ranks on one device). Runs the PRODUCT's multi-GPU forms - dist.personalise_support_sharded, dist.predict_query_sharded,
 learner.py --mode train with dist.GradientBucket - and writes what it computed to <out>.rank<r>.pt."""
 import os
@@ -14,16 +14,25 @@ from orbit_dataset_amd import dist as odist  # noqa: E402
 from orbit_dataset_amd import synthetic  # noqa: E402
 
 
-def sharded(out, adapt):
+def _sharded_case(case):
+    """(extractor, way, frames per class, query frames, label values) of the support/query-sharded tests"""
+    if case == "effnet10":  # BASELINE config 5's head shape: 10-way, D = 1280 -> the [C*D + C] = 12 810-float payload
+        return "efficientnet_b0", 10, 4, 13, None
+    return "resnet18", 4, 5, 11, (2, 5, 6, 9)
+
+
+def sharded(out, adapt, case="resnet4"):
     from orbit_dataset_amd.model.few_shot_recognisers import SingleStepFewShotRecogniser
     rank, world, _ = odist.init_from_env("gloo")
     torch.cuda.set_device(0)
-    model = SingleStepFewShotRecogniser("resnet18", adapt, "proto", 1, 8, False, 16, 1.0)
+    fe, way, per_class, nq, values = _sharded_case(case)
+    model = SingleStepFewShotRecogniser(fe, adapt, "proto", 1, 8, False, 16, 1.0)
     synthetic.init_parameters_(model)
     model._set_device("cuda:0")
     model._send_to_device()
     model.set_test_mode(True)
-    task = synthetic.make_task(9, way=4, shots=1, frames_per_shot=5, num_query=11, frame_size=64, label_values=(2, 5, 6, 9))
+    task = synthetic.make_task(9, way=way, shots=1, frames_per_shot=per_class, num_query=nq, frame_size=64,
+                               label_values=values)
     ctx, lab, tgt = task["context_clips"].cuda(), task["context_labels"].cuda(), task["target_clips"].cuda()
     sh = odist.SupportSharding(rank, world)
     lo, hi = sh.bounds(len(lab))
@@ -34,6 +43,17 @@ def sharded(out, adapt):
                 "logits": logits.cpu(), "bounds": (lo, hi)}, "%s.rank%d.pt" % (out, rank))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()
+
+
+def rank_ordered_sum(x, world):
+    """((x_0 + x_1) + x_2) + ... in fp32 on the host: the order both P2P kernels promise. With more than two addends a
+    different order gives different bits, so equality with this is a real statement about the kernel's summation order."""
+    parts = [torch.empty_like(x) for _ in range(world)]
+    torch.distributed.all_gather(parts, x)
+    acc = parts[0].clone()
+    for q in range(1, world):
+        acc = acc + parts[q]
+    return acc
 
 
 def train(out, argv):
@@ -50,17 +70,17 @@ def train(out, argv):
 
 
 def p2p(out):
-    """One-shot P2P all-reduce between two processes that share GPU 0: IPC-mapped inboxes, flags, rank-order sums."""
+    """One-shot P2P all-reduce between `world` processes that share GPU 0: IPC-mapped inboxes, flags, rank-order sums."""
     import time
     rank, world, _ = odist.init_from_env("gloo")
     torch.cuda.set_device(0)
     ar = odist.P2PAllReduce(rank, world, max_floats=16384)
-    res = {}
+    res = {"memory_kind": ar.memory_kind}
     g = torch.Generator().manual_seed(100 + rank)
-    for n in (6405, 65, 1, 16384, 6405):  # prototype payload (5 x 1280 + 5), embedding sums, a scalar, a full slot
-        x = torch.randn(n, generator=g)
-        want = x.clone()
-        torch.distributed.all_reduce(want)  # gloo on the host: the reference sum
+    # prototype payloads (5 x 1280 + 5; 10 x 1280 + 10 = BASELINE config 5), embedding sums, a scalar, a full slot
+    for n in (6405, 12810, 65, 1, 16384, 6405):
+        x = torch.randn(n, generator=g) * (10.0 ** (rank % 3))  # mixed magnitudes: the summation order shows in the bits
+        want = rank_ordered_sum(x, world)
         dev = x.cuda()
         ar(dev)
         torch.cuda.synchronize()
@@ -98,31 +118,59 @@ def p2p(out):
     torch.distributed.destroy_process_group()
 
 
+def p2p_timeout(out):
+    """A peer that never shows up: the waiting rank's kernel gives up after ~4 s, its buffer comes back as NaN (not as a
+    partial sum) and the error word names the missing rank; P2PAllReduce.raise_on_error turns that into an exception."""
+    rank, world, _ = odist.init_from_env("gloo")
+    torch.cuda.set_device(0)
+    ar = odist.P2PAllReduce(rank, world, max_floats=4096)
+    x = torch.full((1000,), float(rank + 1)).cuda()
+    ar(x)  # epoch 1: both ranks
+    torch.cuda.synchronize()
+    res = {"first": x.cpu(), "error_before": ar.error()}
+    if rank == 0:
+        y = torch.ones(1000).cuda()
+        ar(y)  # epoch 2: rank 1 never calls
+        torch.cuda.synchronize()
+        res["poisoned"] = y.cpu()
+        res["error_after"] = ar.error()
+        try:
+            ar.raise_on_error()
+            res["raised"] = False
+        except RuntimeError as e:
+            res["raised"] = str(e)
+    torch.save(res, "%s.rank%d.pt" % (out, rank))
+    torch.distributed.barrier()
+    ar.close()
+    torch.distributed.destroy_process_group()
+
+
 def p2p_bucket(out):
-    """Sharded P2P all-reduce (direct reduce-scatter + all-gather) of gradient-bucket-sized vectors, two processes on GPU 0."""
+    """Sharded P2P all-reduce (direct reduce-scatter + all-gather) of gradient-bucket-sized vectors, `world` processes on GPU 0."""
     import time
     rank, world, _ = odist.init_from_env("gloo")
     torch.cuda.set_device(0)
     big = 5_288_548 + 64 * 213  # efficientnet_b0's parameters in 256-byte slots
     ar = odist.P2PAllReduce(rank, world, max_floats=odist.P2PAllReduce.floats_for_bucket(big, world))
-    res = {"got": [], "want": []}
+    res = {"got": [], "want": [], "memory_kind": ar.memory_kind}
     g = torch.Generator().manual_seed(200 + rank)
-    for n in (big, 32769, 100001, 1_000_003, big, 40000):  # odd lengths: ragged last shard / last slice
-        x = torch.randn(n, generator=g)
-        want = x.clone()
-        torch.distributed.all_reduce(want)
+    # odd lengths: ragged last shard / last slice, n % world != 0, shards shorter than the 64-block grid
+    for n in (big, 32769, 100001, 1_000_003, big, 40000, 32771):
+        x = torch.randn(n, generator=g) * (10.0 ** (rank % 3))
+        want = rank_ordered_sum(x, world)
         dev = x.cuda()
         ar(dev)
         torch.cuda.synchronize()
         res["got"].append(dev.cpu())
         res["want"].append(want)
     # interleaved with the one-shot form on the same inbox (epochs are shared)
+    total = float(world * (world + 1) // 2)
     small = torch.full((6405,), float(rank + 1)).cuda()
     ar(small)
     dev = torch.ones(big).cuda() * (rank + 1)
     ar(dev)
     torch.cuda.synchronize()
-    res["mixed_small"], res["mixed_big"] = small.cpu(), dev.cpu()
+    res["mixed_small"], res["mixed_big"], res["mixed_total"] = small.cpu(), dev.cpu(), total
     dev = torch.randn(big).cuda()
     for _ in range(3):
         ar(dev)
@@ -144,7 +192,9 @@ def p2p_bucket(out):
 if __name__ == "__main__":
     mode, out = sys.argv[1], sys.argv[2]
     if mode == "sharded":
-        sharded(out, adapt=sys.argv[3] == "1")
+        sharded(out, adapt=sys.argv[3] == "1", case=sys.argv[4] if len(sys.argv) > 4 else "resnet4")
+    elif mode == "p2p_timeout":
+        p2p_timeout(out)
     elif mode == "p2p":
         p2p(out)
     elif mode == "p2p_bucket":

@@ -204,3 +204,38 @@ def test_gradient_bucket_matches_single_process_and_skips_gradless_parameters():
         assert np.allclose(a, want[0].numpy(), atol=1e-6) and np.allclose(b, want[1].numpy(), atol=1e-6)
         assert np.array_equal(c, init.c.detach().numpy()) and np.array_equal(c, want[2].numpy())
     assert all(np.array_equal(x, y) for x, y in zip(result[0], result[1]))  # bit-identical replicas
+
+
+# ---- the layout decision of GradientBucket is collective -------------------------------------------------
+def _late_param_worker(rank, world, port, result):
+    """Window 1: only `a` has a gradient (on both ranks). Window 2: `c` starts to receive a gradient on rank 0 while rank 1
+    had NO task in that window (total_steps % world != 0): rank 0 alone sees a stale layout. Both ranks must rebuild
+    together - a rank rebuilding alone pairs its mask all-reduce with the peer's bucket all-reduce (hang / corruption)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = odist.init_from_env("gloo")
+    m = _toy()
+    bucket = odist.GradientBucket(m.parameters())
+    (m.a.sum() * (r + 1)).backward()
+    bucket.sync()
+    assert m.c.grad is None and torch.allclose(m.a.grad, torch.full_like(m.a, 3.0))
+    bucket.zero_()
+    if r == 0:
+        (m.a.sum() + 2.0 * m.c.sum()).backward()
+    bucket.sync()
+    assert m.c.grad is not None and torch.allclose(m.c.grad, torch.full_like(m.c, 2.0))  # on BOTH ranks
+    assert torch.allclose(m.a.grad, torch.ones_like(m.a))
+    assert m.c.grad.untyped_storage().data_ptr() == bucket.flat.untyped_storage().data_ptr()
+    result[rank] = True
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_bucket_rebuilds_collectively_when_one_rank_sees_a_new_gradient():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_late_param_worker, args=(2, port, result), nprocs=2, join=True)
+    assert result[0] and result[1]

@@ -1,6 +1,6 @@
-"""The product's multi-rank forms executed by TWO processes on hardware (both ranks on GPU 0, gloo backend - the GPU box
-has one device and RCCL refuses two ranks on it; the exchange steps are the same torch.distributed calls the nccl backend
-serves on a multi-GPU node):
+"""The product's multi-rank forms executed by 2 / 4 / 8 processes on hardware (all ranks on GPU 0, gloo backend - the GPU
+box has one device and RCCL refuses two ranks on it; the exchange steps are the same torch.distributed calls the nccl
+backend serves on a multi-GPU node; the peer-to-peer kernels of csrc/comm.hip run at the node's real world size, 8):
   * dist.personalise_support_sharded + dist.predict_query_sharded: each rank extracts features for ITS slice of the
     support clips, ONE all-reduce of the [C*D + C] prototype payload, bit-identical prototypes on both ranks, equal to
     the single-process personalise()/predict();
@@ -52,27 +52,47 @@ def _launch(world, args, timeout=600):
     return outs
 
 
-@pytest.mark.parametrize("adapt", [False, True])
-def test_support_and_query_sharded_on_two_ranks(device, adapt, tmp_path):
-    out = str(tmp_path / "sh")
-    _launch(2, ["sharded", out, "1" if adapt else "0"])
-    r0, r1 = torch.load(out + ".rank0.pt"), torch.load(out + ".rank1.pt")
-    assert r0["bounds"] == (0, 10) and r1["bounds"] == (10, 20)
-    assert torch.equal(r0["W"], r1["W"]) and torch.equal(r0["b"], r1["b"])  # bit-identical prototypes on both ranks
-    assert torch.equal(r0["logits"], r1["logits"])
-    model = SingleStepFewShotRecogniser("resnet18", adapt, "proto", 1, 8, False, 16, 1.0)
+def _single_process_reference(device, fe, adapt, way, per_class, nq, values):
+    model = SingleStepFewShotRecogniser(fe, adapt, "proto", 1, 8, False, 16, 1.0)
     synthetic.init_parameters_(model)
     model._set_device(device)
     model._send_to_device()
     model.set_test_mode(True)
-    task = synthetic.make_task(9, way=4, shots=1, frames_per_shot=5, num_query=11, frame_size=64, label_values=(2, 5, 6, 9))
+    task = synthetic.make_task(9, way=way, shots=1, frames_per_shot=per_class, num_query=nq, frame_size=64,
+                               label_values=values)
     with torch.no_grad():
         model.personalise(task["context_clips"].cuda(), task["context_labels"].cuda())
         want = model.predict(task["target_clips"].cuda()).cpu()
-    W = model.classifier.weight.detach().cpu()
-    assert (r0["W"] - W).abs().max().item() < 1e-5 * max(1.0, W.abs().max().item())
-    assert (r0["logits"] - want).abs().max().item() < 1e-3
-    assert torch.equal(r0["logits"].argmax(1), want.argmax(1))
+    return model.classifier.weight.detach().cpu(), want
+
+
+@pytest.mark.parametrize("world,adapt,case", [(2, False, "resnet4"), (2, True, "resnet4"), (4, True, "resnet4"),
+                                              (4, False, "effnet10"), (8, False, "effnet10"), (8, True, "resnet4")])
+def test_support_and_query_sharded_on_ranks(device, world, adapt, case, tmp_path):
+    """dist.personalise_support_sharded / predict_query_sharded on 2, 4 and 8 ranks (BASELINE config 5 splits 8 ways):
+    ragged support slices (20 clips over 8 ranks; 40 over 8), the 10-way D = 1280 prototype payload, prototypes
+    bit-identical on all ranks and equal (fp32 rounding of a different summation order) to the single-process run."""
+    out = str(tmp_path / "sh")
+    _launch(world, ["sharded", out, "1" if adapt else "0", case])
+    rs = [torch.load("%s.rank%d.pt" % (out, r)) for r in range(world)]
+    fe, way, per_class, nq, values = ("efficientnet_b0", 10, 4, 13, None) if case == "effnet10" else \
+        ("resnet18", 4, 5, 11, (2, 5, 6, 9))
+    n = way * per_class
+    assert [r["bounds"] for r in rs] == [_bounds(n, r, world) for r in range(world)]
+    for r in rs[1:]:  # bit-identical prototypes and logits on every rank
+        assert torch.equal(rs[0]["W"], r["W"]) and torch.equal(rs[0]["b"], r["b"])
+        assert torch.equal(rs[0]["logits"], r["logits"])
+    W, want = _single_process_reference(device, fe, adapt, way, per_class, nq, values)
+    assert rs[0]["W"].shape == W.shape
+    assert (rs[0]["W"] - W).abs().max().item() < 1e-5 * max(1.0, W.abs().max().item())
+    assert (rs[0]["logits"] - want).abs().max().item() < 1e-3
+    assert torch.equal(rs[0]["logits"].argmax(1), want.argmax(1))
+
+
+def _bounds(n, rank, world):
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return (lo, lo + q + (1 if rank < r else 0))
 
 
 TRAIN = ["--mode", "train", "--with_lite", "--num_lite_samples", "4", "--frame_size", "64", "--way", "3", "--shots", "1",
@@ -112,49 +132,86 @@ def test_task_parallel_training_step_equals_single_process(device, recipe, tmp_p
         assert torch.equal(b[k], init_sd[k].to(b[k].dtype)), k
 
 
-def test_one_shot_p2p_allreduce_two_processes(device, tmp_path):
-    """csrc/comm.hip orbit_p2p_*: two processes map each other's inbox through HIP IPC (both on GPU 0 here; over xGMI on
-    a multi-GPU node), push + flag + rank-order sum. Sums equal the host all-reduce to fp32 rounding, are BIT-IDENTICAL
-    on both ranks, successive epochs do not interfere, and dist.personalise_support_sharded through it gives the
-    single-process prototypes."""
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_one_shot_p2p_allreduce(device, world, tmp_path):
+    """csrc/comm.hip orbit_p2p_*: `world` processes map each other's inbox through HIP IPC (all on GPU 0 here; over xGMI on
+    a multi-GPU node), push + flag + rank-order sum. The results are BIT-IDENTICAL on every rank and equal, bit for bit, to
+    ((x0 + x1) + x2) + ... computed on the host - with 4 and 8 addends of mixed magnitude that pins the summation order
+    (two addends commute). Payloads: the 5-way and the 10-way D = 1280 prototype vectors, 65 embedding sums, a
+    scalar, a full slot. The inbox is uncached / fine-grained device memory; successive epochs do not
+    interfere; dist.personalise_support_sharded through the exchange gives the single-process prototypes."""
     out = str(tmp_path / "p2p")
-    _launch(2, ["p2p", out], timeout=300)
-    r0, r1 = torch.load(out + ".rank0.pt"), torch.load(out + ".rank1.pt")
-    assert r0["error"] == 0 and r1["error"] == 0
-    for got0, got1, want in zip(r0["got"], r1["got"], r0["want"]):
-        assert torch.equal(got0, got1)  # rank-order summation: identical bits on every rank
-        assert torch.equal(got0, want)  # two addends: fp32 addition is commutative, so also equal to the host sum
-    assert torch.equal(r0["W"], r1["W"]) and torch.equal(r0["logits"], r1["logits"])
-    model = SingleStepFewShotRecogniser("resnet18", True, "proto", 1, 8, False, 16, 1.0)
-    synthetic.init_parameters_(model)
-    model._set_device(device)
-    model._send_to_device()
-    model.set_test_mode(True)
-    task = synthetic.make_task(9, way=4, shots=1, frames_per_shot=5, num_query=11, frame_size=64, label_values=(2, 5, 6, 9))
-    with torch.no_grad():
-        model.personalise(task["context_clips"].cuda(), task["context_labels"].cuda())
-        want = model.predict(task["target_clips"].cuda()).cpu()
-    assert (r0["logits"] - want).abs().max().item() < 1e-3 and torch.equal(r0["logits"].argmax(1), want.argmax(1))
-    print("one-shot P2P all-reduce of 25.6 KB between two processes on one GPU: %.1f / %.1f us per call (host-synchronised)"
-          % (r0["us_per_allreduce"], r1["us_per_allreduce"]))
+    _launch(world, ["p2p", out], timeout=400)
+    rs = [torch.load("%s.rank%d.pt" % (out, r)) for r in range(world)]
+    for r in rs:
+        assert r["error"] == 0
+        assert r["memory_kind"] in (1, 2), "the inbox must be uncached or fine-grained device memory"
+        for got, got0, want in zip(r["got"], rs[0]["got"], rs[0]["want"]):
+            assert torch.equal(got, got0)   # identical bits on every rank
+            assert torch.equal(got, want)   # and exactly the rank-ordered sum
+        assert torch.equal(r["W"], rs[0]["W"]) and torch.equal(r["logits"], rs[0]["logits"])
+    _, want = _single_process_reference(device, "resnet18", True, 4, 5, 11, (2, 5, 6, 9))
+    assert (rs[0]["logits"] - want).abs().max().item() < 1e-3 and torch.equal(rs[0]["logits"].argmax(1), want.argmax(1))
+    print("one-shot P2P all-reduce of 25.6 KB between %d processes on one GPU: %s us per call (host-synchronised)"
+          % (world, " / ".join("%.1f" % r["us_per_allreduce"] for r in rs)))
 
 
-def test_sharded_p2p_allreduce_of_gradient_buckets(device, tmp_path):
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_sharded_p2p_allreduce_of_gradient_buckets(device, world, tmp_path):
     """csrc/comm.hip orbit_p2p_allreduce_sum_sharded (direct reduce-scatter + all-gather): vectors of the
-    gradient bucket's size (21 MB) and ragged lengths; equal to the host sum, bit-identical on both ranks, repeatable
-    across epochs and interleaved with the one-shot form on the same inbox."""
+    gradient bucket's size (21 MB) and ragged lengths (n % world != 0, last shard / last slice short, shards shorter than
+    the 64-block grid); bit-identical on all ranks and equal to the rank-ordered host sum, repeatable across epochs and
+    interleaved with the one-shot form on the same inbox. World 8 = 8 x 64 spinning blocks co-resident on one GPU."""
     out = str(tmp_path / "p2pb")
-    _launch(2, ["p2p_bucket", out], timeout=400)
+    _launch(world, ["p2p_bucket", out], timeout=600)
+    rs = [torch.load("%s.rank%d.pt" % (out, r)) for r in range(world)]
+    for r in rs:
+        assert r["error"] == 0 and r["memory_kind"] in (1, 2)
+        for got, want in zip(r["got"], rs[0]["want"]):
+            assert torch.equal(got, want)
+        assert torch.equal(r["mixed_small"], torch.full_like(r["mixed_small"], r["mixed_total"]))
+        assert torch.equal(r["mixed_big"], torch.full_like(r["mixed_big"], r["mixed_total"]))
+    print("sharded P2P all-reduce of %.1f MB between %d processes on one GPU: %s us per call"
+          % (rs[0]["bytes"] / 1e6, world, " / ".join("%.0f" % r["us_per_allreduce"] for r in rs)))
+
+
+def test_p2p_timeout_poisons_the_buffer_and_raises(device, tmp_path):
+    """a peer that never arrives must not yield a silently wrong sum. The waiting kernel gives up after ~4 s,
+    returns NaN instead of the partial sum, and the host sees the error without a device-wide hipMemcpy."""
+    out = str(tmp_path / "p2pt")
+    _launch(2, ["p2p_timeout", out], timeout=300)
     r0, r1 = torch.load(out + ".rank0.pt"), torch.load(out + ".rank1.pt")
-    assert r0["error"] == 0 and r1["error"] == 0
-    for got0, got1, want in zip(r0["got"], r1["got"], r0["want"]):
-        assert torch.equal(got0, got1)
-        assert torch.equal(got0, want)  # two addends: commutative, so equal to the host all-reduce bit for bit
-    for r in (r0, r1):
-        assert torch.equal(r["mixed_small"], torch.full_like(r["mixed_small"], 3.0))
-        assert torch.equal(r["mixed_big"], torch.full_like(r["mixed_big"], 3.0))
-    print("sharded P2P all-reduce of %.1f MB between two processes on one GPU: %.0f / %.0f us per call"
-          % (r0["bytes"] / 1e6, r0["us_per_allreduce"], r1["us_per_allreduce"]))
+    assert torch.equal(r0["first"], torch.full((1000,), 3.0)) and torch.equal(r1["first"], r0["first"])
+    assert r0["error_before"] == 0 and r1["error_before"] == 0
+    assert bool(torch.isnan(r0["poisoned"]).all())
+    assert r0["error_after"] == 2  # 1 + the rank whose flag never came
+    assert r0["raised"] and "rank 1" in r0["raised"]
+
+
+def test_rccl_communicator_behind_the_c_abi(device):
+    """csrc/comm.hip orbit_comm_* (RCCL): a one-rank communicator on this box's GPU - unique id, init, all-reduce, destroy.
+    (World > 1 needs one GPU per rank: bench.py --gpus N runs the same check over all ranks and reports `rccl_ranks`.)"""
+    import ctypes
+    from orbit_dataset_amd import _lib
+    code = ("import ctypes, torch, orbit_dataset_amd\n"
+            "from orbit_dataset_amd import _lib\n"
+            "lib = _lib.load()\n"
+            "uid = ctypes.create_string_buffer(128)\n"
+            "_lib.check(lib.orbit_comm_unique_id(uid), 'id')\n"
+            "_lib.check(lib.orbit_comm_init(0, 1, uid), 'init')\n"
+            "assert lib.orbit_comm_world() == 1 and lib.orbit_comm_rank() == 0\n"
+            "x = torch.arange(6405, dtype=torch.float32, device='cuda')\n"
+            "_lib.check(lib.orbit_allreduce_sum(_lib.dptr(x), x.numel(), _lib.stream_handle()), 'allreduce')\n"
+            "torch.cuda.synchronize()\n"
+            "assert torch.equal(x.cpu(), torch.arange(6405, dtype=torch.float32))\n"
+            "assert lib.orbit_comm_init(0, 1, uid) != 0  # already initialised\n"
+            "lib.orbit_comm_destroy()\n"
+            "assert lib.orbit_comm_world() == 0\n"
+            "print('rccl ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                       env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0 and "rccl ok" in r.stdout, (r.stdout + r.stderr)[-3000:]
 
 
 def test_training_step_with_p2p_gradient_bucket(device, tmp_path):

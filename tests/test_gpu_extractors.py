@@ -151,3 +151,28 @@ def test_largest_forward_of_the_reference_configuration(device):
         big = fe(x)
         small = torch.cat([fe(x[i:i + 256]) for i in range(0, 2048, 256)])
     assert torch.isfinite(big).all() and torch.equal(big, small)
+
+
+def test_row_streaming_plan_refuses_a_changed_band_option(device):
+    """`mbrows_band` is read when a plan is built (it sizes the squeeze-excite pooling partials) and again at
+    launch. Changing it in between must fail loudly instead of writing a different number of partials than the gate sums."""
+    from orbit_dataset_amd import _lib
+    lib = _lib.load()
+    fe, _ = create_feature_extractor("efficientnet_b0", True, False, False)
+    synthetic.init_parameters_(fe)
+    fe = fe.cuda().eval()
+    x = _frames(2, 224).to(device)
+    with torch.no_grad():
+        want = fe(x).clone()
+    graph = lib.orbit_get_option(b"graph")
+    lib.orbit_set_option(b"graph", 0)  # a replayed graph would not re-enter the launch code
+    lib.orbit_set_option(b"mbrows_band", 14)
+    try:
+        with pytest.raises(_lib.OrbitHipError, match="mbrows_band"):
+            with torch.no_grad():
+                fe(x)
+    finally:
+        lib.orbit_set_option(b"mbrows_band", 0)
+        lib.orbit_set_option(b"graph", graph)
+    with torch.no_grad():
+        assert torch.equal(fe(x), want)
