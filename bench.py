@@ -340,6 +340,19 @@ def rccl_check(lib, rank, world, backend, dist, device):
     in every element. Returns that sum (None when ranks share a GPU under the gloo self-test: RCCL refuses that)."""
     if backend != "nccl":
         return None
+    # RCCL prints a version banner on STDOUT when it initialises; this process owes its caller exactly one JSON line there
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        return _rccl_check(lib, rank, world, dist, device)
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
+
+
+def _rccl_check(lib, rank, world, dist, device):
     uid = ctypes.create_string_buffer(128)
     if rank == 0:
         _lib.check(lib.orbit_comm_unique_id(uid), "orbit_comm_unique_id")

@@ -72,7 +72,16 @@ struct ConvDesc {
     int x_nchw;  // stem gather from NCHW frames
     float prof_flop_scale = 1.f;  // algorithmic / executed flops (strided dgrad runs on the zero-inserted grid)
     float* splitk_ws = nullptr;   // scratch for split-K partial tiles (conv_splitk_floats(d) floats) or nullptr: no split
+    // train-mode BatchNorm statistics from the epilogue (the LITE step, csrc/extractor_train.hip): every block of output
+    // rows writes the column sums of its RAW outputs (before scale / shift / residual / activation) and of their squares to
+    // stats[row_block][2][Cout] - the layout bn_stats_finalize reads - so the separate statistics pass over y disappears.
+    // `stats` needs conv_stats_floats(M, Cout) floats; *stats_blocks receives the number of row blocks written, or 0 when
+    // this launch could not emit them (fused pooling, split-K, the narrow-pointwise kernel): the caller then runs
+    // launch_bn_stats' own pass.
+    float* stats = nullptr;
+    int* stats_blocks = nullptr;
 };
+inline size_t conv_stats_floats(size_t M, int Cout) { return ((M + 31) / 32) * 2 * (size_t)Cout; }  // smallest tile: 32 rows
 // split-K (small output, long reduction): number of K splits launch_conv uses for this conv when scratch is provided
 // (1 = none) and the scratch it needs
 int conv_splitk(const ConvDesc& d);
@@ -103,9 +112,12 @@ void prof_stop(int idx, hipStream_t s);  // per-launch event profiling is on (gr
 int dwconv_se_chunks(int Ho);
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                      float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
-                     int Wo, int act, hipStream_t s);
+                     int Wo, int act, hipStream_t s, int stats = 0);
+// stats != 0: pool_partial receives [B * dwconv_se_chunks(Ho)][2][C] column sums / sums of squares of the outputs instead
+// (train-mode BatchNorm statistics from the producing kernel; the partial layout bn_stats_finalize reads)
 int launch_se_gate2(const float* partial, int chunks, int HW, const float* w1, const float* b1, const float* w2t,
-                    const float* b2, float* gate, int B, int C, int R, hipStream_t s);
+                    const float* b2, float* gate, int B, int C, int R, hipStream_t s, float* pooled_out = nullptr);
+// (pooled_out, optional: the pooled means [B][C] the gate was computed from - the training tape keeps them)
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
 // fused expand(1x1, MFMA) + BN + SiLU + depthwise + BN + SiLU (+ SE pooling partials [B][tiles][mid]); csrc/mbconv.hip
 bool mbconv_front_supported(int Cin, int mid, int K, int stride);
@@ -160,8 +172,18 @@ int bn_reduce_blocks(int M, int C);  // rows of the [blocks][2][C] partial buffe
 int launch_bn_stats(const float* y, int M, int C, float eps, float momentum, const float* gamma, const float* beta,
                     const float* conv_bias, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
                     float* running_var, float* partial, hipStream_t s);
+// the same from [nblk][2][C] partials a producing kernel wrote (ConvDesc::stats, launch_dwconv_se(..., stats)); `partial` is
+// bn_partial_floats(nblk, C) floats (room for the compaction stage of very long partial lists)
+size_t bn_partial_floats(size_t nblk, int C);
+int launch_bn_stats_from_partials(float* partial, int nblk, int M, int C, float eps, float momentum, const float* gamma,
+                                  const float* beta, const float* conv_bias, float* mean, float* invstd, float* scale,
+                                  float* shift, float* running_mean, float* running_var, hipStream_t s);
 int launch_scale_shift_act(const float* y, const float* scale, const float* shift, const float* residual, int act,
                            size_t M, int C, float* out, hipStream_t s);
+// a = act(y * scale + shift) for [B][HW][C] plus the squeeze-excite pooling partials pool[B][se_pool_chunks][C] of a
+int se_pool_chunks(int B, int HW, int C);
+int launch_scale_shift_act_pool(const float* y, const float* scale, const float* shift, int act, int B, int HW, int C,
+                                float* out, float* pool, hipStream_t s);
 // coef: 3*C floats of scratch; dy nullable (reductions only); dres nullable (gradient of the residual input)
 // scale/shift: folded BatchNorm of the forward (needed to rebuild the SiLU pre-activation), else nullable
 int launch_bn_backward(const float* dout, const float* out, const float* y, const float* mean, const float* invstd,
@@ -182,9 +204,23 @@ int launch_gate_mul(const float* x, const float* gate, float* xg, int B, int HW,
 size_t se_bwd_scratch_floats(int B, int C, int R);
 // dxg: gradient of x*gate; writes dx (through the product, the gate MLP and the average pool) and, when dw1 != NULL, the
 // gradients of the four SE tensors (W1 [R][C], b1 [R], W2 [C][R], b2 [C])
+// bn (optional): x = act(BatchNorm(y)); then `dx` receives g = d x * act'(.) instead of d x and bn->partial the per-(frame,
+// chunk) sums of g and g * xhat ([B * se_pool_chunks(B, HW, C)][2][C]): launch_bn_backward_reduced finishes that BatchNorm's
+// backward without a reduction pass of its own
+struct SeBnFuse {
+    const float *y, *mean, *invstd, *scale, *shift;
+    int act;
+    float* partial;
+};
 int launch_se_gate_backward(const float* dxg, const float* x, const float* pooled, const float* gate, const float* w1,
                             const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1,
-                            float* dw2, float* db2, float* scratch, int B, int HW, int C, int R, hipStream_t s);
+                            float* dw2, float* db2, float* scratch, int B, int HW, int C, int R, hipStream_t s,
+                            const SeBnFuse* bn = nullptr);
+// BatchNorm backward whose reduction pass already ran (g = dout * act'(.) in `g`, [nblk][2][C] sums of g and g * xhat in
+// `partial`): finalize + apply only. coef: 3*C floats
+int launch_bn_backward_reduced(const float* g, const float* y, const float* mean, const float* invstd, const float* gamma,
+                               int train, int M, int C, float* dy, float* dgamma, float* dbeta, float* partial, int nblk,
+                               float* coef, hipStream_t s);
 // flip_scratch (K*K*C floats, optional): stride-1 layers then run as a FORWARD depthwise convolution of dy with the flipped
 // taps through the LDS-patch kernels of csrc/ops.hip instead of the per-pixel gather
 int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, int H, int W, int C, int K, int stride,
@@ -194,7 +230,8 @@ int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scrat
                         int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s);
 size_t conv_wgrad_scratch_floats(int B, int Cin, int Cout, int KH, int KW, int Ho, int Wo);
 int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
-                      int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float* scratch, hipStream_t s);
+                      int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float* scratch, hipStream_t s,
+                      const float* gate = nullptr);  // gate [B][Cin]: the filter gradient w.r.t. x * gate without materialising it
 size_t conv_dgrad_packed_floats(int Cin, int Cout, int KH, int KW);
 int conv_pack_dgrad_weights(const float* w_oihw, float* w_packed, int Cin, int Cout, int KH, int KW, hipStream_t s);
 int launch_conv_dgrad(const float* dy, const float* w_dgrad_packed, const float* accumulate, float* dx, float* up, int B,

@@ -65,6 +65,7 @@ struct ConvParams {
     int stem_table;            // stem mode: use the interior fast path (conv_stem_fast option, A/B)
     int ksplit, kt_per_split;  // split-K: blockIdx = split * tiles + tile; raw partial tiles go to part[split][M][Cout]
     float* part;
+    float* stats;              // [m_tiles][2][Cout] column sums / sums of squares of the raw outputs (train-mode BatchNorm) or null
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -459,6 +460,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         const int mout = POOL2 ? (p.M >> 2) : p.M;
         float* yout = p.ksplit > 1 ? p.part + (size_t)split * p.M * p.Cout : p.y;
         constexpr int ITER = (OROWS + RPO - 1) / RPO;  // output rows per thread (4 for the 64x64 and 128x32 tiles)
+        f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};  // column sums of this thread's rows (p.stats)
         if (n < p.Cout && p.epi_batch && ITER <= 8) {
             // batched form: the LDS reads and the residual loads of all of a thread's rows are issued before the first use
             // (row by row, every row paid an LDS - and with a skip connection an L2 - round trip of its own)
@@ -480,6 +482,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 const int r = tid / TPO + it * RPO;
                 if (r < OROWS && mo0 + r < mout) {
                     f32x4 o = v[it];
+                    st_s += o, st_q += o * o;
                     if (!POOL2 && p.ksplit <= 1) {
                         o += res[it];
                         o[0] = apply_act(o[0], p.act), o[1] = apply_act(o[1], p.act);
@@ -496,12 +499,29 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 f32x4 v = *reinterpret_cast<const f32x4*>(smem + r * CS + oc);
 #pragma unroll
                 for (int q = 1; q < WGK; ++q) v += *reinterpret_cast<const f32x4*>(smem + (q * OROWS + r) * CS + oc);
+                st_s += v, st_q += v * v;
                 if (!POOL2 && p.ksplit <= 1) {
                     if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.Cout + n);
                     v[0] = apply_act(v[0], p.act), v[1] = apply_act(v[1], p.act);
                     v[2] = apply_act(v[2], p.act), v[3] = apply_act(v[3], p.act);
                 }
                 *reinterpret_cast<f32x4*>(yout + (size_t)m * p.Cout + n) = v;
+            }
+        }
+        // train-mode BatchNorm statistics of this tile's rows (rows beyond M never entered the sums): the RPO row lanes of a
+        // column quad are combined through LDS in a fixed order, one float4 pair per (row block, column quad) goes out
+        if (p.stats != nullptr) {  // uniform
+            __syncthreads();       // every thread is done reading the C tile
+            f32x4* red = reinterpret_cast<f32x4*>(smem);  // [2][256]
+            red[tid] = st_s, red[256 + tid] = st_q;
+            __syncthreads();
+            if (tid < TPO && n < p.Cout) {
+                f32x4 a = red[tid], b = red[256 + tid];
+#pragma unroll 4
+                for (int r = 1; r < RPO; ++r) a += red[r * TPO + tid], b += red[256 + r * TPO + tid];
+                const size_t mt = (size_t)(tile / p.n_tiles);
+                *reinterpret_cast<f32x4*>(p.stats + (mt * 2 + 0) * p.Cout + n) = a;
+                *reinterpret_cast<f32x4*>(p.stats + (mt * 2 + 1) * p.Cout + n) = b;
             }
         }
     }
@@ -761,6 +781,7 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     ORBIT_REQUIRE(!(d.pool2 && d.residual), "conv: pool2 cannot be combined with a residual input");
     ORBIT_REQUIRE(d.Cout % 4 == 0, "conv: Cout %% 4 != 0 (Cout=%d): the epilogue writes float4 rows", d.Cout);
     const bool pw = !d.x_nchw && d.KH == 1 && d.KW == 1 && d.pad_t == 0 && d.pad_l == 0;
+    if (d.stats_blocks) *d.stats_blocks = 0;
     if (pw && pw_narrow_supported(d)) return launch_pw_narrow(d, s);
     ORBIT_REQUIRE(!d.gate || (!d.x_nchw && !d.pool2), "conv: the squeeze-excite gate needs the NHWC path without fused pooling");
     const ConvPackGeom g = conv_pack_geom(d.Cin, d.Cout, d.KH, d.KW, d.x_nchw);
@@ -789,11 +810,15 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     p.ksplit = d.splitk_ws ? conv_splitk(d) : 1;
     p.kt_per_split = p.ksplit > 1 ? cdiv(g.kt / bk, p.ksplit) : 0;
     p.part = d.splitk_ws;
+    // statistics of the raw outputs for a train-mode BatchNorm: whole-tile launches only (a split-K partial is not the output,
+    // the fused max-pool stores pooled rows)
+    p.stats = (d.stats && d.stats_blocks && p.ksplit <= 1 && !d.pool2) ? d.stats : nullptr;
     int rc;
     if (d.x_nchw) rc = d.pool2 ? launch_bk<1, true, false, false>(p, bk, s) : launch_bk<1, false, false, false>(p, bk, s);
     else if (pw && !d.pool2) rc = d.gate ? launch_bk<0, false, true, true>(p, bk, s) : launch_bk<0, false, false, true>(p, bk, s);
     else if (d.gate) rc = launch_bk<0, false, true, false>(p, bk, s);
     else rc = d.pool2 ? launch_bk<0, true, false, false>(p, bk, s) : launch_bk<0, false, false, false>(p, bk, s);
+    if (rc == ORBIT_OK && p.stats) *d.stats_blocks = p.m_tiles;  // (launch_cfg2 set the tiling it chose)
     if (rc != ORBIT_OK || p.ksplit <= 1) return rc;
     const size_t mn4 = (size_t)p.M * p.Cout / 4;
     const int blocks = (int)std::min<size_t>((mn4 + 255) / 256, 4096);

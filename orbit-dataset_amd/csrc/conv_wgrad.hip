@@ -24,6 +24,7 @@ using f32x4 = __attribute__((ext_vector_type(4))) float;
 struct WgradParams {
     const float* x;
     const float* dy;
+    const float* gate;  // [B][Cin] squeeze-excite gate multiplied into x on the fly (NHWC mode), or nullptr
     float* partial;  // [splits][Cout][NC]
     int B, H, W, Cin, Cout, KH, KW, stride, pad_t, pad_l, Ho, Wo;
     int M, NC;
@@ -80,6 +81,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 
     f32x4 a_stage[2];
     f32x4 b_stage[2];  // MODE 1 reuses these as 8 scalars
+    f32x4 g_stage[2];  // gate quads of the two staged rows (multiplied in at the LDS store, so the loads share one wait)
 
     auto load_step = [&](int step) {
         const int mb = m_begin + step * WG_BKM;
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
         for (int i = 0; i < 2; ++i) {
             const int m = mb + lrow + 16 * i;
             f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+            g_stage[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
             if (m < m_end) {
                 if (a_col_ok) va = *reinterpret_cast<const f32x4*>(p.dy + (size_t)m * p.Cout + co0 + c4 * 4);
                 if (MODE == 0 && b_col_ok) {
@@ -96,6 +99,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
                     const int hi = ho * p.stride - p.pad_t + kh0, wi = wo * p.stride - p.pad_l + kw0;
                     if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W)
                         vb = *reinterpret_cast<const f32x4*>(p.x + (((size_t)b * p.H + hi) * p.W + wi) * p.Cin + ci0);
+                    if (p.gate) g_stage[i] = *reinterpret_cast<const f32x4*>(p.gate + (size_t)b * p.Cin + ci0);
                 }
             }
             a_stage[i] = va;
@@ -123,7 +127,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradParams p) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             *reinterpret_cast<f32x4*>(&As[buf][lrow + 16 * i][c4 * 4]) = a_stage[i];
-            if (MODE == 0) *reinterpret_cast<f32x4*>(&Bs[buf][lrow + 16 * i][c4 * 4]) = b_stage[i];
+            if (MODE == 0)
+                *reinterpret_cast<f32x4*>(&Bs[buf][lrow + 16 * i][c4 * 4]) = p.gate ? b_stage[i] * g_stage[i] : b_stage[i];
         }
         if (MODE == 1) {
 #pragma unroll
@@ -214,12 +219,14 @@ size_t conv_wgrad_scratch_floats(int B, int Cin, int Cout, int KH, int KW, int H
 }
 
 int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
-                      int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float* scratch, hipStream_t s) {
+                      int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float* scratch, hipStream_t s,
+                      const float* gate) {
     ORBIT_REQUIRE(x && dy && dw_oihw && scratch, "conv_wgrad: null pointer");
+    ORBIT_REQUIRE(!gate || !x_nchw, "conv_wgrad: the squeeze-excite gate needs the NHWC path");
     ORBIT_REQUIRE(Cout % 4 == 0, "conv_wgrad: Cout %% 4 != 0");
     ORBIT_REQUIRE(x_nchw || Cin % 4 == 0, "conv_wgrad: NHWC path needs Cin %% 4 == 0");
     WgradParams p;
-    p.x = x, p.dy = dy, p.partial = scratch;
+    p.x = x, p.dy = dy, p.partial = scratch, p.gate = gate;
     p.B = B, p.H = H, p.W = W, p.Cin = Cin, p.Cout = Cout, p.KH = KH, p.KW = KW, p.stride = stride;
     p.pad_t = pad_t, p.pad_l = pad_l, p.Ho = Ho, p.Wo = Wo;
     p.M = B * Ho * Wo, p.NC = KH * KW * Cin;

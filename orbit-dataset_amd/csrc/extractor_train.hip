@@ -39,7 +39,7 @@ struct TapeLayout {
     // byte offsets per op ((size_t)-1: none). conv / depthwise: y raw output, a activation, p/idx fused pool, xg gated
     // input. squeeze-excite: p = pooled means [B][C], a = gate [B][C]. max-pool: p output, idx argmax.
     std::vector<size_t> y, a, p, idx, xg;
-    size_t mean = 0, invstd = 0, scale = 0, shift = 0, partial = 0, total = 0;
+    size_t mean = 0, invstd = 0, scale = 0, shift = 0, partial = 0, pool = 0, total = 0;
 };
 
 static const size_t NONE = (size_t)-1;
@@ -58,8 +58,31 @@ static bool has_bn(const Op& o) { return o.kind == OP_CONV || o.kind == OP_DWCON
 static size_t max_bn_partial_floats(const orbit_extractor* fe, int B) {
     size_t m = 4;
     for (const Op& o : fe->ops)
-        if (has_bn(o))
-            m = std::max(m, (size_t)bn_reduce_blocks(B * o.Ho * o.Wo, o.Cout) * 2 * o.Cout + 3 * (size_t)o.Cout);
+        if (has_bn(o)) {
+            const size_t M = (size_t)B * o.Ho * o.Wo;
+            m = std::max(m, (size_t)bn_reduce_blocks((int)M, o.Cout) * 2 * o.Cout + 3 * (size_t)o.Cout);
+            // statistics partials written by the producing kernel's epilogue (one per 32+ conv rows / per depthwise chunk)
+            if (o.kind == OP_CONV) m = std::max(m, bn_partial_floats((M + 31) / 32, o.Cout));
+            else m = std::max(m, bn_partial_floats((size_t)B * dwconv_se_chunks(o.Ho), o.Cout));
+            // backward of a depthwise BatchNorm whose reduction rides on the squeeze-excite backward (+ 3*C coefficients)
+            if (o.kind == OP_DWCONV)
+                m = std::max(m, bn_partial_floats((size_t)B * se_pool_chunks(B, o.Ho * o.Wo, o.Cout), o.Cout) + 3 * (size_t)o.Cout);
+        }
+    return m;
+}
+
+// squeeze-excite pooling partials of the pooled apply pass (launch_scale_shift_act_pool): [B][chunks][C]
+static size_t max_se_pool_floats(const orbit_extractor* fe, int B) {
+    size_t m = 4;
+    int last_dw = -1;
+    for (size_t i = 0; i < fe->ops.size(); ++i) {
+        const Op& o = fe->ops[i];
+        if (o.kind == OP_DWCONV) last_dw = (int)i;
+        if (o.kind == OP_SE && last_dw >= 0) {
+            const Op& dw = fe->ops[last_dw];
+            m = std::max(m, (size_t)B * se_pool_chunks(B, dw.Ho * dw.Wo, o.Cin) * o.Cin);
+        }
+    }
     return m;
 }
 
@@ -82,7 +105,8 @@ static TapeLayout tape_layout(const orbit_extractor* fe, int B) {
                 const size_t pe = (size_t)B * (o.Ho / 2) * (o.Wo / 2) * o.Cout;
                 L.p[i] = take(pe * 4), L.idx[i] = take(pe);
             }
-            if (o.use_gate) L.xg[i] = take((size_t)B * o.H * o.W * o.Cin * 4);
+            // (a gated projection reads x and the gate separately - forward through the GATE prologue of conv_igemm, filter
+            // gradient through conv_wgrad's - so the product x * gate is never materialised; L.xg stays unused)
         } else if (o.kind == OP_DWCONV) {
             const size_t e = (size_t)B * o.Ho * o.Wo * o.Cout;
             L.y[i] = take(e * 4), L.a[i] = take(e * 4);
@@ -96,6 +120,7 @@ static TapeLayout tape_layout(const orbit_extractor* fe, int B) {
     L.mean = take(fe->fold_floats * 4), L.invstd = take(fe->fold_floats * 4);
     L.scale = take(fe->fold_floats * 4), L.shift = take(fe->fold_floats * 4);
     L.partial = take(max_bn_partial_floats(fe, B) * 4);
+    L.pool = take(max_se_pool_floats(fe, B) * 4);
     L.total = off;
     return L;
 }
@@ -289,20 +314,20 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
     std::map<int, const float*> cur;  // buffer id -> tensor currently held
     cur[-1] = frames;
     int last_dw = -1;
+    bool dw_pooled = false;  // the last depthwise op's activation pass left pooling partials in L.pool
     for (size_t i = 0; i < fe->ops.size(); ++i) {
         const Op& o = fe->ops[i];
         int rc = ORBIT_OK;
         if (o.kind == OP_CONV) {
             const BNDesc& bn = fe->bns[o.bn];
             const float* xin = cur[o.in];
-            if (o.use_gate) {  // squeeze-excite: the projection reads x * gate; the product is kept for the filter gradient
-                rc = launch_gate_mul(xin, cur[102], fl(L.xg[i]), B, o.H * o.W, o.Cin, s);
-                if (rc != ORBIT_OK) return rc;
-                xin = fl(L.xg[i]);
-            }
             ConvDesc d;
             d.x = xin, d.w_packed = fe->d_packed + o.packed_off, d.y = fl(L.y[i]);
             d.scale = d.shift = d.residual = d.gate = nullptr;
+            // squeeze-excite: the projection multiplies the gate into its A operand on the fly (as the inference plan does)
+            if (o.use_gate) d.gate = cur[102];
+            int stat_blocks = 0;  // train-mode BatchNorm: column sums of the raw outputs come from the conv's epilogue
+            if (bn_train) d.stats = fl(L.partial), d.stats_blocks = &stat_blocks;
             d.B = B, d.H = o.H, d.W = o.W, d.Cin = o.Cin, d.Cout = o.Cout, d.KH = o.KH, d.KW = o.KW;
             d.stride = o.stride, d.pad_t = o.pad_t, d.pad_l = o.pad_l, d.Ho = o.Ho, d.Wo = o.Wo;
             d.act = ORBIT_ACT_NONE, d.pool2 = 0, d.x_nchw = o.x_nchw;
@@ -311,13 +336,19 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
             const int M = B * o.Ho * o.Wo;
             if (bn_train) {
                 const bool fm = film && bn.film_off >= 0;
-                rc = launch_bn_stats(d.y, M, o.Cout, bn.eps, momentum,
-                                     fm ? film_gamma + bn.film_off : fe->d_pool + fe->params[bn.gamma].off,
-                                     fm ? film_beta + bn.film_off : fe->d_pool + fe->params[bn.beta].off,
-                                     bn.conv_bias >= 0 ? fe->d_pool + fe->params[bn.conv_bias].off : nullptr,
-                                     mean + bn.fold_off, invstd + bn.fold_off, scale + bn.fold_off, shift + bn.fold_off,
-                                     fe->d_pool + fe->params[bn.mean].off, fe->d_pool + fe->params[bn.var].off,
-                                     fl(L.partial), s);
+                const float* gam = fm ? film_gamma + bn.film_off : fe->d_pool + fe->params[bn.gamma].off;
+                const float* bet = fm ? film_beta + bn.film_off : fe->d_pool + fe->params[bn.beta].off;
+                const float* cb = bn.conv_bias >= 0 ? fe->d_pool + fe->params[bn.conv_bias].off : nullptr;
+                if (stat_blocks > 0)
+                    rc = launch_bn_stats_from_partials(fl(L.partial), stat_blocks, M, o.Cout, bn.eps, momentum, gam, bet, cb,
+                                                       mean + bn.fold_off, invstd + bn.fold_off, scale + bn.fold_off,
+                                                       shift + bn.fold_off, fe->d_pool + fe->params[bn.mean].off,
+                                                       fe->d_pool + fe->params[bn.var].off, s);
+                else  // (fused pooling / split-K launches do not emit them: the statistics pass of its own)
+                    rc = launch_bn_stats(d.y, M, o.Cout, bn.eps, momentum, gam, bet, cb, mean + bn.fold_off,
+                                         invstd + bn.fold_off, scale + bn.fold_off, shift + bn.fold_off,
+                                         fe->d_pool + fe->params[bn.mean].off, fe->d_pool + fe->params[bn.var].off,
+                                         fl(L.partial), s);
                 if (rc != ORBIT_OK) return rc;
             }
             rc = launch_scale_shift_act(d.y, scale + bn.fold_off, shift + bn.fold_off,
@@ -333,34 +364,51 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
         } else if (o.kind == OP_DWCONV) {
             const BNDesc& bn = fe->bns[o.bn];
             float* y = fl(L.y[i]);
-            rc = launch_dwconv_se(cur[o.in], fe->d_packed + o.packed_off, y, nullptr, nullptr, nullptr, B, o.H, o.W, o.Cin,
-                                  o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, ORBIT_ACT_NONE, s);
+            // train-mode BatchNorm: the depthwise kernel itself emits the column sums / sums of squares of its raw outputs
+            rc = launch_dwconv_se(cur[o.in], fe->d_packed + o.packed_off, y, nullptr, nullptr,
+                                  bn_train ? fl(L.partial) : nullptr, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l,
+                                  o.Ho, o.Wo, ORBIT_ACT_NONE, s, bn_train ? 1 : 0);
             if (rc != ORBIT_OK) return rc;
             const int M = B * o.Ho * o.Wo;
             if (bn_train) {
                 const bool fm = film && bn.film_off >= 0;
-                rc = launch_bn_stats(y, M, o.Cout, bn.eps, momentum,
-                                     fm ? film_gamma + bn.film_off : fe->d_pool + fe->params[bn.gamma].off,
-                                     fm ? film_beta + bn.film_off : fe->d_pool + fe->params[bn.beta].off, nullptr,
-                                     mean + bn.fold_off, invstd + bn.fold_off, scale + bn.fold_off, shift + bn.fold_off,
-                                     fe->d_pool + fe->params[bn.mean].off, fe->d_pool + fe->params[bn.var].off,
-                                     fl(L.partial), s);
+                rc = launch_bn_stats_from_partials(fl(L.partial), B * dwconv_se_chunks(o.Ho), M, o.Cout, bn.eps, momentum,
+                                                   fm ? film_gamma + bn.film_off : fe->d_pool + fe->params[bn.gamma].off,
+                                                   fm ? film_beta + bn.film_off : fe->d_pool + fe->params[bn.beta].off,
+                                                   nullptr, mean + bn.fold_off, invstd + bn.fold_off, scale + bn.fold_off,
+                                                   shift + bn.fold_off, fe->d_pool + fe->params[bn.mean].off,
+                                                   fe->d_pool + fe->params[bn.var].off, s);
                 if (rc != ORBIT_OK) return rc;
             }
-            rc = launch_scale_shift_act(y, scale + bn.fold_off, shift + bn.fold_off, nullptr, o.act, (size_t)M, o.Cout,
-                                        fl(L.a[i]), s);
+            // the activation pass also produces the squeeze-excite pooling partials when an SE op consumes this tensor
+            dw_pooled = i + 1 < fe->ops.size() && fe->ops[i + 1].kind == OP_SE;
+            if (dw_pooled)
+                rc = launch_scale_shift_act_pool(y, scale + bn.fold_off, shift + bn.fold_off, o.act, B, o.Ho * o.Wo, o.Cout,
+                                                 fl(L.a[i]), fl(L.pool), s);
+            else
+                rc = launch_scale_shift_act(y, scale + bn.fold_off, shift + bn.fold_off, nullptr, o.act, (size_t)M, o.Cout,
+                                            fl(L.a[i]), s);
             cur[o.out] = fl(L.a[i]);
             last_dw = (int)i;
         } else if (o.kind == OP_SE) {
             // squeeze (mean over the depthwise output) + excite MLP -> gate [B][C]
             if (last_dw < 0) return set_err(ORBIT_ERR_STATE, "extractor_train_forward: squeeze-excite without a producer");
             const Op& dw = fe->ops[last_dw];
-            rc = launch_colmean(fl(L.a[last_dw]), fl(L.p[i]), B, dw.Ho * dw.Wo, o.Cin, s);
-            if (rc != ORBIT_OK) return rc;
-            // the inference gate kernel, fed with the means as a single "partial sum" over one element
-            rc = launch_se_gate2(fl(L.p[i]), 1, 1, fe->d_pool + fe->params[o.se_w1].off,
-                                 fe->d_pool + fe->params[o.se_b1].off, fe->d_packed + o.packed_off,
-                                 fe->d_pool + fe->params[o.se_b2].off, fl(L.a[i]), B, o.Cin, o.R, s);
+            if (dw_pooled) {
+                // the inference gate kernel on the partial sums the activation pass left; the pooled means it forms go on the
+                // tape (the gate MLP's backward reads them)
+                rc = launch_se_gate2(fl(L.pool), se_pool_chunks(B, dw.Ho * dw.Wo, o.Cin), dw.Ho * dw.Wo,
+                                     fe->d_pool + fe->params[o.se_w1].off, fe->d_pool + fe->params[o.se_b1].off,
+                                     fe->d_packed + o.packed_off, fe->d_pool + fe->params[o.se_b2].off, fl(L.a[i]), B, o.Cin,
+                                     o.R, s, fl(L.p[i]));
+            } else {
+                rc = launch_colmean(fl(L.a[last_dw]), fl(L.p[i]), B, dw.Ho * dw.Wo, o.Cin, s);
+                if (rc != ORBIT_OK) return rc;
+                // the inference gate kernel, fed with the means as a single "partial sum" over one element
+                rc = launch_se_gate2(fl(L.p[i]), 1, 1, fe->d_pool + fe->params[o.se_w1].off,
+                                     fe->d_pool + fe->params[o.se_b1].off, fe->d_packed + o.packed_off,
+                                     fe->d_pool + fe->params[o.se_b2].off, fl(L.a[i]), B, o.Cin, o.R, s);
+            }
             cur[102] = fl(L.a[i]);
         } else if (o.kind == OP_MAXPOOL) {
             rc = launch_maxpool_idx(cur[o.in], fl(L.p[i]), reinterpret_cast<uint8_t*>(tp + L.idx[i]), B, o.H, o.W, o.Cin,
@@ -450,6 +498,9 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
 
     bool used[BwdLayout::NSLOTS] = {false};
     std::vector<int> grad_slot(n, -1);  // gradient w.r.t. the OUTPUT tensor of op i
+    // > 0: the slot of op i already holds g = d out * act'(.) and `partial` the [n][2][C] sums of its BatchNorm backward
+    // (written by the squeeze-excite backward of the block, launch_se_gate_backward with SeBnFuse)
+    std::vector<int> pre_reduced(n, 0);
     auto slot_ptr = [&](int k) { return reinterpret_cast<float*>(ws + W.slots + (size_t)k * W.slot_bytes); };
     auto alloc = [&]() {
         for (int k = 0; k < BwdLayout::NSLOTS; ++k)
@@ -518,10 +569,17 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                 kdy = alloc();
                 if (kdy < 0) return set_err(ORBIT_ERR_STATE, "extractor_backward: gradient slots exhausted");
             }
-            float* coef = partial + (size_t)bn_reduce_blocks(M, o.Cout) * 2 * o.Cout;
-            rc = launch_bn_backward(slot_ptr(g), tf(L.a[i]), tf(L.y[i]), mean + bn.fold_off, invstd + bn.fold_off, gamma,
-                                    scale + bn.fold_off, shift + bn.fold_off, bn_train, o.act, M, o.Cout,
-                                    need_dy ? slot_ptr(kdy) : nullptr, nullptr, 0, dgam, dbet, nullptr, partial, coef, s);
+            if (pre_reduced[i] > 0) {
+                float* coef = partial + bn_partial_floats((size_t)pre_reduced[i], o.Cout);
+                rc = launch_bn_backward_reduced(slot_ptr(g), tf(L.y[i]), mean + bn.fold_off, invstd + bn.fold_off, gamma,
+                                                bn_train, M, o.Cout, need_dy ? slot_ptr(kdy) : nullptr, dgam, dbet, partial,
+                                                pre_reduced[i], coef, s);
+            } else {
+                float* coef = partial + (size_t)bn_reduce_blocks(M, o.Cout) * 2 * o.Cout;
+                rc = launch_bn_backward(slot_ptr(g), tf(L.a[i]), tf(L.y[i]), mean + bn.fold_off, invstd + bn.fold_off, gamma,
+                                        scale + bn.fold_off, shift + bn.fold_off, bn_train, o.act, M, o.Cout,
+                                        need_dy ? slot_ptr(kdy) : nullptr, nullptr, 0, dgam, dbet, nullptr, partial, coef, s);
+            }
             if (rc != ORBIT_OK) return rc;
             release(g), grad_slot[i] = -1;
             if (wg) {
@@ -592,10 +650,10 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
             }
             release(g), grad_slot[i] = -1;
             if (wg) {
-                rc = launch_conv_wgrad(o.use_gate ? tf(L.xg[i]) : out_tensor(src), o.x_nchw, slot_ptr(kdy),
-                                       param_grads + fe->params[o.weight].off, B,
+                // a gated projection: d/dW of conv(x * gate) - the gate is multiplied into x inside the kernel
+                rc = launch_conv_wgrad(out_tensor(src), o.x_nchw, slot_ptr(kdy), param_grads + fe->params[o.weight].off, B,
                                        o.H, o.W, o.Cin, o.Cout, o.KH, o.KW, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo,
-                                       wgrad_scratch, s);
+                                       wgrad_scratch, s, o.use_gate ? tf(L.a[P.gate[i]]) : nullptr);
                 if (rc != ORBIT_OK) return rc;
             }
             if (need_dx && o.use_gate) {
@@ -610,6 +668,18 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                 SLOT_OR_FAIL(k);
                 grad_slot[src] = k;
                 float* pg = wg ? param_grads : nullptr;
+                // x = SiLU(BatchNorm(depthwise output)): the first (reduction) pass of that BatchNorm's backward is folded
+                // into the last pass of the squeeze-excite backward
+                SeBnFuse fuse;
+                const SeBnFuse* fuse_ptr = nullptr;
+                if (fe->ops[src].kind == OP_DWCONV && get_option("se_bn_fuse")) {
+                    const BNDesc& sbn = fe->bns[fe->ops[src].bn];
+                    fuse.y = tf(L.y[src]), fuse.mean = mean + sbn.fold_off, fuse.invstd = invstd + sbn.fold_off;
+                    fuse.scale = scale + sbn.fold_off, fuse.shift = shift + sbn.fold_off, fuse.act = fe->ops[src].act;
+                    fuse.partial = partial;
+                    fuse_ptr = &fuse;
+                    pre_reduced[src] = B * se_pool_chunks(B, o.H * o.W, o.Cin);
+                }
                 rc = launch_se_gate_backward(slot_ptr(kt), out_tensor(src), tf(L.p[se]), tf(L.a[se]),
                                              fe->d_pool + fe->params[so.se_w1].off, fe->d_pool + fe->params[so.se_b1].off,
                                              fe->d_pool + fe->params[so.se_w2].off, fe->d_pool + fe->params[so.se_b2].off,
@@ -617,7 +687,7 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                                              pg ? pg + fe->params[so.se_b1].off : nullptr,
                                              pg ? pg + fe->params[so.se_w2].off : nullptr,
                                              pg ? pg + fe->params[so.se_b2].off : nullptr, se_scratch, B, o.H * o.W, o.Cin,
-                                             so.R, s);
+                                             so.R, s, fuse_ptr);
                 release(kt);
             } else if (need_dx) {
                 const float* acc = nullptr;

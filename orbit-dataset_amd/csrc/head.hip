@@ -43,6 +43,7 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"dw_dgrad_forward", "ORBIT_DW_DGRAD_FORWARD", 1, false},
                              {"graph", "ORBIT_GRAPH", 2, false},
                              {"train_graph", "ORBIT_TRAIN_GRAPH", 0, false},
+                             {"se_bn_fuse", "ORBIT_SE_BN_FUSE", 1, false},
                              {"stem_direct", "ORBIT_STEM_DIRECT", 1, false},
                              {"se_wide", "ORBIT_SE_WIDE", 1, false},
                              {"conv_tile", "ORBIT_CONV_TILE", 0, false},

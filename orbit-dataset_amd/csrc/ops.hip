@@ -35,7 +35,11 @@ __global__ __launch_bounds__(256) void dw_pack_kernel(const float* __restrict__ 
 // channel slice x K*K taps) sit in LDS. Every thread owns a FIXED channel quad, so its running sum of activated
 // outputs is the squeeze-excite pooling partial: reduced across the block's column lanes in a fixed order and
 // written to pool_partial[b][row_chunk][c] (deterministic; orbit se_gate sums the row chunks).
-template <int K, int S>
+// STATS (all four depthwise kernels): instead of the squeeze-excite pooling partials [B][chunk][C], `pool_partial` receives
+// the column sums AND sums of squares of the outputs, [B * chunks][2][C] - the per-block layout the train-mode BatchNorm
+// finalize reads (csrc/train_ops.hip); the training forward launches these kernels without scale / shift / activation, so
+// the sums are those of the raw depthwise outputs and BatchNorm needs no statistics pass of its own over y.
+template <int K, int S, bool STATS = false>
 __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         float* __restrict__ y, const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
@@ -61,7 +65,7 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
     float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (scale) sc = *reinterpret_cast<const float4*>(scale + c);
     if (shift) sh = *reinterpret_cast<const float4*>(shift + c);
-    float4 psum = make_float4(0.f, 0.f, 0.f, 0.f);
+    float4 psum = make_float4(0.f, 0.f, 0.f, 0.f), psq = make_float4(0.f, 0.f, 0.f, 0.f);
     const float* xb = x + (size_t)b * H * W * C + c;
     float* yb = y + (size_t)b * Ho * Wo * C + c;
     const int ho_end = min(Ho, (chunk + 1) * rows_per_chunk);
@@ -109,6 +113,7 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
                         o.w = act_fn(acc[j].w * sc.w + sh.w, act);
                         *reinterpret_cast<float4*>(yb + ((size_t)ho * Wo + wo) * C) = o;
                         psum.x += o.x, psum.y += o.y, psum.z += o.z, psum.w += o.w;
+                        if (STATS) psq.x += o.x * o.x, psq.y += o.y * o.y, psq.z += o.z * o.z, psq.w += o.w * o.w;
                     }
                 }
             }
@@ -117,13 +122,27 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
     if (pool_partial == nullptr) return;
     if (active) red[lw * cb4 + lc] = psum;
     __syncthreads();
+    const size_t prow = ((size_t)b * gridDim.y + chunk) * (STATS ? 2 : 1);
     if (tid < cb4) {
         float4 t = red[tid];
         for (int l = 1; l < WL; ++l) {
             const float4 u = red[l * cb4 + tid];
             t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
         }
-        *reinterpret_cast<float4*>(pool_partial + ((size_t)b * gridDim.y + chunk) * C + (c4_0 + tid) * 4) = t;
+        *reinterpret_cast<float4*>(pool_partial + prow * C + (c4_0 + tid) * 4) = t;
+    }
+    if (STATS) {
+        __syncthreads();
+        if (active) red[lw * cb4 + lc] = psq;
+        __syncthreads();
+        if (tid < cb4) {
+            float4 t = red[tid];
+            for (int l = 1; l < WL; ++l) {
+                const float4 u = red[l * cb4 + tid];
+                t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
+            }
+            *reinterpret_cast<float4*>(pool_partial + (prow + 1) * C + (c4_0 + tid) * 4) = t;
+        }
     }
 }
 
@@ -133,7 +152,7 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
 // output group. Here every load is unconditional (column / row clamped to a valid address, the value multiplied by a
 // 0/1 mask afterwards - the masks of the columns are computed once per column strip) and tap row kh+1 is requested
 // before row kh is consumed, so the waits are counted and one row of loads is always in flight.
-template <int K, int S>
+template <int K, int S, bool STATS = false>
 __global__ __launch_bounds__(256) void dwconv_pipe_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           float* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift,
@@ -156,7 +175,7 @@ __global__ __launch_bounds__(256) void dwconv_pipe_kernel(const float* __restric
         wl[i] = *reinterpret_cast<const v4f*>(w + (size_t)tap * C + (c4_0 + cc) * 4);
     }
     __syncthreads();
-    v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, psum = {0.f, 0.f, 0.f, 0.f};
+    v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, psum = {0.f, 0.f, 0.f, 0.f}, psq = {0.f, 0.f, 0.f, 0.f};
     if (scale) sc = *reinterpret_cast<const v4f*>(scale + c);
     if (shift) sh = *reinterpret_cast<const v4f*>(shift + c);
     const float* xb = x + (size_t)b * H * W * C + c;
@@ -218,6 +237,7 @@ __global__ __launch_bounds__(256) void dwconv_pipe_kernel(const float* __restric
                         o[0] = act_fn(o[0], act), o[1] = act_fn(o[1], act), o[2] = act_fn(o[2], act), o[3] = act_fn(o[3], act);
                         *reinterpret_cast<v4f*>(yb + ((size_t)ho * Wo + wo) * C) = o;
                         psum += o;
+                        if (STATS) psq += o * o;
                     }
                 }
             }
@@ -226,10 +246,21 @@ __global__ __launch_bounds__(256) void dwconv_pipe_kernel(const float* __restric
     if (pool_partial == nullptr) return;
     if (active) red[lw * cb4 + lc] = psum;
     __syncthreads();
+    const size_t prow = ((size_t)b * gridDim.y + chunk) * (STATS ? 2 : 1);
     if (tid < cb4) {
         v4f t = red[tid];
         for (int l = 1; l < WL; ++l) t += red[l * cb4 + tid];
-        *reinterpret_cast<v4f*>(pool_partial + ((size_t)b * gridDim.y + chunk) * C + (c4_0 + tid) * 4) = t;
+        *reinterpret_cast<v4f*>(pool_partial + prow * C + (c4_0 + tid) * 4) = t;
+    }
+    if (STATS) {
+        __syncthreads();
+        if (active) red[lw * cb4 + lc] = psq;
+        __syncthreads();
+        if (tid < cb4) {
+            v4f t = red[tid];
+            for (int l = 1; l < WL; ++l) t += red[l * cb4 + tid];
+            *reinterpret_cast<v4f*>(pool_partial + (prow + 1) * C + (c4_0 + tid) * 4) = t;
+        }
     }
 }
 
@@ -238,7 +269,7 @@ __global__ __launch_bounds__(256) void dwconv_pipe_kernel(const float* __restric
 // (K x NCOL quads) in registers: every output row loads only the S new input rows instead of all K, i.e. 3-5x fewer
 // L1/L2 requests (the plain kernel re-reads each input ~K*NCOL/NOUT times and is L2-bandwidth-bound on the 5x5 layers).
 // The ring slot of an input row is static: the row loop is unrolled over one ring period (K steps).
-template <int K, int S, int NOUT>
+template <int K, int S, int NOUT, bool STATS = false>
 __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          float* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
@@ -261,7 +292,7 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
         wl[i] = *reinterpret_cast<const v4f*>(w + (size_t)tap * C + (c4_0 + cc) * 4);
     }
     __syncthreads();
-    v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, psum = {0.f, 0.f, 0.f, 0.f};
+    v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, psum = {0.f, 0.f, 0.f, 0.f}, psq = {0.f, 0.f, 0.f, 0.f};
     if (scale) sc = *reinterpret_cast<const v4f*>(scale + c);
     if (shift) sh = *reinterpret_cast<const v4f*>(shift + c);
     const float* xb = x + (size_t)b * H * W * C + c;
@@ -321,6 +352,7 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
                                 o[3] = act_fn(o[3], act);
                                 *reinterpret_cast<v4f*>(yb + ((size_t)ho * Wo + wo) * C) = o;
                                 psum += o;
+                                if (STATS) psq += o * o;
                             }
                         }
                     }
@@ -331,10 +363,21 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
     if (pool_partial == nullptr) return;
     if (active) red[lw * cb4 + lc] = psum;
     __syncthreads();
+    const size_t prow = ((size_t)b * gridDim.y + chunk) * (STATS ? 2 : 1);
     if (tid < cb4) {
         v4f t = red[tid];
         for (int l = 1; l < WL; ++l) t += red[l * cb4 + tid];
-        *reinterpret_cast<v4f*>(pool_partial + ((size_t)b * gridDim.y + chunk) * C + (c4_0 + tid) * 4) = t;
+        *reinterpret_cast<v4f*>(pool_partial + prow * C + (c4_0 + tid) * 4) = t;
+    }
+    if (STATS) {
+        __syncthreads();
+        if (active) red[lw * cb4 + lc] = psq;
+        __syncthreads();
+        if (tid < cb4) {
+            v4f t = red[tid];
+            for (int l = 1; l < WL; ++l) t += red[l * cb4 + tid];
+            *reinterpret_cast<v4f*>(pool_partial + (prow + 1) * C + (c4_0 + tid) * 4) = t;
+        }
     }
 }
 
@@ -345,7 +388,7 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
 // once - and the taps are ds_read_b128 (4x the L1's bytes per clock). Pixel stride is padded by one quad so that the
 // lanes of a read (same channel quad, neighbouring pixels) spread over the banks.
 // Thread = channel quad x (4-column output group, row lane); outputs, pooling partials and chunking as dwconv_se_kernel.
-template <int K, int S, int U>
+template <int K, int S, int U, bool STATS = false>
 __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          float* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
@@ -406,7 +449,7 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict
     for (int u = 0; u < 2; ++u)
         if (tid + u * 256 < K * K * cs4) wl[tid + u * 256] = wq[u];
     __syncthreads();
-    v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, psum = {0.f, 0.f, 0.f, 0.f};
+    v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, psum = {0.f, 0.f, 0.f, 0.f}, psq = {0.f, 0.f, 0.f, 0.f};
     if (scale) sc = *reinterpret_cast<const v4f*>(scale + c);
     if (shift) sh = *reinterpret_cast<const v4f*>(shift + c);
     const int RL = P / G;                            // row lanes
@@ -444,6 +487,7 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict
                     o[0] = act_fn(o[0], act), o[1] = act_fn(o[1], act), o[2] = act_fn(o[2], act), o[3] = act_fn(o[3], act);
                     *reinterpret_cast<v4f*>(yb + ((size_t)ho * Wo + wo) * C) = o;
                     psum += o;
+                    if (STATS) psq += o * o;
                 }
             }
         }
@@ -451,10 +495,21 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict
     if (pool_partial == nullptr) return;
     red[p * cs4 + lc] = psum;
     __syncthreads();
+    const size_t prow = ((size_t)b * gridDim.y + chunk) * (STATS ? 2 : 1);
     if (tid < cs4) {
         v4f t = red[tid];
         for (int l = 1; l < P; ++l) t += red[l * cs4 + tid];
-        *reinterpret_cast<v4f*>(pool_partial + ((size_t)b * gridDim.y + chunk) * C + c0 + tid * 4) = t;
+        *reinterpret_cast<v4f*>(pool_partial + prow * C + c0 + tid * 4) = t;
+    }
+    if (STATS) {
+        __syncthreads();
+        red[p * cs4 + lc] = psq;
+        __syncthreads();
+        if (tid < cs4) {
+            v4f t = red[tid];
+            for (int l = 1; l < P; ++l) t += red[l * cs4 + tid];
+            *reinterpret_cast<v4f*>(pool_partial + (prow + 1) * C + c0 + tid * 4) = t;
+        }
     }
 }
 
@@ -481,7 +536,8 @@ template <int NT>
 __global__ __launch_bounds__(NT) void se_gate2_kernel(const float* __restrict__ partial, int chunks, float inv_hw,
                                                        const float* __restrict__ w1, const float* __restrict__ b1,
                                                        const float* __restrict__ w2t, const float* __restrict__ b2,
-                                                       float* __restrict__ gate, int C, int R) {
+                                                       float* __restrict__ gate, int C, int R,
+                                                       float* __restrict__ pooled_out) {
     extern __shared__ __attribute__((aligned(16))) float sm2[];  // [C] pooled, [R] hidden
     v4f* sp4 = reinterpret_cast<v4f*>(sm2);
     float* hid = sm2 + C;
@@ -515,6 +571,8 @@ __global__ __launch_bounds__(NT) void se_gate2_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
+    if (pooled_out != nullptr)  // training: the pooled means go on the tape (input of the gate MLP's backward)
+        for (int c4 = tid; c4 < C4; c4 += NT) reinterpret_cast<v4f*>(pooled_out)[(size_t)b * C4 + c4] = sp4[c4];
     // layer 1: wave w takes hidden units w, w + 4, ...; four units at a time, lanes stride the channel quads
     const int lane = tid & 63, wave = tid >> 6;
     const v4f* w14 = reinterpret_cast<const v4f*>(w1);
@@ -680,8 +738,9 @@ int dwconv_se_chunks(int Ho) { return cdiv(Ho, dwconv_se_rows_per_chunk(Ho)); }
 
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                      float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
-                     int Wo, int act, hipStream_t s) {
+                     int Wo, int act, hipStream_t s, int stats) {
     ORBIT_REQUIRE(x && w_khwc && y, "dwconv_se: null pointer");
+    ORBIT_REQUIRE(!stats || pool_partial, "dwconv_se: statistics requested without a buffer");
     ORBIT_REQUIRE(C % 4 == 0, "dwconv_se: C %% 4 != 0 (C=%d)", C);
     ORBIT_REQUIRE((K == 3 || K == 5) && (stride == 1 || stride == 2), "dwconv_se: K=%d stride=%d not instantiated", K,
                   stride);
@@ -716,7 +775,10 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
                 const bool deep = IHmax * IWA > 8 * (256 / cs4);
 #define ORBIT_DWL(KK, SS)                                                                                              \
     do {                                                                                                               \
-        if (deep)                                                                                                      \
+        if (stats)                                                                                                     \
+            dwconv_lds_kernel<KK, SS, 8, true><<<gl, 256, ldsb, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C,  \
+                                                                     pad_t, pad_l, Ho, Wo, act, cs4, rpc, G, IWA);     \
+        else if (deep)                                                                                                 \
             dwconv_lds_kernel<KK, SS, 12><<<gl, 256, ldsb, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t, \
                                                                 pad_l, Ho, Wo, act, cs4, rpc, G, IWA);                 \
         else                                                                                                           \
@@ -740,9 +802,15 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     // VGPRs, 1 wave/SIMD) and on stride 2. dw_window: 1 = auto (default), 0 = never, 2 = always.
     const int win_opt = get_option("dw_window");
     if (win_opt == 2 || (win_opt == 1 && K == 3 && stride == 1 && Ho >= 14)) {
-#define ORBIT_DWW(KK, SS, NO)                                                                                    \
-    dwconv_win_kernel<KK, SS, NO><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t, \
-                                                         pad_l, Ho, Wo, act, cb4, rpc)
+#define ORBIT_DWW(KK, SS, NO)                                                                                          \
+    do {                                                                                                               \
+        if (stats)                                                                                                     \
+            dwconv_win_kernel<KK, SS, NO, true><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, \
+                                                                       pad_t, pad_l, Ho, Wo, act, cb4, rpc);           \
+        else                                                                                                           \
+            dwconv_win_kernel<KK, SS, NO><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t, \
+                                                                 pad_l, Ho, Wo, act, cb4, rpc);                        \
+    } while (0)
         if (K == 3 && stride == 1) ORBIT_DWW(3, 1, 4);
         else if (K == 3) ORBIT_DWW(3, 2, 4);
         else if (stride == 1) ORBIT_DWW(5, 1, 2);
@@ -755,9 +823,15 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     // stride-2 layers (112x96 3x3, 56x144 5x5), slower on the small maps (two tap rows of registers -> 2 waves per SIMD)
     const int pipe_opt = get_option("dw_pipe");
     if (pipe_opt == 2 || (pipe_opt == 1 && stride == 2 && Ho >= 28)) {
-#define ORBIT_DWP(KK, SS)                                                                                           \
-    dwconv_pipe_kernel<KK, SS><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t, pad_l, \
-                                                      Ho, Wo, act, cb4, rpc)
+#define ORBIT_DWP(KK, SS)                                                                                              \
+    do {                                                                                                               \
+        if (stats)                                                                                                     \
+            dwconv_pipe_kernel<KK, SS, true><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C,    \
+                                                                    pad_t, pad_l, Ho, Wo, act, cb4, rpc);              \
+        else                                                                                                           \
+            dwconv_pipe_kernel<KK, SS><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t,   \
+                                                              pad_l, Ho, Wo, act, cb4, rpc);                           \
+    } while (0)
         if (K == 3 && stride == 1) ORBIT_DWP(3, 1);
         else if (K == 3) ORBIT_DWP(3, 2);
         else if (stride == 1) ORBIT_DWP(5, 1);
@@ -766,9 +840,15 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
         ORBIT_LAUNCH_CHECK();
         return ORBIT_OK;
     }
-#define ORBIT_DW(KK, SS)                                                                                         \
-    dwconv_se_kernel<KK, SS><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t, pad_l, \
-                                                    Ho, Wo, act, cb4, rpc)
+#define ORBIT_DW(KK, SS)                                                                                               \
+    do {                                                                                                               \
+        if (stats)                                                                                                     \
+            dwconv_se_kernel<KK, SS, true><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C,      \
+                                                                  pad_t, pad_l, Ho, Wo, act, cb4, rpc);                \
+        else                                                                                                           \
+            dwconv_se_kernel<KK, SS><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t,     \
+                                                            pad_l, Ho, Wo, act, cb4, rpc);                             \
+    } while (0)
     if (K == 3 && stride == 1) ORBIT_DW(3, 1);
     else if (K == 3) ORBIT_DW(3, 2);
     else if (stride == 1) ORBIT_DW(5, 1);
@@ -779,7 +859,7 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
 }
 
 int launch_se_gate2(const float* partial, int chunks, int HW, const float* w1, const float* b1, const float* w2t,
-                    const float* b2, float* gate, int B, int C, int R, hipStream_t s) {
+                    const float* b2, float* gate, int B, int C, int R, hipStream_t s, float* pooled_out) {
     ORBIT_REQUIRE(partial && w1 && b1 && w2t && b2 && gate, "se_gate2: null pointer");
     ORBIT_REQUIRE(C % 4 == 0, "se_gate2: C %% 4 != 0 (C=%d)", C);
     // wide blocks for the wide layers: the gate of a frame is a chain of L2 latencies through ONE CU (up to 2 x 221 KB of
@@ -787,9 +867,9 @@ int launch_se_gate2(const float* partial, int chunks, int HW, const float* w1, c
     // pass (19-20 us -> measured below), 256 stay best for the narrow early blocks
     const size_t lds = (size_t)(((C + R + 3) & ~3) + 4 * 1024) * sizeof(float);
     if (C >= 1024 && get_option("se_wide"))  // measured per 200 frames: C = 1152: 19-20 -> 14.2-14.8 us; C = 672: 11.0-11.3 -> 11.3-13.1 (worse)
-        se_gate2_kernel<1024><<<B, 1024, lds, s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2, gate, C, R);
+        se_gate2_kernel<1024><<<B, 1024, lds, s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2, gate, C, R, pooled_out);
     else
-        se_gate2_kernel<256><<<B, 256, lds, s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2, gate, C, R);
+        se_gate2_kernel<256><<<B, 256, lds, s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2, gate, C, R, pooled_out);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }

@@ -94,6 +94,67 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_kernel(const float* __rest
     }
 }
 
+// The same, fused with the first pass of the depthwise BatchNorm's backward (the tensor dx is the gradient of that
+// BatchNorm's activation output): g = (dxg * gate + dpooled / HW) * act'(y * scale + shift) is written instead of dx, and
+// the per-channel sums of g and g * xhat (xhat = (y - mean) * invstd) of every (frame, row chunk) go to
+// partial[(b * chunks + chunk)][2][C] - what bn_bwd_finalize reads. The BatchNorm backward then needs no reduction pass
+// over (dx, y) of its own and its apply pass takes g as is. Block = (row chunk, column group, frame), thread = channel quad x
+// row lane (the layout of scale_shift_act_pool_kernel).
+__global__ __launch_bounds__(256) void gate_bwd_apply_bn_kernel(const float* __restrict__ dxg,
+                                                                const float* __restrict__ gate,
+                                                                const float* __restrict__ dpooled,
+                                                                const float* __restrict__ y,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int act, int HW, int C,
+                                                                int rows_per_chunk, int G, int R, float* __restrict__ gout,
+                                                                float* __restrict__ partial) {
+    __shared__ f32x4 red[2][256];
+    const int tid = threadIdx.x;
+    const int rl = tid / G, qi = tid - rl * G, q = blockIdx.y * G + qi;
+    const bool active = rl < R && q < (C >> 2);
+    const int chunk = blockIdx.x, b = blockIdx.z;
+    const int r0 = chunk * rows_per_chunk, r1 = min(HW, r0 + rows_per_chunk);
+    f32x4 s = {0.f, 0.f, 0.f, 0.f}, sx = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const f32x4 gt = *reinterpret_cast<const f32x4*>(gate + (size_t)b * C + q * 4);
+        const f32x4 dp = *reinterpret_cast<const f32x4*>(dpooled + (size_t)b * C + q * 4) * (1.0f / (float)HW);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(mean + q * 4), is = *reinterpret_cast<const f32x4*>(invstd + q * 4);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + q * 4), sh = *reinterpret_cast<const f32x4*>(shift + q * 4);
+        const size_t base = (size_t)b * HW * C + q * 4;
+#pragma unroll 2
+        for (int r = r0 + rl; r < r1; r += R) {
+            const size_t o = base + (size_t)r * C;
+            f32x4 g = *reinterpret_cast<const f32x4*>(dxg + o) * gt + dp;
+            const f32x4 yv = *reinterpret_cast<const f32x4*>(y + o);
+            if (act == ORBIT_ACT_SILU) {
+                const f32x4 z = yv * sc + sh;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z[k]));
+                    g[k] *= sg * (1.0f + z[k] * (1.0f - sg));
+                }
+            } else if (act == ORBIT_ACT_RELU) {
+                const f32x4 z = yv * sc + sh;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) g[k] = z[k] > 0.f ? g[k] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(gout + o) = g;
+            s += g;
+            sx += g * ((yv - mu) * is);
+        }
+    }
+    red[0][tid] = s, red[1][tid] = sx;
+    __syncthreads();
+    if (rl == 0 && q < (C >> 2)) {
+        for (int j = 1; j < R; ++j) s += red[0][j * G + qi], sx += red[1][j * G + qi];
+        const size_t blk = (size_t)b * gridDim.x + chunk;
+        *reinterpret_cast<f32x4*>(partial + (blk * 2 + 0) * C + q * 4) = s;
+        *reinterpret_cast<f32x4*>(partial + (blk * 2 + 1) * C + q * 4) = sx;
+    }
+}
+
 // SE MLP backward for one frame per block: pooled p[C] -> v = W1 p + b1 -> h = silu(v) -> u = W2 h + b2 -> g = sigmoid(u)
 // given dgate: du = dgate g (1-g); dh = W2^T du; dv = dh silu'(v); dp = W1^T dv.  W1 [R][C], W2 [C][R].
 // Writes du[b][C], dv[b][R], h[b][R] (for the parameter gradients) and dp[b][C].
@@ -170,13 +231,14 @@ __global__ __launch_bounds__(256) void se_param_grad_kernel(const float* __restr
         float s = 0.f;
         if (i < C * R) {  // dW2[c][r]
             const int c = i / R, r = i - c * R;
-            // 8 frames' loads in flight per pass (rolled, the 200-long loop was one L2 round trip per frame: 74 us)
-#pragma unroll 8
+            // 20 frames' loads in flight per pass (rolled, the 200-long loop was one L2 round trip per frame; 8 per pass still
+            // left 25 dependent round trips: 74 us per launch)
+#pragma unroll 20
             for (int b = 0; b < B; ++b) s = fmaf(du[(size_t)b * C + c], h[(size_t)b * R + r], s);
             dw2[i] = s;
         } else if (i < 2 * C * R) {  // dW1[r][c]
             const int j = i - C * R, r = j / C, c = j - r * C;
-#pragma unroll 8
+#pragma unroll 20
             for (int b = 0; b < B; ++b) s = fmaf(dv[(size_t)b * R + r], pooled[(size_t)b * C + c], s);
             dw1[j] = s;
         } else if (i < 2 * C * R + C) {
@@ -357,7 +419,8 @@ size_t se_bwd_scratch_floats(int B, int C, int R) { return (size_t)B * (3 * (siz
 
 int launch_se_gate_backward(const float* dxg, const float* x, const float* pooled, const float* gate, const float* w1,
                             const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1,
-                            float* dw2, float* db2, float* scratch, int B, int HW, int C, int R, hipStream_t s) {
+                            float* dw2, float* db2, float* scratch, int B, int HW, int C, int R, hipStream_t s,
+                            const SeBnFuse* bn) {
     ORBIT_REQUIRE(C % 4 == 0 && R > 0 && R <= 256, "se_gate_backward: bad sizes (C=%d R=%d)", C, R);
     float* du = scratch;
     float* dv = du + (size_t)B * C;
@@ -374,6 +437,20 @@ int launch_se_gate_backward(const float* dxg, const float* x, const float* poole
     if (dw1) {
         se_param_grad_kernel<<<cdiv(2 * C * R + C + R, 256), 256, 0, s>>>(du, dv, h, pooled, B, C, R, dw1, db1, dw2, db2);
         ORBIT_LAUNCH_CHECK();
+    }
+    if (bn != nullptr) {
+        // the producer of x is a BatchNorm(+activation): its backward's reduction pass rides on this one
+        const int chunks = se_pool_chunks(B, HW, C);
+        int Gc, Rc, ygc;
+        {
+            const int Q = C / 4;
+            Gc = Q < 256 ? Q : 256, Rc = 256 / Gc, ygc = cdiv(Q, Gc);  // the column layout of the BatchNorm kernels
+        }
+        gate_bwd_apply_bn_kernel<<<dim3(chunks, ygc, B), 256, 0, s>>>(dxg, gate, dp, bn->y, bn->mean, bn->invstd, bn->scale,
+                                                                      bn->shift, bn->act, HW, C, cdiv(HW, chunks), Gc, Rc, dx,
+                                                                      bn->partial);
+        ORBIT_LAUNCH_CHECK();
+        return ORBIT_OK;
     }
     const size_t total4 = (size_t)B * HW * (C / 4);
     ORBIT_REQUIRE((unsigned long long)(total4) < (1ull << 32), "tensor too large for the 32-bit index arithmetic of this kernel");

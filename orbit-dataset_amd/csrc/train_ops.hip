@@ -149,6 +149,63 @@ __global__ __launch_bounds__(256) void scale_shift_act_kernel(const float* __res
     }
 }
 
+// Partials that come from a producing kernel's epilogue (conv_igemm: one per 32-128 output rows; the depthwise kernels: one
+// per frame and row chunk) can number tens of thousands; the finalize kernel walks them with 16 lanes per channel. Above
+// BN_COMPACT_ABOVE blocks a first pass adds groups of GS consecutive blocks (fixed order): out[g][2][C], float4 columns.
+constexpr int BN_COMPACT_ABOVE = 2048, BN_COMPACT_TO = 1024;
+__global__ __launch_bounds__(256) void bn_partial_compact_kernel(const float* __restrict__ partial, int nblk, int cols4,
+                                                                 int GS, int nout, float* __restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)nout * cols4) return;
+    const int g = (int)(i / cols4), q = (int)(i - (size_t)g * cols4);
+    const int b0 = g * GS, b1 = min(nblk, b0 + GS);
+    const f32x4* src = reinterpret_cast<const f32x4*>(partial) + (size_t)b0 * cols4 + q;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+    for (int b = b0; b < b1; ++b, src += cols4) acc += *src;
+    reinterpret_cast<f32x4*>(out)[i] = acc;
+}
+
+// a = act(y * scale + shift) with the squeeze-excite pooling partials of a from the same pass (the train-mode depthwise
+// BatchNorm of an MBConv block: timm SqueezeExcite starts with x.mean((2, 3)) of exactly this tensor). Block = (row chunk,
+// column group, frame); thread = one channel quad x one row lane, walking its rows 4 at a time; pool[b][chunk][C] holds the
+// chunk's column sums (fixed order: row lanes combined through LDS), which se_gate2 adds up and scales by 1 / HW.
+__global__ __launch_bounds__(256) void scale_shift_act_pool_kernel(const float* __restrict__ y,
+                                                                   const float* __restrict__ scale,
+                                                                   const float* __restrict__ shift, int act, int HW, int C,
+                                                                   int rows_per_chunk, int G, int R,
+                                                                   float* __restrict__ out, float* __restrict__ pool) {
+    __shared__ f32x4 red[256];
+    const int tid = threadIdx.x;
+    const int rl = tid / G, qi = tid - rl * G, q = blockIdx.y * G + qi;
+    const bool active = rl < R && q < (C >> 2);
+    const int chunk = blockIdx.x, b = blockIdx.z;
+    const int r0 = chunk * rows_per_chunk, r1 = min(HW, r0 + rows_per_chunk);
+    f32x4 psum = {0.f, 0.f, 0.f, 0.f};
+    if (active) {
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(scale + q * 4), sh = *reinterpret_cast<const f32x4*>(shift + q * 4);
+        const size_t base = (size_t)b * HW * C + q * 4;
+#pragma unroll 4
+        for (int r = r0 + rl; r < r1; r += R) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(y + base + (size_t)r * C) * sc + sh;
+            if (act == ORBIT_ACT_RELU) {
+                v[0] = fmaxf(v[0], 0.f), v[1] = fmaxf(v[1], 0.f), v[2] = fmaxf(v[2], 0.f), v[3] = fmaxf(v[3], 0.f);
+            } else if (act == ORBIT_ACT_SILU) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[k] = v[k] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[k]));
+            }
+            *reinterpret_cast<f32x4*>(out + base + (size_t)r * C) = v;
+            psum += v;
+        }
+    }
+    red[tid] = psum;
+    __syncthreads();
+    if (rl == 0 && q < (C >> 2)) {
+        for (int j = 1; j < R; ++j) psum += red[j * G + qi];
+        *reinterpret_cast<f32x4*>(pool + ((size_t)b * gridDim.x + chunk) * C + q * 4) = psum;
+    }
+}
+
 // d silu(z) / dz = s (1 + z (1 - s)), s = sigmoid(z); same fast exp/rcp as the forward activation
 __device__ __forceinline__ f32x4 silu_grad(f32x4 g, f32x4 z) {
 #pragma unroll
@@ -365,6 +422,30 @@ static int grid_for(size_t total) {
 }
 
 // ---- launchers (declared in common.h) -----------------------------------------------------------------------------
+// finalize from [nblk][2][C] partials, whoever produced them (bn_stats_partial_kernel, a conv epilogue, a depthwise kernel).
+// `partial` must have room for the compaction stage behind the nblk blocks: bn_partial_floats(nblk, C) floats in all.
+size_t bn_partial_floats(size_t nblk, int C) {
+    return (nblk + (nblk > (size_t)BN_COMPACT_ABOVE ? (size_t)BN_COMPACT_TO : 0)) * 2 * (size_t)C;
+}
+int launch_bn_stats_from_partials(float* partial, int nblk, int M, int C, float eps, float momentum, const float* gamma,
+                                  const float* beta, const float* conv_bias, float* mean, float* invstd, float* scale,
+                                  float* shift, float* running_mean, float* running_var, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0 && M > 0 && nblk > 0 && partial, "bn_stats: bad arguments");
+    const float* src = partial;
+    if (nblk > BN_COMPACT_ABOVE) {
+        const int GS = cdiv(nblk, BN_COMPACT_TO), nout = cdiv(nblk, GS), cols4 = 2 * C / 4;
+        float* out = partial + (size_t)nblk * 2 * C;
+        const size_t items = (size_t)nout * cols4;
+        bn_partial_compact_kernel<<<(unsigned)((items + 255) / 256), 256, 0, s>>>(partial, nblk, cols4, GS, nout, out);
+        ORBIT_LAUNCH_CHECK();
+        src = out, nblk = nout;
+    }
+    bn_stats_finalize_kernel<<<cdiv(C, 16), 256, 0, s>>>(src, nblk, M, C, eps, momentum, gamma, beta, conv_bias, mean, invstd,
+                                                          scale, shift, running_mean, running_var);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
 int launch_bn_stats(const float* y, int M, int C, float eps, float momentum, const float* gamma, const float* beta,
                     const float* conv_bias, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
                     float* running_var, float* partial, hipStream_t s) {
@@ -373,8 +454,26 @@ int launch_bn_stats(const float* y, int M, int C, float eps, float momentum, con
     const int nblk = bn_reduce_blocks(M, C);
     bn_stats_partial_kernel<<<dim3(nblk, L.ygroups), 256, 0, s>>>(y, M, C, bn_rows_per_block(M, C), L.G, L.R, partial);
     ORBIT_LAUNCH_CHECK();
-    bn_stats_finalize_kernel<<<cdiv(C, 16), 256, 0, s>>>(partial, nblk, M, C, eps, momentum, gamma, beta, conv_bias, mean,
-                                                          invstd, scale, shift, running_mean, running_var);
+    return launch_bn_stats_from_partials(partial, nblk, M, C, eps, momentum, gamma, beta, conv_bias, mean, invstd, scale,
+                                         shift, running_mean, running_var, s);
+}
+
+// chunks per frame of the pooled apply pass: enough blocks to fill the chip at any batch size, >= 4 rows per row lane
+int se_pool_chunks(int B, int HW, int C) {
+    const ColLayout L = col_layout(C);
+    int want = cdiv(2048, B * L.ygroups);
+    const int most = cdiv(HW, 4 * L.R);
+    if (want > most) want = most;
+    if (want < 1) want = 1;
+    return cdiv(HW, cdiv(HW, want));
+}
+int launch_scale_shift_act_pool(const float* y, const float* scale, const float* shift, int act, int B, int HW, int C,
+                                float* out, float* pool, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0 && y && scale && shift && out && pool, "scale_shift_act_pool: bad arguments");
+    const ColLayout L = col_layout(C);
+    const int chunks = se_pool_chunks(B, HW, C);
+    scale_shift_act_pool_kernel<<<dim3(chunks, L.ygroups, B), 256, 0, s>>>(y, scale, shift, act, HW, C, cdiv(HW, chunks), L.G,
+                                                                            L.R, out, pool);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
@@ -407,6 +506,30 @@ int launch_bn_backward(const float* dout, const float* out, const float* y, cons
         const size_t total4 = (size_t)M * (C / 4);
         bn_bwd_apply_kernel<<<grid_for(total4), 256, 0, s>>>(dout, out, y, mean, invstd, scale, shift, coef, act, total4,
                                                              C / 4, dy, dres, dres_accumulate);
+        ORBIT_LAUNCH_CHECK();
+    }
+    return ORBIT_OK;
+}
+
+int launch_bn_backward_reduced(const float* g, const float* y, const float* mean, const float* invstd, const float* gamma,
+                               int train, int M, int C, float* dy, float* dgamma, float* dbeta, float* partial, int nblk,
+                               float* coef, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0 && M > 0 && nblk > 0 && g && y && partial && coef, "bn_backward_reduced: bad arguments");
+    const float* src = partial;
+    if (nblk > BN_COMPACT_ABOVE) {
+        const int GS = cdiv(nblk, BN_COMPACT_TO), nout = cdiv(nblk, GS), cols4 = 2 * C / 4;
+        float* out = partial + (size_t)nblk * 2 * C;
+        const size_t items = (size_t)nout * cols4;
+        bn_partial_compact_kernel<<<(unsigned)((items + 255) / 256), 256, 0, s>>>(partial, nblk, cols4, GS, nout, out);
+        ORBIT_LAUNCH_CHECK();
+        src = out, nblk = nout;
+    }
+    bn_bwd_finalize_kernel<<<cdiv(C, 16), 256, 0, s>>>(src, nblk, M, C, train, gamma, invstd, dgamma, dbeta, nullptr, coef);
+    ORBIT_LAUNCH_CHECK();
+    if (dy) {
+        const size_t total4 = (size_t)M * (C / 4);
+        bn_bwd_apply_kernel<<<grid_for(total4), 256, 0, s>>>(g, nullptr, y, mean, invstd, nullptr, nullptr, coef,
+                                                             ORBIT_ACT_NONE, total4, C / 4, dy, nullptr, 0);
         ORBIT_LAUNCH_CHECK();
     }
     return ORBIT_OK;
