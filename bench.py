@@ -266,13 +266,32 @@ def metric_variants(model, tasks, device, steps):
     h2d8 = lambda i: run_task(model, host8[i % len(host8)])
     timed(h2d8, 2)
     t_h2d8 = timed(h2d8, steps)
+    # ... and through the input pipeline (data/pipeline.TaskPrefetcher): a staging thread uploads the 8-bit frames of task
+    # i+1 on a copy stream and normalises them there while the extractor runs task i (pinned ring of 3 slots)
+    from orbit_dataset_amd.data.pipeline import TaskPrefetcher
+
+    def prefetched(n):
+        pf = TaskPrefetcher((host8[i % len(host8)] for i in range(n)), device, depth=3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in pf:
+            run_task(model, t)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        pf.close()
+        return dt
+    prefetched(3)
+    t_pf = prefetched(steps)
     return {"predict_only_query_frames_per_s": NUM_QUERY * steps / t_pred,
             "h2d_inclusive_query_frames_per_s": NUM_QUERY * steps / t_h2d,
-            "h2d_inclusive_uint8_query_frames_per_s": NUM_QUERY * steps / t_h2d8,
+            "h2d_inclusive_uint8_query_frames_per_s": NUM_QUERY * steps / t_pf,
+            "h2d_inclusive_uint8_unpipelined_query_frames_per_s": NUM_QUERY * steps / t_h2d8,
             "note": "predict-only: predict() of 200 resident query frames after one personalise(); h2d-inclusive: whole "
                     "task with support + query clips uploaded from pinned host memory per mini-batch inside the timed "
                     "region; the uint8 variant uploads 8-bit frames (a quarter of the bytes) and applies to_tensor + normalize on "
-                    "the GPU (orbit_frames_from_uint8)"}
+                    "the GPU (orbit_frames_from_uint8) - through data/pipeline.TaskPrefetcher (pinned ring, staging thread, copy "
+                    "stream double-buffered against the extractor; first task's upload included), and 'unpipelined' = uploaded "
+                    "per mini-batch on the compute / query stream as in round 2"}
 
 
 def cpu_baseline(workload, model, train=False, way=WAY):

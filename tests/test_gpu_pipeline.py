@@ -1,0 +1,94 @@
+"""TaskPrefetcher on hardware: tasks decoded from a JPEG tree, uploaded as 8-bit frames on a copy stream and normalised on
+the GPU while the extractor works on the previous task, give logits BIT-EQUAL to the same frames held resident; the transform
+is the reference's to_tensor + normalize (data/datasets.py:422-431)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import orbit_dataset_amd  # noqa: E402,F401
+from orbit_dataset_amd import synthetic  # noqa: E402
+from orbit_dataset_amd.data import pipeline  # noqa: E402
+from orbit_dataset_amd.data.utils import NORMALIZE_STATS, frames_from_uint8  # noqa: E402
+from orbit_dataset_amd.model.few_shot_recognisers import SingleStepFewShotRecogniser  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def tree(tmp_path_factory):
+    root = str(tmp_path_factory.mktemp("orbit"))
+    pipeline.write_synthetic_orbit_directory(root, users=4, objects_per_user=3, clean_videos=2, clutter_videos=2,
+                                             frames_per_video=5, frame_size=64)
+    return root
+
+
+def _model(device):
+    model = SingleStepFewShotRecogniser("resnet18", False, "proto", 1, 8, False, 16, 1.0)
+    synthetic.init_parameters_(model)
+    model._set_device(device)
+    model._send_to_device()
+    model.set_test_mode(True)
+    return model
+
+
+def test_prefetched_tasks_give_bit_equal_logits(device, tree):
+    model = _model(device)
+    directory = pipeline.ORBITDirectory(tree)
+    host_tasks = list(pipeline.DirectoryTaskSource(directory, workers=4))
+    assert len(host_tasks) == 4
+    want = []
+    with torch.no_grad():
+        for t in host_tasks:  # resident reference: the same bytes, normalised up front
+            ctx = frames_from_uint8(t["context_clips"], device, channels_last=True)
+            tgt = frames_from_uint8(t["target_clips"], device, channels_last=True)
+            # the GPU transform is the reference transform, bit for bit
+            mean, std = NORMALIZE_STATS["imagenet"]
+            x = t["context_clips"][0, 0].permute(2, 0, 1).float().div(255.0)
+            ref = (x - torch.tensor(mean)[:, None, None]) / torch.tensor(std)[:, None, None]
+            assert torch.equal(ctx[0, 0].cpu(), ref)
+            model.personalise(ctx, t["context_labels"].to(device))
+            want.append(model.predict(tgt).clone())
+            model._reset()
+    got = []
+    pf = pipeline.TaskPrefetcher(pipeline.DirectoryTaskSource(directory, workers=4), device, depth=2)
+    with torch.no_grad():
+        for t in pf:
+            assert t["context_clips"].is_cuda and t["context_clips"].dtype == torch.float32
+            assert t["context_clips"].shape[-3:] == (3, 64, 64) and t["context_labels"].is_cuda
+            model.personalise(t["context_clips"], t["context_labels"])
+            got.append(model.predict(t["target_clips"]).clone())  # (slot tensors are only valid until the next task)
+            model._reset()
+    pf.close()
+    assert len(got) == len(want) == 4
+    for a, b in zip(got, want):
+        assert torch.equal(a, b)
+
+
+def test_prefetcher_with_pinned_host_tasks_and_more_tasks_than_slots(device):
+    """Pre-decoded tasks (pinned, channels-first uint8 as the recogniser's own 8-bit path takes them): 7 tasks through 3
+    slots, every one bit-equal to the resident run; a failing source surfaces in the consumer."""
+    model = _model(device)
+    g = torch.Generator().manual_seed(3)
+    tasks = [{"context_clips": torch.randint(0, 256, (12, 1, 3, 64, 64), dtype=torch.uint8, generator=g).pin_memory(),
+              "context_labels": torch.arange(12) % 3,
+              "target_clips": torch.randint(0, 256, (9, 1, 3, 64, 64), dtype=torch.uint8, generator=g)} for _ in range(7)]
+    with torch.no_grad():
+        want = []
+        for t in tasks:
+            model.personalise(t["context_clips"], t["context_labels"].to(device))  # the recogniser's own uint8 upload path
+            want.append(model.predict(t["target_clips"]).clone())
+            model._reset()
+        pf = pipeline.TaskPrefetcher(iter(tasks), device, depth=3)
+        for i, t in enumerate(pf):
+            model.personalise(t["context_clips"], t["context_labels"])
+            assert torch.equal(model.predict(t["target_clips"]), want[i])
+            model._reset()
+        assert i == 6
+
+    def broken():
+        yield tasks[0]
+        raise RuntimeError("decoder died")
+
+    pf = pipeline.TaskPrefetcher(broken(), device)
+    next(pf)
+    with pytest.raises(RuntimeError, match="decoder died"):
+        next(pf)

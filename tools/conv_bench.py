@@ -28,12 +28,13 @@ SHAPES = {
         ("se_l1", 200, 224, 3, 64, 3, 1, 1, 1), ("se_l2", 200, 112, 64, 64, 3, 1, 1, 0), ("se_l3", 200, 56, 64, 64, 3, 1, 1, 0),
         ("se_l4", 200, 28, 64, 64, 3, 1, 1, 0), ("se_l5", 200, 14, 64, 64, 3, 1, 1, 0)],
 }
-TILES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "64x32k2", 6: "32x32k4", 7: "32x64k2"}
+TILES = {0: "auto", 1: "128x128", 2: "128x64", 3: "64x64", 4: "128x32", 5: "64x32k2", 6: "32x32k4", 7: "32x64k2",
+         8: "32x96k4", 9: "64x96k2", 10: "128x96", 11: "32x128k4", 12: "64x128k2", 13: "128x128w4"}
 
 
 def main():
     which = sys.argv[1] if len(sys.argv) > 1 else "resnet18_84"
-    sweep = len(sys.argv) > 2 and sys.argv[2] == "sweep"
+    sweep = len(sys.argv) > 2 and sys.argv[2] in ("sweep", "gatesweep")
     lib = _lib.load()
     dev = torch.device("cuda", 0)
     import ctypes
@@ -43,7 +44,7 @@ def main():
         w = torch.randn(Cout, Cin, K, K, device=dev)
         y = torch.empty(B, Ho, Ho, Cout, device=dev)
         sc, sh = torch.rand(Cout, device=dev), torch.rand(Cout, device=dev)
-        use_gate = len(sys.argv) > 2 and sys.argv[2] in ("gate", "abgate") and not nchw and K == 1
+        use_gate = len(sys.argv) > 2 and sys.argv[2] in ("gate", "abgate", "gatesweep") and not nchw and K == 1 and name.startswith("pwl")
         gate = torch.rand(B, Cin, device=dev) if use_gate else None
 
         def run():
@@ -89,7 +90,12 @@ def main():
             line += "  | %s=0 %.1f us  =1 %.1f us  (%+.1f%%)" % (sys.argv[3], a0, a1, 100 * (a0 / a1 - 1))
             lib.orbit_set_option(opt, 1)
         if sweep:
-            res = {t: measure(t)[0] for t in (2, 3, 4, 5, 6, 7)}
+            cand = (2, 3, 4, 5, 6, 7)
+            if K == 1 and not nchw and Cout <= 96:
+                cand += (8, 9, 10)
+            if K == 1 and not nchw and Cout <= 128:
+                cand += (11, 12, 13)
+            res = {t: measure(t)[0] for t in cand}
             best = min(res, key=res.get)
             line += "  | " + "  ".join("%s %.1f" % (TILES[t], res[t]) for t in res) + "  -> best %s (%.0f%% vs auto)" % (
                 TILES[best], 100 * (us / res[best] - 1))
