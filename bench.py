@@ -367,6 +367,7 @@ def rccl_check(lib, rank, world, backend, dist, device):
         return _rccl_check(lib, rank, world, dist, device)
     finally:
         sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)  # the banner sits in C stdio's buffer: flush it while fd 1 still points at stderr
         os.dup2(saved, 1)
         os.close(saved)
 

@@ -41,6 +41,32 @@ def test_bench_line_contract():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert cb["max_abs_dlogit_vs_gpu"] <= 1e-3 and cb["argmax_identical"] is True
     assert d["median_task_ms"] > 0 and d["value_overlap_off"] > 0
+    # the C-ABI's RCCL communicator ran (one rank here): all-reduce of ones == world
+    assert d["rccl_ranks"] == 1 and d["ranks_share_gpus"] is False
+    v = d["variants_of_the_metric"]
+    assert v["h2d_inclusive_uint8_query_frames_per_s"] > 0 and v["h2d_inclusive_uint8_unpipelined_query_frames_per_s"] > 0
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (it used to
+    run one rank and print n_gpus 1). Two ranks share this box's GPU through the gloo self-test backend; with the RCCL
+    backend (one rank per GPU) the same command must refuse instead of printing a line with the wrong n_gpus."""
+    env = dict(os.environ, ORBIT_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                          "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["tasks_per_step"] == 2 and d["ranks_share_gpus"] is True
+    assert d["rccl_ranks"] is None  # RCCL refuses two ranks on one device: only checked one rank per GPU
+    import torch
+    if torch.cuda.device_count() < 2:
+        env.pop("ORBIT_BENCH_BACKEND")
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1",
+                              "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert out.returncode != 0 and not [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
 
 
 def test_bench_other_modes_run():
