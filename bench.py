@@ -127,6 +127,23 @@ class LiteTrainStep:
         return torch.cat(out)
 
 
+def trained_checkpoint(workload):
+    """The meta-trained checkpoint of a workload (tools/meta_train.py: LITE meta-training through the native kernels on
+    synthetic tasks of the "blobs" family; fp16-rounded values, so the HIP path and the CPU oracle load identical numbers)
+    or None. ORBIT_BENCH_WEIGHTS=synthetic keeps the deterministic random initialisation of rounds 1-2."""
+    if os.environ.get("ORBIT_BENCH_WEIGHTS", "trained") != "trained" or HEADS.get(workload):
+        return None
+    fe_name, adapt, size = WORKLOADS[workload]
+    path = os.path.join(ROOT, "orbit-dataset_amd", "assets", "meta_trained_%s_%d.npz" % (fe_name, size))
+    return path if (not adapt and os.path.exists(path)) else None
+
+
+def load_trained_checkpoint(model, path):
+    import numpy as np
+    sd = {k: torch.from_numpy(v.astype(np.float32) if v.dtype == np.float16 else v) for k, v in np.load(path).items()}
+    model.load_state_dict(sd)
+
+
 def parity_gate(model, fe_name, device):
     """Cheap gate that runs on EVERY rank before the clock starts: the extractor on the committed frames of
     tests/golden/G12_extractors_hf.npz must reproduce the features Hugging Face transformers computed for them (an
@@ -294,7 +311,7 @@ def metric_variants(model, tasks, device, steps):
                     "per mini-batch on the compute / query stream as in round 2"}
 
 
-def cpu_baseline(workload, model, train=False, way=WAY):
+def cpu_baseline(workload, model, train=False, way=WAY, template="noise"):
     """The oracle (CPU restatement of the reference path) on ONE task of the same workload, all host cores."""
     from oracle.recogniser import OracleRecogniser
     fe_name, adapt, size = WORKLOADS[workload]
@@ -309,7 +326,7 @@ def cpu_baseline(workload, model, train=False, way=WAY):
         ref.set_encoder.load_state_dict({k[len("set_encoder."):]: v for k, v in sd.items() if k.startswith("set_encoder.")})
         ref.build_film_generator().load_state_dict(
             {k[len("film_generator."):]: v for k, v in sd.items() if k.startswith("film_generator.")})
-    task = synthetic.make_task(0, way, 1, WAY * SHOTS * FRAMES_PER_SHOT // way, NUM_QUERY, size)
+    task = synthetic.make_task(0, way, 1, WAY * SHOTS * FRAMES_PER_SHOT // way, NUM_QUERY, size, template=template)
     # Thread count: BASELINE.md asks for os.cpu_count(); PyTorch-CPU gets SLOWER past the point where the small
     # convolutions stop scaling, so every candidate up to and including os.cpu_count() is timed on a probe with the batch
     # shape of the real task (one 64-frame extractor batch + one 64-frame query batch; the round-1 probe used 32 frames,
@@ -446,7 +463,12 @@ def main():
     fe_name, adapt, size = WORKLOADS[args.workload]
     train = args.mode == "lite_train"
     model = build_model(args.workload, device, args.batch_size, train=train)
-    gate = parity_gate(model, fe_name, device)  # every rank, before anything is timed
+    gate = parity_gate(model, fe_name, device)  # every rank, before anything is timed (on the synthetic checkpoint the
+    #                                             transformers fixture was recorded for)
+    ckpt = trained_checkpoint(args.workload)
+    template = "blobs" if ckpt else "noise"
+    if ckpt:  # the accuracy half of the metric needs weights that carry class signal: the meta-trained checkpoint
+        load_trained_checkpoint(model, ckpt)
     run_step = LiteTrainStep(model, world, args.batch_size, args.tasks_per_rank) if train else run_task
     per_step = args.tasks_per_rank if train else 1  # run_step calls (= tasks) per bench step on this rank
     # each rank owns its own tasks (task index = rank + world * i): weak scaling, independent units
@@ -454,7 +476,8 @@ def main():
     if (WAY * SHOTS * FRAMES_PER_SHOT) % way:
         raise SystemExit("--way must divide %d support frames" % (WAY * SHOTS * FRAMES_PER_SHOT))
     frames_per_class = WAY * SHOTS * FRAMES_PER_SHOT // way  # keep 200 support frames per task
-    tasks = [synthetic.make_task_on_device(rank + world * i, way, 1, frames_per_class, NUM_QUERY, size, 1, device)
+    tasks = [synthetic.make_task_on_device(rank + world * i, way, 1, frames_per_class, NUM_QUERY, size, 1, device,
+                                           template=template)
              for i in range(max(1, args.distinct_tasks))]
     # label sets of the resident tasks are resolved here (memoised per label tensor, classifier_heads.unique_labels): the
     # one device sync torch.unique needs per NEW task otherwise lands in the timed region for every task the warm-up
@@ -624,6 +647,9 @@ def main():
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "weights": ("meta-trained with LITE through the native kernels (tools/meta_train.py), file %s" % os.path.relpath(ckpt, ROOT))
+                   if ckpt else "deterministic random initialisation (synthetic.init_parameters_)",
+        "task_family": template,
         "config": {"workload": "%s%s: ProtoNet + %s%s, %dx%d, %d-way, %d support frames (%d shots x %d), %d query "
                                "frames, clip_length 1, batch_size 256, inputs resident in HBM" % (
                                    args.workload,
@@ -663,7 +689,7 @@ def main():
         out["variants_of_the_metric"] = metric_variants(model, tasks, device, min(args.steps, 20))
     if not args.no_cpu_baseline and world == 1:
         sd_before = {k: v.clone() for k, v in model.state_dict().items()} if train else None
-        base, task, want = cpu_baseline(args.workload, model, train=train, way=way)
+        base, task, want = cpu_baseline(args.workload, model, train=train, way=way, template=template)
         if train:  # the same LITE step on the same weights and permutation
             import numpy as np
             model.load_state_dict(sd_before)
@@ -671,6 +697,9 @@ def main():
         got = run_step(model, {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in task.items()}).cpu()
         base["max_abs_dlogit_vs_gpu"] = float((got - want).abs().max().item())
         base["argmax_identical"] = bool(torch.equal(got.argmax(1), want.argmax(1)))
+        # the accuracy half of the metric on this task, both sides (utils/eval_metrics.py:27-36)
+        base["frame_accuracy_gpu"] = float((got.argmax(1) == task["target_labels"]).float().mean())
+        base["frame_accuracy_oracle"] = float((want.argmax(1) == task["target_labels"]).float().mean())
         out["cpu_baseline"] = base
         # parity gate (no timing is reported for a path that does not reproduce the reference's logits)
         if not (base["max_abs_dlogit_vs_gpu"] <= 1e-3 and base["argmax_identical"]):

@@ -7,7 +7,10 @@ throughput are measured on synthetic tasks with the layout the reference's data 
 machine: each tensor is drawn from a torch CPU generator seeded by (seed, crc32(state_dict key))).
 
 Frames emulate normalised pixels (reference data/datasets.py:82-83,430): frame = 0.5 * class template + unit
-noise, so classes are separable but not trivially (argmax parity is a real test). Parameters use He-normal
+noise, so classes are separable but not trivially (argmax parity is a real test). `template="blobs"` draws LOW-FREQUENCY
+class templates instead (7x7 colour grids, bilinearly enlarged) with a per-frame low-frequency distractor and pixel noise:
+objects that differ in coarse colour layout, the family the meta-trained checkpoint (tools/meta_train.py) is trained and
+evaluated on - a white-noise template carries no signal a convolutional extractor could be trained to keep. Parameters use He-normal
 convolutions and NON-trivial BatchNorm statistics (gamma ~ U(.5,1.5), beta, running_mean ~ N(0,.1),
 running_var ~ U(.5,1.5)) so that BN folding and FiLM are genuinely exercised; the last BatchNorm of every
 residual branch is scaled down so activations keep O(1) magnitude through the depth of the network.
@@ -133,8 +136,17 @@ def init_parameters_(module, seed=DEFAULT_SEED, prefix="", film_strength=0.1, us
     return module
 
 
+BLOBS = (0.9, 0.6, 0.5)  # template, per-frame distractor and pixel-noise amplitudes of the "blobs" family
+
+
+def _lowfreq(n, H, W, g, device="cpu"):
+    """n smooth random colour fields [n,3,H,W]: 7x7 grids of N(0,1) enlarged bilinearly (unit-ish variance)."""
+    coarse = torch.randn(n, 3, 7, 7, generator=g, device=device)
+    return torch.nn.functional.interpolate(coarse, size=(H, W), mode="bilinear", align_corners=False) * 1.4
+
+
 def make_task(task_index=0, way=5, shots=5, frames_per_shot=8, num_query=200, frame_size=84, clip_length=1,
-              seed=DEFAULT_SEED, device="cpu", label_values=None, dtype=torch.float32):
+              seed=DEFAULT_SEED, device="cpu", label_values=None, dtype=torch.float32, template="noise"):
     """One synthetic task in the reference's task_dict layout.
 
     Support: way * shots * frames_per_shot frames grouped into clips of `clip_length` frames
@@ -150,12 +162,23 @@ def make_task(task_index=0, way=5, shots=5, frames_per_shot=8, num_query=200, fr
     assert frames_per_class % T == 0, "frames per class must be a multiple of clip_length"
     clips_per_class = frames_per_class // T
     N = way * clips_per_class
-    templates = torch.randn(way, 3, H, W, generator=g)
-    cls = torch.arange(way).repeat_interleave(clips_per_class)
-    cls = cls[torch.randperm(N, generator=g)]
-    context_clips = 0.5 * templates[cls][:, None] + torch.randn(N, T, 3, H, W, generator=g)
-    qcls = torch.randint(0, way, (num_query,), generator=g)
-    target_clips = 0.5 * templates[qcls][:, None] + torch.randn(num_query, T, 3, H, W, generator=g)
+    if template == "blobs":
+        a, b, c = BLOBS
+        templates = _lowfreq(way, H, W, g)
+        cls = torch.arange(way).repeat_interleave(clips_per_class)
+        cls = cls[torch.randperm(N, generator=g)]
+        context_clips = (a * templates[cls][:, None] + b * _lowfreq(N * T, H, W, g).view(N, T, 3, H, W)
+                         + c * torch.randn(N, T, 3, H, W, generator=g))
+        qcls = torch.randint(0, way, (num_query,), generator=g)
+        target_clips = (a * templates[qcls][:, None] + b * _lowfreq(num_query * T, H, W, g).view(num_query, T, 3, H, W)
+                        + c * torch.randn(num_query, T, 3, H, W, generator=g))
+    else:
+        templates = torch.randn(way, 3, H, W, generator=g)
+        cls = torch.arange(way).repeat_interleave(clips_per_class)
+        cls = cls[torch.randperm(N, generator=g)]
+        context_clips = 0.5 * templates[cls][:, None] + torch.randn(N, T, 3, H, W, generator=g)
+        qcls = torch.randint(0, way, (num_query,), generator=g)
+        target_clips = 0.5 * templates[qcls][:, None] + torch.randn(num_query, T, 3, H, W, generator=g)
     values = torch.arange(way) if label_values is None else torch.as_tensor(label_values, dtype=torch.long)
     task = {
         "context_clips": context_clips.to(dtype),
@@ -170,7 +193,7 @@ def make_task(task_index=0, way=5, shots=5, frames_per_shot=8, num_query=200, fr
 
 
 def make_task_on_device(task_index, way, shots, frames_per_shot, num_query, frame_size, clip_length, device,
-                        seed=DEFAULT_SEED):
+                        seed=DEFAULT_SEED, template="noise"):
     """Same distribution as make_task but drawn directly in HBM (for throughput runs: no 100+ MB host copy).
     Values differ from make_task's (different generator); use make_task when CPU/GPU parity is checked."""
     g = torch.Generator(device=device)
@@ -179,13 +202,19 @@ def make_task_on_device(task_index, way, shots, frames_per_shot, num_query, fram
     T = int(clip_length)
     clips_per_class = shots * frames_per_shot // T
     N = way * clips_per_class
-    templates = torch.randn(way, 3, H, W, generator=g, device=device)
+    blobs = template == "blobs"
+    a, b, c = BLOBS if blobs else (0.5, 0.0, 1.0)
+    templates = _lowfreq(way, H, W, g, device) if blobs else torch.randn(way, 3, H, W, generator=g, device=device)
     cls = torch.arange(way, device=device).repeat_interleave(clips_per_class)
     cls = cls[torch.randperm(N, generator=g, device=device)]
     context_clips = torch.randn(N, T, 3, H, W, generator=g, device=device)
-    context_clips.add_(templates[cls][:, None], alpha=0.5)
+    if blobs:
+        context_clips.mul_(c).add_(_lowfreq(N * T, H, W, g, device).view(N, T, 3, H, W), alpha=b)
+    context_clips.add_(templates[cls][:, None], alpha=a)
     qcls = torch.randint(0, way, (num_query,), generator=g, device=device)
     target_clips = torch.randn(num_query, T, 3, H, W, generator=g, device=device)
-    target_clips.add_(templates[qcls][:, None], alpha=0.5)
+    if blobs:
+        target_clips.mul_(c).add_(_lowfreq(num_query * T, H, W, g, device).view(num_query, T, 3, H, W), alpha=b)
+    target_clips.add_(templates[qcls][:, None], alpha=a)
     return {"context_clips": context_clips, "context_labels": cls.long(), "target_clips": target_clips,
             "target_labels": qcls.long(), "object_list": ["object_%d" % i for i in range(way)]}
