@@ -304,3 +304,57 @@ def allreduce_tensors(tensors, average=False):
         n = t.numel()
         t.copy_(flat[off:off + n].view_as(t))
         off += n
+
+
+class RunningStatSync:
+    """BatchNorm running statistics of a task-parallel training window, combined as SEQUENTIAL updates would have been.
+
+    The reference trains on one device: every train-mode forward does r <- (1 - m) r + m s, so after the N forwards of a
+    window r_end = a^N r_0 + (1 - a^N) s_avg (a = 1 - m, s_avg a recency-weighted mean of the batch statistics). Under task
+    parallelism rank k only sees its n_k forwards: r_k = a^n_k r_0 + (1 - a^n_k) s_k. Plainly averaging the r_k (round 2)
+    keeps a^(N / world) of the window's starting value instead of a^N - with 8 ranks the statistics would adapt 8 times
+    slower than the reference's. Here every rank recovers its s_k, the ranks all-reduce sum_k n_k s_k and sum_k n_k in ONE
+    flat message, and every rank sets r <- a^N r_0 + (1 - a^N) sum_k n_k s_k / N, num_batches_tracked += N - n_k: exact when
+    the ranks' batch statistics agree, otherwise off only by the order in which the recency weights fall on the tasks
+    (bounded by tests/test_gpu_dist.py). Call `begin()` after every optimizer step (window start), `sync()` before it."""
+
+    def __init__(self, module, momentum=0.1, group=None):
+        self.momentum, self.group = float(momentum), group
+        self.stats, self.counters = [], []
+        for name, buf in module.named_buffers():
+            if name.endswith("running_mean") or name.endswith("running_var"):
+                self.stats.append(buf)
+            elif name.endswith("num_batches_tracked"):
+                self.counters.append(buf)
+        self.begin()
+
+    def begin(self):
+        self.start = [b.detach().clone() for b in self.stats]
+        self.start_count = [int(c.item()) for c in self.counters[:1]]  # all layers of a network advance together
+
+    def sync(self):
+        if not self.stats or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return
+        n_local = (int(self.counters[0].item()) - self.start_count[0]) if self.counters else 0
+        a = 1.0 - self.momentum
+        flat = torch.zeros(sum(b.numel() for b in self.stats) + 1, device=self.stats[0].device, dtype=torch.float32)
+        if n_local > 0:
+            an = a ** n_local
+            off = 0
+            for b, r0 in zip(self.stats, self.start):
+                k = b.numel()
+                flat[off:off + k] = ((b.reshape(-1) - an * r0.reshape(-1)) / (1.0 - an)) * n_local  # n_k * s_k
+                off += k
+            flat[-1] = n_local
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+        N = int(round(float(flat[-1].item())))
+        if N == 0:
+            return
+        aN = a ** N
+        off = 0
+        for b, r0 in zip(self.stats, self.start):
+            k = b.numel()
+            b.copy_((aN * r0.reshape(-1) + (1.0 - aN) * flat[off:off + k] / N).view_as(b))
+            off += k
+        for c in self.counters:
+            c += N - n_local

@@ -19,7 +19,8 @@ checkpoint rotation of the reference loop are not part of the hot path and are l
 Multi-GPU: launched under torchrun, tasks are dealt round-robin to ranks (task i -> rank i % world). Test mode has no
 data-path collective (per-task statistics are all-gathered at the end). Training all-reduces (SUM, RCCL) one flat
 gradient bucket per optimizer step: every task's loss already carries 1/tasks_per_batch, so the sum over ranks
-reproduces single-GPU accumulation; BatchNorm running statistics are averaged over ranks at the same point.
+reproduces single-GPU accumulation; BatchNorm running statistics are combined at the same point as the reference's
+sequential updates would have left them (dist.RunningStatSync).
 """
 import argparse
 import json
@@ -203,9 +204,10 @@ class Learner:
         if self.world == 1:
             return
         self.grad_bucket.sync()
-        stats = [b for n, b in self.model.named_buffers() if n.endswith("running_mean") or n.endswith("running_var")]
-        if stats and self.model.learn_extractor:
-            odist.allreduce_tensors(stats, average=True)
+        if self.model.learn_extractor:
+            # train-mode BatchNorm: the window's running-statistic updates of all ranks, combined as the reference's
+            # sequential updates would have been (dist.RunningStatSync; round 2 averaged the ranks' values)
+            self.stat_sync.sync()  # (in-place copies: the plans see the new buffer versions and re-upload them)
 
     def train(self):
         a = self.args
@@ -218,6 +220,9 @@ class Learner:
                 cap = sum(-(-q.numel() // 64) * 64 for q in self.model.parameters() if q.requires_grad)
                 p2p = odist.P2PAllReduce(self.rank, self.world, odist.P2PAllReduce.floats_for_bucket(cap, self.world))
             self.grad_bucket = odist.GradientBucket(self.model.parameters(), p2p=p2p)
+            if self.model.learn_extractor:
+                self.stat_sync = odist.RunningStatSync(self.model.feature_extractor,
+                                                       getattr(self.model.feature_extractor, "bn_momentum", 0.1))
         train_task_fn = self.train_task_with_lite if a.with_lite else self.train_task
         losses, accs, times = [], [], []
         prev = torch.is_grad_enabled()
@@ -257,6 +262,8 @@ class Learner:
                                                               if p.requires_grad and p.grad is None)
                         self.optimizer.step()
                         if self.grad_bucket is not None:
+                            if self.model.learn_extractor:
+                                self.stat_sync.begin()  # the next window's running statistics start from here
                             self.grad_bucket.zero_()  # one memset; gradients keep living inside the flat bucket
                         else:
                             self.optimizer.zero_grad()

@@ -239,3 +239,57 @@ def test_gradient_bucket_rebuilds_collectively_when_one_rank_sees_a_new_gradient
     result = mgr.dict()
     mp.spawn(_late_param_worker, args=(2, port, result), nprocs=2, join=True)
     assert result[0] and result[1]
+
+
+# ---- BatchNorm running statistics of a task-parallel window = the reference's sequential updates ---------------------
+def _stat_worker(rank, world, port, result):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    odist.init_from_env("gloo")
+    bn = torch.nn.BatchNorm2d(6)
+    g = torch.Generator().manual_seed(1)
+    bn.running_mean.copy_(torch.randn(6, generator=g)), bn.running_var.copy_(torch.rand(6, generator=g) + 0.5)
+    sync = odist.RunningStatSync(bn, momentum=0.1)
+    # a window of 7 train-mode forwards dealt round-robin (rank 0: 4, rank 1: 3); batch statistics differ per task
+    batches = [torch.randn(5, 6, 4, 4, generator=g) * (1.0 + 0.05 * t) + 0.1 * t for t in range(7)]
+    bn.train()
+    for t, x in enumerate(batches):
+        if t % world == rank:
+            bn(x)
+    sync.sync()
+    result[rank] = (bn.running_mean.clone().numpy(), bn.running_var.clone().numpy(), int(bn.num_batches_tracked))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_running_statistics_combine_like_sequential_updates():
+    """dist.RunningStatSync (rank-AVERAGED statistics were an unbounded deviation): after a 7-forward window on
+    2 ranks the statistics carry a^7 of the window's starting value, exactly as 7 sequential updates do, and differ from
+    the single-process result only by the recency weighting of the tasks (bounded here); plain averaging is far off."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mgr = mp.Manager()
+    result = mgr.dict()
+    mp.spawn(_stat_worker, args=(2, port, result), nprocs=2, join=True)
+    bn = torch.nn.BatchNorm2d(6)
+    g = torch.Generator().manual_seed(1)
+    bn.running_mean.copy_(torch.randn(6, generator=g)), bn.running_var.copy_(torch.rand(6, generator=g) + 0.5)
+    start = bn.running_mean.clone()
+    batches = [torch.randn(5, 6, 4, 4, generator=g) * (1.0 + 0.05 * t) + 0.1 * t for t in range(7)]
+    bn.train()
+    for x in batches:
+        bn(x)
+    want_mean, want_var = bn.running_mean.numpy(), bn.running_var.numpy()
+    assert np.array_equal(result[0][0], result[1][0]) and np.array_equal(result[0][1], result[1][1])  # identical replicas
+    assert result[0][2] == result[1][2] == 7
+    gap = np.abs(want_mean - start.numpy()).max()  # how far the window moved the statistics
+    assert np.abs(result[0][0] - want_mean).max() < 0.08 * gap
+    assert np.abs(result[0][1] - want_var).max() < 0.08 * np.abs(want_var).max()
+    # identical batch statistics on every forward: the combination is exact
+    a = 0.9
+    r0, s = 2.0, 5.0
+    seq = a ** 7 * r0 + (1 - a ** 7) * s
+    parts = [(a ** n * r0 + (1 - a ** n) * s, n) for n in (4, 3)]
+    comb = a ** 7 * r0 + (1 - a ** 7) * sum(n * (r - a ** n * r0) / (1 - a ** n) for r, n in parts) / 7
+    assert abs(comb - seq) < 1e-12 and abs(sum(r for r, _ in parts) / 2 - seq) > 0.3

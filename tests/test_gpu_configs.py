@@ -21,6 +21,7 @@ from oracle.training import LiteTrainer  # noqa: E402
 from orbit_dataset_amd import synthetic  # noqa: E402
 from orbit_dataset_amd.model.few_shot_recognisers import SingleStepFewShotRecogniser  # noqa: E402
 
+CONFIG2 = "config2_protonet_resnet18_84_5way"  # BASELINE configs[1]: ProtoNet + resnet18, 84x84, 200 + 200 frames
 CONFIGS = {
     # name: (extractor, adapt_features, way, learn_extractor when meta-training)
     "config3_protonet_efficientnet_b0_224_5way": ("efficientnet_b0", False, 5, True),
@@ -119,9 +120,52 @@ def test_one_lite_step_matches_oracle_at_224(device, name):
 
 
 @pytest.mark.parametrize("name", sorted(CONFIGS))
-def test_full_size_task_properties(device, name):
-    """The configs' real sizes: 200 support + 200 query frames of 224x224."""
+def test_inference_matches_oracle_at_224_100_support_50_query_slow(device, name):
+    """the 224x224 oracle comparisons were 20-40 support / 10-12 query frames. Here 100 + 50 frames per config
+    (the CPU oracle needs ~10 s for them); the full 200 + 200 is compared inside bench.py's cpu_baseline gate."""
     fe_name, adapt, way, _ = CONFIGS[name]
+    model = _native(fe_name, adapt, False, 256)
+    ref = _oracle_of(model, fe_name, adapt, 256)
+    task = synthetic.make_task(80 + way, way=way, shots=1, frames_per_shot=100 // way, num_query=50, frame_size=SIZE)
+    with torch.no_grad():
+        model.personalise(task["context_clips"].cuda(), task["context_labels"].cuda())
+        got = model.predict(task["target_clips"].cuda()).cpu()
+    ref.personalise(task["context_clips"], task["context_labels"])
+    want = ref.predict(task["target_clips"])
+    assert got.shape == want.shape == (50, way)
+    assert (got - want).abs().max().item() < 1e-3
+    assert torch.equal(got.argmax(1), want.argmax(1))
+
+
+def test_config2_full_size_matches_oracle(device):
+    """BASELINE configs[1] at its FULL size - ProtoNet + resnet18, 84x84, 5-way, 200 support + 200 query frames - logits
+    against the CPU oracle (1e-3, identical argmax, identical frame accuracy), clip_length 1 and the T = 8 layout
+    (25 support clips x 8 frames through the pooler)."""
+    model = _native("resnet18", False, False, 256)
+    ref = _oracle_of(model, "resnet18", False, 256)
+    for T in (1, 8):
+        model.clip_length = model.frame_pooler.T = T
+        ref.clip_length = T
+        task = synthetic.make_task(2, way=5, shots=5, frames_per_shot=8, num_query=200 // T, frame_size=84, clip_length=T)
+        assert task["context_clips"].shape[:2] == (200 // T, T)
+        with torch.no_grad():
+            model.personalise(task["context_clips"].cuda(), task["context_labels"].cuda())
+            got = model.predict(task["target_clips"].cuda()).cpu()
+        model._reset()
+        ref.personalise(task["context_clips"], task["context_labels"])
+        want = ref.predict(task["target_clips"])
+        assert got.shape == want.shape == (200 // T, 5)
+        assert (got - want).abs().max().item() < 1e-3
+        assert torch.equal(got.argmax(1), want.argmax(1))
+        acc = lambda z: (z.argmax(1) == task["target_labels"]).float().mean().item()
+        assert acc(got) == acc(want) and acc(got) > 0.3
+
+
+@pytest.mark.parametrize("name", sorted(CONFIGS) + [CONFIG2])
+def test_full_size_task_properties(device, name):
+    """The configs' real sizes: 200 support + 200 query frames of 224x224 (config 2: 84x84)."""
+    fe_name, adapt, way, _ = CONFIGS.get(name, ("resnet18", False, 5, True))
+    SIZE = 84 if name == CONFIG2 else 224
     model = _native(fe_name, adapt, False, 256)
     task = synthetic.make_task_on_device(3, way, 1, 200 // way, 200, SIZE, 1, device)
     ctx, lab, tgt = task["context_clips"], task["context_labels"], task["target_clips"]
