@@ -60,35 +60,58 @@ typedef void* orbit_stream_t; /* hipStream_t */
 
 /* ---- library ---------------------------------------------------------------------------------- */
 int orbit_version(void);
+/* Call once per device before the first launch (idempotent): freed stream-ordered scratch stays in the device's default
+ * memory pool instead of being returned - and synchronously re-allocated - around every task. */
+int orbit_runtime_init(void);
 const char* orbit_last_error(void);
 /* number of visible HIP devices (<=0: no usable GPU); does not create a context on failure */
 int orbit_device_count(void);
-/* tuning switches (initial value from the environment ORBIT_DW_WINDOW / ORBIT_MBCONV_FUSION / ORBIT_GRAPH):
- *   "dw_window"     register-window depthwise kernel: 1 = where it wins (3x3, stride 1, >= 14 rows; default), 0 = never,
- *                   2 = always
- *   "dw_lds"        depthwise kernel that stages its input patch in LDS: 1 = stride-1 5x5 and small 3x3 maps (default), 0 = never,
+/* Tuning switches. Every option has an environment default ORBIT_<NAME in upper case>; all defaults are the measured-best
+ * path, the switches exist so that A/B comparisons run inside one process on one box.
+ *  extractor forward - which kernel serves which MBConv block (read when a plan is created, unless noted):
+ *   "mbconv_rows"   1 (default) = EfficientNet blocks 1.0 .. 3.0 (112x112 .. 28x28 maps) run the ROW-STREAMING fused front
+ *                   (csrc/mbconv_rows.hip: expand 1x1 + BN + SiLU + depthwise + BN + SiLU + SE partials, expanded rows in an
+ *                   LDS ring, no tile halo); 0 = the tiled fused kernel / the kernel pair as "mbconv_fusion" says
+ *   "stem_rows"     1 (default) = conv_stem + BN + SiLU + the first depthwise as one row-streaming kernel; 0 = direct stem
+ *                   kernel + depthwise kernel
+ *   "mbrows_band"   output rows per band of the two row-streaming kernels: 0 = 28 (default); the band count sizes a plan's
+ *                   SE pooling partials, so a launch REFUSES a value that differs from the one its plan was built with
+ *   "mbconv_fusion" tiled fused front (csrc/mbconv.hip) for blocks the row-streaming kernel does not take: 2 (default) =
+ *                   where it measured faster than the conv + depthwise pair, 1 = every supported block (incl. the stem
+ *                   form), 0 = never. A plan that records a training tape is always built without fused blocks
+ *   "mbconv_map"    whole-map fused front for the 14x14 / 7x7 stages (csrc/mbconv_map.hip): 0 (default) = off, 1 = where
+ *                   it beats the pair, 2 = everywhere it applies; "mbmap_groups": its channel-chunk groups per block (0 = auto)
+ *   "stem_direct"   1 (default) = EfficientNet's stem as the direct LDS-row kernel (csrc/stem.hip) when not fused; 0 = implicit GEMM
+ *   "pw_narrow"     0 (default) / 1 = narrow pointwise projections (Cout 16 / 24) through csrc/pw_narrow.hip
+ *   "dw_window"     register-window depthwise kernel: 1 = where it wins (3x3, stride 1, >= 14 rows; default), 0 = never, 2 = always
+ *   "dw_lds"        depthwise kernel staging its input patch in LDS: 1 = stride-1 5x5 and small 3x3 maps (default), 0 = never,
  *                   2 = whenever the patch fits in 64 KiB
- *   "dw_pipe"       streaming depthwise kernel with unconditional, software-pipelined tap-row loads: 1 = large stride-2
- *                   layers (default), 0 = never, 2 = always
- *   "mbconv_fusion" fused expand+depthwise kernel (csrc/mbconv.hip): 2 (default) = where it is measured faster than the
- *                   kernel pair (EfficientNet's first two MBConv blocks: -40 % / -12 %), 1 = every supported block and
- *                   the stem + first depthwise (slower), 0 = never. Read when an extractor is created. A fused block has no training form:
- *                   create the extractor with 0 for orbit_extractor_train_forward (the Python modules do)
+ *   "dw_pipe"       software-pipelined streaming depthwise kernel: 1 = large stride-2 layers (default), 0 = never, 2 = always
+ *   "se_wide"       1 (default) = 1024-thread squeeze-excite gate blocks for C >= 1024
  *   "graph"         HIP-graph replay of extractor forwards: 0 = never, 1 = always, 2 = adaptive (default: only while an
- *                   eager kernel launch costs > ~12 us of host time on this host)
- *   "conv_tile"     force the implicit-GEMM block tile: 0 = heuristic (default), 1 = 128x128, 2 = 128x64, 3 = 64x64,
- *                   4 = 128x32 (tuning sweeps only)
- *   "conv_bk"       cap the K-tile width: 0 = widest of 32/16/8 dividing Cin (default), 8, 16, 32 (tuning sweeps only;
- *                   read when weights are packed AND at launch, so set it before creating/finalizing an extractor)
- *   "conv_uncond"   staged conv loads without predicates: 1 = pointwise convs only (default), 0 = never,
- *                   2 = everywhere (A/B)
- *   "conv_splitk"   1 (default) = convs with few output tiles and a long reduction are split over K (partial tiles +
- *                   a deterministic reduce); 0 = never
- *   "conv_stem_fast", "conv_early_sc", "conv_epi_batch"  1 (default) / 0: A/B switches of three conv-kernel details
- *                   (interior fast path of the NCHW stem gather; epilogue scale/shift requested before the K loop;
- *                   batched epilogue output pass) - see csrc/conv_igemm.hip
- *   "head_lds"      1 (default) = the distance kernel stages the class weights in LDS for launches with >= 64 query
- *                   rows; 0 = always the one-wave-per-row form */
+ *                   eager kernel launch costs > ~12 us of host time on this host); read per forward
+ *  implicit-GEMM convolution (csrc/conv_igemm.hip):
+ *   "conv_tile"     force the block tile: 0 = heuristic (default); 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32,
+ *                   5 = 64x32 k-split 2, 6 = 32x32 k-split 4, 7 = 32x64 k-split 2; pointwise convs only: 8 / 9 / 10 = 32 / 64 /
+ *                   128 rows x 96 columns and 11 / 12 / 13 = x 128 columns (one pass over N for Cout <= 96 / 128) - sweeps
+ *   "conv_bk"       cap the K-tile width: 0 = widest of 32/16/8 dividing Cin (default), 8, 16, 32 (read when weights are
+ *                   packed AND at launch: set it before creating / finalizing an extractor)
+ *   "conv_uncond"   staged loads without predicates: 1 = pointwise convs only (default), 0 = never, 2 = everywhere
+ *   "conv_splitk"   1 (default) = convs with few output tiles and a long reduction are split over K (partial tiles + a
+ *                   deterministic reduce), 0 = never; "conv_splitk_tiles": the tile-count threshold (0 = 320)
+ *   "conv_stem_fast", "conv_early_sc", "conv_epi_batch"  1 (default) / 0: interior fast path of the NCHW stem gather;
+ *                   epilogue scale / shift requested before the K loop; batched epilogue output pass
+ *  prototype head (csrc/head.hip):
+ *   "head_stream"   2 (default) = the streaming distance kernel (rows requested before the weight staging, 8 waves x 2 rows)
+ *                   for launches with >= 64 query rows, 1 = always, 0 = never
+ *   "head_lds"      1 (default) = otherwise the LDS-staged kernel for >= 64 query rows; 0 = the one-wave-per-row form
+ *  LITE training step (csrc/extractor_train.hip, train_*.hip):
+ *   "train_graph"   0 (default) / 1 = the training entry points replay captured HIP graphs (frees host time; the step is
+ *                   GPU-bound, so it is opt-in)
+ *   "dw_dgrad_forward"  1 (default) = the input gradient of a stride-1 depthwise conv runs through the forward LDS-patch
+ *                   kernels with rotated taps; 0 = the gather kernel
+ *   "se_bn_fuse"    1 (default) = the last pass of the squeeze-excite backward also carries the reduction pass of the
+ *                   depthwise BatchNorm's backward (csrc/train_mbconv.hip gate_bwd_apply_bn_kernel); 0 = separate passes */
 int orbit_set_option(const char* name, int value);
 /* current value of an option (after its environment default was applied), -1 for an unknown name */
 int orbit_get_option(const char* name);

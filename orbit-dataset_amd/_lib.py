@@ -96,6 +96,7 @@ _SIGNATURES = {
     "orbit_prof_num_variants": (c_int, []),
     "orbit_prof_variant": (c_int, [c_int, ctypes.c_char_p, POINTER(ctypes.c_long), POINTER(c_double),
                                    POINTER(c_double), POINTER(c_double)]),
+    "orbit_runtime_init": (c_int, []),
     "orbit_comm_unique_id": (c_int, [P]),
     "orbit_comm_init": (c_int, [c_int, c_int, P]),
     "orbit_comm_world": (c_int, []),
@@ -191,6 +192,7 @@ def require_gpu():
     load()
     if not torch.cuda.is_available():
         raise OrbitHipError("no HIP device is visible to torch; the ORBIT hot path has no CPU fallback")
+    check(load().orbit_runtime_init(), "orbit_runtime_init")  # (current device; other devices: first launch on them)
     _gpu_ok = True
 
 

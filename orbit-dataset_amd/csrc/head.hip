@@ -501,6 +501,23 @@ extern "C" {
 
 int orbit_version(void) { return 100; }
 
+/* Once per device the library is used on: keep freed stream-ordered allocations in the device's default memory pool. The
+ * few entry points that take scratch with hipMallocAsync / hipFreeAsync (single-operator test entries, the FiLM generator's
+ * backward) otherwise hit a pool whose release threshold is 0: every synchronisation trims it, the next call allocates for
+ * real, and the real free that follows synchronises the device under the host's feet. */
+int orbit_runtime_init(void) {
+    int dev = 0;
+    ORBIT_HIP_CHECK(hipGetDevice(&dev));
+    static bool done[64] = {false};
+    if (dev < 0 || dev >= 64 || done[dev]) return ORBIT_OK;
+    hipMemPool_t pool = nullptr;
+    ORBIT_HIP_CHECK(hipDeviceGetDefaultMemPool(&pool, dev));
+    uint64_t keep = UINT64_MAX;
+    ORBIT_HIP_CHECK(hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep));
+    done[dev] = true;
+    return ORBIT_OK;
+}
+
 int orbit_set_option(const char* name, int value) {
     ORBIT_REQUIRE(name, "set_option: null name");
     Option* o = find_option(name);

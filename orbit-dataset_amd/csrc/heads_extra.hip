@@ -373,7 +373,7 @@ size_t orbit_mahalanobis_workspace_bytes(int N, int M, int D, int C) {
     size_t fl = (size_t)(C + 1) * D      /* means incl. task mean */
                 + 2 * (size_t)(C + 1)     /* counts, single-example scalars */
                 + (size_t)C * D + C       /* per-class sums / counts of the configure kernel */
-                + (size_t)(C + 1) * DD    /* covariance estimates */
+                + 2 * (size_t)(C + 1) * DD    /* covariance estimates + the blended matrices that are inverted in place */
                 + (size_t)(C + 1) * GJ_NB * GJ_NB;
     const size_t predict = 2 * (size_t)M * D + DD + conv_packed_floats(D, D, 1, 1, 0);
     if (predict > fl) fl = predict;
@@ -397,7 +397,8 @@ int orbit_mahalanobis_configure(const float* features, const int64_t* labels, co
     float* counts = sums + (size_t)C * D;           // [C]
     float* cov = counts + C;                        // [C+1][D][D]
     cov = reinterpret_cast<float*>(align_up(reinterpret_cast<uintptr_t>(cov), 16));
-    float* dinv = cov + (size_t)(C + 1) * DD;
+    float* sigma = cov + (size_t)(C + 1) * DD;       // [C+1][D][D] blended covariances, inverted in place
+    float* dinv = sigma + (size_t)(C + 1) * DD;
     // per-class sums / counts in ascending row order (the prototype kernel), then means
     if (int rc = orbit_proto_configure(features, labels, class_ids, 1, N, 1, D, C, sums, counts, stream)) return rc;
     task_mean_kernel<<<cdiv(D, 256), 256, 0, s>>>(sums, counts, C, D, mu, cnt);
@@ -407,9 +408,9 @@ int orbit_mahalanobis_configure(const float* features, const int64_t* labels, co
     ORBIT_LAUNCH_CHECK();
     cov_single_kernel<<<C, 256, 0, s>>>(features, labels, class_ids, N, D, C, cnt, scalar);
     ORBIT_LAUNCH_CHECK();
-    // sigma is assembled straight into the output buffers: precisions [C][D][D] then inverted in place
-    float* sigma = nullptr;
-    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&sigma), (size_t)(C + 1) * DD * sizeof(float), s));
+    // sigma lives in the caller's workspace: a stream-ordered allocation here (hipMallocAsync / hipFreeAsync of 6-26 MB per
+    // task, rounds 1-2) falls back to real allocations and frees once the pool has been trimmed, and a free synchronises
+    // the device - the host then sat out the whole task (host enqueue 16.9 of 17.35 ms in the simple-CNAPs bench line)
     cov_blend_kernel<<<4096, 256, 0, s>>>(cov, cnt, scalar, D, C, sigma);
     hipError_t e = hipGetLastError();
     int rc = ORBIT_OK;
@@ -424,7 +425,6 @@ int orbit_mahalanobis_configure(const float* features, const int64_t* labels, co
             e = hipMemcpyAsync(task_mean, mu + (size_t)C * D, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, s);
         if (e != hipSuccess) rc = set_err(ORBIT_ERR_HIP, "mahalanobis_configure: %s", hipGetErrorString(e));
     }
-    (void)hipFreeAsync(sigma, s);
     return rc;
 }
 
