@@ -43,7 +43,11 @@ class PrototypicalClassifier(nn.Module):
     def _cosine(self):
         return 1 if self.distance_fn == "cosine" else 0
 
-    _unique_cache = {}  # (data_ptr, version, numel, device) -> class_ids; small, cleared when it grows
+    # (data_ptr, version, numel, device) -> (weak reference to the label tensor, class_ids). Shared by the heads of a
+    # process, guarded by a lock; entries hold the label tensor only WEAKLY (round 2 pinned up to 256 of them alive) and
+    # die with it, so a recycled storage address cannot hit a stale entry
+    _unique_cache = {}
+    _unique_lock = __import__("threading").Lock()
 
     @classmethod
     def unique_labels(cls, context_labels, device):
@@ -52,17 +56,26 @@ class PrototypicalClassifier(nn.Module):
         count, exactly like the reference's torch.unique(...).item() loop (:96-100). The result is memoised per
         label tensor (storage address + version counter): LITE re-personalises the same task once per query batch
         (single-step-learner.py:220-222), and a resident task set is re-used across epochs."""
+        import weakref
         key = (context_labels.data_ptr(), context_labels._version, context_labels.numel(), str(context_labels.device))
-        hit = cls._unique_cache.get(key)
-        if hit is not None and hit[0] is context_labels:
-            return hit[1]
+        with cls._unique_lock:
+            hit = cls._unique_cache.get(key)
+            if hit is not None and hit[0]() is context_labels:
+                return hit[1]
         if context_labels.is_cuda:
             ids = torch.unique(context_labels.to(torch.int64))
         else:
             ids = torch.unique(context_labels.to(torch.int64)).to(device, non_blocking=True)
-        if len(cls._unique_cache) > 256:
-            cls._unique_cache.clear()
-        cls._unique_cache[key] = (context_labels, ids)  # holding the tensor keeps its address from being re-used
+        cache, lock = cls._unique_cache, cls._unique_lock
+
+        def drop(ref, key=key):  # the label tensor died: its address may be handed out again
+            with lock:
+                if cache.get(key, (None,))[0] is ref:
+                    del cache[key]
+        with lock:
+            if len(cache) > 256:
+                cache.clear()
+            cache[key] = (weakref.ref(context_labels, drop), ids)
         return ids
 
     def configure(self, context_features, context_labels, ops_counter=None, frames_per_clip: int = 1,

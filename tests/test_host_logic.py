@@ -152,3 +152,32 @@ def test_mark_parameters_changed():
     mark_parameters_changed(root)
     assert net.__dict__["_plans"][(8, 8)].stamp is None and gen.__dict__["_stamp"] is None
 
+
+
+def test_unique_label_cache_is_weak_and_thread_safe():
+    """the memo of `unique_labels` no longer pins label tensors alive and can be shared by threads."""
+    import gc
+    import threading
+    from orbit_dataset_amd.model.classifier_heads import PrototypicalClassifier as P
+    P._unique_cache.clear()
+    lab = torch.tensor([7, 3, 3, 9, 7])
+    ids = P.unique_labels(lab, "cpu")
+    assert ids.tolist() == [3, 7, 9] and P.unique_labels(lab, "cpu") is ids and len(P._unique_cache) == 1
+    lab += 0  # in-place op: new version -> new entry, not a stale hit
+    assert P.unique_labels(lab, "cpu") is not ids
+    del lab
+    gc.collect()
+    assert len(P._unique_cache) == 0  # entries die with their tensor
+    errors = []
+
+    def work(seed):
+        try:
+            g = torch.Generator().manual_seed(seed)
+            for _ in range(200):
+                t = torch.randint(0, 6, (12,), generator=g)
+                assert P.unique_labels(t, "cpu").tolist() == sorted(set(t.tolist()))
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+    threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
+    [t.start() for t in threads], [t.join() for t in threads]
+    assert not errors
