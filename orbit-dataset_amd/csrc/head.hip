@@ -366,14 +366,27 @@ __global__ __launch_bounds__(256) void proto_predict_lds_kernel(
 // from registers against LDS after the barrier. The 64-task launch (67 MB) is ~8 us of HBM time: what it can lose is
 // exactly such serialised latencies (round 1: W staging -> barrier -> first row load, 2.7 TB/s). Same per-lane accumulation
 // order as proto_predict_lds_kernel (d ascending), hence bit-identical logits.
+// Block -> (task, row block): the hardware deals consecutive block ids round-robin over the 8 XCDs, each with its own L2. A
+// task's weights (C x D floats, 25.6 KB) are staged by every one of its row blocks; dealt round-robin, a task's 13 blocks sat
+// on 8 different XCDs and its weights were fetched from memory 8 times (PMC: 79.3 MB of traffic per 64-task launch against
+// 67.4 MB of algorithmic bytes, 1.18x). The bijective remap below gives every XCD a contiguous run of logical blocks, so the
+// blocks of one task share one L2 and the weights cross the fabric once.
+__device__ __forceinline__ int head_xcd_remap(int bid, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + slot;
+}
+
 template <int NW, int R, int NI>
 __global__ __launch_bounds__(NW * 64) void proto_predict_stream_kernel(
     const float* __restrict__ Q, const float* __restrict__ W, const float* __restrict__ bias, int M, int D, int C,
-    float logit_scale, int cosine, float* __restrict__ logits, int32_t* __restrict__ argmax) {
+    float logit_scale, int cosine, float* __restrict__ logits, int32_t* __restrict__ argmax, int blocks_per_task) {
     extern __shared__ __attribute__((aligned(16))) float Ws[];  // [C][D] weights, then [C] norms
-    const int task = blockIdx.y;
+    const int logical = head_xcd_remap(blockIdx.x, gridDim.x);
+    const int task = logical / blocks_per_task, bx = logical - task * blocks_per_task;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    const int m0 = (blockIdx.x * NW + wave) * R;
+    const int m0 = (bx * NW + wave) * R;
     const bool wave_ok = m0 < M;
     float4 x[R][NI];
     bool row_ok[R];
@@ -583,8 +596,8 @@ int orbit_proto_predict(const float* Q, const float* W, const float* b, int n_ta
         const int stream_opt = get_option("head_stream");
         if (stream_opt && T == 1 && (D == 1280 || D == 512)) {
 #define ORBIT_HEAD_STREAM(NW_, R_, NI_)                                                                                  \
-    proto_predict_stream_kernel<NW_, R_, NI_><<<dim3(cdiv(M, NW_ * R_), n_tasks), NW_ * 64, lds, s>>>(Q, W, b, M, D, C,  \
-                                                                                                 logit_scale, cosine, logits, argmax)
+    proto_predict_stream_kernel<NW_, R_, NI_><<<cdiv(M, NW_ * R_) * n_tasks, NW_ * 64, lds, s>>>(                         \
+        Q, W, b, M, D, C, logit_scale, cosine, logits, argmax, cdiv(M, NW_ * R_))
             if (stream_opt == 1) { if (D == 1280) ORBIT_HEAD_STREAM(4, 4, 5); else ORBIT_HEAD_STREAM(4, 4, 2); }
             else if (stream_opt == 3) { if (D == 1280) ORBIT_HEAD_STREAM(4, 2, 5); else ORBIT_HEAD_STREAM(4, 2, 2); }
             else { if (D == 1280) ORBIT_HEAD_STREAM(8, 2, 5); else ORBIT_HEAD_STREAM(8, 2, 2); }

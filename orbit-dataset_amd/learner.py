@@ -83,6 +83,13 @@ def build_parser():
     p.add_argument("--momentum", type=float, default=0.0)
     p.add_argument("--print_by_step", action="store_true")
     p.add_argument("--results_path", default=None)
+    p.add_argument("--data_root", default=None,
+                   help="--mode test: a frame directory laid out like ORBIT (root/<user>/<object>/<clean|clutter>/<video>/*.jpg, "
+                        "reference data/datasets.py:139-200). Tasks are the users' (context = clean videos, target = clutter "
+                        "videos); frames are decoded with PIL by --num_workers threads, uploaded as 8-bit on a copy stream and "
+                        "normalised on the GPU (data/pipeline.TaskPrefetcher) while the previous task runs")
+    p.add_argument("--num_workers", type=int, default=4, help="decode threads (reference data/queues.py:34: 4 in test mode)")
+    p.add_argument("--frame_norm_method", default="imagenet", choices=["imagenet", "imagenet_inception", "openai_clip"])
     return p
 
 
@@ -285,8 +292,58 @@ class Learner:
                      self.world))
         return stats
 
+    def test_directory(self):
+        """The reference's test loop (single-step-learner.py:298-375) over a JPEG directory: one task per user, personalise
+        on the context clips, then per target VIDEO predict on its frame history, frame accuracy per video averaged per
+        task. Decode, 8-bit upload and normalisation of task i+1 overlap the extractor work of task i."""
+        from .data.pipeline import DirectoryTaskSource, ORBITDirectory, TaskPrefetcher
+        a = self.args
+        self.model.set_test_mode(True)
+        self.model.frame_norm_method = a.frame_norm_method
+        directory = ORBITDirectory(a.data_root)
+        users = directory.users[self.rank::self.world][:a.num_test_tasks]
+        source = DirectoryTaskSource(directory, a.clip_length, a.num_workers, users=users)
+        task_acc, personalise_ms, inference_ms, frames = [], [], [], 0
+        t_all = time.perf_counter()
+        prefetch = TaskPrefetcher(source, self.device, depth=3, frame_norm_method=a.frame_norm_method)
+        with torch.no_grad():
+            for task in prefetch:
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                self.model.personalise(task["context_clips"], task["context_labels"])
+                torch.cuda.synchronize()
+                personalise_ms.append(1e3 * (time.perf_counter() - t0))
+                accs = []
+                target = task["target_clips"][:, 0]  # [M,3,H,W]: the videos' frames, in video order
+                for lo, hi in task["target_videos"]:
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    logits = self.model.predict_video(target[lo:hi])  # = predict(attach_frame_history(frames, clip_length))
+                    torch.cuda.synchronize()
+                    inference_ms.append(1e3 * (time.perf_counter() - t0) / float((hi - lo) * self.model.clip_length))
+                    accs.append(frame_accuracy(logits, task["target_labels"][lo:hi]))
+                    frames += hi - lo
+                task_acc.append(float(np.mean(accs)))
+                self.model._reset()
+        prefetch.close()
+        wall = time.perf_counter() - t_all
+        stats = {"frame_acc": mean_ci(task_acc), "personalise_ms": mean_ci(personalise_ms),
+                 "inference_ms_per_frame": mean_ci(inference_ms), "num_tasks": len(task_acc), "world_size": self.world,
+                 "target_frames": frames, "wall_s": wall, "data_root": a.data_root}
+        if self.rank == 0:
+            print("test (%s): frame_acc %.2f (%.2f) %% | time to personalise %.2f (%.2f) ms | inference %.4f (%.4f) ms/frame "
+                  "| %d tasks, %d target frames in %.1f s incl. JPEG decode (%d threads)"
+                  % (a.data_root, 100 * stats["frame_acc"][0], 100 * stats["frame_acc"][1], *stats["personalise_ms"],
+                     *stats["inference_ms_per_frame"], stats["num_tasks"], frames, wall, a.num_workers))
+            if a.results_path:
+                with open(a.results_path, "w") as f:
+                    json.dump(stats, f)
+        return stats
+
     def test(self):
         a = self.args
+        if getattr(a, "data_root", None):
+            return self.test_directory()
         self.model.set_test_mode(True)
         # synthetic tasks live on the host and are uploaded per mini-batch, so the query pass may run on its own stream
         self.model.overlap_query = True

@@ -92,3 +92,29 @@ def test_prefetcher_with_pinned_host_tasks_and_more_tasks_than_slots(device):
     next(pf)
     with pytest.raises(RuntimeError, match="decoder died"):
         next(pf)
+
+
+def test_learner_test_mode_over_a_jpeg_directory(device, tree, tmp_path):
+    """learner.py --mode test --data_root: the reference's per-user / per-video test loop (single-step-learner.py:298-375)
+    fed by the input pipeline; the per-task accuracies equal a plain loop over the decoded tasks."""
+    from orbit_dataset_amd import learner
+    args = learner.build_parser().parse_args(["--mode", "test", "--feature_extractor", "resnet18", "--frame_size", "64",
+                                              "--data_root", tree, "--num_test_tasks", "4", "--num_workers", "3",
+                                              "--batch_size", "16", "--results_path", str(tmp_path / "res.json")])
+    L = learner.Learner(args)
+    stats = L.run()["test"]
+    assert stats["num_tasks"] == 4 and stats["target_frames"] == 4 * 3 * 2 * 5
+    model = L.model
+    accs = []
+    with torch.no_grad():
+        for t in pipeline.DirectoryTaskSource(pipeline.ORBITDirectory(tree), workers=2):
+            ctx = frames_from_uint8(t["context_clips"], device, channels_last=True)
+            tgt = frames_from_uint8(t["target_clips"], device, channels_last=True)[:, 0]
+            model.personalise(ctx, t["context_labels"].to(device))
+            per_video = []
+            for lo, hi in t["target_videos"]:
+                logits = model.predict_video(tgt[lo:hi])
+                per_video.append((logits.argmax(1).cpu() == t["target_labels"][lo:hi]).float().mean().item())
+            accs.append(sum(per_video) / len(per_video))
+            model._reset()
+    assert abs(stats["frame_acc"][0] - sum(accs) / len(accs)) < 1e-6
