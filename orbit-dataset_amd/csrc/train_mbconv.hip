@@ -4,6 +4,7 @@
 //   squeeze-excite: gate multiply, its backward (d gate = sum_hw dxg * x; dx = dxg * gate + d pooled / HW), the SE MLP
 //   backward and its parameter gradients.
 // NHWC fp32, float4 over channels; every reduction has a fixed order (deterministic, no atomics). All HBM-bound.
+#include <algorithm>
 #include "common.h"
 
 namespace orbit {
@@ -288,6 +289,74 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restri
     }
 }
 
+// Stride-2 form: a thread owns a channel quad and a 2x2 block of dx (rows h0, h0+1 / columns w0, w0+1, h0 and w0 even).
+// With stride 2 an input pixel only receives the taps whose parity matches (kh = (h + pad_t) mod 2, +2, ...): the four pixels
+// of the block together use every tap exactly once, and all of them read the same (K+1)/2 rows x columns of dy. The
+// thread loads that dy patch once (4 quads for 3x3, 9 for 5x5; the gather kernel above issues up to K*K dy loads and K*K
+// filter loads behind per-tap branches for EVERY pixel: 561 / 409 us on the 112x112x96 / 56x56x144 layers of
+// efficientnet_b0 against ~240 / ~90 us of HBM time) and the filter taps from LDS. PT / PL = parity of pad_t / pad_l
+// (compile time, so that every register index is static).
+template <int K, int PT, int PL>
+__global__ __launch_bounds__(256) void dwconv_dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
+                                                              float* __restrict__ dx, int B, int H, int W, int C4,
+                                                              int pad_t, int pad_l, int Ho, int Wo, int G, int R) {
+    constexpr int NR = (K + 1) / 2;  // dy rows / columns one 2x2 block touches (2 for 3x3, 3 for 5x5)
+    extern __shared__ __attribute__((aligned(16))) float smd[];
+    f32x4* wl = reinterpret_cast<f32x4*>(smd);  // [K*K][G]
+    const int tid = threadIdx.x;
+    const int rl = tid / G, qi = tid - rl * G, q = blockIdx.y * G + qi;
+    for (int i = tid; i < K * K * G; i += 256) {
+        const int tap = i / G, qq = blockIdx.y * G + (i - tap * G);
+        wl[i] = qq < C4 ? reinterpret_cast<const f32x4*>(w)[(size_t)tap * C4 + qq] : (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();
+    if (rl >= R || q >= C4) return;
+    const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
+    const unsigned total = (unsigned)B * H2 * W2;  // 2x2 blocks (launcher: < 2^31)
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (unsigned i = blockIdx.x * R + rl; i < total; i += gridDim.x * R) {
+        const unsigned bw = i / (unsigned)W2, b = bw / (unsigned)H2;
+        const int w0 = (int)(i - bw * W2) * 2, h0 = (int)(bw - b * H2) * 2;
+        // dy patch: rows hb .. hb + NR - 1, hb = the smallest output row any tap of row h0 reaches
+        const int hb = (h0 + pad_t - (K - 1) + (((K - 1) ^ PT) & 1)) / 2;  // (h0 + pad_t - kh_max) / 2, kh_max of parity PT
+        const int wb = (w0 + pad_l - (K - 1) + (((K - 1) ^ PL) & 1)) / 2;
+        // (h0 + pad_t - K + 1 can be negative by at most K - 1: the division above is exact on an even numerator >= -(K-1))
+        const f32x4* dyb = reinterpret_cast<const f32x4*>(dy) + (size_t)b * Ho * Wo * C4 + q;
+        f32x4 patch[NR][NR];
+#pragma unroll
+        for (int r = 0; r < NR; ++r) {
+            const int ho = hb + r;
+            const bool rok = (unsigned)ho < (unsigned)Ho;
+#pragma unroll
+            for (int c = 0; c < NR; ++c) {
+                const int wo = wb + c;
+                const bool ok = rok && (unsigned)wo < (unsigned)Wo;
+                const f32x4 v = dyb[(size_t)((ok ? ho : 0) * Wo + (ok ? wo : 0)) * C4];
+                patch[r][c] = ok ? v : zero;
+            }
+        }
+        f32x4* dxb = reinterpret_cast<f32x4*>(dx) + (size_t)b * H * W * C4 + q;
+#pragma unroll
+        for (int dh = 0; dh < 2; ++dh) {
+#pragma unroll
+            for (int dw = 0; dw < 2; ++dw) {
+                f32x4 acc = zero;
+#pragma unroll
+                for (int kh = (dh + PT) & 1; kh < K; kh += 2) {
+                    // ho = (h0 + dh + pad_t - kh) / 2; relative to hb: static index because parities are compile time
+                    const int r = (dh + ((K - 1) - (((K - 1) ^ PT) & 1)) - kh) / 2 + 0;
+#pragma unroll
+                    for (int kw = (dw + PL) & 1; kw < K; kw += 2) {
+                        const int c = (dw + ((K - 1) - (((K - 1) ^ PL) & 1)) - kw) / 2;
+                        acc += patch[r][c] * wl[(kh * K + kw) * G + qi];
+                    }
+                }
+                if (h0 + dh < H && w0 + dw < W) dxb[(size_t)((h0 + dh) * W + (w0 + dw)) * C4] = acc;
+            }
+        }
+    }
+}
+
 // partial[chunk][tap][c] = sum over the chunk's output pixels of dy * x(tap); block = (chunk of OUTPUT ROWS, group of G quads).
 // A thread (channel quad, row lane) walks whole output rows, NB output columns at a time: per tap row it loads the
 // (NB-1)*S + K input columns those NB outputs touch ONCE and reuses them across the K taps and the NB outputs -
@@ -481,6 +550,26 @@ int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, 
     }
 
     ORBIT_REQUIRE(C % 4 == 0 && (K == 3 || K == 5), "dwconv_dgrad: C %% 4 != 0 or K not in {3,5}");
+    if (stride == 2 && get_option("dw_dgrad_s2") && (long long)B * ((H + 1) / 2) * ((W + 1) / 2) < (1ll << 31)) {
+        // 2x2-block form: one dy patch + LDS taps per four outputs (see dwconv_dgrad_s2_kernel)
+        int G, R, yg;
+        dw_layout(C, G, R, yg);
+        const size_t blocks2 = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+        int gx = (int)std::min<size_t>((blocks2 + R - 1) / R, 16384);
+        const size_t lds = (size_t)K * K * G * sizeof(f32x4);
+#define ORBIT_DG2(KK, PT_, PL_)                                                                                       \
+    dwconv_dgrad_s2_kernel<KK, PT_, PL_><<<dim3(gx, yg), 256, lds, s>>>(dy, w_khwc, dx, B, H, W, C / 4, pad_t, pad_l, Ho, \
+                                                                        Wo, G, R)
+        const int pt = pad_t & 1, pl = pad_l & 1;
+        if (K == 3) {
+            if (!pt && !pl) ORBIT_DG2(3, 0, 0); else if (!pt) ORBIT_DG2(3, 0, 1); else if (!pl) ORBIT_DG2(3, 1, 0); else ORBIT_DG2(3, 1, 1);
+        } else {
+            if (!pt && !pl) ORBIT_DG2(5, 0, 0); else if (!pt) ORBIT_DG2(5, 0, 1); else if (!pl) ORBIT_DG2(5, 1, 0); else ORBIT_DG2(5, 1, 1);
+        }
+#undef ORBIT_DG2
+        ORBIT_LAUNCH_CHECK();
+        return ORBIT_OK;
+    }
     const int grid = grid_for((size_t)B * H * W * (C / 4));
     ORBIT_REQUIRE((unsigned long long)((size_t)B * H * W * (C / 4)) < (1ull << 32), "tensor too large for the 32-bit index arithmetic of this kernel");
     if (K == 3) dwconv_dgrad_kernel<3><<<grid, 256, 0, s>>>(dy, w_khwc, dx, B, H, W, C / 4, stride, pad_t, pad_l, Ho, Wo);

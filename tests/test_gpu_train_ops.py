@@ -273,6 +273,9 @@ DW_CASES = [
     (2, 240, 9, 9, 5, 1, 2, 2),
     (4, 24, 20, 20, 5, 2, 1, 2),     # TF "SAME": 1 before, 2 after
     (2, 1152, 4, 4, 3, 1, 1, 1),
+    (2, 40, 11, 9, 3, 2, 1, 1),      # stride 2, odd map, padding parity 1 (the 2x2-block data-gradient kernel's 4th variant)
+    (3, 672, 14, 14, 5, 2, 1, 2),    # efficientnet_b0 block 5.0's depthwise layer
+    (1, 96, 112, 112, 3, 2, 0, 1),   # block 1.0's (the largest tensor of the network)
 ]
 
 
