@@ -110,6 +110,9 @@ int orbit_device_count(void);
  *                   GPU-bound, so it is opt-in)
  *   "dw_dgrad_forward"  1 (default) = the input gradient of a stride-1 depthwise conv runs through the forward LDS-patch
  *                   kernels with rotated taps; 0 = the gather kernel
+ *   "train_dw_xf"   1 (default) = ORBIT_TRAIN_NO_BACKWARD forwards skip the activation pass between an expand / stem conv and
+ *                   its depthwise conv (applied on load instead); 0 = always the separate pass
+ *   "dw_dgrad_s2"   1 (default) = the input gradient of a stride-2 depthwise conv as the 2x2-block kernel; 0 = the gather kernel
  *   "se_bn_fuse"    1 (default) = the last pass of the squeeze-excite backward also carries the reduction pass of the
  *                   depthwise BatchNorm's backward (csrc/train_mbconv.hip gate_bwd_apply_bn_kernel); 0 = separate passes */
 int orbit_set_option(const char* name, int value);
@@ -305,6 +308,15 @@ int orbit_extractor_export_bn_stats(orbit_extractor_t* fe, float* dst, orbit_str
 int orbit_extractor_train_forward(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
                                   const float* film_beta, int bn_train, float momentum, float* feats, void* tape,
                                   size_t tape_bytes, orbit_stream_t stream);
+/* The same with flags. ORBIT_TRAIN_NO_BACKWARD: no backward will be run on this tape - the forwards the reference issues
+ * under torch.no_grad() while the extractor is in train() (LITE's cache passes, few_shot_recognisers.py:134-146,388-437):
+ * batch statistics and running-stat updates as above, but activations no later kernel of THIS forward needs are not
+ * materialised (the depthwise convs apply the preceding BatchNorm + activation while loading the raw conv output). Features
+ * are bit-identical to the flag-less call; orbit_extractor_backward on such a tape is undefined. */
+#define ORBIT_TRAIN_NO_BACKWARD 1
+int orbit_extractor_train_forward_ex(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
+                                     const float* film_beta, int bn_train, float momentum, float* feats, void* tape,
+                                     size_t tape_bytes, int flags, orbit_stream_t stream);
 /* Reverse pass for the tape of one train_forward (same frames / B / film / bn_train).
  *   dfeats [B][D]: gradient w.r.t. the features.
  *   param_grads: NULL (frozen extractor) or orbit_extractor_grad_floats() floats; the gradient of parameter i is

@@ -73,6 +73,7 @@ _SIGNATURES = {
     "orbit_extractor_bn_stat_floats": (c_size_t, [P]),
     "orbit_extractor_export_bn_stats": (c_int, [P, P, P]),
     "orbit_extractor_train_forward": (c_int, [P, P, c_int, P, P, c_int, c_float, P, P, c_size_t, P]),
+    "orbit_extractor_train_forward_ex": (c_int, [P, P, c_int, P, P, c_int, c_float, P, P, c_size_t, c_int, P]),
     "orbit_extractor_backward": (c_int, [P, P, c_int, P, P, c_int, P, P, c_size_t, P, c_int, P, P, P, c_size_t, P]),
     "orbit_filmgen_grad_floats": (c_size_t, [P]),
     "orbit_filmgen_param_offset": (c_size_t, [P, c_int, c_char_p]),

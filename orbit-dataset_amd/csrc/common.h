@@ -112,7 +112,10 @@ void prof_stop(int idx, hipStream_t s);  // per-launch event profiling is on (gr
 int dwconv_se_chunks(int Ho);
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                      float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
-                     int Wo, int act, hipStream_t s, int stats = 0);
+                     int Wo, int act, hipStream_t s, int stats = 0, const float* in_scale = nullptr,
+                     const float* in_shift = nullptr, int in_act = 0);
+// in_scale / in_shift (with stats): x is the RAW output of the producing conv; act(x * in_scale[c] + in_shift[c]) is applied
+// as the kernel loads it, so the activated tensor of that layer is never written (no-backward passes of the LITE step)
 // stats != 0: pool_partial receives [B * dwconv_se_chunks(Ho)][2][C] column sums / sums of squares of the outputs instead
 // (train-mode BatchNorm statistics from the producing kernel; the partial layout bn_stats_finalize reads)
 int launch_se_gate2(const float* partial, int chunks, int HW, const float* w1, const float* b1, const float* w2t,

@@ -236,7 +236,7 @@ static int ensure_dgrad_filters(orbit_extractor* fe, orbit_train_state** out, hi
 
 static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
                              const float* film_beta, int bn_train, float momentum, float* feats, void* tape,
-                             hipStream_t s);
+                             hipStream_t s, bool no_backward = false);
 static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const float* frames, int B, const float* film_gamma,
                         const float* film_beta, int bn_train, const float* dfeats, const void* tape, float* param_grads,
                         int filter_grads, float* dfilm_gamma, float* dfilm_beta, void* workspace, hipStream_t s);
@@ -273,7 +273,16 @@ int orbit_extractor_export_bn_stats(orbit_extractor_t* fe, float* dst, orbit_str
 int orbit_extractor_train_forward(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
                                   const float* film_beta, int bn_train, float momentum, float* feats, void* tape,
                                   size_t tape_bytes, orbit_stream_t stream) {
+    return orbit_extractor_train_forward_ex(fe, frames, B, film_gamma, film_beta, bn_train, momentum, feats, tape, tape_bytes,
+                                            0, stream);
+}
+
+int orbit_extractor_train_forward_ex(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
+                                     const float* film_beta, int bn_train, float momentum, float* feats, void* tape,
+                                     size_t tape_bytes, int flags, orbit_stream_t stream) {
     ORBIT_REQUIRE(fe && frames && feats && tape, "extractor_train_forward: null pointer");
+    ORBIT_REQUIRE((flags & ~ORBIT_TRAIN_NO_BACKWARD) == 0, "extractor_train_forward: unknown flags %d", flags);
+    const bool no_backward = (flags & ORBIT_TRAIN_NO_BACKWARD) != 0;
     ORBIT_REQUIRE(B > 0, "extractor_train_forward: empty batch");
     if (!fe->finalized) return set_err(ORBIT_ERR_STATE, "extractor_train_forward: call orbit_extractor_finalize first");
     if (!plan_trainable(fe))
@@ -286,10 +295,10 @@ int orbit_extractor_train_forward(orbit_extractor_t* fe, const float* frames, in
     orbit_extractor::TrainGraphKey key;
     memset(&key, 0, sizeof(key));
     key.p[0] = frames, key.p[1] = film_gamma, key.p[2] = film_beta, key.p[3] = feats, key.p[4] = tape;
-    key.v[0] = 1 /* forward */, key.v[1] = B, key.v[2] = bn_train;
+    key.v[0] = no_backward ? 3 : 1 /* forward */, key.v[1] = B, key.v[2] = bn_train;
     memcpy(&key.v[3], &momentum, sizeof(float));
     return fe->run_train_graphed(key, (hipStream_t)stream, [&](hipStream_t s) {
-        return train_forward_run(fe, frames, B, film_gamma, film_beta, bn_train, momentum, feats, tape, s);
+        return train_forward_run(fe, frames, B, film_gamma, film_beta, bn_train, momentum, feats, tape, s, no_backward);
     });
 }
 
@@ -297,7 +306,7 @@ int orbit_extractor_train_forward(orbit_extractor_t* fe, const float* frames, in
 
 static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
                              const float* film_beta, int bn_train, float momentum, float* feats, void* tape,
-                             hipStream_t s) {
+                             hipStream_t s, bool no_backward) {
     const TapeLayout L = tape_layout(fe, B);
     char* tp = static_cast<char*>(tape);
     auto fl = [&](size_t off) { return reinterpret_cast<float*>(tp + off); };
@@ -315,6 +324,8 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
     cur[-1] = frames;
     int last_dw = -1;
     bool dw_pooled = false;  // the last depthwise op's activation pass left pooling partials in L.pool
+    bool dw_in_raw = false;  // the tensor the next depthwise op reads is a RAW conv output (see ORBIT_TRAIN_NO_BACKWARD)
+    int dw_in_bn = -1, dw_in_act = ORBIT_ACT_NONE;
     for (size_t i = 0; i < fe->ops.size(); ++i) {
         const Op& o = fe->ops[i];
         int rc = ORBIT_OK;
@@ -351,6 +362,17 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
                                          fl(L.partial), s);
                 if (rc != ORBIT_OK) return rc;
             }
+            // No backward will read this tape (a cache pass under torch.no_grad(), ORBIT_TRAIN_NO_BACKWARD) and the only
+            // consumer is the depthwise conv that follows: it applies this BatchNorm + activation as it loads the raw output
+            // (DwInXf, csrc/ops.hip), so the activated 6x-expanded tensor is neither written nor read back
+            dw_in_raw = no_backward && bn_train && get_option("train_dw_xf") && !o.pool2 && o.res < 0 &&
+                        i + 1 < fe->ops.size() && fe->ops[i + 1].kind == OP_DWCONV && fe->ops[i + 1].in == o.out &&
+                        o.Cout % 4 == 0;
+            if (dw_in_raw) {
+                cur[o.out] = d.y;
+                dw_in_bn = o.bn, dw_in_act = o.act;
+                continue;
+            }
             rc = launch_scale_shift_act(d.y, scale + bn.fold_off, shift + bn.fold_off,
                                         o.res >= 0 ? cur[o.res] : nullptr, o.act, (size_t)M, o.Cout, fl(L.a[i]), s);
             if (rc != ORBIT_OK) return rc;
@@ -365,9 +387,12 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
             const BNDesc& bn = fe->bns[o.bn];
             float* y = fl(L.y[i]);
             // train-mode BatchNorm: the depthwise kernel itself emits the column sums / sums of squares of its raw outputs
+            const float* in_sc = dw_in_raw ? scale + fe->bns[dw_in_bn].fold_off : nullptr;
+            const float* in_sh = dw_in_raw ? shift + fe->bns[dw_in_bn].fold_off : nullptr;
             rc = launch_dwconv_se(cur[o.in], fe->d_packed + o.packed_off, y, nullptr, nullptr,
                                   bn_train ? fl(L.partial) : nullptr, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l,
-                                  o.Ho, o.Wo, ORBIT_ACT_NONE, s, bn_train ? 1 : 0);
+                                  o.Ho, o.Wo, ORBIT_ACT_NONE, s, bn_train ? 1 : 0, in_sc, in_sh, dw_in_act);
+            dw_in_raw = false;
             if (rc != ORBIT_OK) return rc;
             const int M = B * o.Ho * o.Wo;
             if (bn_train) {

@@ -19,6 +19,27 @@ __device__ __forceinline__ float act_fn(float v, int act) {
     return v;
 }
 
+// Input transform of the depthwise kernels (XF): the kernel reads the RAW output y of the producing convolution and applies
+// that layer's BatchNorm + activation, act(y * in_scale[c] + in_shift[c]), as it loads - the activated tensor is never
+// written. Used by the batch-statistics forward of passes that run no backward (csrc/extractor_train.hip): for those the
+// separate activation pass (read y, write a) over the 6x-expanded tensor disappears. Same arithmetic as
+// scale_shift_act_kernel, so the depthwise outputs are bit-identical to the two-pass form.
+struct DwInXf {
+    const float* scale;
+    const float* shift;
+    int act;
+};
+__device__ __forceinline__ v4f dw_xf(v4f v, v4f isc, v4f ish, int act) {
+    v = v * isc + ish;
+    if (act == ORBIT_ACT_RELU) {
+        v[0] = fmaxf(v[0], 0.f), v[1] = fmaxf(v[1], 0.f), v[2] = fmaxf(v[2], 0.f), v[3] = fmaxf(v[3], 0.f);
+    } else if (act == ORBIT_ACT_SILU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) v[k] = v[k] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[k]));
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(256) void dw_pack_kernel(const float* __restrict__ w, float* __restrict__ wp,
                                                       int C, int K) {
     const int total = C * K * K;
@@ -39,13 +60,13 @@ __global__ __launch_bounds__(256) void dw_pack_kernel(const float* __restrict__ 
 // the column sums AND sums of squares of the outputs, [B * chunks][2][C] - the per-block layout the train-mode BatchNorm
 // finalize reads (csrc/train_ops.hip); the training forward launches these kernels without scale / shift / activation, so
 // the sums are those of the raw depthwise outputs and BatchNorm needs no statistics pass of its own over y.
-template <int K, int S, bool STATS = false>
+template <int K, int S, bool STATS = false, bool XF = false>
 __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                         float* __restrict__ y, const float* __restrict__ scale,
                                                         const float* __restrict__ shift,
                                                         float* __restrict__ pool_partial, int H, int W, int C,
                                                         int pad_t, int pad_l, int Ho, int Wo, int act, int cb4,
-                                                        int rows_per_chunk) {
+                                                        int rows_per_chunk, DwInXf xf = DwInXf{nullptr, nullptr, 0}) {
     constexpr int NCOL = 3 * S + K;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float4* wl = reinterpret_cast<float4*>(sm);             // [K*K][cb4]
@@ -66,6 +87,8 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
     if (scale) sc = *reinterpret_cast<const float4*>(scale + c);
     if (shift) sh = *reinterpret_cast<const float4*>(shift + c);
     float4 psum = make_float4(0.f, 0.f, 0.f, 0.f), psq = make_float4(0.f, 0.f, 0.f, 0.f);
+    v4f isc = {1.f, 1.f, 1.f, 1.f}, ish = {0.f, 0.f, 0.f, 0.f};
+    if (XF) isc = *reinterpret_cast<const v4f*>(xf.scale + c), ish = *reinterpret_cast<const v4f*>(xf.shift + c);
     const float* xb = x + (size_t)b * H * W * C + c;
     float* yb = y + (size_t)b * Ho * Wo * C + c;
     const int ho_end = min(Ho, (chunk + 1) * rows_per_chunk);
@@ -88,6 +111,10 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
                         const int wi = wi0 + q;
                         col[q] = (unsigned)wi < (unsigned)W ? *reinterpret_cast<const float4*>(xr + (size_t)wi * C)
                                                             : make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (XF && (unsigned)wi < (unsigned)W) {
+                            const v4f t = dw_xf((v4f){col[q].x, col[q].y, col[q].z, col[q].w}, isc, ish, xf.act);
+                            col[q] = make_float4(t[0], t[1], t[2], t[3]);
+                        }
                     }
 #pragma unroll
                     for (int kw = 0; kw < K; ++kw) {
@@ -152,13 +179,13 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
 // output group. Here every load is unconditional (column / row clamped to a valid address, the value multiplied by a
 // 0/1 mask afterwards - the masks of the columns are computed once per column strip) and tap row kh+1 is requested
 // before row kh is consumed, so the waits are counted and one row of loads is always in flight.
-template <int K, int S, bool STATS = false>
+template <int K, int S, bool STATS = false, bool XF = false>
 __global__ __launch_bounds__(256) void dwconv_pipe_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                           float* __restrict__ y, const float* __restrict__ scale,
                                                           const float* __restrict__ shift,
                                                           float* __restrict__ pool_partial, int H, int W, int C,
                                                           int pad_t, int pad_l, int Ho, int Wo, int act, int cb4,
-                                                          int rows_per_chunk) {
+                                                          int rows_per_chunk, DwInXf xf = DwInXf{nullptr, nullptr, 0}) {
     constexpr int NCOL = 3 * S + K;
     extern __shared__ __attribute__((aligned(16))) float smp[];
     v4f* wl = reinterpret_cast<v4f*>(smp);  // [K*K][cb4]
@@ -178,6 +205,8 @@ __global__ __launch_bounds__(256) void dwconv_pipe_kernel(const float* __restric
     v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, psum = {0.f, 0.f, 0.f, 0.f}, psq = {0.f, 0.f, 0.f, 0.f};
     if (scale) sc = *reinterpret_cast<const v4f*>(scale + c);
     if (shift) sh = *reinterpret_cast<const v4f*>(shift + c);
+    v4f isc = {1.f, 1.f, 1.f, 1.f}, ish = {0.f, 0.f, 0.f, 0.f};
+    if (XF) isc = *reinterpret_cast<const v4f*>(xf.scale + c), ish = *reinterpret_cast<const v4f*>(xf.shift + c);
     const float* xb = x + (size_t)b * H * W * C + c;
     float* yb = y + (size_t)b * Ho * Wo * C + c;
     const int ho_end = min(Ho, (chunk + 1) * rows_per_chunk);
@@ -209,7 +238,7 @@ __global__ __launch_bounds__(256) void dwconv_pipe_kernel(const float* __restric
                     const float rm = (unsigned)(hi0 + kh) < (unsigned)H ? 1.f : 0.f;  // uniform over the block
                     v4f col[NCOL];
 #pragma unroll
-                    for (int q = 0; q < NCOL; ++q) col[q] = src[q] * (cm[q] * rm);
+                    for (int q = 0; q < NCOL; ++q) col[q] = (XF ? dw_xf(src[q], isc, ish, xf.act) : src[q]) * (cm[q] * rm);
                     const v4f* wk = wl + (size_t)kh * K * cb4 + lc;
 #pragma unroll
                     for (int kw = 0; kw < K; ++kw) {
@@ -269,13 +298,13 @@ __global__ __launch_bounds__(256) void dwconv_pipe_kernel(const float* __restric
 // (K x NCOL quads) in registers: every output row loads only the S new input rows instead of all K, i.e. 3-5x fewer
 // L1/L2 requests (the plain kernel re-reads each input ~K*NCOL/NOUT times and is L2-bandwidth-bound on the 5x5 layers).
 // The ring slot of an input row is static: the row loop is unrolled over one ring period (K steps).
-template <int K, int S, int NOUT, bool STATS = false>
+template <int K, int S, int NOUT, bool STATS = false, bool XF = false>
 __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          float* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          float* __restrict__ pool_partial, int H, int W, int C,
                                                          int pad_t, int pad_l, int Ho, int Wo, int act, int cb4,
-                                                         int rows_per_chunk) {
+                                                         int rows_per_chunk, DwInXf xf = DwInXf{nullptr, nullptr, 0}) {
     constexpr int NCOL = (NOUT - 1) * S + K;
     extern __shared__ __attribute__((aligned(16))) float smw[];
     v4f* wl = reinterpret_cast<v4f*>(smw);  // [K*K][cb4]
@@ -295,6 +324,8 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
     v4f sc = {1.f, 1.f, 1.f, 1.f}, sh = {0.f, 0.f, 0.f, 0.f}, psum = {0.f, 0.f, 0.f, 0.f}, psq = {0.f, 0.f, 0.f, 0.f};
     if (scale) sc = *reinterpret_cast<const v4f*>(scale + c);
     if (shift) sh = *reinterpret_cast<const v4f*>(shift + c);
+    v4f isc = {1.f, 1.f, 1.f, 1.f}, ish = {0.f, 0.f, 0.f, 0.f};
+    if (XF) isc = *reinterpret_cast<const v4f*>(xf.scale + c), ish = *reinterpret_cast<const v4f*>(xf.shift + c);
     const float* xb = x + (size_t)b * H * W * C + c;
     float* yb = y + (size_t)b * Ho * Wo * C + c;
     const int ho0 = chunk * rows_per_chunk;
@@ -317,7 +348,10 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
                 const float* xr = xb + (size_t)(row_ok ? hi : 0) * W * C;
                 const float rm = row_ok ? 1.f : 0.f;
 #pragma unroll
-                for (int q = 0; q < NCOL; ++q) dst[q] = *reinterpret_cast<const v4f*>(xr + coff[q]) * (rm * cmask[q]);
+                for (int q = 0; q < NCOL; ++q) {
+                    const v4f raw = *reinterpret_cast<const v4f*>(xr + coff[q]);
+                    dst[q] = (XF ? dw_xf(raw, isc, ish, xf.act) : raw) * (rm * cmask[q]);
+                }
             };
             const int hi_base = ho0 * S - pad_t;  // input row of ring position 0
 #pragma unroll
@@ -388,13 +422,14 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
 // once - and the taps are ds_read_b128 (4x the L1's bytes per clock). Pixel stride is padded by one quad so that the
 // lanes of a read (same channel quad, neighbouring pixels) spread over the banks.
 // Thread = channel quad x (4-column output group, row lane); outputs, pooling partials and chunking as dwconv_se_kernel.
-template <int K, int S, int U, bool STATS = false>
+template <int K, int S, int U, bool STATS = false, bool XF = false>
 __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          float* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          float* __restrict__ pool_partial, int H, int W, int C,
                                                          int pad_t, int pad_l, int Ho, int Wo, int act, int cs4,
-                                                         int rows_per_chunk, int G, int IWA) {
+                                                         int rows_per_chunk, int G, int IWA,
+                                                         DwInXf xf = DwInXf{nullptr, nullptr, 0}) {
     constexpr int NCOL = 3 * S + K;
     extern __shared__ __attribute__((aligned(16))) float sml[];
     const int CSP = cs4 * 4 + 4;                     // padded pixel stride (floats)
@@ -429,20 +464,26 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict
         for (int i0 = p; i0 < n_items; i0 += U * P) {
             v4f v[U];
             int dst[U];
+            unsigned loaded = 0;  // XF: the transform applies to pixels of the image only (the zero padding stays zero)
+            v4f xsc = {1.f, 1.f, 1.f, 1.f}, xsh = {0.f, 0.f, 0.f, 0.f};
+            if (XF) xsc = *reinterpret_cast<const v4f*>(xf.scale + c), xsh = *reinterpret_cast<const v4f*>(xf.shift + c);
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const bool in = i0 + u * P < n_items;
                 const int hi = hi0 + r, wi = col - pad_l;
                 v[u] = (v4f){0.f, 0.f, 0.f, 0.f};
                 dst[u] = in ? (r * IWA + col) * CSP + lc * 4 : -1;
-                if (in && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W)
+                if (in && (unsigned)hi < (unsigned)H && (unsigned)wi < (unsigned)W) {
                     v[u] = *reinterpret_cast<const v4f*>(xb + ((size_t)hi * W + wi) * C);
+                    loaded |= 1u << u;
+                }
                 r += dr, col += dc;
                 if (col >= IWA) col -= IWA, ++r;
             }
 #pragma unroll
             for (int u = 0; u < U; ++u)
-                if (dst[u] >= 0) *reinterpret_cast<v4f*>(tile + dst[u]) = v[u];
+                if (dst[u] >= 0)
+                    *reinterpret_cast<v4f*>(tile + dst[u]) = (XF && ((loaded >> u) & 1u)) ? dw_xf(v[u], xsc, xsh, xf.act) : v[u];
         }
     }
 #pragma unroll
@@ -738,9 +779,13 @@ int dwconv_se_chunks(int Ho) { return cdiv(Ho, dwconv_se_rows_per_chunk(Ho)); }
 
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                      float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
-                     int Wo, int act, hipStream_t s, int stats) {
+                     int Wo, int act, hipStream_t s, int stats, const float* in_scale, const float* in_shift, int in_act) {
     ORBIT_REQUIRE(x && w_khwc && y, "dwconv_se: null pointer");
     ORBIT_REQUIRE(!stats || pool_partial, "dwconv_se: statistics requested without a buffer");
+    ORBIT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dwconv_se: the input transform needs scale and shift");
+    ORBIT_REQUIRE(!in_scale || stats, "dwconv_se: the input transform is instantiated for the statistics form only");
+    const DwInXf xf{in_scale, in_shift, in_act};
+    const bool use_xf = in_scale != nullptr;
     ORBIT_REQUIRE(C % 4 == 0, "dwconv_se: C %% 4 != 0 (C=%d)", C);
     ORBIT_REQUIRE((K == 3 || K == 5) && (stride == 1 || stride == 2), "dwconv_se: K=%d stride=%d not instantiated", K,
                   stride);
@@ -775,7 +820,11 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
                 const bool deep = IHmax * IWA > 8 * (256 / cs4);
 #define ORBIT_DWL(KK, SS)                                                                                              \
     do {                                                                                                               \
-        if (stats)                                                                                                     \
+        if (use_xf)                                                                                                    \
+            dwconv_lds_kernel<KK, SS, 8, true, true><<<gl, 256, ldsb, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, \
+                                                                           C, pad_t, pad_l, Ho, Wo, act, cs4, rpc, G,  \
+                                                                           IWA, xf);                                   \
+        else if (stats)                                                                                                \
             dwconv_lds_kernel<KK, SS, 8, true><<<gl, 256, ldsb, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C,  \
                                                                      pad_t, pad_l, Ho, Wo, act, cs4, rpc, G, IWA);     \
         else if (deep)                                                                                                 \
@@ -804,7 +853,11 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     if (win_opt == 2 || (win_opt == 1 && K == 3 && stride == 1 && Ho >= 14)) {
 #define ORBIT_DWW(KK, SS, NO)                                                                                          \
     do {                                                                                                               \
-        if (stats)                                                                                                     \
+        if (use_xf)                                                                                                    \
+            dwconv_win_kernel<KK, SS, NO, true, true><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, \
+                                                                             W, C, pad_t, pad_l, Ho, Wo, act, cb4, rpc, \
+                                                                             xf);                                      \
+        else if (stats)                                                                                                \
             dwconv_win_kernel<KK, SS, NO, true><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, \
                                                                        pad_t, pad_l, Ho, Wo, act, cb4, rpc);           \
         else                                                                                                           \
@@ -825,7 +878,10 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     if (pipe_opt == 2 || (pipe_opt == 1 && stride == 2 && Ho >= 28)) {
 #define ORBIT_DWP(KK, SS)                                                                                              \
     do {                                                                                                               \
-        if (stats)                                                                                                     \
+        if (use_xf)                                                                                                    \
+            dwconv_pipe_kernel<KK, SS, true, true><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, \
+                                                                          C, pad_t, pad_l, Ho, Wo, act, cb4, rpc, xf); \
+        else if (stats)                                                                                                \
             dwconv_pipe_kernel<KK, SS, true><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C,    \
                                                                     pad_t, pad_l, Ho, Wo, act, cb4, rpc);              \
         else                                                                                                           \
@@ -842,7 +898,10 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     }
 #define ORBIT_DW(KK, SS)                                                                                               \
     do {                                                                                                               \
-        if (stats)                                                                                                     \
+        if (use_xf)                                                                                                    \
+            dwconv_se_kernel<KK, SS, true, true><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, \
+                                                                        pad_t, pad_l, Ho, Wo, act, cb4, rpc, xf);      \
+        else if (stats)                                                                                                \
             dwconv_se_kernel<KK, SS, true><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C,      \
                                                                   pad_t, pad_l, Ho, Wo, act, cb4, rpc);                \
         else                                                                                                           \

@@ -318,10 +318,11 @@ class HipNetwork(nn.Module):
         else:
             feats = out if out is not None else torch.empty(B, self.output_size, device=x.device, dtype=torch.float32)
             tape = torch.empty(lib.orbit_extractor_tape_bytes(plan.handle, B), dtype=torch.uint8, device=x.device)
-            _lib.check(lib.orbit_extractor_train_forward(
+            # no autograd node will ever read this tape (a cache pass under torch.no_grad()): ORBIT_TRAIN_NO_BACKWARD = 1
+            _lib.check(lib.orbit_extractor_train_forward_ex(
                 plan.handle, _lib.dptr(x, torch.float32), B, _lib.dptr(gamma), _lib.dptr(beta), int(bn_train),
                 float(self.bn_momentum), _lib.dptr(feats, torch.float32), ctypes.c_void_p(tape.data_ptr()), tape.numel(),
-                _lib.stream_handle()), "orbit_extractor_train_forward")
+                1, _lib.stream_handle()), "orbit_extractor_train_forward_ex")
         if bn_train:
             self._pull_running_stats(plan)
         return feats

@@ -500,3 +500,39 @@ def test_training_graph_replay_is_bit_identical(device, lib):
         lib.orbit_set_option(b"train_graph", prev)
     # torch's caching allocator returns the tape / gradient buffers at the same addresses in this steady loop
     assert after[0] - before[0] >= 4, (before, after)
+
+
+@pytest.mark.parametrize("B,size", [(6, 96), (3, 224)])
+def test_no_backward_forward_is_bit_identical_to_the_taped_forward(device, B, size):
+    """ORBIT_TRAIN_NO_BACKWARD (the batch-statistics forwards LITE issues under torch.no_grad(): few_shot_recognisers.py:
+    134-146 cache passes): the depthwise convs apply the preceding BatchNorm + SiLU while loading the raw conv output
+    instead of reading a materialised activation. Features AND every running statistic must equal the taped forward's bit
+    for bit (same kernels up to where the activation is applied)."""
+    from orbit_dataset_amd.model.feature_extractors import create_feature_extractor
+    fe, _ = create_feature_extractor("efficientnet_b0", True, False, True)
+    synthetic.init_parameters_(fe)
+    fe = fe.cuda().train()
+    sd0 = {k: v.clone() for k, v in fe.state_dict().items()}
+    x = torch.randn(B, 3, size, size, device=device, generator=torch.Generator(device=device).manual_seed(5))
+    with torch.enable_grad():
+        taped = fe(x).detach().clone()
+    sd_taped = {k: v.clone() for k, v in fe.state_dict().items()}
+    fe.load_state_dict(sd0)
+    with torch.no_grad():
+        plain = fe(x).clone()
+    sd_plain = fe.state_dict()
+    assert torch.isfinite(taped).all() and torch.equal(plain, taped)
+    moved = 0
+    for k in sd_taped:
+        assert torch.equal(sd_plain[k], sd_taped[k]), k
+        moved += int(k.endswith("running_mean") and not torch.equal(sd_taped[k], sd0[k]))
+    assert moved >= 40  # the forwards really ran on batch statistics and updated them
+    from orbit_dataset_amd import _lib
+    lib = _lib.load()
+    lib.orbit_set_option(b"train_dw_xf", 0)
+    try:
+        fe.load_state_dict(sd0)
+        with torch.no_grad():
+            assert torch.equal(fe(x), taped)
+    finally:
+        lib.orbit_set_option(b"train_dw_xf", 1)
