@@ -237,14 +237,16 @@ def head_roofline(device, n_tasks=64, M=200, D=1280, C=5, reps=40):
         u2, b2, g2 = measure(nt, sets)
         larger["%d_tasks" % nt] = {"avg_launch_us": u2, "bytes_per_launch": b2, "achieved_GBps": g2, "frac": g2 / 8000.0}
     traffic, source = None, "none"
-    tpath = os.path.join(ROOT, "profiles", "r02_head_traffic.json")
-    if os.path.exists(tpath):
-        with open(tpath) as f:
+    for tname in sorted((f for f in os.listdir(os.path.join(ROOT, "profiles")) if f.endswith("_head_traffic.json")),
+                        reverse=True):  # the latest round's PMC passes of this kernel
+        with open(os.path.join(ROOT, "profiles", tname)) as f:
             tj = json.load(f)
         if tj.get("kernel_sources_sha16") == kernel_sources_sha16():
-            traffic, source = tj.get("traffic_bytes_per_launch"), "file profiles/r02_head_traffic.json (rocprofv3 --pmc passes)"
+            traffic = tj.get("traffic_bytes_per_launch")
+            source = "file profiles/%s (rocprofv3 --pmc passes)" % tname
         else:
-            source = "refused: profiles/r02_head_traffic.json was measured on other kernel sources"
+            source = "refused: profiles/%s was measured on other kernel sources" % tname
+        break
     return {"kernel": "orbit::proto_predict_stream_kernel<8 waves, 2 rows> (64 tasks x 200 queries x 1280, euclidean, 5-way)",
             "bound": "hbm", "achieved": gbs, "peak": 8000.0, "unit": "GB/s", "frac": gbs / 8000.0, "avg_launch_us": us,
             "bytes_per_launch": nbytes, "traffic": traffic, "traffic_source": source,

@@ -36,6 +36,61 @@ struct BNDev {         // device descriptor for the fold kernel
 
 enum OpKind { OP_CONV, OP_DWCONV, OP_MAXPOOL, OP_AVGPOOL, OP_SE, OP_MBFRONT };
 
+// One weight re-layout of a plan (orbit_extractor_finalize / the dgrad filters of the training runtime). A LITE step repacks
+// every filter after the optimizer moved it: ~80 + 32 launches of ~4 us each per step as separate kernels; all jobs of a
+// plan run as ONE launch (blockIdx.y = job, grid-stride over the job's destination elements).
+struct PackJob {
+    const float* src;
+    float* dst;
+    int kind;  // 0 conv OIHW -> [cout_pad][KT] (vector mode), 1 same in stem mode, 2 depthwise [C][1][K][K] -> [K][K][C],
+               // 3 transpose [rows][cols] -> [cols][rows], 4 dgrad filter (rotated, channels swapped) -> packed
+    int Cin, Cout, KH, KW, cin_pad, KT, cout_pad;
+    unsigned total;
+};
+static __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __restrict__ jobs) {
+    const PackJob j = jobs[blockIdx.y];
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < j.total; i += gridDim.x * 256) {
+        float v = 0.f;
+        if (j.kind == 0 || j.kind == 1) {
+            const int n = (int)(i / (unsigned)j.KT), k = (int)(i % (unsigned)j.KT);
+            const int per = j.kind == 1 ? j.Cin : j.cin_pad;
+            const int tap = k / per, ci = k % per;
+            if (n < j.Cout && tap < j.KH * j.KW && ci < j.Cin)
+                v = j.src[(((size_t)n * j.Cin + ci) * j.KH + tap / j.KW) * j.KW + tap % j.KW];
+        } else if (j.kind == 2) {  // Cin = channels, KH = K
+            const int c = (int)(i % (unsigned)j.Cin), tap = (int)(i / (unsigned)j.Cin);
+            v = j.src[(size_t)c * j.KH * j.KH + tap];
+        } else if (j.kind == 3) {  // Cin = rows, Cout = cols of the source
+            const int r = (int)(i / (unsigned)j.Cout), c = (int)(i % (unsigned)j.Cout);
+            j.dst[(size_t)c * j.Cin + r] = j.src[i];
+            continue;
+        } else {  // dgrad: n = ci (output channel of the dgrad conv), k = (tap', co)
+            const int n = (int)(i / (unsigned)j.KT), k = (int)(i % (unsigned)j.KT);
+            const int tap = k / j.cin_pad, co = k % j.cin_pad;
+            if (n < j.Cin && tap < j.KH * j.KW && co < j.Cout) {
+                const int kh = j.KH - 1 - tap / j.KW, kw = j.KW - 1 - tap % j.KW;
+                v = j.src[(((size_t)co * j.Cin + n) * j.KH + kh) * j.KW + kw];
+            }
+        }
+        j.dst[i] = v;
+    }
+}
+// upload a job list (once: the plan's buffers never move) and run it
+static inline int run_pack_jobs(const std::vector<PackJob>& jobs, PackJob** d_jobs, hipStream_t s) {
+    if (jobs.empty()) return ORBIT_OK;
+    if (*d_jobs == nullptr) {
+        ORBIT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(d_jobs), jobs.size() * sizeof(PackJob)));
+        ORBIT_HIP_CHECK(hipMemcpy(*d_jobs, jobs.data(), jobs.size() * sizeof(PackJob), hipMemcpyHostToDevice));
+    }
+    unsigned most = 0;
+    for (const PackJob& j : jobs) most = std::max(most, j.total);
+    unsigned gx = (most + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    pack_jobs_kernel<<<dim3(gx, (unsigned)jobs.size()), 256, 0, s>>>(*d_jobs);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
 struct Op {
     OpKind kind;
     int in = -1, out = -1, res = -1;  // buffer ids: -1 frames, 0..2 activations, 100 feats, 101 pooled, 102 gate
@@ -107,6 +162,9 @@ struct orbit_extractor {
     std::vector<const float*> h_src;
     size_t* d_dst_meta = nullptr;  // [n][2] = offset, numel
     float* d_packed = nullptr;
+    std::vector<PackJob> pack_jobs;   // filter re-layouts of orbit_extractor_finalize (built at the first call)
+    PackJob* d_pack_jobs = nullptr;
+    int pack_jobs_bk = -1;            // the conv_bk option the job list was built under (it fixes the packed geometry)
     float* d_fold = nullptr;  // static (non-FiLM) scale | shift
     BNDev* d_bn = nullptr;
     std::vector<BNDev> bn_dev;  // host copy of the fold descriptors

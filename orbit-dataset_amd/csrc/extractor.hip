@@ -349,6 +349,7 @@ void orbit_extractor_destroy(orbit_extractor_t* fe) {
     (void)hipFree(fe->d_src);
     (void)hipFree(fe->d_dst_meta);
     (void)hipFree(fe->d_packed);
+    (void)hipFree(fe->d_pack_jobs);
     (void)hipFree(fe->d_fold);
     (void)hipFree(fe->d_bn);
     delete fe;
@@ -436,26 +437,42 @@ int orbit_extractor_finalize(orbit_extractor_t* fe, orbit_stream_t stream) {
         ORBIT_REQUIRE(p.loaded, "extractor_finalize: parameter '%s' was never loaded", p.key.c_str());
     if (int rc = fe->ensure_device()) return rc;
     hipStream_t s = (hipStream_t)stream;
-    for (const Op& o : fe->ops) {
-        if (o.kind == OP_CONV) {
-            int rc = conv_pack_weights(fe->d_pool + fe->params[o.weight].off, fe->d_packed + o.packed_off, o.Cin,
-                                       o.Cout, o.KH, o.KW, o.x_nchw, s);
-            if (rc != ORBIT_OK) return rc;
-        } else if (o.kind == OP_DWCONV) {
-            int rc = dwconv_pack_weights(fe->d_pool + fe->params[o.weight].off, fe->d_packed + o.packed_off, o.Cin,
-                                         o.KH, s);
-            if (rc != ORBIT_OK) return rc;
-        } else if (o.kind == OP_MBFRONT) {
-            int rc = dwconv_pack_weights(fe->d_pool + fe->params[o.weight2].off, fe->d_packed + o.packed_off, o.Cout,
-                                         o.KH, s);
-            if (rc == ORBIT_OK && o.stem)
-                rc = stem_pack_weights(fe->d_pool + fe->params[o.weight].off, fe->d_packed + o.packed_off2, o.Cout, s);
-            if (rc != ORBIT_OK) return rc;
-        } else if (o.kind == OP_SE) {
-            int rc = launch_transpose(fe->d_pool + fe->params[o.se_w2].off, fe->d_packed + o.packed_off, o.Cin, o.R, s);
-            if (rc != ORBIT_OK) return rc;
+    if (fe->pack_jobs_bk != get_option("conv_bk")) {  // (tuning sweeps change the K-tile width, i.e. the packed geometry)
+        fe->pack_jobs.clear();
+        (void)hipFree(fe->d_pack_jobs);
+        fe->d_pack_jobs = nullptr;
+        fe->pack_jobs_bk = get_option("conv_bk");
+    }
+    if (fe->pack_jobs.empty()) {
+        auto job = [&](int kind, const float* src, float* dst, int Cin, int Cout, int KH, int KW, int cin_pad, int KT,
+                       int cout_pad, size_t total) {
+            PackJob j;
+            j.src = src, j.dst = dst, j.kind = kind, j.Cin = Cin, j.Cout = Cout, j.KH = KH, j.KW = KW;
+            j.cin_pad = cin_pad, j.KT = KT, j.cout_pad = cout_pad, j.total = (unsigned)total;
+            fe->pack_jobs.push_back(j);
+        };
+        for (const Op& o : fe->ops) {
+            if (o.kind == OP_CONV) {
+                const ConvPackGeom g = conv_pack_geom(o.Cin, o.Cout, o.KH, o.KW, o.x_nchw);
+                job(o.x_nchw ? 1 : 0, fe->d_pool + fe->params[o.weight].off, fe->d_packed + o.packed_off, o.Cin, o.Cout, o.KH,
+                    o.KW, g.cin_pad, g.kt, g.cout_pad, (size_t)g.cout_pad * g.kt);
+            } else if (o.kind == OP_DWCONV) {
+                job(2, fe->d_pool + fe->params[o.weight].off, fe->d_packed + o.packed_off, o.Cin, 0, o.KH, o.KH, 0, 0, 0,
+                    (size_t)o.Cin * o.KH * o.KH);
+            } else if (o.kind == OP_MBFRONT) {
+                job(2, fe->d_pool + fe->params[o.weight2].off, fe->d_packed + o.packed_off, o.Cout, 0, o.KH, o.KH, 0, 0, 0,
+                    (size_t)o.Cout * o.KH * o.KH);
+            } else if (o.kind == OP_SE) {
+                job(3, fe->d_pool + fe->params[o.se_w2].off, fe->d_packed + o.packed_off, o.Cin, o.R, 0, 0, 0, 0, 0,
+                    (size_t)o.Cin * o.R);
+            }
         }
     }
+    if (int rc = run_pack_jobs(fe->pack_jobs, &fe->d_pack_jobs, s)) return rc;
+    for (const Op& o : fe->ops)  // (the fused stem's [mid][32] filter layout has its own kernel; inference plans only)
+        if (o.kind == OP_MBFRONT && o.stem)
+            if (int rc = stem_pack_weights(fe->d_pool + fe->params[o.weight].off, fe->d_packed + o.packed_off2, o.Cout, s))
+                return rc;
     dim3 grid((unsigned)fe->bns.size(), 2);
     bn_fold_all_kernel<<<grid, 256, 0, s>>>(fe->d_bn, fe->d_pool, nullptr, nullptr, fe->d_fold,
                                             fe->d_fold + fe->fold_floats);

@@ -183,6 +183,8 @@ using namespace orbit;
 // lazily built training-side device state of a plan
 struct orbit_train_state {
     float* d_dgrad = nullptr;  // dgrad-packed filters
+    std::vector<PackJob> jobs;  // their re-layouts, one launch for all layers (PackJob kind 4)
+    PackJob* d_jobs = nullptr;
     std::vector<size_t> dgrad_off;
     size_t dgrad_floats = 0;
     bool packed = false;
@@ -202,6 +204,7 @@ void extractor_train_release(const orbit_extractor* fe) {
     auto it = train_states().find(fe);
     if (it == train_states().end()) return;
     (void)hipFree(it->second.d_dgrad);
+    (void)hipFree(it->second.d_jobs);
     train_states().erase(it);
 }
 }  // namespace orbit
@@ -221,13 +224,19 @@ static int ensure_dgrad_filters(orbit_extractor* fe, orbit_train_state** out, hi
         ORBIT_HIP_CHECK(hipMalloc(reinterpret_cast<void**>(&st.d_dgrad), st.dgrad_floats * sizeof(float)));
     }
     if (!st.packed) {
-        for (size_t i = 0; i < fe->ops.size(); ++i) {
-            const Op& o = fe->ops[i];
-            if (st.dgrad_off[i] == NONE) continue;
-            if (int rc = conv_pack_dgrad_weights(fe->d_pool + fe->params[o.weight].off, st.d_dgrad + st.dgrad_off[i],
-                                                 o.Cin, o.Cout, o.KH, o.KW, s))
-                return rc;
+        if (st.jobs.empty()) {
+            for (size_t i = 0; i < fe->ops.size(); ++i) {
+                const Op& o = fe->ops[i];
+                if (st.dgrad_off[i] == NONE) continue;
+                const ConvPackGeom g = conv_pack_geom(o.Cout, o.Cin, o.KH, o.KW, 0);  // the dgrad conv: Cin' = Cout, Cout' = Cin
+                PackJob j;
+                j.src = fe->d_pool + fe->params[o.weight].off, j.dst = st.d_dgrad + st.dgrad_off[i], j.kind = 4;
+                j.Cin = o.Cin, j.Cout = o.Cout, j.KH = o.KH, j.KW = o.KW, j.cin_pad = g.cin_pad, j.KT = g.kt;
+                j.cout_pad = g.cout_pad, j.total = (unsigned)((size_t)g.cout_pad * g.kt);
+                st.jobs.push_back(j);
+            }
         }
+        if (int rc = run_pack_jobs(st.jobs, &st.d_jobs, s)) return rc;
         st.packed = true;
     }
     *out = &st;

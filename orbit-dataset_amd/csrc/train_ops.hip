@@ -64,18 +64,20 @@ __global__ __launch_bounds__(256) void bn_stats_partial_kernel(const float* __re
     }
 }
 
-// Sum of the [nblk][2][C] partials for 16 channels per block: 16 lanes per channel take every 16th partial (double
-// accumulation, fixed order), then a 16-way LDS reduction. (A one-thread-per-channel loop over ~1000 partials is a
-// 200 us latency chain; this form is ~10 us.)
+// Sum of the [nblk][2][C] partials for BN_FIN_CH channels per block: BN_FIN_LANES lanes per channel take every
+// BN_FIN_LANES-th partial (double accumulation, fixed order), then an LDS reduction in lane order. (A one-thread-per-channel
+// loop over ~1000 partials is a 200 us latency chain; 16 lanes per channel were ~8 us, of which the launch is ~3: these
+// kernels run 200 times per LITE step, so the chain is cut to nblk / 64 dependent round trips with 8 loads in flight.)
+constexpr int BN_FIN_CH = 4, BN_FIN_LANES = 64;
 __device__ __forceinline__ bool reduce_partials(const float* __restrict__ partial, int nblk, int C, double& s0,
                                                 double& s1, int& c_out) {
-    __shared__ double sh[2][16][16];
-    const int cl = threadIdx.x & 15, ln = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cl;
+    __shared__ double sh[2][BN_FIN_LANES][BN_FIN_CH];
+    const int cl = threadIdx.x % BN_FIN_CH, ln = threadIdx.x / BN_FIN_CH;
+    const int c = blockIdx.x * BN_FIN_CH + cl;
     double a0 = 0.0, a1 = 0.0;
     if (c < C) {
 #pragma unroll 4
-        for (int b = ln; b < nblk; b += 16) {
+        for (int b = ln; b < nblk; b += BN_FIN_LANES) {
             a0 += (double)partial[((size_t)b * 2 + 0) * C + c];
             a1 += (double)partial[((size_t)b * 2 + 1) * C + c];
         }
@@ -83,7 +85,7 @@ __device__ __forceinline__ bool reduce_partials(const float* __restrict__ partia
     sh[0][ln][cl] = a0, sh[1][ln][cl] = a1;
     __syncthreads();
     if (ln != 0 || c >= C) return false;
-    for (int j = 1; j < 16; ++j) a0 += sh[0][j][cl], a1 += sh[1][j][cl];
+    for (int j = 1; j < BN_FIN_LANES; ++j) a0 += sh[0][j][cl], a1 += sh[1][j][cl];
     s0 = a0, s1 = a1, c_out = c;
     return true;
 }
@@ -440,7 +442,7 @@ int launch_bn_stats_from_partials(float* partial, int nblk, int M, int C, float 
         ORBIT_LAUNCH_CHECK();
         src = out, nblk = nout;
     }
-    bn_stats_finalize_kernel<<<cdiv(C, 16), 256, 0, s>>>(src, nblk, M, C, eps, momentum, gamma, beta, conv_bias, mean, invstd,
+    bn_stats_finalize_kernel<<<cdiv(C, BN_FIN_CH), 256, 0, s>>>(src, nblk, M, C, eps, momentum, gamma, beta, conv_bias, mean, invstd,
                                                           scale, shift, running_mean, running_var);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
@@ -499,7 +501,7 @@ int launch_bn_backward(const float* dout, const float* out, const float* y, cons
     bn_bwd_partial_kernel<<<dim3(nblk, L.ygroups), 256, 0, s>>>(dout, out, y, mean, invstd, scale, shift, act, M, C,
                                                                 bn_rows_per_block(M, C), L.G, L.R, partial);
     ORBIT_LAUNCH_CHECK();
-    bn_bwd_finalize_kernel<<<cdiv(C, 16), 256, 0, s>>>(partial, nblk, M, C, train, gamma, invstd, dgamma, dbeta, dbias,
+    bn_bwd_finalize_kernel<<<cdiv(C, BN_FIN_CH), 256, 0, s>>>(partial, nblk, M, C, train, gamma, invstd, dgamma, dbeta, dbias,
                                                         coef);
     ORBIT_LAUNCH_CHECK();
     if (dy) {
@@ -524,7 +526,7 @@ int launch_bn_backward_reduced(const float* g, const float* y, const float* mean
         ORBIT_LAUNCH_CHECK();
         src = out, nblk = nout;
     }
-    bn_bwd_finalize_kernel<<<cdiv(C, 16), 256, 0, s>>>(src, nblk, M, C, train, gamma, invstd, dgamma, dbeta, nullptr, coef);
+    bn_bwd_finalize_kernel<<<cdiv(C, BN_FIN_CH), 256, 0, s>>>(src, nblk, M, C, train, gamma, invstd, dgamma, dbeta, nullptr, coef);
     ORBIT_LAUNCH_CHECK();
     if (dy) {
         const size_t total4 = (size_t)M * (C / 4);
