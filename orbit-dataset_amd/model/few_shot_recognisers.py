@@ -267,8 +267,16 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         # tools/overlap_probe.py). Opt-in because the query clips must then be READY when predict() is called: clips that
         # an earlier, still pending operation on the caller's stream produces after personalise() would be read too early
         # (host-resident clips are always safe: their upload is issued on the second stream).
+        # overlap_query = 2 ("pipelined") additionally runs the HEAD on the second stream and does NOT join it back: the
+        # caller's stream is free to start the next task's personalise() while this task's query pass is still running, so
+        # consecutive tasks overlap out of phase (one stream in its HBM-bound early layers while the other is in its small
+        # late layers) instead of both passes of a task marching through the same layers together. The returned logits are
+        # then produced on the second stream: `logits_ready` (an event) must be waited for - or the device synchronised -
+        # before another stream reads them.
         self.overlap_query = False
         self._film_ready = None
+        self._configured = None
+        self.logits_ready = None
 
     def refresh_initial_film_parameters(self):
         """Re-take the generator's snapshot of the FiLM layers' BatchNorm weights / biases from the extractor's current
@@ -286,6 +294,7 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         self.film_dict = None
         self._generated_film_dict = None
         self._film_ready = None
+        self._configured = None
         self.classifier.reset()
 
     def _clear_caches(self):
@@ -313,6 +322,9 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         context_features = self._get_features_in_batches(context_clips, self.film_dict, ops_counter)
         context_features = self._pool_features(context_features, ops_counter)
         self.classifier.configure(context_features, context_labels, ops_counter, class_ids=class_ids)
+        if self.overlap_query == 2:
+            self._configured = torch.cuda.Event()
+            self._configured.record(torch.cuda.current_stream(self.device))
 
     def personalise_with_lite(self, context_clips, context_labels):
         """LITE forward (reference :328-343): a random subset of `num_lite_samples` clips is re-encoded on
@@ -421,6 +433,21 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
                 side.wait_event(self._film_ready)  # FiLM vectors + uploaded parameters: all the query pass needs
             else:  # personalised through another route (sharded / LITE): order after everything queued so far
                 side.wait_stream(main)
+            if self.overlap_query == 2 and self._configured is not None:
+                # pipelined: extractor, pooling AND head on the second stream; no join (see __init__)
+                with torch.cuda.stream(side):
+                    target_features = self._get_features_in_batches(target_clips, self.film_dict)
+                    side.wait_event(self._configured)  # the head needs this task's class weights
+                    logits = self.classifier.predict(self._pool_features(target_features))
+                    self.logits_ready = torch.cuda.Event()
+                    self.logits_ready.record(side)
+                # the class weights are dropped (and their memory handed back to the caller's stream) by _reset(): keep
+                # them alive for the kernels queued on the second stream
+                for t in (getattr(self.classifier, "weight", None), getattr(self.classifier, "bias", None)):
+                    if isinstance(t, torch.Tensor) and t.is_cuda:
+                        t.record_stream(side)
+                logits.record_stream(main)
+                return logits
             with torch.cuda.stream(side):
                 target_features = self._get_features_in_batches(target_clips, self.film_dict)
             main.wait_stream(side)

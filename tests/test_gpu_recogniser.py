@@ -303,3 +303,33 @@ def test_edge_empty_query_and_ragged_batches(device):
     one = synthetic.make_task(13, way=1, shots=1, frames_per_shot=3, num_query=4, frame_size=64)
     model.personalise(one["context_clips"].cuda(), one["context_labels"].cuda())
     assert tuple(model.predict(one["target_clips"].cuda()).shape) == (4, 1)
+
+
+def test_pipelined_overlap_is_bit_identical_over_consecutive_tasks(device):
+    """overlap_query = 2: extractor + head of predict() on the second stream, not joined, so the next task's personalise()
+    starts while this task's query pass runs. Same kernels on the same inputs: bit-identical logits for every task of a
+    back-to-back sequence (class weights of task i must survive _reset() until the second stream has used them)."""
+    model = SingleStepFewShotRecogniser("resnet18", False, "proto", 1, 16, False, 16, 1.0)
+    synthetic.init_parameters_(model)
+    model._set_device(device)
+    model._send_to_device()
+    model.set_test_mode(True)
+    tasks = [synthetic.make_task_on_device(50 + i, 5, 1, 6, 40, 64, 1, device) for i in range(6)]
+
+    def run(mode):
+        model.overlap_query = mode
+        outs = []
+        with torch.no_grad():
+            for _ in range(2):
+                for t in tasks:
+                    model.personalise(t["context_clips"], t["context_labels"])
+                    outs.append(model.predict(t["target_clips"]))
+                    model._reset()
+        torch.cuda.synchronize()
+        model.overlap_query = False
+        return [o.clone() for o in outs]
+
+    base, piped = run(False), run(2)
+    assert len(piped) == 12 and model.logits_ready is not None
+    for a, b in zip(base, piped):
+        assert torch.equal(a, b)
