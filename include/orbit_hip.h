@@ -229,6 +229,18 @@ int orbit_op_conv2d(const float* x, int x_nchw, const float* w, float* y,
 int orbit_op_dwconv2d(const float* x, const float* w, float* y, const float* scale, const float* shift,
                       int B, int H, int W, int C, int K, int stride, int pad_top, int pad_left,
                       int Ho, int Wo, int act, orbit_stream_t stream);
+/* Training forms of the two ops (single-operator entries of the parity tests, like the ones above): the convolution without
+ * epilogue whose kernel also emits the train-mode BatchNorm statistics of its output (per-channel sums and sums of squares,
+ * stats [2][Cout]; *stat_blocks = row blocks written, 0 when this launch shape does not emit them), optionally with the
+ * squeeze-excite gate multiplied into x; and the depthwise convolution that applies the PRECEDING layer's BatchNorm +
+ * activation to x as it loads it (in_scale / in_shift nullable) and emits the statistics of its own output. Reference: the
+ * nn.Conv2d -> nn.BatchNorm2d (train()) pairs of the extractor under model/few_shot_recognisers.py:176-183. */
+int orbit_op_conv2d_train(const float* x, int x_nchw, const float* w, float* y, const float* gate, int B, int H, int W,
+                          int Cin, int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                          float* stats, int* stat_blocks, orbit_stream_t stream);
+int orbit_op_dwconv2d_train(const float* x, const float* w, float* y, const float* in_scale, const float* in_shift,
+                            int in_act, int B, int H, int W, int C, int K, int stride, int pad_top, int pad_left, int Ho,
+                            int Wo, float* stats, orbit_stream_t stream);
 /* max-pool NHWC, -inf padding */
 int orbit_op_maxpool2d(const float* x, float* y, int B, int H, int W, int C, int K, int stride, int pad,
                        int Ho, int Wo, orbit_stream_t stream);

@@ -52,6 +52,8 @@ _SIGNATURES = {
     "orbit_filmgen_forward": (c_int, [P, P, P, P, P, P]),
     "orbit_op_conv2d": (c_int, [P, c_int, P, P, P, P, P, P] + [c_int] * 14 + [P]),
     "orbit_op_dwconv2d": (c_int, [P, P, P, P, P] + [c_int] * 11 + [P]),
+    "orbit_op_conv2d_train": (c_int, [P, c_int, P, P, P] + [c_int] * 12 + [P, POINTER(c_int), P]),
+    "orbit_op_dwconv2d_train": (c_int, [P, P, P, P, P] + [c_int] * 11 + [P, P]),
     "orbit_op_maxpool2d": (c_int, [P, P] + [c_int] * 9 + [P]),
     "orbit_op_avgpool": (c_int, [P, P, c_int, c_int, c_int, P]),
     "orbit_op_se_gate": (c_int, [P, P, P, P, P, P, c_int, c_int, c_int, P]),

@@ -178,6 +178,7 @@ int launch_bn_stats(const float* y, int M, int C, float eps, float momentum, con
 // the same from [nblk][2][C] partials a producing kernel wrote (ConvDesc::stats, launch_dwconv_se(..., stats)); `partial` is
 // bn_partial_floats(nblk, C) floats (room for the compaction stage of very long partial lists)
 size_t bn_partial_floats(size_t nblk, int C);
+int launch_sum_partials(const float* partial, int nblk, int C, float* stats /* [2][C] */, hipStream_t s);
 int launch_bn_stats_from_partials(float* partial, int nblk, int M, int C, float eps, float momentum, const float* gamma,
                                   const float* beta, const float* conv_bias, float* mean, float* invstd, float* scale,
                                   float* shift, float* running_mean, float* running_var, hipStream_t s);

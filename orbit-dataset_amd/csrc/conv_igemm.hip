@@ -903,6 +903,34 @@ int orbit_prof_variant(int i, char* name48, long* launches, double* ms, double* 
     return ORBIT_OK;
 }
 
+/* Training form (single-operator entry for the parity tests): y = conv(x * gate) without epilogue, plus the per-channel sums
+ * and sums of squares of y that the epilogue emits per row block, reduced to stats [2][Cout]; *stat_blocks receives the
+ * number of row blocks the kernel wrote (0: this shape does not emit them - fused pooling, split-K, narrow-pointwise). */
+int orbit_op_conv2d_train(const float* x, int x_nchw, const float* w, float* y, const float* gate, int B, int H, int W,
+                          int Cin, int Cout, int KH, int KW, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                          float* stats, int* stat_blocks, orbit_stream_t stream) {
+    ORBIT_REQUIRE(x && w && y && stats && stat_blocks, "op_conv2d_train: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t nfl = conv_packed_floats(Cin, Cout, KH, KW, x_nchw);
+    const size_t M = (size_t)B * Ho * Wo;
+    const size_t pfl = bn_partial_floats((M + 31) / 32, Cout);
+    float* tmp = nullptr;
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), (nfl + pfl + 64) * sizeof(float), s));
+    float* part = tmp + ((nfl + 63) & ~(size_t)63);
+    int rc = conv_pack_weights(w, tmp, Cin, Cout, KH, KW, x_nchw, s);
+    if (rc == ORBIT_OK) {
+        ConvDesc d;
+        d.x = x, d.w_packed = tmp, d.y = y, d.scale = d.shift = d.residual = nullptr, d.gate = gate;
+        d.B = B, d.H = H, d.W = W, d.Cin = Cin, d.Cout = Cout, d.KH = KH, d.KW = KW, d.stride = stride;
+        d.pad_t = pad_top, d.pad_l = pad_left, d.Ho = Ho, d.Wo = Wo, d.act = ORBIT_ACT_NONE, d.pool2 = 0, d.x_nchw = x_nchw;
+        d.stats = part, d.stats_blocks = stat_blocks;
+        rc = launch_conv(d, s);
+        if (rc == ORBIT_OK && *stat_blocks > 0) rc = launch_sum_partials(part, *stat_blocks, Cout, stats, s);
+    }
+    (void)hipFreeAsync(tmp, s);
+    return rc;
+}
+
 int orbit_op_conv2d(const float* x, int x_nchw, const float* w, float* y, const float* scale,
                                const float* shift, const float* residual, const float* gate, int B, int H,
                                int W, int Cin, int Cout, int KH, int KW, int stride, int pad_top,

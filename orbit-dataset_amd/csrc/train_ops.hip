@@ -448,6 +448,21 @@ int launch_bn_stats_from_partials(float* partial, int nblk, int M, int C, float 
     return ORBIT_OK;
 }
 
+// stats[0][c] = sum_b partial[b][0][c], stats[1][c] = sum_b partial[b][1][c] (double accumulation): the raw sums behind a
+// train-mode BatchNorm, for the single-operator test entries
+__global__ __launch_bounds__(256) void sum_partials_kernel(const float* __restrict__ partial, int nblk, int C,
+                                                           float* __restrict__ stats) {
+    double s, ss;
+    int c;
+    if (!reduce_partials(partial, nblk, C, s, ss, c)) return;
+    stats[c] = (float)s, stats[C + c] = (float)ss;
+}
+int launch_sum_partials(const float* partial, int nblk, int C, float* stats, hipStream_t s) {
+    sum_partials_kernel<<<cdiv(C, BN_FIN_CH), 256, 0, s>>>(partial, nblk, C, stats);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
 int launch_bn_stats(const float* y, int M, int C, float eps, float momentum, const float* gamma, const float* beta,
                     const float* conv_bias, float* mean, float* invstd, float* scale, float* shift, float* running_mean,
                     float* running_var, float* partial, hipStream_t s) {

@@ -325,3 +325,107 @@ def test_se_gate_backward(device, B, HW, C, R):
     assert rel_err(dx.cpu(), x.grad) < 2e-5
     for got, ref in zip(outs, (w1, b1, w2, b2)):
         assert rel_err(got.cpu(), ref.grad) < 5e-5
+
+
+# ---- round 3: train-mode BatchNorm statistics from the producing kernels, activation applied on load --------------------
+CONV_TRAIN_CASES = [
+    # B, H, W, Cin, Cout, K, stride, pad, nchw, gate
+    (3, 14, 14, 80, 480, 1, 1, 0, 0, False),     # efficientnet expand: 64x64 tiles, BK 16
+    (2, 14, 14, 480, 80, 1, 1, 0, 0, True),      # gated projection: 128x32 tiles, Cout not a multiple of 32
+    (2, 14, 14, 672, 112, 1, 1, 0, 0, True),
+    (3, 9, 11, 24, 144, 1, 1, 0, 0, False),      # M = 297 rows: ragged last row block, BK 8
+    (2, 7, 7, 1152, 320, 1, 1, 0, 0, True),
+    (1, 56, 56, 16, 96, 1, 1, 0, 0, False),      # 3136 rows
+    (2, 20, 20, 64, 64, 3, 1, 1, 0, False),      # resnet18 3x3
+    (2, 21, 21, 64, 128, 3, 2, 1, 0, False),
+    (2, 64, 64, 3, 32, 3, 2, 0, 1, False),       # NCHW stem gather
+]
+
+
+@pytest.mark.parametrize("case", CONV_TRAIN_CASES, ids=lambda c: "x".join(str(int(v)) for v in c))
+def test_conv_emits_batchnorm_statistics(device, case):
+    """conv_igemm's epilogue (ConvDesc::stats): per-channel sums / sums of squares of the RAW outputs, one partial per row
+    block, equal to the sums of the tensor it wrote; the gate variant multiplies x * gate[b][ci] on the fly."""
+    import ctypes
+    lib = _lib.load()
+    B, H, W, Cin, Cout, K, stride, pad, nchw_in, gated = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    gate = torch.rand(B, Cin, generator=g) if gated else None
+    if nchw_in:  # TF-SAME stem: output ceil(H / 2), padding on the bottom / right
+        Ho = -(-H // stride)
+        tot = max((Ho - 1) * stride + K - H, 0)
+        xin = F.pad(x, [0, tot, 0, tot])
+        pt = 0
+    else:
+        Ho = (H + 2 * pad - K) // stride + 1
+        xin = F.pad(x, [pad] * 4)
+        pt = pad
+    Wo = Ho if H == W else (W + 2 * pad - K) // stride + 1
+    xg = xin * gate[:, :, None, None] if gated else xin
+    want = F.conv2d(xg.double(), w.double(), None, stride)
+    assert want.shape[2:] == (Ho, Wo)
+    xd = x.contiguous().to(device) if nchw_in else nhwc(x).to(device)
+    y = torch.full((B, Ho, Wo, Cout), float("nan"), device=device)
+    stats = torch.full((2, Cout), float("nan"), device=device)
+    nblk = ctypes.c_int(-1)
+    wd, gd = w.to(device), (gate.to(device) if gated else None)  # named: a temporary would be freed (and its block re-used
+    #                                                              by the next upload) before the launch reads it
+    _lib.check(lib.orbit_op_conv2d_train(_lib.dptr(xd), nchw_in, _lib.dptr(wd), _lib.dptr(y),
+                                         _lib.dptr(gd) if gated else None, B, H, W, Cin, Cout, K, K, stride, pt,
+                                         pt, Ho, Wo, _lib.dptr(stats), ctypes.byref(nblk), _st()), "conv2d_train")
+    torch.cuda.synchronize()
+    assert rel_err(nchw(y.cpu()), want) < 2e-5
+    assert nblk.value >= -(-B * Ho * Wo // 128), nblk.value  # one partial per 32..128-row block
+    s = want.sum(dim=(0, 2, 3)), (want * want).sum(dim=(0, 2, 3))
+    assert rel_err(stats[0].cpu(), s[0]) < 1e-5 * max(1.0, float(s[0].abs().max() and want.abs().sum() / s[0].abs().max()))
+    assert rel_err(stats[1].cpu(), s[1]) < 2e-5
+    # and exactly the sums of what the kernel wrote (fp32, double accumulation of the partials)
+    yc = y.cpu().double().reshape(-1, Cout)
+    assert rel_err(stats[1].cpu(), (yc * yc).sum(0)) < 2e-6
+
+
+@pytest.mark.parametrize("C,K,stride,HW", [(32, 3, 1, 28), (96, 3, 2, 28), (144, 5, 2, 28), (480, 5, 1, 14),
+                                           (672, 5, 2, 14), (1152, 3, 1, 7), (240, 3, 2, 15)])
+@pytest.mark.parametrize("window,patch,pipe", [(0, 0, 0), (2, 0, 0), (1, 2, 0), (0, 0, 2)])
+@pytest.mark.parametrize("in_act", [None, 2, 1])
+def test_dwconv_train_form(device, C, K, stride, HW, window, patch, pipe, in_act):
+    """The four depthwise kernels in their training form: statistics of the raw output (STATS) and, with in_act, the
+    preceding BatchNorm + activation applied while loading the raw conv output (XF) - the zero padding of the ACTIVATED
+    tensor must stay zero."""
+    lib = _lib.load()
+    lib.orbit_set_option(b"dw_window", window)
+    lib.orbit_set_option(b"dw_lds", patch)
+    lib.orbit_set_option(b"dw_pipe", pipe)
+    try:
+        g = torch.Generator().manual_seed(C + K + stride)
+        B = 3
+        x = torch.randn(B, C, HW, HW, generator=g) * 1.5
+        w = torch.randn(C, 1, K, K, generator=g) / K
+        Ho = -(-HW // stride)
+        total = max((Ho - 1) * stride + K - HW, 0)
+        pt = total // 2
+        sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3 + 0.2
+        a = x.double()
+        if in_act is not None:
+            a = a * sc.double()[None, :, None, None] + sh.double()[None, :, None, None]
+            a = F.silu(a) if in_act == 2 else F.relu(a)
+        want = F.conv2d(F.pad(a, [pt, total - pt, pt, total - pt]), w.double(), None, stride, 0, 1, C)
+        y = torch.full((B, Ho, Ho, C), float("nan"), device=device)
+        stats = torch.full((2, C), float("nan"), device=device)
+        xd, wd, scd, shd = nhwc(x).to(device), w.to(device), sc.to(device), sh.to(device)  # named: kept alive for the launch
+        _lib.check(lib.orbit_op_dwconv2d_train(_lib.dptr(xd), _lib.dptr(wd), _lib.dptr(y),
+                                               _lib.dptr(scd) if in_act is not None else None,
+                                               _lib.dptr(shd) if in_act is not None else None,
+                                               in_act or 0, B, HW, HW, C, K, stride, pt, pt, Ho, Ho, _lib.dptr(stats), _st()),
+                   "dwconv2d_train")
+        torch.cuda.synchronize()
+    finally:
+        lib.orbit_set_option(b"dw_window", 1)
+        lib.orbit_set_option(b"dw_lds", 1)
+        lib.orbit_set_option(b"dw_pipe", 1)
+    assert rel_err(nchw(y.cpu()), want) < 2e-5
+    yc = y.cpu().double().reshape(-1, C)
+    assert rel_err(stats[0].cpu(), yc.sum(0)) < 2e-6 * max(1.0, float(yc.abs().sum(0).max() / yc.sum(0).abs().max()))
+    assert rel_err(stats[1].cpu(), (yc * yc).sum(0)) < 2e-6
