@@ -17,6 +17,10 @@ for W in efficientnet_b0_224 resnet18_84 resnet18_224; do
       python $R/bench.py --workload $W --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_$W.json 2> $O/${TAG}_bench_$W.err
   cp $(ls $O/stats_$W/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_$W.csv
 done
+# the LITE meta-training step (forward + backward + optimizer) of the headline extractor
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_lite -- \
+    python $R/bench.py --mode lite_train --steps 10 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_lite_train_profiled.json 2> $O/${TAG}_bench_lite.err
+cp $(ls $O/stats_lite/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_lite_train_efficientnet_b0_224.csv
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$C -- \
       python $R/bench.py --workload efficientnet_b0_224 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/${TAG}_pmc_$C.err
