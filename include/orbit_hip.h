@@ -112,6 +112,8 @@ int orbit_device_count(void);
  *                   kernels with rotated taps; 0 = the gather kernel
  *   "train_dw_xf"   1 (default) = ORBIT_TRAIN_NO_BACKWARD forwards skip the activation pass between an expand / stem conv and
  *                   its depthwise conv (applied on load instead); 0 = always the separate pass
+ *   "train_dual_write"  1 (default) = under running-statistics BatchNorm (frozen extractor) a taped conv writes its raw output
+ *                   AND the activation from one epilogue; 0 = raw output + a separate activation pass
  *   "dw_dgrad_s2"   1 (default) = the input gradient of a stride-2 depthwise conv as the 2x2-block kernel; 0 = the gather kernel
  *   "se_bn_fuse"    1 (default) = the last pass of the squeeze-excite backward also carries the reduction pass of the
  *                   depthwise BatchNorm's backward (csrc/train_mbconv.hip gate_bwd_apply_bn_kernel); 0 = separate passes */

@@ -80,6 +80,10 @@ struct ConvDesc {
     // launch_bn_stats' own pass.
     float* stats = nullptr;
     int* stats_blocks = nullptr;
+    // dual write (training tape under running-statistics BatchNorm, where scale / shift are known before the conv runs):
+    // the raw conv output goes to y_raw and y receives act(raw * scale + shift + residual) - the activation pass over the
+    // tensor (read y, write a) disappears. Not with fused pooling, split-K or the narrow-pointwise kernel.
+    float* y_raw = nullptr;
 };
 inline size_t conv_stats_floats(size_t M, int Cout) { return ((M + 31) / 32) * 2 * (size_t)Cout; }  // smallest tile: 32 rows
 // split-K (small output, long reduction): number of K splits launch_conv uses for this conv when scratch is provided

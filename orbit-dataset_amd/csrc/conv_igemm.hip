@@ -66,6 +66,8 @@ struct ConvParams {
     int ksplit, kt_per_split;  // split-K: blockIdx = split * tiles + tile; raw partial tiles go to part[split][M][Cout]
     float* part;
     float* stats;              // [m_tiles][2][Cout] column sums / sums of squares of the raw outputs (train-mode BatchNorm) or null
+    float* y_raw;              // dual write (training tape under running-statistics BatchNorm): the RAW conv output goes
+                               // here, y receives act(raw * scale + shift + residual); null = single output
 };
 
 __device__ __forceinline__ float apply_act(float v, int act) {
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn + j * 32 + l31;
-            const bool use = n < p.Cout && p.ksplit <= 1;
+            const bool use = n < p.Cout && p.ksplit <= 1 && p.y_raw == nullptr;  // dual write: the tile is staged raw
             sc_pre[j] = (use && p.scale) ? p.scale[n] : 1.0f;
             sh_pre[j] = (use && p.shift && wk == 0) ? p.shift[n] : 0.0f;
         }
@@ -438,7 +440,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     for (int j = 0; j < TN; ++j) {
         const int n = n0 + wn + j * 32 + l31;
         const bool n_ok = n < p.Cout;
-        const bool raw = p.ksplit > 1;  // split-K partial: plain sums, the reduce kernel applies the epilogue
+        const bool raw = p.ksplit > 1 || p.y_raw != nullptr;  // split-K partial: plain sums, the reduce kernel applies the
+                                                              // epilogue; dual write: scale / shift enter in the output pass
         float sc, sh;
         if (p.early_sc) {
             sc = sc_pre[j], sh = sh_pre[j];
@@ -481,6 +484,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
             // (row by row, every row paid an LDS - and with a skip connection an L2 - round trip of its own)
             f32x4 v[ITER], res[ITER];
             const bool has_res = !POOL2 && p.ksplit <= 1 && p.residual != nullptr;
+            const bool dual = p.y_raw != nullptr;  // (launcher: never with pooling or split-K)
+            f32x4 dsc = {1.f, 1.f, 1.f, 1.f}, dsh = {0.f, 0.f, 0.f, 0.f};
+            if (dual && p.scale) dsc = *reinterpret_cast<const f32x4*>(p.scale + n), dsh = *reinterpret_cast<const f32x4*>(p.shift + n);
 #pragma unroll
             for (int it = 0; it < ITER; ++it) {
                 const int r = tid / TPO + it * RPO;
@@ -498,6 +504,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                 if (r < OROWS && mo0 + r < mout) {
                     f32x4 o = v[it];
                     st_s += o, st_q += o * o;
+                    if (dual) {
+                        *reinterpret_cast<f32x4*>(p.y_raw + (size_t)(mo0 + r) * p.Cout + n) = o;
+                        o = o * dsc + dsh;
+                    }
                     if (!POOL2 && p.ksplit <= 1) {
                         o += res[it];
                         o[0] = apply_act(o[0], p.act), o[1] = apply_act(o[1], p.act);
@@ -515,6 +525,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
 #pragma unroll
                 for (int q = 1; q < WGK; ++q) v += *reinterpret_cast<const f32x4*>(smem + (q * OROWS + r) * CS + oc);
                 st_s += v, st_q += v * v;
+                if (p.y_raw != nullptr) {
+                    *reinterpret_cast<f32x4*>(p.y_raw + (size_t)m * p.Cout + n) = v;
+                    if (p.scale) v = v * *reinterpret_cast<const f32x4*>(p.scale + n) + *reinterpret_cast<const f32x4*>(p.shift + n);
+                }
                 if (!POOL2 && p.ksplit <= 1) {
                     if (p.residual) v += *reinterpret_cast<const f32x4*>(p.residual + (size_t)m * p.Cout + n);
                     v[0] = apply_act(v[0], p.act), v[1] = apply_act(v[1], p.act);
@@ -805,7 +819,7 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     ORBIT_REQUIRE(d.Cout % 4 == 0, "conv: Cout %% 4 != 0 (Cout=%d): the epilogue writes float4 rows", d.Cout);
     const bool pw = !d.x_nchw && d.KH == 1 && d.KW == 1 && d.pad_t == 0 && d.pad_l == 0;
     if (d.stats_blocks) *d.stats_blocks = 0;
-    if (pw && pw_narrow_supported(d)) return launch_pw_narrow(d, s);
+    if (pw && !d.y_raw && pw_narrow_supported(d)) return launch_pw_narrow(d, s);
     ORBIT_REQUIRE(!d.gate || (!d.x_nchw && !d.pool2), "conv: the squeeze-excite gate needs the NHWC path without fused pooling");
     const ConvPackGeom g = conv_pack_geom(d.Cin, d.Cout, d.KH, d.KW, d.x_nchw);
     ConvParams p;
@@ -836,6 +850,9 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     // statistics of the raw outputs for a train-mode BatchNorm: whole-tile launches only (a split-K partial is not the output,
     // the fused max-pool stores pooled rows)
     p.stats = (d.stats && d.stats_blocks && p.ksplit <= 1 && !d.pool2) ? d.stats : nullptr;
+    ORBIT_REQUIRE(!d.y_raw || (!d.pool2 && p.ksplit <= 1 && (d.scale == nullptr) == (d.shift == nullptr)),
+                  "conv: the dual (raw + activated) output needs the whole-tile epilogue without fused pooling");
+    p.y_raw = d.y_raw;
     int rc;
     if (d.x_nchw) rc = d.pool2 ? launch_bk<1, true, false, false>(p, bk, s) : launch_bk<1, false, false, false>(p, bk, s);
     else if (pw && !d.pool2) rc = d.gate ? launch_bk<0, false, true, true>(p, bk, s) : launch_bk<0, false, false, true>(p, bk, s);

@@ -351,8 +351,22 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
             d.B = B, d.H = o.H, d.W = o.W, d.Cin = o.Cin, d.Cout = o.Cout, d.KH = o.KH, d.KW = o.KW;
             d.stride = o.stride, d.pad_t = o.pad_t, d.pad_l = o.pad_l, d.Ho = o.Ho, d.Wo = o.Wo;
             d.act = ORBIT_ACT_NONE, d.pool2 = 0, d.x_nchw = o.x_nchw;
+            // running-statistics BatchNorm (frozen extractor: CNAPs meta-training, FiLM fine-tuning): scale / shift are known
+            // before the conv runs, so its epilogue writes BOTH the raw output (tape: xhat and the SiLU derivative need it)
+            // and the activation - no separate activation pass over the tensor
+            const bool dual = !bn_train && !o.pool2 && get_option("train_dual_write");
+            if (dual) {
+                d.y_raw = fl(L.y[i]), d.y = fl(L.a[i]);
+                d.scale = scale + bn.fold_off, d.shift = shift + bn.fold_off;
+                d.residual = o.res >= 0 ? cur[o.res] : nullptr;
+                d.act = o.act;
+            }
             rc = launch_conv(d, s);
             if (rc != ORBIT_OK) return rc;
+            if (dual) {
+                cur[o.out] = fl(L.a[i]);
+                continue;
+            }
             const int M = B * o.Ho * o.Wo;
             if (bn_train) {
                 const bool fm = film && bn.film_off >= 0;

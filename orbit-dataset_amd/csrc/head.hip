@@ -43,6 +43,7 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"dw_dgrad_forward", "ORBIT_DW_DGRAD_FORWARD", 1, false},
                              {"dw_dgrad_s2", "ORBIT_DW_DGRAD_S2", 1, false},
                              {"train_dw_xf", "ORBIT_TRAIN_DW_XF", 1, false},
+                             {"train_dual_write", "ORBIT_TRAIN_DUAL_WRITE", 1, false},
                              {"graph", "ORBIT_GRAPH", 2, false},
                              {"train_graph", "ORBIT_TRAIN_GRAPH", 0, false},
                              {"se_bn_fuse", "ORBIT_SE_BN_FUSE", 1, false},
