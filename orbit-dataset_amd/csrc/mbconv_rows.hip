@@ -54,6 +54,7 @@ struct MbRowsParams {
     float* pool;       // [B][tiles][mid] or nullptr
     int H, W, Cin, mid, pad_t, pad_l, Ho, Wo;
     int SWo, SWi, strips, band_rows, bands, nchunk, total;
+    int dbg;
 };
 
 constexpr int ROWS_ES = 36;  // ring pixel stride (floats): 32 channels + 4 (conflict-free ds_read_b128 across pixels)
@@ -280,9 +281,9 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows_kernel(const 
     expand(1);
     __syncthreads();
     for (int i = 0; i < NI; ++i) {
-        if (i + 2 <= NI) expand(i + 2);
-        depthwise(i);
-        __syncthreads();
+        if (i + 2 <= NI && !(p.dbg & 1)) expand(i + 2);
+        if (!(p.dbg & 2)) depthwise(i);
+        if (!(p.dbg & 4)) __syncthreads();
     }
 
     // ---- pooling partial of this (frame, tile, chunk): the 32 slots summed in slot order (deterministic)
@@ -294,6 +295,273 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows_kernel(const 
             v4f t4 = red[tid];
             for (int sl = 1; sl < 32; ++sl) t4 += red[sl * 8 + tid];
             *reinterpret_cast<v4f*>(p.pool + ((size_t)b * tiles + tile) * p.mid + cq) = t4;
+        }
+    }
+}
+
+// ---- 3x3 form, rebuilt on two measurements (tools/coexec_probe.hip, tools/valu_probe.hip; profiles/r03_coexec_probe.txt):
+//  (1) on gfx950 a SIMD runs EITHER an MFMA OR VALU instructions, never both: a VALU stream under another wave's (or its
+//      own) v_mfma_f32_32x32x2_f32 chain takes exactly MFMA time + VALU time, for fp32 and bf16 MFMAs alike. A fused kernel's
+//      SIMD time is the SUM of its matrix and vector instruction time; specialising waves (expand waves / depthwise waves,
+//      four per SIMD) was built and measured: 194 us against 195 us for block 1.1, i.e. nothing.
+//  (2) the symmetric kernel above spends 137 us of SIMD time per 200 frames of block 1.1 (MFMA 37 + VALU 100) for a 195 us
+//      launch, and a third of that VALU time is not arithmetic: the masked expand epilogue (every 32-pixel tile of a 58-pixel
+//      ring row holds a pad column, so the six-instruction-per-element select path always ran), per-item address arithmetic
+//      with 32-bit integer multiplies (quarter rate) and a division by the group count, and ds_read_b128 bank conflicts
+//      (0.54 conflict cycles per active cycle: with the 36-float pixel stride two of the four slots of a 16-lane service
+//      group land on the same banks).
+// This form keeps the walk, the MFMA k-order and every float operation of the kernel above (y is bit-identical; the pooling
+// partials sum the same values in a different slot order) and changes the bookkeeping: validity is one bit-field extract +
+// AND per expanded element; an item's ring addresses are `scalar window base + per-lane constant` (the item pattern of a
+// step never changes); the output address is `scalar row pointer + per-lane constant`; and the lane -> (slot, channel quad)
+// map puts slots u and u + 4 (288 floats = 32 banks apart) with both channel halves into each ds_read_b128 service group,
+// which makes the reads conflict-free at the same 36-float stride.
+template <int S, int TO, int NOUT, int NG, int SPR, bool EXACT>
+__global__ __launch_bounds__(256, 3) void mbconv_rows3_kernel(const MbRowsParams p) {
+    constexpr int K = 3;
+    constexpr int NEW = TO * S;
+    constexpr int NCOL = (NOUT - 1) * S + K;
+    constexpr int ES = ROWS_ES;
+    static_assert((TO - 1) * S + K <= 2 * NEW, "an output step reads two windows");
+    static_assert(NEW <= 4, "row-in-window index is packed in 2 bits");
+
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int n_new = NEW * p.SWi;
+    float* ring = smem;  // [3][n_new][ES]
+
+    const int per = gridDim.x >> 3;
+    const int v = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (v >= p.total) return;
+    const int chunk = v % p.nchunk;
+    const int t = v / p.nchunk;
+    const int tiles = p.strips * p.bands;
+    const int tile = t % tiles, b = t / tiles;
+    const int strip = tile % p.strips, band = tile / p.strips;
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int c0 = chunk * 32;
+    const int x0 = strip * p.SWo, y0 = band * p.band_rows;
+    const int y1 = y0 + p.band_rows < p.Ho ? y0 + p.band_rows : p.Ho;
+    const int wi0 = x0 * S - p.pad_l;
+    const int r_first = y0 * S - p.pad_t;
+    const int NI = (y1 - y0 + TO - 1) / TO;
+
+    // ---- expand stage constants (as in the kernel above)
+    const int tstart = wave * 32 < n_new - 32 ? wave * 32 : n_new - 32;
+    int a_off, a_rl;
+    bool a_colok;
+    {
+        const int f = tstart + l31;
+        a_rl = f / p.SWi;
+        const int col = f - a_rl * p.SWi, wi = wi0 + col;
+        a_colok = (unsigned)wi < (unsigned)p.W;
+        a_off = (a_rl * p.W + wi) * p.Cin + 4 * lh;
+    }
+    // validity bits of the lane's 16 accumulator elements, per row of the window: rowsel[r] = elements that lie in window
+    // row r AND in a column inside the image (a window's valid elements = OR of rowsel[r] over its rows inside the image)
+    unsigned rowsel[NEW];
+#pragma unroll
+    for (int r = 0; r < NEW; ++r) rowsel[r] = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int f = tstart + 8 * (e >> 2) + 4 * lh + (e & 3);
+        const int rl = f / p.SWi, col = f - rl * p.SWi;
+        const bool cok = (unsigned)(wi0 + col) < (unsigned)p.W;
+#pragma unroll
+        for (int r = 0; r < NEW; ++r)
+            if (cok && rl == r) rowsel[r] |= 1u << e;
+    }
+    v4f wb[NG];
+    float s1 = 0.f, h1 = 0.f;
+    {
+        const int ch = c0 + l31;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            wb[g] = (v4f){0.f, 0.f, 0.f, 0.f};
+            if (ch < p.mid) wb[g] = *reinterpret_cast<const v4f*>(p.w1 + (size_t)ch * p.Cin + 8 * g + 4 * lh);
+        }
+        if (ch < p.mid) s1 = p.sc1[ch], h1 = p.sh1[ch];
+    }
+    const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
+    v4f xa[NG];
+    auto load_x = [&](int w) {
+        const int hi0 = r_first + w * NEW;
+        const bool ok = a_colok && (unsigned)(hi0 + a_rl) < (unsigned)p.H;
+        const float* src = ok ? xb + (ptrdiff_t)hi0 * p.W * p.Cin + a_off : xb + 4 * lh;
+#pragma unroll
+        for (int g = 0; g < NG; ++g) xa[g] = *reinterpret_cast<const v4f*>(src + 8 * g);
+    };
+    float* const Ew0 = ring + tstart * ES + l31;
+    // One load site per window, outside every branch: with the request inside the two arms of the `rowmask == 0` test the
+    // compiler gave the arms different registers, joined them with moves and therefore put s_waitcnt vmcnt(0) right after the
+    // loads - the "prefetch" waited for its own data on every step (the symmetric kernel above still does).
+    auto expand = [&](int w, int slot3) {  // slot3 = w % 3, tracked by the caller
+        float* Ew = Ew0 + slot3 * n_new * ES;
+        const int hi0 = r_first + w * NEW;
+        unsigned rowmask = 0;
+#pragma unroll
+        for (int r = 0; r < NEW; ++r) rowmask |= ((unsigned)(hi0 + r) < (unsigned)p.H ? 1u : 0u) << r;
+        f32x16 acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+        if (rowmask != 0) {  // (a window entirely above / below the image is zeros: no arithmetic)
+#pragma unroll
+            for (int g = 0; g < NG; ++g)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[g][kk], wb[g][kk], acc, 0, 0, 0);
+        }
+        load_x(w + 1 <= NI ? w + 1 : NI);  // the last call re-requests window NI (unused)
+        unsigned okbits = 0;
+#pragma unroll
+        for (int r = 0; r < NEW; ++r) okbits |= ((rowmask >> r) & 1u) ? rowsel[r] : 0u;
+        const v2f s1v = {s1, s1}, h1v = {h1, h1};
+#pragma unroll
+        for (int e = 0; e < 16; e += 2) {
+            const v2f val = silu2(fma2((v2f){acc[e], acc[e + 1]}, s1v, h1v));
+            const int m0 = __builtin_amdgcn_sbfe((int)okbits, e, 1), m1 = __builtin_amdgcn_sbfe((int)okbits, e + 1, 1);  // 0 / -1
+            const float vx = val.x, vy = val.y;  // (__builtin_bit_cast of a vector ELEMENT reads element 0: copy to scalars first)
+            Ew[(8 * (e >> 2) + 4 * lh + (e & 3)) * ES] = __int_as_float(__float_as_int(vx) & m0);
+            Ew[(8 * (e >> 2) + 4 * lh + (e & 3) + 1) * ES] = __int_as_float(__float_as_int(vy) & m1);
+        }
+    };
+
+    // ---- depthwise stage constants. A wave's 16 four-lane chunks map to (slot-in-wave, channel half) so that each
+    // ds_read_b128 service group ({chunks 0,3,5,6}, {1,2,4,7}, {8,11,13,14}, {9,10,12,15}) holds slots u and u + 4 with both
+    // halves: nibble c of the table = (slot << 1) | half
+    const unsigned long long CHUNK_MAP = 0xFDCE5764B98A1320ull;
+    const int ck = (int)((CHUNK_MAP >> (4 * (lane >> 2))) & 15u);
+    const int lc = (p.dbg & 8) ? (tid & 7) : ((ck & 1) << 2) | (lane & 3);  // channel quad of the chunk
+    const int u = (p.dbg & 8) ? (tid >> 3) : wave * 8 + (ck >> 1);           // output slot 0 .. 31
+    // EXACT (host-checked: strips tile the width, bands are whole steps, the last chunk is full or half full): every slot
+    // stores unconditionally - an idle slot and a channel quad beyond `mid` recompute a real owner's output and store the same
+    // bits to the same address. The point is the instruction count, not the few lanes: with a FIXED number of stores after the
+    // window prefetch the compiler waits for the prefetch alone (s_waitcnt vmcnt(stores)); with stores under a branch it has
+    // to use vmcnt(0), which also waits for the stores issued a moment ago
+    const bool q_real = c0 + lc * 4 < p.mid;
+    const int lce = EXACT && !q_real ? lc - 4 : lc;  // the quad this thread computes
+    const int cq = c0 + lce * 4;
+    const bool q_ok = EXACT || q_real;
+    static_assert(TO % (32 / SPR) == 0, "a pass covers whole rows of the step");
+    v4f s2 = {0.f, 0.f, 0.f, 0.f}, h2 = {0.f, 0.f, 0.f, 0.f};
+    if (q_ok) s2 = *reinterpret_cast<const v4f*>(p.sc2 + cq), h2 = *reinterpret_cast<const v4f*>(p.sh2 + cq);
+    v4f tapr[K * K];
+#pragma unroll
+    for (int tap = 0; tap < K * K; ++tap)
+        tapr[tap] = q_ok ? *reinterpret_cast<const v4f*>(p.wdw + (size_t)tap * p.mid + cq) : (v4f){0.f, 0.f, 0.f, 0.f};
+    // Items of a step: output row j, column group g (NOUT outputs). Slot u serves row u / SPR and group u % SPR of each
+    // pass (SPR = 32 or 16 slots per row, a power of two: no division, and with SPR = 32 the row of an item is the pass
+    // number - every ring row address is then `scalar + per-lane column constant`)
+    constexpr int RPP = 32 / SPR;                // rows per pass
+    constexpr int NPASS = (TO + RPP - 1) / RPP;
+    const int G = p.SWo / NOUT;                  // <= SPR (rows_geom)
+    const int jl = u / SPR, g = u % SPR;
+    const int gc = g < G ? g : G - 1;            // idle slots recompute the last group and store nothing
+    const int rowfl = p.SWi * ES;                // floats per ring row
+    const int colpart = gc * (NOUT * S * ES) + lce * 4;
+    const int o_col = (x0 + gc * NOUT) * p.mid + cq;
+    unsigned okn = 0;                            // which of the NOUT columns this thread stores
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n)
+        if (g < G && q_ok && x0 + g * NOUT + n < p.Wo) okn |= 1u << n;
+    const bool own = g < G && q_real;            // EXACT: this slot owns its outputs (the others store duplicates)
+    float* ystep = p.y + ((size_t)b * p.Ho + y0) * p.Wo * p.mid;
+    const int ystride = TO * p.Wo * p.mid;
+    const int orow = p.Wo * p.mid;
+    const int band_len = y1 - y0;
+    const int winfl = n_new * ES;  // floats per window
+    v4f psum = {0.f, 0.f, 0.f, 0.f};
+
+    auto depthwise = [&](int i, int slotA) {  // slotA = i % 3
+        const int baseA = slotA * winfl;
+        const int baseB = slotA == 2 ? 0 : baseA + winfl;
+        v2f alo[NOUT], ahi[NOUT];
+        v4f cA[NCOL], cB[NCOL];
+        auto fetch = [&](v4f* c, int pass, int kh) {
+            const float* erow;
+            if constexpr (RPP == 1) {
+                const int rr = pass * S + kh;  // compile-time
+                erow = ring + ((rr >= NEW ? baseB + (rr - NEW) * rowfl : baseA + rr * rowfl) + colpart);
+            } else {
+                const int rr = (pass * RPP + jl) * S + kh;  // per lane
+                erow = ring + ((rr >= NEW ? baseB - NEW * rowfl : baseA) + __mul24(rr, rowfl) + colpart);
+            }
+#pragma unroll
+            for (int q = 0; q < NCOL; ++q) c[q] = *reinterpret_cast<const v4f*>(erow + q * ES);
+        };
+        auto mac = [&](const v4f* c, int kh) {
+#pragma unroll
+            for (int kw = 0; kw < K; ++kw) {
+                const v4f t4 = tapr[kh * K + kw];
+                const v2f flo = {t4[0], t4[1]}, fhi = {t4[2], t4[3]};
+#pragma unroll
+                for (int n = 0; n < NOUT; ++n) {
+                    const v4f cv = c[n * S + kw];
+                    alo[n] = fma2((v2f){cv[0], cv[1]}, flo, alo[n]);
+                    ahi[n] = fma2((v2f){cv[2], cv[3]}, fhi, ahi[n]);
+                }
+            }
+        };
+        fetch(cA, 0, 0);
+#pragma unroll
+        for (int pass = 0; pass < NPASS; ++pass) {
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n) alo[n] = (v2f){0.f, 0.f}, ahi[n] = (v2f){0.f, 0.f};
+#pragma unroll
+            for (int kh = 0; kh < K; ++kh) {
+                const int f = pass * K + kh;  // running row index: the two row buffers alternate across passes too
+                v4f* cur = (f & 1) ? cB : cA;
+                v4f* nxt = (f & 1) ? cA : cB;
+                if (kh + 1 < K) fetch(nxt, pass, kh + 1);
+                else if (pass + 1 < NPASS) fetch(nxt, pass + 1, 0);  // the next pass's first row arrives under this epilogue
+                mac(cur, kh);
+            }
+            const int j = pass * RPP + jl;
+            const bool rowok = j < TO && i * TO + j < band_len;
+            float* yrow = ystep + j * orow;
+#pragma unroll
+            for (int n = 0; n < NOUT; ++n) {
+                if constexpr (EXACT) {
+                    const v2f olo = silu2(fma2(alo[n], (v2f){s2[0], s2[1]}, (v2f){h2[0], h2[1]}));
+                    const v2f ohi = silu2(fma2(ahi[n], (v2f){s2[2], s2[3]}, (v2f){h2[2], h2[3]}));
+                    const v4f o = {olo.x, olo.y, ohi.x, ohi.y};
+                    *reinterpret_cast<v4f*>(yrow + (o_col + n * p.mid)) = o;
+                    psum += own ? o : (v4f){0.f, 0.f, 0.f, 0.f};
+                } else if (rowok && ((okn >> n) & 1u)) {
+                    const v2f olo = silu2(fma2(alo[n], (v2f){s2[0], s2[1]}, (v2f){h2[0], h2[1]}));
+                    const v2f ohi = silu2(fma2(ahi[n], (v2f){s2[2], s2[3]}, (v2f){h2[2], h2[3]}));
+                    const v4f o = {olo.x, olo.y, ohi.x, ohi.y};
+                    *reinterpret_cast<v4f*>(yrow + (o_col + n * p.mid)) = o;
+                    psum += o;
+                }
+            }
+        }
+        ystep += ystride;
+    };
+
+    load_x(0);
+    expand(0, 0);
+    expand(1, 1);
+    __syncthreads();
+    // every request made so far (taps, BN vectors, window 2) has landed before the loop: the loop then sees the same queue on
+    // entry and on its back edge - the window prefetch followed by a fixed number of stores - and waits with vmcnt(stores)
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    int sa = 0;  // i % 3
+    for (int i = 0; i < NI; ++i) {
+        if (i + 2 <= NI) expand(i + 2, sa == 0 ? 2 : sa - 1);  // (i + 2) % 3
+        depthwise(i, sa);
+        sa = sa == 2 ? 0 : sa + 1;
+        __syncthreads();
+    }
+    if (p.pool) {
+        v4f* red = reinterpret_cast<v4f*>(ring);
+        red[u * 8 + lc] = psum;
+        __syncthreads();
+        if (tid < 8 && c0 + tid * 4 < p.mid) {
+            v4f t4 = red[tid];
+            for (int sl = 1; sl < 32; ++sl) t4 += red[sl * 8 + tid];
+            *reinterpret_cast<v4f*>(p.pool + ((size_t)b * tiles + tile) * p.mid + c0 + tid * 4) = t4;
         }
     }
 }
@@ -359,6 +627,7 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
     p.SWo = g.SWo, p.SWi = g.SWi, p.strips = g.strips, p.band_rows = g.band_rows, p.bands = g.bands;
     p.nchunk = cdiv(mid, 32);
     p.total = p.nchunk * g.strips * g.bands * B;
+    { const char* e = getenv("ORBIT_MBROWS_DBG"); p.dbg = e ? atoi(e) : 0; }
     const int grid = cdiv(p.total, 8) * 8;
     const int n_new = g.TO * stride * g.SWi;
     const size_t lds = (size_t)3 * n_new * ROWS_ES * sizeof(float) + (K == 3 ? 0 : (size_t)K * K * 8 * 16);
@@ -377,12 +646,32 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
         kern<<<grid, 256, lds, s>>>(p);                                                                 \
     } while (0)
     const int ng = Cin / 8;
-    if (K == 3 && stride == 2 && ng == 2) ORBIT_MBR(3, 2, 1, 1, 2);  // the (TO, NOUT) of rows_geom
+    static const int v3 = getenv("ORBIT_MBROWS_V3") ? atoi(getenv("ORBIT_MBROWS_V3")) : 1;
+#define ORBIT_MBR3(SS, TO_, NOUT_, NG_, SPR_, EX_)                                                         \
+    do {                                                                                                \
+        auto kern = mbconv_rows3_kernel<SS, TO_, NOUT_, NG_, SPR_, EX_>;                                     \
+        static bool attr_set = false;                                                                   \
+        if (!attr_set) {                                                                                \
+            ORBIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                    \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+            attr_set = true;                                                                            \
+        }                                                                                               \
+        kern<<<grid, 256, lds, s>>>(p);                                                                 \
+    } while (0)
+    // branch-free stores need: strips tile the width exactly, every band is a whole number of steps, and the last 32-channel
+    // chunk is full or exactly half full (a missing quad duplicates the quad 16 channels below)
+    const bool exact = g.strips * g.SWo == Wo && Ho % g.TO == 0 && g.band_rows % g.TO == 0 && (mid % 32 == 0 || mid % 32 == 16) &&
+                       g.SWo % g.NOUT == 0 && !(getenv("ORBIT_MBROWS_NOEXACT"));
+    if (v3 && K == 3 && stride == 2 && ng == 2) { if (exact) ORBIT_MBR3(2, 1, 1, 2, 32, true); else ORBIT_MBR3(2, 1, 1, 2, 32, false); }
+    else if (v3 && K == 3 && stride == 1 && ng == 3) { if (exact) ORBIT_MBR3(1, 2, 2, 3, 32, true); else ORBIT_MBR3(1, 2, 2, 3, 32, false); }
+    else if (v3 && K == 3 && stride == 2 && ng == 5) { if (exact) ORBIT_MBR3(2, 2, 1, 5, 16, true); else ORBIT_MBR3(2, 2, 1, 5, 16, false); }
+    else if (K == 3 && stride == 2 && ng == 2) ORBIT_MBR(3, 2, 1, 1, 2);  // the (TO, NOUT) of rows_geom
     else if (K == 3 && stride == 1 && ng == 3) ORBIT_MBR(3, 1, 2, 2, 3);
     else if (K == 5 && stride == 2 && ng == 3) ORBIT_MBR(5, 2, 2, 1, 3);
     else if (K == 5 && stride == 1 && ng == 5) ORBIT_MBR(5, 1, 4, 4, 5);
     else ORBIT_MBR(3, 2, 2, 1, 5);
 #undef ORBIT_MBR
+#undef ORBIT_MBR3
     prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
