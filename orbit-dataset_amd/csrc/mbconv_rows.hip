@@ -54,250 +54,9 @@ struct MbRowsParams {
     float* pool;       // [B][tiles][mid] or nullptr
     int H, W, Cin, mid, pad_t, pad_l, Ho, Wo;
     int SWo, SWi, strips, band_rows, bands, nchunk, total;
-    int dbg;
 };
 
-constexpr int ROWS_ES = 36;  // ring pixel stride (floats): 32 channels + 4 (conflict-free ds_read_b128 across pixels)
-
-template <int K, int S, int TO, int NOUT, int NG>
-__global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows_kernel(const MbRowsParams p) {
-    constexpr int NEW = TO * S;                  // input rows per window
-    constexpr int NCOL = (NOUT - 1) * S + K;
-    constexpr int ES = ROWS_ES;
-    static_assert((TO - 1) * S + K <= 2 * NEW, "an output step reads two windows");
-    static_assert(NEW <= 4, "row-in-window index is packed in 2 bits");
-
-    extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int n_new = NEW * p.SWi;               // ring pixels per window (32 < n_new <= 128)
-    float* ring = smem;                          // [3][n_new][ES]
-
-    // block -> (chunk, strip, band, frame). Consecutive ids go round-robin over the 8 XCDs: remap so that the chunk-blocks
-    // of one strip (which read the same input rows) run on the same XCD at about the same time (one L2 fetch of the input)
-    const int per = gridDim.x >> 3;
-    const int v = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (v >= p.total) return;
-    const int chunk = v % p.nchunk;
-    int t = v / p.nchunk;
-    const int tiles = p.strips * p.bands;
-    const int tile = t % tiles, b = t / tiles;
-    const int strip = tile % p.strips, band = tile / p.strips;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int l31 = lane & 31, lh = lane >> 5;
-    const int c0 = chunk * 32;
-    const int x0 = strip * p.SWo, y0 = band * p.band_rows;
-    const int y1 = y0 + p.band_rows < p.Ho ? y0 + p.band_rows : p.Ho;
-    const int wi0 = x0 * S - p.pad_l;            // input column of ring column 0
-    const int r_first = y0 * S - p.pad_t;        // input row of window 0, row 0
-    const int NI = (y1 - y0 + TO - 1) / TO;      // output steps; windows 0 .. NI are needed
-
-    // ---- per-lane constants of the expand stage (the pixel pattern of a window is the same for every window)
-    const int tstart = wave * 32 < n_new - 32 ? wave * 32 : n_new - 32;  // last tile ends at the window's end
-    int a_off;       // float offset of this lane's A pixel inside the frame, relative to the window's first input row
-    bool a_colok;
-    int a_rl;
-    {
-        const int f = tstart + l31;
-        a_rl = f / p.SWi;
-        const int col = f - a_rl * p.SWi, wi = wi0 + col;
-        a_colok = (unsigned)wi < (unsigned)p.W;
-        a_off = (a_rl * p.W + wi) * p.Cin + 4 * lh;
-    }
-    // accumulator element e = rq*4 + j sits at tile row 8*rq + 4*lh + j: its column validity and its row inside the window
-    unsigned colmask = 0, rlpack = 0;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int f = tstart + 8 * (e >> 2) + 4 * lh + (e & 3);
-        const int rl = f / p.SWi, col = f - rl * p.SWi;
-        if ((unsigned)(wi0 + col) < (unsigned)p.W) colmask |= 1u << e;
-        rlpack |= (unsigned)rl << (2 * e);
-    }
-    const bool cols_all = __all(colmask == 0xffffu);  // wave-uniform: no pad column in this wave's tile
-
-    // expand weights of the chunk as MFMA B-fragments (lane = channel l31, k = 8g + 4*lh ..+3), BN1 of that channel
-    v4f wb[NG];
-    float s1 = 0.f, h1 = 0.f;
-    {
-        const int ch = c0 + l31;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) {
-            wb[g] = (v4f){0.f, 0.f, 0.f, 0.f};
-            if (ch < p.mid) wb[g] = *reinterpret_cast<const v4f*>(p.w1 + (size_t)ch * p.Cin + 8 * g + 4 * lh);
-        }
-        if (ch < p.mid) s1 = p.sc1[ch], h1 = p.sh1[ch];
-    }
-    // depthwise: thread = (channel quad lc, output slot)
-    const int lc = tid & 7, slot = tid >> 3;
-    const int cq = c0 + lc * 4;
-    const bool q_ok = cq < p.mid;
-    v4f s2 = {0.f, 0.f, 0.f, 0.f}, h2 = {0.f, 0.f, 0.f, 0.f};
-    if (q_ok) s2 = *reinterpret_cast<const v4f*>(p.sc2 + cq), h2 = *reinterpret_cast<const v4f*>(p.sh2 + cq);
-    v4f* Ds = reinterpret_cast<v4f*>(ring + 3 * n_new * ES);  // 5x5 only: [K*K][8] depthwise taps of the chunk
-    v4f tapr[K == 3 ? K * K : 1];  // 3x3: this thread's nine tap quads stay in registers for the whole walk
-    if constexpr (K == 3) {
-#pragma unroll
-        for (int tap = 0; tap < K * K; ++tap)
-            tapr[tap] = q_ok ? *reinterpret_cast<const v4f*>(p.wdw + (size_t)tap * p.mid + cq) : (v4f){0.f, 0.f, 0.f, 0.f};
-    } else if (tid < K * K * 8) {
-        const int tap = tid >> 3;
-        Ds[tid] = q_ok ? *reinterpret_cast<const v4f*>(p.wdw + (size_t)tap * p.mid + cq) : (v4f){0.f, 0.f, 0.f, 0.f};
-    }
-
-    const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
-    v4f xa[NG];
-    // A-fragments of window w. A pixel outside the image reads the frame's first pixel instead of being zeroed: an MFMA
-    // output row depends on its own A row only, and the epilogue forces those rows to zero - a select on the loaded value
-    // would make the wave wait for the load right where it is issued, i.e. no prefetch at all
-    auto load_x = [&](int w) {
-        const int hi0 = r_first + w * NEW;
-        const bool ok = a_colok && (unsigned)(hi0 + a_rl) < (unsigned)p.H;
-        const float* src = ok ? xb + (ptrdiff_t)hi0 * p.W * p.Cin + a_off : xb + 4 * lh;
-#pragma unroll
-        for (int g = 0; g < NG; ++g) xa[g] = *reinterpret_cast<const v4f*>(src + 8 * g);
-    };
-    auto expand = [&](int w) {  // window w -> ring slot w % 3 (uses xa; requests window w+1's fragments under the epilogue)
-        float* Ew = ring + (w % 3) * n_new * ES + tstart * ES + l31;
-        const int hi0 = r_first + w * NEW;
-        unsigned rowmask = 0;
-#pragma unroll
-        for (int r = 0; r < NEW; ++r) rowmask |= ((unsigned)(hi0 + r) < (unsigned)p.H ? 1u : 0u) << r;
-        if (rowmask == 0) {  // window entirely above / below the image: zeros, no arithmetic
-            if (w + 1 <= NI) load_x(w + 1);
-#pragma unroll
-            for (int e = 0; e < 16; ++e) Ew[(8 * (e >> 2) + 4 * lh + (e & 3)) * ES] = 0.f;
-            return;
-        }
-        f32x16 acc;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[r] = 0.f;
-#pragma unroll
-        for (int g = 0; g < NG; ++g)
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[g][kk], wb[g][kk], acc, 0, 0, 0);
-        if (w + 1 <= NI) load_x(w + 1);
-        const v2f s1v = {s1, s1}, h1v = {h1, h1};
-        if (rowmask == (1u << NEW) - 1u && cols_all) {
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                const v2f val = silu2(fma2((v2f){acc[e], acc[e + 1]}, s1v, h1v));
-                Ew[(8 * (e >> 2) + 4 * lh + (e & 3)) * ES] = val.x;
-                Ew[(8 * (e >> 2) + 4 * lh + (e & 3) + 1) * ES] = val.y;
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < 16; e += 2) {
-                const bool ok0 = ((colmask >> e) & 1u) && ((rowmask >> ((rlpack >> (2 * e)) & 3u)) & 1u);
-                const bool ok1 = ((colmask >> (e + 1)) & 1u) && ((rowmask >> ((rlpack >> (2 * e + 2)) & 3u)) & 1u);
-                const v2f val = silu2(fma2((v2f){acc[e], acc[e + 1]}, s1v, h1v));
-                Ew[(8 * (e >> 2) + 4 * lh + (e & 3)) * ES] = ok0 ? val.x : 0.f;
-                Ew[(8 * (e >> 2) + 4 * lh + (e & 3) + 1) * ES] = ok1 ? val.y : 0.f;
-            }
-        }
-    };
-
-    const int G = p.SWo / NOUT;       // output column groups per row
-    const int items = TO * G;
-    v4f psum = {0.f, 0.f, 0.f, 0.f};
-    auto depthwise = [&](int i) {
-        const float* EA = ring + (i % 3) * n_new * ES;
-        const float* EB = ring + ((i + 1) % 3) * n_new * ES;
-        for (int it = slot; it < items; it += 32) {
-            const int j = it / G, ox = (it - j * G) * NOUT;
-            const int ho = y0 + i * TO + j;
-            if (ho >= y1) break;  // rows are enumerated in order
-            v2f alo[NOUT], ahi[NOUT];  // channel pairs (0,1) / (2,3) of the quad: packed FMAs
-#pragma unroll
-            for (int n = 0; n < NOUT; ++n) alo[n] = (v2f){0.f, 0.f}, ahi[n] = (v2f){0.f, 0.f};
-            auto row_of = [&](int kh) {
-                const int rr = j * S + kh;
-                return (rr >= NEW ? EB + (rr - NEW) * p.SWi * ES : EA + rr * p.SWi * ES) + ox * S * ES + lc * 4;
-            };
-            auto mac = [&](const v4f* c, const v4f* t) {
-#pragma unroll
-                for (int kw = 0; kw < K; ++kw) {
-                    const v2f flo = {t[kw][0], t[kw][1]}, fhi = {t[kw][2], t[kw][3]};
-#pragma unroll
-                    for (int n = 0; n < NOUT; ++n) {
-                        const v4f cv = c[n * S + kw];
-                        alo[n] = fma2((v2f){cv[0], cv[1]}, flo, alo[n]);
-                        ahi[n] = fma2((v2f){cv[2], cv[3]}, fhi, ahi[n]);
-                    }
-                }
-            };
-            // two row buffers: row kh+1 is requested before row kh is consumed
-            v4f cA[NCOL], cB[NCOL];
-            auto fetch = [&](v4f* c, int kh) {
-                const float* erow = row_of(kh);
-#pragma unroll
-                for (int q = 0; q < NCOL; ++q) c[q] = *reinterpret_cast<const v4f*>(erow + q * ES);
-            };
-            fetch(cA, 0);
-            if constexpr (K == 3) {
-                // 3x3: the thread's nine tap quads live in registers (kh unrolled: static register indices)
-#pragma unroll
-                for (int kh = 0; kh < K; ++kh) {
-                    v4f* cur = (kh & 1) ? cB : cA;
-                    v4f* nxt = (kh & 1) ? cA : cB;
-                    if (kh + 1 < K) fetch(nxt, kh + 1);
-                    mac(cur, tapr + kh * K);
-                }
-            } else {
-                // 5x5: 25 tap quads do not fit the register budget (unrolled, hipcc also hoists every row's reads and
-                // spills): taps come from LDS with their row, the loop over row pairs stays rolled
-                v4f tA[K], tB[K];
-                auto taps = [&](v4f* t, int kh) {
-#pragma unroll
-                    for (int kw = 0; kw < K; ++kw) t[kw] = Ds[(kh * K + kw) * 8 + lc];
-                };
-                taps(tA, 0);
-#pragma unroll 1
-                for (int kh = 0; kh + 1 < K; kh += 2) {
-                    fetch(cB, kh + 1), taps(tB, kh + 1);
-                    mac(cA, tA);
-                    if (kh + 2 < K) fetch(cA, kh + 2), taps(tA, kh + 2);
-                    mac(cB, tB);
-                }
-                if (K & 1) mac(cA, tA);
-            }
-            if (q_ok) {
-#pragma unroll
-                for (int n = 0; n < NOUT; ++n) {
-                    const int wo = x0 + ox + n;
-                    if (wo < p.Wo) {
-                        const v2f olo = silu2(fma2(alo[n], (v2f){s2[0], s2[1]}, (v2f){h2[0], h2[1]}));
-                        const v2f ohi = silu2(fma2(ahi[n], (v2f){s2[2], s2[3]}, (v2f){h2[2], h2[3]}));
-                        const v4f o = {olo.x, olo.y, ohi.x, ohi.y};
-                        *reinterpret_cast<v4f*>(p.y + (((size_t)b * p.Ho + ho) * p.Wo + wo) * p.mid + cq) = o;
-                        psum += o;
-                    }
-                }
-            }
-        }
-    };
-
-    // ---- the walk: windows 0 and 1, then one window ahead of the depthwise stage
-    load_x(0);
-    expand(0);
-    expand(1);
-    __syncthreads();
-    for (int i = 0; i < NI; ++i) {
-        if (i + 2 <= NI && !(p.dbg & 1)) expand(i + 2);
-        if (!(p.dbg & 2)) depthwise(i);
-        if (!(p.dbg & 4)) __syncthreads();
-    }
-
-    // ---- pooling partial of this (frame, tile, chunk): the 32 slots summed in slot order (deterministic)
-    if (p.pool) {
-        v4f* red = reinterpret_cast<v4f*>(ring);  // the ring is free after the last barrier
-        red[slot * 8 + lc] = psum;
-        __syncthreads();
-        if (tid < 8 && q_ok) {
-            v4f t4 = red[tid];
-            for (int sl = 1; sl < 32; ++sl) t4 += red[sl * 8 + tid];
-            *reinterpret_cast<v4f*>(p.pool + ((size_t)b * tiles + tile) * p.mid + cq) = t4;
-        }
-    }
-}
+constexpr int ROWS_ES = 36;  // ring pixel stride (floats): 32 channels + 4
 
 // ---- 3x3 form, rebuilt on two measurements (tools/coexec_probe.hip, tools/valu_probe.hip; profiles/r03_coexec_probe.txt):
 //  (1) on gfx950 a SIMD runs EITHER an MFMA OR VALU instructions, never both: a VALU stream under another wave's (or its
@@ -316,9 +75,8 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows_kernel(const 
 // step never changes); the output address is `scalar row pointer + per-lane constant`; and the lane -> (slot, channel quad)
 // map puts slots u and u + 4 (288 floats = 32 banks apart) with both channel halves into each ds_read_b128 service group,
 // which makes the reads conflict-free at the same 36-float stride.
-template <int S, int TO, int NOUT, int NG, int SPR, bool EXACT>
-__global__ __launch_bounds__(256, 3) void mbconv_rows3_kernel(const MbRowsParams p) {
-    constexpr int K = 3;
+template <int K, int S, int TO, int NOUT, int NG, int SPR, bool EXACT>
+__global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const MbRowsParams p) {
     constexpr int NEW = TO * S;
     constexpr int NCOL = (NOUT - 1) * S + K;
     constexpr int ES = ROWS_ES;
@@ -428,12 +186,14 @@ __global__ __launch_bounds__(256, 3) void mbconv_rows3_kernel(const MbRowsParams
     };
 
     // ---- depthwise stage constants. A wave's 16 four-lane chunks map to (slot-in-wave, channel half) so that each
-    // ds_read_b128 service group ({chunks 0,3,5,6}, {1,2,4,7}, {8,11,13,14}, {9,10,12,15}) holds slots u and u + 4 with both
-    // halves: nibble c of the table = (slot << 1) | half
-    const unsigned long long CHUNK_MAP = 0xFDCE5764B98A1320ull;
+    // ds_read_b128 service group ({chunks 0,3,5,6}, {1,2,4,7}, {8,11,13,14}, {9,10,12,15}) holds two slots 32 banks apart, each
+    // with both halves: nibble c of the table = (slot << 1) | half
+    // (2-pixel item pitch = 72 floats: slots u, u + 4 are 32 banks apart; 4-pixel pitch = 144 floats: slots u, u + 2)
+    static_assert(NOUT * S == 2 || NOUT * S == 4, "lane map is built for a 2- or 4-pixel item pitch");
+    const unsigned long long CHUNK_MAP = NOUT * S == 2 ? 0xFDCE5764B98A1320ull : 0xFDCE9BA875461320ull;
     const int ck = (int)((CHUNK_MAP >> (4 * (lane >> 2))) & 15u);
-    const int lc = (p.dbg & 8) ? (tid & 7) : ((ck & 1) << 2) | (lane & 3);  // channel quad of the chunk
-    const int u = (p.dbg & 8) ? (tid >> 3) : wave * 8 + (ck >> 1);           // output slot 0 .. 31
+    const int lc = ((ck & 1) << 2) | (lane & 3);  // channel quad of the chunk
+    const int u = wave * 8 + (ck >> 1);           // output slot 0 .. 31
     // EXACT (host-checked: strips tile the width, bands are whole steps, the last chunk is full or half full): every slot
     // stores unconditionally - an idle slot and a channel quad beyond `mid` recompute a real owner's output and store the same
     // bits to the same address. The point is the instruction count, not the few lanes: with a FIXED number of stores after the
@@ -446,12 +206,19 @@ __global__ __launch_bounds__(256, 3) void mbconv_rows3_kernel(const MbRowsParams
     static_assert(TO % (32 / SPR) == 0, "a pass covers whole rows of the step");
     v4f s2 = {0.f, 0.f, 0.f, 0.f}, h2 = {0.f, 0.f, 0.f, 0.f};
     if (q_ok) s2 = *reinterpret_cast<const v4f*>(p.sc2 + cq), h2 = *reinterpret_cast<const v4f*>(p.sh2 + cq);
-    v4f tapr[K * K];
+    // 3x3: the thread's nine tap quads stay in registers; 5x5: 25 quads do not fit, the chunk's taps sit in LDS behind the ring
+    v4f* Ds = reinterpret_cast<v4f*>(ring + 3 * n_new * ES);  // 5x5 only: [K*K][8]
+    v4f tapr[K == 3 ? K * K : 1];
+    if constexpr (K == 3) {
 #pragma unroll
-    for (int tap = 0; tap < K * K; ++tap)
-        tapr[tap] = q_ok ? *reinterpret_cast<const v4f*>(p.wdw + (size_t)tap * p.mid + cq) : (v4f){0.f, 0.f, 0.f, 0.f};
+        for (int tap = 0; tap < K * K; ++tap)
+            tapr[tap] = q_ok ? *reinterpret_cast<const v4f*>(p.wdw + (size_t)tap * p.mid + cq) : (v4f){0.f, 0.f, 0.f, 0.f};
+    } else if (tid < K * K * 8) {
+        const int tq = c0 + (tid & 7) * 4;
+        Ds[tid] = tq < p.mid ? *reinterpret_cast<const v4f*>(p.wdw + (size_t)(tid >> 3) * p.mid + tq) : (v4f){0.f, 0.f, 0.f, 0.f};
+    }
     // Items of a step: output row j, column group g (NOUT outputs). Slot u serves row u / SPR and group u % SPR of each
-    // pass (SPR = 32 or 16 slots per row, a power of two: no division, and with SPR = 32 the row of an item is the pass
+    // pass (SPR = 32, 16 or 8 slots per row, a power of two: no division, and with SPR = 32 the row of an item is the pass
     // number - every ring row address is then `scalar + per-lane column constant`)
     constexpr int RPP = 32 / SPR;                // rows per pass
     constexpr int NPASS = (TO + RPP - 1) / RPP;
@@ -481,7 +248,7 @@ __global__ __launch_bounds__(256, 3) void mbconv_rows3_kernel(const MbRowsParams
         auto fetch = [&](v4f* c, int pass, int kh) {
             const float* erow;
             if constexpr (RPP == 1) {
-                const int rr = pass * S + kh;  // compile-time
+                const int rr = pass * S + kh;  // wave-uniform
                 erow = ring + ((rr >= NEW ? baseB + (rr - NEW) * rowfl : baseA + rr * rowfl) + colpart);
             } else {
                 const int rr = (pass * RPP + jl) * S + kh;  // per lane
@@ -490,11 +257,10 @@ __global__ __launch_bounds__(256, 3) void mbconv_rows3_kernel(const MbRowsParams
 #pragma unroll
             for (int q = 0; q < NCOL; ++q) c[q] = *reinterpret_cast<const v4f*>(erow + q * ES);
         };
-        auto mac = [&](const v4f* c, int kh) {
+        auto mac = [&](const v4f* c, const v4f* t) {
 #pragma unroll
             for (int kw = 0; kw < K; ++kw) {
-                const v4f t4 = tapr[kh * K + kw];
-                const v2f flo = {t4[0], t4[1]}, fhi = {t4[2], t4[3]};
+                const v2f flo = {t[kw][0], t[kw][1]}, fhi = {t[kw][2], t[kw][3]};
 #pragma unroll
                 for (int n = 0; n < NOUT; ++n) {
                     const v4f cv = c[n * S + kw];
@@ -508,14 +274,34 @@ __global__ __launch_bounds__(256, 3) void mbconv_rows3_kernel(const MbRowsParams
         for (int pass = 0; pass < NPASS; ++pass) {
 #pragma unroll
             for (int n = 0; n < NOUT; ++n) alo[n] = (v2f){0.f, 0.f}, ahi[n] = (v2f){0.f, 0.f};
+            if constexpr (K == 3) {
 #pragma unroll
-            for (int kh = 0; kh < K; ++kh) {
-                const int f = pass * K + kh;  // running row index: the two row buffers alternate across passes too
-                v4f* cur = (f & 1) ? cB : cA;
-                v4f* nxt = (f & 1) ? cA : cB;
-                if (kh + 1 < K) fetch(nxt, pass, kh + 1);
-                else if (pass + 1 < NPASS) fetch(nxt, pass + 1, 0);  // the next pass's first row arrives under this epilogue
-                mac(cur, kh);
+                for (int kh = 0; kh < K; ++kh) {
+                    const int f = pass * K + kh;  // running row index: the two row buffers alternate across passes too
+                    v4f* cur = (f & 1) ? cB : cA;
+                    v4f* nxt = (f & 1) ? cA : cB;
+                    if (kh + 1 < K) fetch(nxt, pass, kh + 1);
+                    else if (pass + 1 < NPASS) fetch(nxt, pass + 1, 0);  // the next pass's first row arrives under this epilogue
+                    mac(cur, tapr + kh * K);
+                }
+            } else {
+                // 5x5 (one pass per step): taps come from LDS with their row, the loop over row pairs stays rolled (unrolled,
+                // hipcc hoists every row's reads and spills)
+                static_assert(K == 3 || NPASS == 1, "the 5x5 row loop assumes one pass");
+                v4f tA[K], tB[K];
+                auto taps = [&](v4f* t, int kh) {
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw) t[kw] = Ds[(kh * K + kw) * 8 + lce];
+                };
+                taps(tA, 0);
+#pragma unroll 1
+                for (int kh = 0; kh + 1 < K; kh += 2) {
+                    fetch(cB, pass, kh + 1), taps(tB, kh + 1);
+                    mac(cA, tA);
+                    if (kh + 2 < K) fetch(cA, pass, kh + 2), taps(tA, kh + 2);
+                    mac(cB, tB);
+                }
+                if (K & 1) mac(cA, tA);
             }
             const int j = pass * RPP + jl;
             const bool rowok = j < TO && i * TO + j < band_len;
@@ -627,16 +413,15 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
     p.SWo = g.SWo, p.SWi = g.SWi, p.strips = g.strips, p.band_rows = g.band_rows, p.bands = g.bands;
     p.nchunk = cdiv(mid, 32);
     p.total = p.nchunk * g.strips * g.bands * B;
-    { const char* e = getenv("ORBIT_MBROWS_DBG"); p.dbg = e ? atoi(e) : 0; }
     const int grid = cdiv(p.total, 8) * 8;
     const int n_new = g.TO * stride * g.SWi;
     const size_t lds = (size_t)3 * n_new * ROWS_ES * sizeof(float) + (K == 3 ? 0 : (size_t)K * K * 8 * 16);
     const double pix = (double)B * H * W;
     const int rec = prof_start("mbconv_rows", 2.0 * pix * Cin * mid + 2.0 * B * Ho * Wo * mid * K * K,
                                4.0 * (pix * Cin + (double)B * Ho * Wo * mid), s);
-#define ORBIT_MBR(KK, SS, TO_, NOUT_, NG_)                                                              \
+#define ORBIT_MBR3(KK, SS, TO_, NOUT_, NG_, SPR_, EX_)                                                         \
     do {                                                                                                \
-        auto kern = mbconv_rows_kernel<KK, SS, TO_, NOUT_, NG_>;                                        \
+        auto kern = mbconv_rows3_kernel<KK, SS, TO_, NOUT_, NG_, SPR_, EX_>;                                     \
         static bool attr_set = false;                                                                   \
         if (!attr_set) {                                                                                \
             ORBIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                    \
@@ -646,31 +431,21 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
         kern<<<grid, 256, lds, s>>>(p);                                                                 \
     } while (0)
     const int ng = Cin / 8;
-    static const int v3 = getenv("ORBIT_MBROWS_V3") ? atoi(getenv("ORBIT_MBROWS_V3")) : 1;
-#define ORBIT_MBR3(SS, TO_, NOUT_, NG_, SPR_, EX_)                                                         \
-    do {                                                                                                \
-        auto kern = mbconv_rows3_kernel<SS, TO_, NOUT_, NG_, SPR_, EX_>;                                     \
-        static bool attr_set = false;                                                                   \
-        if (!attr_set) {                                                                                \
-            ORBIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                    \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
-            attr_set = true;                                                                            \
-        }                                                                                               \
-        kern<<<grid, 256, lds, s>>>(p);                                                                 \
-    } while (0)
     // branch-free stores need: strips tile the width exactly, every band is a whole number of steps, and the last 32-channel
     // chunk is full or exactly half full (a missing quad duplicates the quad 16 channels below)
     const bool exact = g.strips * g.SWo == Wo && Ho % g.TO == 0 && g.band_rows % g.TO == 0 && (mid % 32 == 0 || mid % 32 == 16) &&
-                       g.SWo % g.NOUT == 0 && !(getenv("ORBIT_MBROWS_NOEXACT"));
-    if (v3 && K == 3 && stride == 2 && ng == 2) { if (exact) ORBIT_MBR3(2, 1, 1, 2, 32, true); else ORBIT_MBR3(2, 1, 1, 2, 32, false); }
-    else if (v3 && K == 3 && stride == 1 && ng == 3) { if (exact) ORBIT_MBR3(1, 2, 2, 3, 32, true); else ORBIT_MBR3(1, 2, 2, 3, 32, false); }
-    else if (v3 && K == 3 && stride == 2 && ng == 5) { if (exact) ORBIT_MBR3(2, 2, 1, 5, 16, true); else ORBIT_MBR3(2, 2, 1, 5, 16, false); }
-    else if (K == 3 && stride == 2 && ng == 2) ORBIT_MBR(3, 2, 1, 1, 2);  // the (TO, NOUT) of rows_geom
-    else if (K == 3 && stride == 1 && ng == 3) ORBIT_MBR(3, 1, 2, 2, 3);
-    else if (K == 5 && stride == 2 && ng == 3) ORBIT_MBR(5, 2, 2, 1, 3);
-    else if (K == 5 && stride == 1 && ng == 5) ORBIT_MBR(5, 1, 4, 4, 5);
-    else ORBIT_MBR(3, 2, 2, 1, 5);
-#undef ORBIT_MBR
+                       g.SWo % g.NOUT == 0;
+#define ORBIT_MBR3X(KK, SS, TO_, NOUT_, NG_, SPR_)                    \
+    do {                                                              \
+        if (exact) ORBIT_MBR3(KK, SS, TO_, NOUT_, NG_, SPR_, true);   \
+        else ORBIT_MBR3(KK, SS, TO_, NOUT_, NG_, SPR_, false);        \
+    } while (0)
+    if (K == 3 && stride == 2 && ng == 2) ORBIT_MBR3X(3, 2, 1, 1, 2, 32);  // the (TO, NOUT) of rows_geom; SPR >= SWo / NOUT
+    else if (K == 3 && stride == 1 && ng == 3) ORBIT_MBR3X(3, 1, 2, 2, 3, 32);
+    else if (K == 5 && stride == 2 && ng == 3) ORBIT_MBR3X(5, 2, 2, 1, 3, 16);
+    else if (K == 5 && stride == 1 && ng == 5) ORBIT_MBR3X(5, 1, 4, 4, 5, 8);
+    else ORBIT_MBR3X(3, 2, 2, 1, 5, 16);
+#undef ORBIT_MBR3X
 #undef ORBIT_MBR3
     prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();
