@@ -480,6 +480,7 @@ struct StemRowsParams {
 
 constexpr int STEM_PW = 64;  // patch row stride (floats): 2 * 30 + 1 columns
 
+template <bool EXACT>
 __global__ __launch_bounds__(256, 3) void stem_rows_kernel(const StemRowsParams p, const float* __restrict__ w1g,
                                                            const float* __restrict__ sc1g, const float* __restrict__ sh1g) {
     constexpr int K = 3, TO = 2, NEW = 2, NOUT = 2, NCOL = 4, ES = ROWS_ES;
@@ -554,15 +555,15 @@ __global__ __launch_bounds__(256, 3) void stem_rows_kernel(const StemRowsParams 
     float s1c[2], h1c[2];
 #pragma unroll
     for (int h = 0; h < 2; ++h) s1c[h] = sc1g[16 * h + l15], h1c[h] = sh1g[16 * h + l15];
-    // output element r of a lane: pixel 16w + 4 lq + r (C/D layout of the 16x16 MFMA: column = l15, row = 4 lq + r)
-    unsigned o_colok = 0, o_rl = 0, o_inwin = 0;
+    // output element r of a lane: pixel 16w + 4 lq + r (C/D layout of the 16x16 MFMA: column = l15, row = 4 lq + r).
+    // Validity as bit fields (as in mbconv_rows3_kernel): sel[r2] = elements in window row r2 and in a column of the image
+    unsigned o_inwin = 0, sel0 = 0, sel1 = 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int fo = wave * 16 + 4 * lq + r;
         const int rl = fo / p.SWi, col = fo - rl * p.SWi;
         if (fo < n_new) o_inwin |= 1u << r;
-        if ((unsigned)(c_first + col) < (unsigned)p.W) o_colok |= 1u << r;
-        o_rl |= (unsigned)(rl & 1) << r;
+        if (fo < n_new && (unsigned)(c_first + col) < (unsigned)p.W) (rl ? sel1 : sel0) |= 1u << r;
     }
     auto stem = [&](int w) {
         const float* P = patch + (w & 1) * PATCH + a_base;
@@ -576,92 +577,123 @@ __global__ __launch_bounds__(256, 3) void stem_rows_kernel(const StemRowsParams 
             acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av, Wl[(7 + st) * 64 + lane], acc1, 0, 0, 0);
         }
         const int hi0 = r_first + NEW * w;
-        const unsigned rowok = ((unsigned)hi0 < (unsigned)p.H ? 1u : 0u) | ((unsigned)(hi0 + 1) < (unsigned)p.H ? 2u : 0u);
+        const unsigned okbits = ((unsigned)hi0 < (unsigned)p.H ? sel0 : 0u) | ((unsigned)(hi0 + 1) < (unsigned)p.H ? sel1 : 0u);
         float* E = ring + ((w % 3) * n_new + wave * 16 + 4 * lq) * ES + l15;
 #pragma unroll
         for (int r = 0; r < 4; r += 2) {
             const v2f v0 = silu2(fma2((v2f){acc0[r], acc0[r + 1]}, (v2f){s1c[0], s1c[0]}, (v2f){h1c[0], h1c[0]}));
             const v2f v1 = silu2(fma2((v2f){acc1[r], acc1[r + 1]}, (v2f){s1c[1], s1c[1]}, (v2f){h1c[1], h1c[1]}));
-#pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int rr = r + u;
-                const bool ok = ((o_colok >> rr) & 1u) && ((rowok >> ((o_rl >> rr) & 1u)) & 1u);
-                if ((o_inwin >> rr) & 1u) {
-                    E[rr * ES] = ok ? (u ? v0.y : v0.x) : 0.f;
-                    E[rr * ES + 16] = ok ? (u ? v1.y : v1.x) : 0.f;
-                }
+            const float a0 = v0.x, a1 = v0.y, b0 = v1.x, b1 = v1.y;
+            const int m0 = __builtin_amdgcn_sbfe((int)okbits, r, 1), m1 = __builtin_amdgcn_sbfe((int)okbits, r + 1, 1);  // 0 / -1
+            if ((o_inwin >> r) & 1u) {
+                E[r * ES] = __int_as_float(__float_as_int(a0) & m0);
+                E[r * ES + 16] = __int_as_float(__float_as_int(b0) & m0);
+            }
+            if ((o_inwin >> (r + 1)) & 1u) {
+                E[(r + 1) * ES] = __int_as_float(__float_as_int(a1) & m1);
+                E[(r + 1) * ES + 16] = __int_as_float(__float_as_int(b1) & m1);
             }
         }
     };
 
-    // ---- depthwise stage: thread = (channel quad, output slot), taps in registers
-    const int lc = tid & 7, slot = tid >> 3;
+    // ---- depthwise stage (the bookkeeping of mbconv_rows3_kernel: conflict-free lane map for the 2-pixel item pitch, slot u
+    // = row u / 16 and column group u % 16 of the step, ring address = window base + per-lane constant, EXACT = every slot
+    // stores, idle slots duplicate the last group)
+    const unsigned long long CHUNK_MAP = 0xFDCE5764B98A1320ull;
+    const int ck = (int)((CHUNK_MAP >> (4 * (lane >> 2))) & 15u);
+    const int lc = ((ck & 1) << 2) | (lane & 3);
+    const int u = wave * 8 + (ck >> 1);
     const int cq = lc * 4;
     const v4f s2 = *reinterpret_cast<const v4f*>(p.sc2 + cq), h2 = *reinterpret_cast<const v4f*>(p.sh2 + cq);
     v4f tapr[K * K];
 #pragma unroll
     for (int tap = 0; tap < K * K; ++tap) tapr[tap] = *reinterpret_cast<const v4f*>(p.wdw + tap * 32 + cq);
-    const int G = p.SWo / NOUT, items = TO * G;
+    const int G = p.SWo / NOUT;  // <= 14
+    const int jl = u >> 4, g = u & 15;
+    const int gc = g < G ? g : G - 1;
+    const int rowfl = p.SWi * ES, winfl = n_new * ES;
+    const int colpart = gc * (NOUT * ES) + lc * 4;
+    const int o_col = (jl * p.W + x0 + gc * NOUT) * 32 + cq;
+    const bool own = g < G;
+    unsigned okn = 0;
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n)
+        if (g < G && x0 + g * NOUT + n < p.W) okn |= 1u << n;
+    float* ystep = p.y + ((size_t)b * p.H + y0) * p.W * 32;
+    const int band_len = y1 - y0;
     v4f psum = {0.f, 0.f, 0.f, 0.f};
-    auto depthwise = [&](int i) {
-        const float* EA = ring + (i % 3) * n_new * ES;
-        const float* EB = ring + ((i + 1) % 3) * n_new * ES;
-        for (int it = slot; it < items; it += 32) {
-            const int j = it / G, ox = (it - j * G) * NOUT;
-            const int ho = y0 + i * TO + j;
-            if (ho >= y1) break;
-            v2f alo[NOUT], ahi[NOUT];
+    auto depthwise = [&](int i, int slotA) {  // slotA = i % 3
+        const int baseA = slotA * winfl;
+        const int baseB = slotA == 2 ? 0 : baseA + winfl;
+        v2f alo[NOUT], ahi[NOUT];
 #pragma unroll
-            for (int n = 0; n < NOUT; ++n) alo[n] = (v2f){0.f, 0.f}, ahi[n] = (v2f){0.f, 0.f};
-            v4f c[K][NCOL];
+        for (int n = 0; n < NOUT; ++n) alo[n] = (v2f){0.f, 0.f}, ahi[n] = (v2f){0.f, 0.f};
+        v4f cA[NCOL], cB[NCOL];
+        auto fetch = [&](v4f* c, int kh) {
+            const int rr = jl + kh;  // per lane
+            const float* erow = ring + ((rr >= NEW ? baseB - NEW * rowfl : baseA) + __mul24(rr, rowfl) + colpart);
 #pragma unroll
-            for (int kh = 0; kh < K; ++kh) {
-                const int rr = j + kh;
-                const float* erow = (rr >= NEW ? EB + (rr - NEW) * p.SWi * ES : EA + rr * p.SWi * ES) + ox * ES + lc * 4;
+            for (int q = 0; q < NCOL; ++q) c[q] = *reinterpret_cast<const v4f*>(erow + q * ES);
+        };
+        fetch(cA, 0);
 #pragma unroll
-                for (int q = 0; q < NCOL; ++q) c[kh][q] = *reinterpret_cast<const v4f*>(erow + q * ES);
-            }
+        for (int kh = 0; kh < K; ++kh) {
+            v4f* cur = (kh & 1) ? cB : cA;
+            v4f* nxt = (kh & 1) ? cA : cB;
+            if (kh + 1 < K) fetch(nxt, kh + 1);
 #pragma unroll
-            for (int kh = 0; kh < K; ++kh)
+            for (int kw = 0; kw < K; ++kw) {
+                const v4f t = tapr[kh * K + kw];
+                const v2f flo = {t[0], t[1]}, fhi = {t[2], t[3]};
 #pragma unroll
-                for (int kw = 0; kw < K; ++kw) {
-                    const v4f t = tapr[kh * K + kw];
-                    const v2f flo = {t[0], t[1]}, fhi = {t[2], t[3]};
-#pragma unroll
-                    for (int n = 0; n < NOUT; ++n) {
-                        const v4f cv = c[kh][n + kw];
-                        alo[n] = fma2((v2f){cv[0], cv[1]}, flo, alo[n]);
-                        ahi[n] = fma2((v2f){cv[2], cv[3]}, fhi, ahi[n]);
-                    }
-                }
-#pragma unroll
-            for (int n = 0; n < NOUT; ++n) {
-                const int wo = x0 + ox + n;
-                if (wo < p.W) {
-                    const v2f olo = silu2(fma2(alo[n], (v2f){s2[0], s2[1]}, (v2f){h2[0], h2[1]}));
-                    const v2f ohi = silu2(fma2(ahi[n], (v2f){s2[2], s2[3]}, (v2f){h2[2], h2[3]}));
-                    const v4f o = {olo.x, olo.y, ohi.x, ohi.y};
-                    *reinterpret_cast<v4f*>(p.y + (((size_t)b * p.H + ho) * p.W + wo) * 32 + cq) = o;
-                    psum += o;
+                for (int n = 0; n < NOUT; ++n) {
+                    const v4f cv = cur[n + kw];
+                    alo[n] = fma2((v2f){cv[0], cv[1]}, flo, alo[n]);
+                    ahi[n] = fma2((v2f){cv[2], cv[3]}, fhi, ahi[n]);
                 }
             }
         }
+        const bool rowok = i * TO + jl < band_len;
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {
+            if constexpr (EXACT) {
+                const v2f olo = silu2(fma2(alo[n], (v2f){s2[0], s2[1]}, (v2f){h2[0], h2[1]}));
+                const v2f ohi = silu2(fma2(ahi[n], (v2f){s2[2], s2[3]}, (v2f){h2[2], h2[3]}));
+                const v4f o = {olo.x, olo.y, ohi.x, ohi.y};
+                *reinterpret_cast<v4f*>(ystep + (o_col + n * 32)) = o;
+                psum += own ? o : (v4f){0.f, 0.f, 0.f, 0.f};
+            } else if (rowok && ((okn >> n) & 1u)) {
+                const v2f olo = silu2(fma2(alo[n], (v2f){s2[0], s2[1]}, (v2f){h2[0], h2[1]}));
+                const v2f ohi = silu2(fma2(ahi[n], (v2f){s2[2], s2[3]}, (v2f){h2[2], h2[3]}));
+                const v4f o = {olo.x, olo.y, ohi.x, ohi.y};
+                *reinterpret_cast<v4f*>(ystep + (o_col + n * 32)) = o;
+                psum += o;
+            }
+        }
+        ystep += TO * p.W * 32;
     };
 
-    // ---- the walk. Step w: request patch w+1, stem window w (patch w & 1), depthwise of output step w-2, park patch w+1
+    // ---- the walk. Step w: request patch w+1, stem window w (patch w & 1), depthwise of output step w-2, park patch w+1.
+    // EXACT: the stores between the patch request and its parking are a fixed number, so the parking waits with
+    // vmcnt(stores) for the patch alone (see mbconv_rows3_kernel)
     patch_load(0);
     patch_store(0);
     __syncthreads();
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): taps / BN vectors have landed, the loop's queue is the same on entry and back edge
+    int sa = 0;  // (w - 2) % 3
     for (int w = 0; w <= NI + 1; ++w) {
-        if (w + 1 <= NI) patch_load(w + 1);
+        patch_load(w + 1 <= NI ? w + 1 : NI);  // (the last two requests repeat patch NI and are not parked)
         if (w <= NI) stem(w);
-        if (w >= 2) depthwise(w - 2);
+        if (w >= 2) {
+            depthwise(w - 2, sa);
+            sa = sa == 2 ? 0 : sa + 1;
+        }
         if (w + 1 <= NI) patch_store(w + 1);
         __syncthreads();
     }
     if (p.pool) {
         v4f* red = reinterpret_cast<v4f*>(ring);
-        red[slot * 8 + lc] = psum;
+        red[u * 8 + lc] = psum;
         __syncthreads();
         if (tid < 8) {
             v4f t4 = red[tid];
@@ -715,7 +747,9 @@ int launch_stem_rows(const float* frames, const float* w1_packed, const float* s
     const double pix = (double)B * H * W;
     const int rec = prof_start("stem_rows", 2.0 * pix * 32 * 27 + 2.0 * pix * 32 * 9,
                                4.0 * ((double)B * 3 * FH * FW + pix * 32), s);
-    stem_rows_kernel<<<grid, 256, lds, s>>>(p, w1_packed, sc1, sh1);
+    // branch-free stores: strips tile the width exactly and every band is a whole number of 2-row steps
+    if (g.strips * g.SWo == W && H % 2 == 0 && g.band_rows % 2 == 0) stem_rows_kernel<true><<<grid, 256, lds, s>>>(p, w1_packed, sc1, sh1);
+    else stem_rows_kernel<false><<<grid, 256, lds, s>>>(p, w1_packed, sc1, sh1);
     prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
