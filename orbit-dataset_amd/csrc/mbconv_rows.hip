@@ -31,8 +31,8 @@ using v4f = __attribute__((ext_vector_type(4))) float;
 using v2f = __attribute__((ext_vector_type(2))) float;
 
 // SiLU of two values: v * rcp(1 + exp2(-log2(e) * v)), the arithmetic of mbconv.hip's silu_f (bit-identical), with the
-// multiplies and the add as packed-fp32 instructions - the kernel is bound by VALU issue (two transcendentals + four
-// ordinary instructions per expanded element), so v_pk_* halves the ordinary part
+// multiplies and the add as packed-fp32 instructions (v_pk_fma_f32 costs 1.98 ns of a SIMD per 128 lanes-elements against
+// 1.26 ns per 64 for v_fma_f32; the two transcendentals cost 3.9 ns each: profiles/r03_valu_probe.txt)
 __device__ __forceinline__ v2f silu2(v2f x) {
     const v2f t = x * (v2f){-1.44269502f, -1.44269502f};
     const v2f e = {__builtin_amdgcn_exp2f(t.x), __builtin_amdgcn_exp2f(t.y)};
@@ -58,19 +58,21 @@ struct MbRowsParams {
 
 constexpr int ROWS_ES = 36;  // ring pixel stride (floats): 32 channels + 4
 
-// ---- 3x3 form, rebuilt on two measurements (tools/coexec_probe.hip, tools/valu_probe.hip; profiles/r03_coexec_probe.txt):
+// ---- the kernel. Its bookkeeping follows two measurements (tools/coexec_probe.hip, tools/valu_probe.hip;
+// profiles/r03_coexec_probe.txt, r03_valu_probe.txt):
 //  (1) on gfx950 a SIMD runs EITHER an MFMA OR VALU instructions, never both: a VALU stream under another wave's (or its
 //      own) v_mfma_f32_32x32x2_f32 chain takes exactly MFMA time + VALU time, for fp32 and bf16 MFMAs alike. A fused kernel's
 //      SIMD time is the SUM of its matrix and vector instruction time; specialising waves (expand waves / depthwise waves,
-//      four per SIMD) was built and measured: 194 us against 195 us for block 1.1, i.e. nothing.
-//  (2) the symmetric kernel above spends 137 us of SIMD time per 200 frames of block 1.1 (MFMA 37 + VALU 100) for a 195 us
-//      launch, and a third of that VALU time is not arithmetic: the masked expand epilogue (every 32-pixel tile of a 58-pixel
-//      ring row holds a pad column, so the six-instruction-per-element select path always ran), per-item address arithmetic
+//      four per SIMD) was built and measured: 194 us against 195 us for block 1.1, i.e. nothing. Every VALU instruction
+//      that is not arithmetic of the layer is therefore paid in full.
+//  (2) round 2's form of this kernel spent 137 us of SIMD time per 200 frames of block 1.1 (MFMA 37 + VALU 100) for a 195 us
+//      launch, and a third of that VALU time was not arithmetic: the masked expand epilogue (every 32-pixel tile of a 58-pixel
+//      ring row holds a pad column, so a six-instruction-per-element select path always ran), per-item address arithmetic
 //      with 32-bit integer multiplies (quarter rate) and a division by the group count, and ds_read_b128 bank conflicts
 //      (0.54 conflict cycles per active cycle: with the 36-float pixel stride two of the four slots of a 16-lane service
-//      group land on the same banks).
-// This form keeps the walk, the MFMA k-order and every float operation of the kernel above (y is bit-identical; the pooling
-// partials sum the same values in a different slot order) and changes the bookkeeping: validity is one bit-field extract +
+//      group landed on the same banks). Its window prefetch also never overlapped anything (see `expand` below).
+// This form keeps round 2's walk, MFMA k-order and every float operation (y is bit-identical to it and to the unfused pair; the
+// pooling partials sum the same values in a different slot order) and changes the bookkeeping: validity is one bit-field extract +
 // AND per expanded element; an item's ring addresses are `scalar window base + per-lane constant` (the item pattern of a
 // step never changes); the output address is `scalar row pointer + per-lane constant`; and the lane -> (slot, channel quad)
 // map puts slots u and u + 4 (288 floats = 32 banks apart) with both channel halves into each ds_read_b128 service group,
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const
     const int r_first = y0 * S - p.pad_t;
     const int NI = (y1 - y0 + TO - 1) / TO;
 
-    // ---- expand stage constants (as in the kernel above)
+    // ---- expand stage constants
     const int tstart = wave * 32 < n_new - 32 ? wave * 32 : n_new - 32;
     int a_off, a_rl;
     bool a_colok;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const
     float* const Ew0 = ring + tstart * ES + l31;
     // One load site per window, outside every branch: with the request inside the two arms of the `rowmask == 0` test the
     // compiler gave the arms different registers, joined them with moves and therefore put s_waitcnt vmcnt(0) right after the
-    // loads - the "prefetch" waited for its own data on every step (the symmetric kernel above still does).
+    // loads - round 2's "prefetch" waited for its own data on every step.
     auto expand = [&](int w, int slot3) {  // slot3 = w % 3, tracked by the caller
         float* Ew = Ew0 + slot3 * n_new * ES;
         const int hi0 = r_first + w * NEW;
