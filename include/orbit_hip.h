@@ -96,6 +96,9 @@ int orbit_device_count(void);
  *                   128 rows x 96 columns and 11 / 12 / 13 = x 128 columns (one pass over N for Cout <= 96 / 128) - sweeps
  *   "conv_bk"       cap the K-tile width: 0 = widest of 32/16/8 dividing Cin (default), 8, 16, 32 (read when weights are
  *                   packed AND at launch: set it before creating / finalizing an extractor)
+ *   "conv_bk_auto"  1 (default) = a pointwise conv whose Cin is a multiple of 32 runs with 16-wide K-tiles (same packed filter,
+ *                   7 instead of 4 blocks per CU) where that measured faster: Cout <= 32 with Cin <= 128, or 1 025 .. 1 792
+ *                   64x64 output tiles; 0 = always the widest tile. Ignored when "conv_bk" is set
  *   "conv_uncond"   staged loads without predicates: 1 = pointwise convs only (default), 0 = never, 2 = everywhere
  *   "conv_splitk"   1 (default) = convs with few output tiles and a long reduction are split over K (partial tiles + a
  *                   deterministic reduce), 0 = never; "conv_splitk_tiles": the tile-count threshold (0 = 320)

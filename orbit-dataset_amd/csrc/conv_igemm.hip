@@ -840,7 +840,17 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     }
     p.fd_cin = make_fastdiv((unsigned)d.Cin), p.fd_kw = make_fastdiv((unsigned)d.KW);
     ORBIT_REQUIRE((long long)d.B * d.H * d.W * d.Cin < (1ll << 40) && p.M > 0, "conv: tensor too large");
-    const int bk = choose_bk(d.Cin, d.x_nchw);
+    int bk = choose_bk(d.Cin, d.x_nchw);
+    // K-tile of 16 where 32 would also divide Cin (the packed filter is the same: cin_pad and the k-order do not depend on
+    // BK when Cin % 32 == 0). Half the LDS stage = 7 instead of 4 blocks per CU; it pays (tools/conv_bench.py effnet_224 with
+    // ORBIT_CONV_BK=16, 200 frames) on the narrow HBM-bound projections - 32 -> 16 @112x112: 131 -> 115 us, 96 -> 24 @56x56:
+    // 79.5 -> 75.9 - and where the 64x64 tiling gives between one and two rounds of 4 blocks per CU, i.e. a second round that
+    // is mostly empty (480 -> 112 and 672 -> 112 @14x14, 1 226 tiles: 65.7 -> 60.2, 81.0 -> 73.7 us); elsewhere 32 is as good
+    // or better (fewer barriers per K: 1152 -> 320 @7x7 91.8 vs 96.1 us)
+    if (bk == 32 && pw && !d.pool2 && !d.x_nchw && get_option("conv_bk") == 0 && get_option("conv_bk_auto")) {
+        const long tiles64 = (long)cdiv(p.M, 64) * cdiv(d.Cout, 64);
+        if ((d.Cout <= 32 && d.Cin <= 128) || (d.Cout > 32 && tiles64 > 1024 && tiles64 <= 1792)) bk = 16;
+    }
     p.stem_table = get_option("conv_stem_fast");
     p.early_sc = get_option("conv_early_sc");
     p.epi_batch = get_option("conv_epi_batch");

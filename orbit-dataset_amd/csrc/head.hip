@@ -51,6 +51,7 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"se_wide", "ORBIT_SE_WIDE", 1, false},
                              {"conv_tile", "ORBIT_CONV_TILE", 0, false},
                              {"conv_bk", "ORBIT_CONV_BK", 0, false},
+                             {"conv_bk_auto", "ORBIT_CONV_BK_AUTO", 1, false},
                              {"conv_uncond", "ORBIT_CONV_UNCOND", 1, false},
                              {"conv_splitk", "ORBIT_CONV_SPLITK", 1, false},
                              {"conv_splitk_tiles", "ORBIT_CONV_SPLITK_TILES", 0, false},
