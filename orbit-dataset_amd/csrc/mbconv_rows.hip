@@ -177,13 +177,22 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const
 #pragma unroll
         for (int r = 0; r < NEW; ++r) okbits |= ((rowmask >> r) & 1u) ? rowsel[r] : 0u;
         const v2f s1v = {s1, s1}, h1v = {h1, h1};
+        if (__all(okbits == 0xffffu)) {  // wave-uniform: no pad column and no row outside the image in this wave's tile
 #pragma unroll
-        for (int e = 0; e < 16; e += 2) {
-            const v2f val = silu2(fma2((v2f){acc[e], acc[e + 1]}, s1v, h1v));
-            const int m0 = __builtin_amdgcn_sbfe((int)okbits, e, 1), m1 = __builtin_amdgcn_sbfe((int)okbits, e + 1, 1);  // 0 / -1
-            const float vx = val.x, vy = val.y;  // (__builtin_bit_cast of a vector ELEMENT reads element 0: copy to scalars first)
-            Ew[(8 * (e >> 2) + 4 * lh + (e & 3)) * ES] = __int_as_float(__float_as_int(vx) & m0);
-            Ew[(8 * (e >> 2) + 4 * lh + (e & 3) + 1) * ES] = __int_as_float(__float_as_int(vy) & m1);
+            for (int e = 0; e < 16; e += 2) {
+                const v2f val = silu2(fma2((v2f){acc[e], acc[e + 1]}, s1v, h1v));
+                Ew[(8 * (e >> 2) + 4 * lh + (e & 3)) * ES] = val.x;
+                Ew[(8 * (e >> 2) + 4 * lh + (e & 3) + 1) * ES] = val.y;
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < 16; e += 2) {
+                const v2f val = silu2(fma2((v2f){acc[e], acc[e + 1]}, s1v, h1v));
+                const int m0 = __builtin_amdgcn_sbfe((int)okbits, e, 1), m1 = __builtin_amdgcn_sbfe((int)okbits, e + 1, 1);  // 0 / -1
+                const float vx = val.x, vy = val.y;  // (__builtin_bit_cast of a vector ELEMENT reads element 0: copy to scalars first)
+                Ew[(8 * (e >> 2) + 4 * lh + (e & 3)) * ES] = __int_as_float(__float_as_int(vx) & m0);
+                Ew[(8 * (e >> 2) + 4 * lh + (e & 3) + 1) * ES] = __int_as_float(__float_as_int(vy) & m1);
+            }
         }
     };
 
@@ -513,18 +522,34 @@ __global__ __launch_bounds__(256, 3) void stem_rows_kernel(const StemRowsParams 
     float preg[NPL];
     unsigned pmask = 0;  // which of preg[] lie inside the frame: applied when the patch is WRITTEN - a select on the loaded
                          // value would make the wave wait for the load where it is issued (no prefetch at all)
+    // per-thread constants of its NPL patch elements (the patch pattern is the same for every window): frame offset for
+    // patch row 0 at frame row 0, column validity, patch row - a window then costs one add and one bit test per element
+    // (decoding (plane, row, column) and the 64-bit frame offset per element and step was a third of the kernel's VALU work)
+    int poff[NPL];
+    unsigned pcolok = 0, prows = 0;  // bit u / 3-bit field u
+#pragma unroll
+    for (int u = 0; u < NPL; ++u) {
+        const int i = tid + u * 256;
+        const int c = i & (STEM_PW - 1), pr = i >> 6;      // pr = plane * 5 + row
+        const int plane = pr / 5, row = pr - plane * 5;
+        const int fc = fcol0 + c;
+        const bool cok = i < PATCH && c < pcols && (unsigned)fc < (unsigned)p.FW;
+        poff[u] = cok ? (plane * p.FH + row) * p.FW + fc : 0;
+        pcolok |= (cok ? 1u : 0u) << u;
+        prows |= (unsigned)row << (3 * u);
+    }
     auto patch_load = [&](int w) {
         const int frow0 = 2 * (r_first + NEW * w) - p.spad_t;
+        unsigned rmask = 0;  // patch rows inside the frame (wave-uniform)
+#pragma unroll
+        for (int r = 0; r < 5; ++r) rmask |= ((unsigned)(frow0 + r) < (unsigned)p.FH ? 1u : 0u) << r;
+        const int rowbase = frow0 * p.FW;
         pmask = 0;
 #pragma unroll
         for (int u = 0; u < NPL; ++u) {
-            const int i = tid + u * 256;
-            const int c = i & (STEM_PW - 1), pr = i >> 6;      // pr = plane * 5 + row
-            const int plane = pr / 5, row = pr - plane * 5;
-            const int fr = frow0 + row, fc = fcol0 + c;
-            const bool ok = i < PATCH && c < pcols && (unsigned)fr < (unsigned)p.FH && (unsigned)fc < (unsigned)p.FW;
+            const bool ok = ((pcolok >> u) & 1u) && ((rmask >> ((prows >> (3 * u)) & 7u)) & 1u);
             pmask |= (ok ? 1u : 0u) << u;
-            preg[u] = fb[ok ? ((size_t)plane * p.FH + fr) * p.FW + fc : 0];
+            preg[u] = fb[ok ? poff[u] + rowbase : 0];
         }
     };
     auto patch_store = [&](int w) {

@@ -104,3 +104,26 @@ def test_no_cpu_fallback_without_gpu():
     fe, _ = create_feature_extractor("resnet18", True, False, False)
     with pytest.raises(_lib.OrbitHipError):
         fe(torch.zeros(1, 3, 32, 32))
+
+
+def test_every_runtime_option_is_documented_and_resolvable(lib):
+    """The option table of csrc/head.hip (name, environment variable, default) against include/orbit_hip.h: every option a
+    kernel can read is documented in the header's option block under its name, reads back through the C-ABI with the
+    table's default (unless the environment overrides it), and its environment variable is ORBIT_<NAME>. A get_option() call
+    on a name that is not in the table would silently return 0 - every name used in csrc/ must be in the table."""
+    src = open(os.path.join(ROOT, "orbit-dataset_amd", "csrc", "head.hip")).read()
+    table = re.findall(r'\{"([a-z0-9_]+)",\s*"(ORBIT_[A-Z0-9_]+)",\s*(-?\d+),\s*false\}', src)
+    assert len(table) >= 30
+    header = open(os.path.join(ROOT, "include", "orbit_hip.h")).read()
+    for name, env, default in table:
+        assert env == "ORBIT_" + name.upper(), (name, env)
+        assert '"%s"' % name in header, f'option "{name}" is not documented in include/orbit_hip.h'
+        if env not in os.environ:
+            assert lib.orbit_get_option(name.encode()) == int(default), name
+    names = {n for n, _, _ in table}
+    used = set()
+    csrc = os.path.join(ROOT, "orbit-dataset_amd", "csrc")
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".h")):
+            used |= set(re.findall(r'get_option\("([a-z0-9_]+)"\)', open(os.path.join(csrc, f)).read()))
+    assert used <= names, f"options read by kernels but missing from the table: {sorted(used - names)}"
