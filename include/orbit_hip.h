@@ -76,6 +76,11 @@ int orbit_device_count(void);
  *                   kernel + depthwise kernel
  *   "mbrows_band"   output rows per band of the two row-streaming kernels: 0 = 28 (default); the band count sizes a plan's
  *                   SE pooling partials, so a launch REFUSES a value that differs from the one its plan was built with
+ *   "mbrows_exact"  1 (default) = where a map divides evenly (strips tile the width, bands are whole steps, the last 32-channel
+ *                   chunk is full or half full - every shape of a 224 x 224 input) the row-streaming kernels run their
+ *                   branch-free instantiation: every output slot stores, idle slots re-store a real owner's value (same bits,
+ *                   same address), so the window prefetch is waited for with vmcnt(stores). 0 = always the general
+ *                   (predicated) instantiation; outputs are bit-identical either way (tests/test_gpu_ops.py)
  *   "mbconv_fusion" tiled fused front (csrc/mbconv.hip) for blocks the row-streaming kernel does not take: 2 (default) =
  *                   where it measured faster than the conv + depthwise pair, 1 = every supported block (incl. the stem
  *                   form), 0 = never. A plan that records a training tape is always built without fused blocks

@@ -38,6 +38,7 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"mbmap_groups", "ORBIT_MBMAP_GROUPS", 0, false},
                              {"mbconv_rows", "ORBIT_MBCONV_ROWS", 1, false},
                              {"mbrows_band", "ORBIT_MBROWS_BAND", 0, false},
+                             {"mbrows_exact", "ORBIT_MBROWS_EXACT", 1, false},
                              {"stem_rows", "ORBIT_STEM_ROWS", 1, false},
                              {"pw_narrow", "ORBIT_PW_NARROW", 0, false},
                              {"dw_dgrad_forward", "ORBIT_DW_DGRAD_FORWARD", 1, false},

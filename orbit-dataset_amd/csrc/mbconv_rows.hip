@@ -330,7 +330,10 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const
                     const v2f ohi = silu2(fma2(ahi[n], (v2f){s2[2], s2[3]}, (v2f){h2[2], h2[3]}));
                     const v4f o = {olo.x, olo.y, ohi.x, ohi.y};
                     *reinterpret_cast<v4f*>(yrow + (o_col + n * p.mid)) = o;
-                    psum += o;
+                    {
+#pragma clang fp contract(off)  // sum the ROUNDED outputs (what y holds), as the branch-free instantiation does
+                        psum = psum + o;
+                    }
                 }
             }
         }
@@ -445,7 +448,7 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
     // branch-free stores need: strips tile the width exactly, every band is a whole number of steps, and the last 32-channel
     // chunk is full or exactly half full (a missing quad duplicates the quad 16 channels below)
     const bool exact = g.strips * g.SWo == Wo && Ho % g.TO == 0 && g.band_rows % g.TO == 0 && (mid % 32 == 0 || mid % 32 == 16) &&
-                       g.SWo % g.NOUT == 0;
+                       g.SWo % g.NOUT == 0 && get_option("mbrows_exact") != 0;
 #define ORBIT_MBR3X(KK, SS, TO_, NOUT_, NG_, SPR_)                    \
     do {                                                              \
         if (exact) ORBIT_MBR3(KK, SS, TO_, NOUT_, NG_, SPR_, true);   \
@@ -694,7 +697,10 @@ __global__ __launch_bounds__(256, 3) void stem_rows_kernel(const StemRowsParams 
                 const v2f ohi = silu2(fma2(ahi[n], (v2f){s2[2], s2[3]}, (v2f){h2[2], h2[3]}));
                 const v4f o = {olo.x, olo.y, ohi.x, ohi.y};
                 *reinterpret_cast<v4f*>(ystep + (o_col + n * 32)) = o;
-                psum += o;
+                {
+#pragma clang fp contract(off)  // sum the ROUNDED outputs (what y holds), as the branch-free instantiation does
+                    psum = psum + o;
+                }
             }
         }
         ystep += TO * p.W * 32;
@@ -775,7 +781,7 @@ int launch_stem_rows(const float* frames, const float* w1_packed, const float* s
     const int rec = prof_start("stem_rows", 2.0 * pix * 32 * 27 + 2.0 * pix * 32 * 9,
                                4.0 * ((double)B * 3 * FH * FW + pix * 32), s);
     // branch-free stores: strips tile the width exactly and every band is a whole number of 2-row steps
-    if (g.strips * g.SWo == W && H % 2 == 0 && g.band_rows % 2 == 0) stem_rows_kernel<true><<<grid, 256, lds, s>>>(p, w1_packed, sc1, sh1);
+    if (g.strips * g.SWo == W && H % 2 == 0 && g.band_rows % 2 == 0 && get_option("mbrows_exact") != 0) stem_rows_kernel<true><<<grid, 256, lds, s>>>(p, w1_packed, sc1, sh1);
     else stem_rows_kernel<false><<<grid, 256, lds, s>>>(p, w1_packed, sc1, sh1);
     prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();

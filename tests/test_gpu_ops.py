@@ -375,6 +375,47 @@ def test_mbconv_front_whole_map(lib, device, Cin, K, stride, HW, B, groups):
     assert (pool.cpu()[:, 0] - want.sum((2, 3))).abs().max().item() < 2e-3 * max(1.0, want.sum((2, 3)).abs().max().item())
 
 
+@pytest.mark.parametrize("Cin,mid,K,stride,H,W", MBROWS_CASES[:5] + [(24, 144, 3, 1, 28, 56), (40, 240, 3, 2, 28, 14)])
+@pytest.mark.parametrize("band", [0, 4])
+def test_mbconv_rows_exact_and_general_instantiations_agree(lib, device, Cin, mid, K, stride, H, W, band):
+    """The row-streaming kernel's branch-free (EXACT) instantiation - every slot stores, idle slots and channel quads past
+    `mid` re-store a real owner's value - against its general, predicated instantiation (option mbrows_exact = 0) on maps
+    that divide evenly: outputs AND pooling partials must be bit-identical, and no element may stay unwritten (the duplicate
+    stores must hit the owner's address, not a neighbour's)."""
+    g = torch.Generator().manual_seed(Cin + mid + K + H)
+    B = 3
+    x = torch.randn(B, H, W, Cin, generator=g)
+    w1 = torch.randn(mid, Cin, 1, 1, generator=g) / Cin ** 0.5
+    wd = torch.randn(mid, 1, K, K, generator=g) / K
+    s1, h1 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.3
+    s2, h2 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.1
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph, pw = max((Ho - 1) * stride + K - H, 0), max((Wo - 1) * stride + K - W, 0)
+    dev = [t.to(device).contiguous() for t in (x, w1, s1, h1, wd, s2, h2)]
+    prev = lib.orbit_get_option(b"mbconv_rows")
+    lib.orbit_set_option(b"mbconv_rows", 1)
+    lib.orbit_set_option(b"mbrows_band", band)
+    out = []
+    try:
+        tiles = lib.orbit_op_mbconv_front_partials(H, W, Cin, mid, K, stride)
+        for exact in (1, 0):
+            lib.orbit_set_option(b"mbrows_exact", exact)
+            y = torch.full((B, Ho, Wo, mid), float("nan"), device=device)
+            pool = torch.full((B, tiles, mid), float("nan"), device=device)
+            _lib.check(lib.orbit_op_mbconv_front(*[_lib.dptr(t) for t in dev], _lib.dptr(y), _lib.dptr(pool), B, H, W, Cin,
+                                                 mid, K, stride, ph // 2, pw // 2, Ho, Wo, _st()), "mbconv_front (rows)")
+            torch.cuda.synchronize()
+            out.append((y.cpu(), pool.cpu()))
+    finally:
+        lib.orbit_set_option(b"mbrows_exact", 1)
+        lib.orbit_set_option(b"mbrows_band", 0)
+        lib.orbit_set_option(b"mbconv_rows", prev)
+    (ye, pe), (yg, pg) = out
+    assert not torch.isnan(ye).any() and not torch.isnan(pe).any() and not torch.isnan(yg).any()
+    assert torch.equal(ye, yg), (ye - yg).abs().max().item()
+    assert torch.equal(pe, pg), (pe - pg).abs().max().item()
+
+
 @pytest.mark.parametrize("FH,FW,mid", [(64, 64, 32), (37, 45, 32), (30, 30, 32), (21, 52, 16), (224, 224, 32), (97, 131, 32),
                                        (6, 5, 32)])
 @pytest.mark.parametrize("rows,band", [(0, 0), (1, 0), (1, 6)])
@@ -417,6 +458,19 @@ def test_stem_dw_front_fused(lib, device, FH, FW, mid, rows, band):
     assert not torch.isnan(got).any() and not torch.isnan(pool).any()
     assert (got - want).abs().max().item() < 5e-5
     assert (pool.cpu().sum(1) - want.sum((2, 3))).abs().max().item() < 2e-3 * max(1.0, want.sum((2, 3)).abs().max().item())
+    if rows:  # the general (predicated) instantiation of the row-streaming kernel: identical bits, partials included
+        lib.orbit_set_option(b"mbconv_rows", rows), lib.orbit_set_option(b"mbrows_band", band)
+        lib.orbit_set_option(b"mbrows_exact", 0)
+        try:
+            yg = torch.full((B, H, W, mid), float("nan"), device=device)
+            pg = torch.full((B, tiles, mid), float("nan"), device=device)
+            _lib.check(lib.orbit_op_stem_dw_front(*[_lib.dptr(t) for t in dev], _lib.dptr(yg), _lib.dptr(pg), B, FH, FW,
+                                                  ph // 2, pw // 2, H, W, mid, 1, 1, H, W, _st()), "stem_dw_front (general)")
+            torch.cuda.synchronize()
+        finally:
+            lib.orbit_set_option(b"mbrows_exact", 1), lib.orbit_set_option(b"mbrows_band", 0)
+            lib.orbit_set_option(b"mbconv_rows", prev)
+        assert torch.equal(y.cpu(), yg.cpu()) and torch.equal(pool.cpu(), pg.cpu())
     if rows and FW >= 8:  # the unfused pair of the same library (direct stem kernel + depthwise): identical bits
         ex = torch.empty(B, H, W, mid, device=device)
         y2 = torch.empty(B, H, W, mid, device=device)
