@@ -128,6 +128,8 @@ def decode_frames(paths, out=None, pool=None):
     """JPEG files -> uint8 [n, H, W, 3] (RGB, as PIL decodes them: the input of to_tensor in datasets.py:428-429)."""
     from PIL import Image
     paths = list(paths)
+    if not paths:  # a user without context / target frames: an empty batch, not an IndexError
+        return out if out is not None else np.empty((0, 0, 0, 3), dtype=np.uint8)
 
     def one(i):
         with Image.open(paths[i]) as im:
@@ -176,10 +178,44 @@ class DirectoryTaskSource:
                    "target_labels": t["target_labels"], "target_videos": t["target_videos"], "user": user}
 
 
+class DatasetTaskSource:
+    """Host tasks from a data/datasets.py dataset built with frames="uint8" (the reference-pinned sampler: way, video and clip
+    sampling of reference data/datasets.py:289-336,433-469,540-598), in the layout TaskPrefetcher uploads:
+    context_clips u8 [N,T,H,W,3]; a test-mode target set (a list of videos) is concatenated into target_clips u8 [M,1,H,W,3]
+    with `target_videos` = [(lo, hi)] row ranges and one label per frame; a train-mode target set passes through as clips."""
+
+    def __init__(self, dataset, indices=None):
+        if dataset.frames != "uint8":
+            raise ValueError("DatasetTaskSource needs a dataset built with frames='uint8'")
+        self.dataset = dataset
+        self.indices = list(range(len(dataset)) if indices is None else indices)
+
+    def __len__(self):
+        return len(self.indices)
+
+    def __iter__(self):
+        for i in self.indices:
+            t = self.dataset[i]
+            out = {"context_clips": t["context_clips"], "context_labels": t["context_labels"], "context_paths": t["context_paths"],
+                   "object_list": t["object_list"], "task_id": t["task_id"], "user": t["task_id"]}
+            if isinstance(t["target_clips"], list):
+                ranges, lo = [], 0
+                for frames in t["target_clips"]:
+                    ranges.append((lo, lo + len(frames)))
+                    lo += len(frames)
+                out["target_clips"] = torch.cat(t["target_clips"]).unsqueeze(1)
+                out["target_labels"] = torch.cat([lab.reshape(1).expand(hi - lo) for lab, (lo, hi) in
+                                                  zip(t["target_labels"], ranges)]) if ranges else torch.empty(0, dtype=torch.int64)
+                out["target_videos"], out["target_paths"] = ranges, t["target_paths"]
+            else:
+                out["target_clips"], out["target_labels"], out["target_paths"] = t["target_clips"], t["target_labels"], t["target_paths"]
+            yield out
+
+
 # ---- pinned ring + copy stream ---------------------------------------------------------------------------------------------
 class _Slot:
     def __init__(self):
-        self.pinned, self.dev_u8, self.dev_f32 = {}, {}, {}
+        self.pinned, self.dev_u8, self.dev_f32, self.dev_lab = {}, {}, {}, {}
         self.ready = None      # recorded on the copy stream when the slot's fp32 clips are complete
         self.released = None   # recorded on the consumer's stream when it is done with the slot
         self.task = None
@@ -237,7 +273,13 @@ class TaskPrefetcher:
                     for key, val in task.items():
                         if not (isinstance(val, torch.Tensor) and key.endswith("clips")):
                             if isinstance(val, torch.Tensor) and key.endswith("labels"):
-                                out[key] = val.to(self.device, non_blocking=True)
+                                # labels live in the slot like the clips: the slot's `released` event orders their reuse
+                                # after the consumer's kernels (a fresh allocation here would return to the COPY stream's
+                                # pool when the consumer drops the task, while compute-stream kernels may still read it)
+                                lab = self._buffer(slot.dev_lab, (key, val.dtype), val.shape,
+                                                   lambda n, dt=val.dtype: torch.empty(n, dtype=dt, device=self.device))
+                                lab.copy_(val, non_blocking=True)
+                                out[key] = lab
                             continue
                         if val.dtype != torch.uint8:
                             raise ValueError("TaskPrefetcher: %s must be uint8 frames, got %s" % (key, val.dtype))

@@ -88,6 +88,20 @@ def build_parser():
                         "reference data/datasets.py:139-200). Tasks are the users' (context = clean videos, target = clutter "
                         "videos); frames are decoded with PIL by --num_workers threads, uploaded as 8-bit on a copy stream and "
                         "normalised on the GPU (data/pipeline.TaskPrefetcher) while the previous task runs")
+    # dataset-side flags of the reference (utils/args.py:41-73), used with --data_root
+    p.add_argument("--test_way_method", default="max", choices=["random", "max"])
+    p.add_argument("--test_object_cap", type=int, default=15)
+    p.add_argument("--test_context_shot_method", default="max", choices=["specific", "fixed", "random", "max"])
+    p.add_argument("--test_target_shot_method", default="max", choices=["specific", "fixed", "random", "max"])
+    p.add_argument("--context_shot", type=int, default=5)
+    p.add_argument("--target_shot", type=int, default=2)
+    p.add_argument("--context_video_type", default="clean", choices=["clean"])
+    p.add_argument("--target_video_type", default="clutter", choices=["clutter", "clean"])
+    p.add_argument("--subsample_factor", type=int, default=30)
+    p.add_argument("--test_context_clip_method", default="uniform", choices=["random", "random_200", "max", "uniform"])
+    p.add_argument("--test_target_clip_method", default="random_200", choices=["random", "random_200", "max"])
+    p.add_argument("--num_test_tasks_per_user", type=int, default=1,
+                   help="with --data_root: tasks sampled per test user (reference --num_test_tasks, utils/args.py)")
     p.add_argument("--num_workers", type=int, default=4, help="decode threads (reference data/queues.py:34: 4 in test mode)")
     p.add_argument("--frame_norm_method", default="imagenet", choices=["imagenet", "imagenet_inception", "openai_clip"])
     return p
@@ -109,6 +123,8 @@ def frame_accuracy(logits, label):
 def mean_ci(values):
     """mean and 95 % confidence half-width, as the reference's evaluators report (utils/eval_metrics.py:24-25)."""
     v = np.asarray(values, dtype=np.float64)
+    if len(v) == 0:  # a rank (or a run) that saw no task: no statistic, not a numpy warning
+        return float("nan"), 0.0
     return float(v.mean()), float(1.96 * v.std() / math.sqrt(len(v))) if len(v) > 1 else 0.0
 
 
@@ -296,13 +312,24 @@ class Learner:
         """The reference's test loop (single-step-learner.py:298-375) over a JPEG directory: one task per user, personalise
         on the context clips, then per target VIDEO predict on its frame history, frame accuracy per video averaged per
         task. Decode, 8-bit upload and normalisation of task i+1 overlap the extractor work of task i."""
-        from .data.pipeline import DirectoryTaskSource, ORBITDirectory, TaskPrefetcher
+        import random
+        from concurrent.futures import ThreadPoolExecutor
+        from .data.datasets import UserEpisodicORBITDataset
+        from .data.pipeline import DatasetTaskSource, TaskPrefetcher
         a = self.args
         self.model.set_test_mode(True)
         self.model.frame_norm_method = a.frame_norm_method
-        directory = ORBITDirectory(a.data_root)
-        users = directory.users[self.rank::self.world][:a.num_test_tasks]
-        source = DirectoryTaskSource(directory, a.clip_length, a.num_workers, users=users)
+        # the reference's test queue (data/queues.py:44-46 -> data/datasets.py; pinned by fixture G14): every user's objects,
+        # all their videos, context clips sampled uniformly, 200 random clips per target video
+        pool = ThreadPoolExecutor(max_workers=max(1, int(a.num_workers)))
+        dataset = UserEpisodicORBITDataset(
+            a.data_root, a.test_way_method, a.test_object_cap, (a.test_context_shot_method, a.test_target_shot_method),
+            (a.context_shot, a.target_shot), (a.context_video_type, a.target_video_type), a.subsample_factor,
+            (a.test_context_clip_method, a.test_target_clip_method), a.clip_length, a.frame_size, a.frame_norm_method, [],
+            ([], []), True, False, False, None, frames="uint8", rng=random.Random(a.seed + self.rank), decode_pool=pool)
+        # TaskSampler order (data/samplers.py:24-30, no shuffle): user 0 x num_tasks, user 1 x num_tasks, ...; dealt to ranks
+        order = [u for u in range(len(dataset)) for _ in range(a.num_test_tasks_per_user)]
+        source = DatasetTaskSource(dataset, order[self.rank::self.world][:a.num_test_tasks])
         task_acc, personalise_ms, inference_ms, frames = [], [], [], 0
         t_all = time.perf_counter()
         prefetch = TaskPrefetcher(source, self.device, depth=3, frame_norm_method=a.frame_norm_method)
@@ -326,7 +353,16 @@ class Learner:
                 task_acc.append(float(np.mean(accs)))
                 self.model._reset()
         prefetch.close()
+        pool.shutdown()
         wall = time.perf_counter() - t_all
+        if self.world > 1:  # per-task results of every rank, as test() gathers them
+            import torch.distributed as dist
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, (task_acc, personalise_ms, inference_ms, frames))
+            task_acc = [x for g in gathered for x in g[0]]
+            personalise_ms = [x for g in gathered for x in g[1]]
+            inference_ms = [x for g in gathered for x in g[2]]
+            frames = sum(g[3] for g in gathered)
         stats = {"frame_acc": mean_ci(task_acc), "personalise_ms": mean_ci(personalise_ms),
                  "inference_ms_per_frame": mean_ci(inference_ms), "num_tasks": len(task_acc), "world_size": self.world,
                  "target_frames": frames, "wall_s": wall, "data_root": a.data_root}

@@ -444,6 +444,134 @@ def g13_checkpoint(fsr):
     save("G13_checkpoint", **out)
 
 
+# ---- G14: the dataset side (data/datasets.py), f3 -----------------------------------------------------------------------
+G14_TREE = {  # user -> object -> (frames per clean video, frames per clutter video); < 50 clutter frames = below the target floor
+    "P100": {"mug": ((7, 12, 9, 55), (53, 30)), "keys": ((10, 5), (61,)), "remote": ((8,), (20, 12))},   # remote: no valid target
+    "P200": {"cane": ((6, 6, 6, 6, 6, 6, 6), (50, 57)), "wallet": ((11, 4, 52), (70,)), "bottle": ((9, 13, 3), (52, 51, 10))},
+    "P300": {"lamp": ((5,), (49,))},                                                                  # user with no valid object
+}
+
+
+def g14_write_tree(root, frame_size=16, seed=1414):
+    """root/<user>/<object>/<clean|clutter>/<video>/<video>-NNNNN.jpg, ORBIT's layout (reference data/datasets.py:139-167)."""
+    from PIL import Image
+    rng = np.random.RandomState(seed)
+    files = []
+    for user, objs in G14_TREE.items():
+        for obj, (clean, clutter) in objs.items():
+            base = rng.randint(0, 256, size=(4, 4, 3)).astype(np.float32)
+            for kind, counts in (("clean", clean), ("clutter", clutter)):
+                for v, n in enumerate(counts):
+                    name = "%s--%s--%s--%02d" % (user, obj, kind, v)
+                    d = os.path.join(root, user, obj, kind, name)
+                    os.makedirs(d, exist_ok=True)
+                    for f in range(n):
+                        small = np.clip(base + rng.normal(0, 25, base.shape) + 1.5 * f, 0, 255).astype(np.uint8)
+                        img = Image.fromarray(small).resize((frame_size, frame_size), Image.BILINEAR)
+                        path = os.path.join(d, "%s-%05d.jpg" % (name, f + 1))
+                        img.save(path, quality=85)
+                        files.append(os.path.relpath(path, root))
+    return sorted(files)
+
+
+def g14_datasets():
+    """The reference's own dataset classes on a committed JPEG tree. torchvision is absent offline, so its two transforms that
+    data/datasets.py:429-430 calls are stubbed with their documented arithmetic (to_tensor: HWC uint8 -> CHW float32 / 255;
+    normalize: (x - mean) / std in float32) - everything else (index, sampling, grouping, shuffling) is the reference's code."""
+    import random
+    import tempfile
+    import shutil
+
+    tvf = types.ModuleType("torchvision.transforms.functional")
+
+    def to_tensor(pic):
+        a = torch.from_numpy(np.asarray(pic.convert("RGB") if pic.mode != "RGB" else pic).copy())
+        return a.permute(2, 0, 1).contiguous().to(torch.float32).div(255)
+
+    def normalize(t, mean, std):
+        mean = torch.as_tensor(mean, dtype=t.dtype).view(-1, 1, 1)
+        std = torch.as_tensor(std, dtype=t.dtype).view(-1, 1, 1)
+        return t.clone().sub_(mean).div_(std)
+
+    tvf.to_tensor, tvf.normalize = to_tensor, normalize
+    tv = types.ModuleType("torchvision")
+    tvt = types.ModuleType("torchvision.transforms")
+    tv.transforms, tvt.functional = tvt, tvf
+    sys.modules.update({"torchvision": tv, "torchvision.transforms": tvt, "torchvision.transforms.functional": tvf})
+    from data.datasets import UserEpisodicORBITDataset  # the REFERENCE's module
+
+    tmp = tempfile.mkdtemp(prefix="g14_")
+    root = os.path.join(tmp, "test")
+    files = g14_write_tree(root)
+    blob, offsets = [], [0]
+    for rel in files:
+        b = open(os.path.join(root, rel), "rb").read()
+        blob.append(np.frombuffer(b, dtype=np.uint8))
+        offsets.append(offsets[-1] + len(b))
+    out = {"tree_files": np.array(files), "tree_blob": np.concatenate(blob), "tree_offsets": np.array(offsets, dtype=np.int64)}
+
+    file_no = {f: i for i, f in enumerate(files)}
+
+    def rel(paths):  # frame paths -> row numbers of tree_files
+        return np.array([file_no[os.path.relpath(p, root)] for p in np.asarray(paths).reshape(-1)],
+                        dtype=np.int32).reshape(np.asarray(paths).shape)
+
+    cases = {  # name -> (class, ctor kwargs, seeds, indices)
+        "test_default": (UserEpisodicORBITDataset, dict(way_method="max", object_cap=15, shot_methods=("max", "max"), shots=(5, 2),
+                         video_types=("clean", "clutter"), subsample_factor=3, clip_methods=("uniform", "random_200"),
+                         clip_length=1, test_mode=True, with_caps=False)),
+        "test_T4_max": (UserEpisodicORBITDataset, dict(way_method="max", object_cap=2, shot_methods=("specific", "fixed"), shots=(2, 1),
+                        video_types=("clean", "clutter"), subsample_factor=2, clip_methods=("max", "max"),
+                        clip_length=4, test_mode=True, with_caps=False)),
+        "train_random": (UserEpisodicORBITDataset, dict(way_method="random", object_cap=15, shot_methods=("random", "random"), shots=(5, 2),
+                         video_types=("clean", "clutter"), subsample_factor=4, clip_methods=("uniform", "random"),
+                         clip_length=1, test_mode=False, with_caps=True)),
+        "train_cleanclean_T3": (UserEpisodicORBITDataset, dict(way_method="max", object_cap=15, shot_methods=("fixed", "max"), shots=(3, 2),
+                                video_types=("clean", "clean"), subsample_factor=1, clip_methods=("max", "max"),
+                                clip_length=3, test_mode=False, with_caps=False)),
+        # (ObjectEpisodicORBITDataset.__getitem__ calls sample_task without its task_id argument, reference :637: a TypeError
+        # as written, so there is nothing of it to record)
+        "train_r200_uniform": (UserEpisodicORBITDataset, dict(way_method="random", object_cap=2, shot_methods=("max", "fixed"), shots=(5, 1),
+                               video_types=("clean", "clutter"), subsample_factor=5, clip_methods=("random_200", "uniform"),
+                               clip_length=1, test_mode=False, with_caps=False)),
+    }
+    for name, (cls, kw) in cases.items():
+        ds = cls(root, kw["way_method"], kw["object_cap"], kw["shot_methods"], kw["shots"], kw["video_types"],
+                 kw["subsample_factor"], kw["clip_methods"], kw["clip_length"], 16, "imagenet", [], ([], []), kw["test_mode"],
+                 False, kw["with_caps"], None)
+        out[name + "_users"] = np.array(ds.users)
+        out[name + "_num_objects"] = np.array(ds.num_objects)
+        out[name + "_video_ids"] = np.array([os.path.relpath(p, root) for p, _ in sorted(ds.video2id.items(), key=lambda kv: kv[1])])
+        out[name + "_video_frames"] = np.array([len(ds.vid2frames[p]) for p, _ in sorted(ds.video2id.items(), key=lambda kv: kv[1])])
+        random.seed(1991 + len(name))
+        n_items = len(ds)
+        for rep in range(2):          # two passes: the module-level random stream runs on (with_caps state persists)
+            for idx in range(n_items):
+                t = ds[idx]
+                key = "%s_r%d_i%d" % (name, rep, idx)
+                out[key + "_objects"] = np.array(t["object_list"])
+                out[key + "_context_paths"] = rel(t["context_paths"])
+                out[key + "_context_labels"] = t["context_labels"]
+                if rep == 0 and idx == 0:
+                    out[key + "_context_clips"] = t["context_clips"]
+                out[key + "_context_clips_sum"] = t["context_clips"].double().sum(dim=(1, 2, 3, 4))
+                if kw["test_mode"]:
+                    out[key + "_target_videos"] = np.array(len(t["target_paths"]))
+                    for v, (fr, pa, la) in enumerate(zip(t["target_clips"], t["target_paths"], t["target_labels"])):
+                        out[key + "_target%d_paths" % v] = rel(pa)
+                        out[key + "_target%d_label" % v] = la
+                        out[key + "_target%d_frames_sum" % v] = fr.double().sum(dim=(1, 2, 3))
+                        if v == 0 and rep == 0 and idx == 0:
+                            out[key + "_target0_frames"] = fr
+                else:
+                    out[key + "_target_paths"] = rel(t["target_paths"])
+                    out[key + "_target_labels"] = t["target_labels"]
+                    out[key + "_target_clips_sum"] = t["target_clips"].double().sum(dim=(1, 2, 3, 4))
+    out["case_names"] = np.array(list(cases))
+    shutil.rmtree(tmp)
+    save("G14_datasets", **out)
+
+
 def g7_utils():
     from data.utils import attach_frame_history, get_batch_indices
     frames = torch.arange(6 * 3 * 2 * 2, dtype=torch.float32).reshape(6, 3, 2, 2)
@@ -476,6 +604,7 @@ def main():
     g9_lite_efficientnet(fsr)
     g11_finetuner(fsr)
     g13_checkpoint(fsr)
+    g14_datasets()
 
 
 if __name__ == "__main__":
