@@ -109,6 +109,14 @@ int orbit_device_count(void);
  *                   deterministic reduce), 0 = never; "conv_splitk_tiles": the tile-count threshold (0 = 320)
  *   "conv_stem_fast", "conv_early_sc", "conv_epi_batch"  1 (default) / 0: interior fast path of the NCHW stem gather;
  *                   epilogue scale / shift requested before the K loop; batched epilogue output pass
+ *  pointwise convolution as a register GEMM (csrc/pw_rgemm.hip):
+ *   "conv_rgemm"    1 (default) = the barrier-free 16x16x4-MFMA register GEMM on fragment-packed weights serves the stride-1
+ *                   pointwise convs (Cin % 16 == 0) for which it is a gain inside the network: long-K projections of maps under
+ *                   16 384 pixels to more than 256 channels (EfficientNet-B0's 1152 -> 320 at 7x7); 0 = never; 2 = every conv it
+ *                   supports; 16 + mask = chosen classes (1 projections to <= 128 channels, 2 expansions, 4 the default class,
+ *                   8 the rest) for A/B runs
+ *   "conv_rgemm_t", "conv_rgemm_wk"  0 (default) = the launcher's cost model picks the 16-channel tiles per wave (3..8) and the
+ *                   K slices per block (1, 2, 4); other values force them (sweeps: tools/conv_bench.py)
  *  prototype head (csrc/head.hip):
  *   "head_stream"   2 (default) = the streaming distance kernel (rows requested before the weight staging, 8 waves x 2 rows)
  *                   for launches with >= 64 query rows, 1 = always, 0 = never

@@ -61,6 +61,8 @@ __device__ __forceinline__ unsigned fdiv(unsigned n, FastDiv f) { return (__umul
 struct ConvDesc {
     const float* x;         // NHWC activations, or NCHW frames when x_nchw
     const float* w_packed;  // [CoutPad][KT], K = (kh, kw, ci) with ci fastest, zero padded
+    const float* w_frag = nullptr;  // the same filter in MFMA-fragment order (conv_frag_floats / conv_frag_pack_weights) or
+                                    // nullptr: pointwise convs then stay on the LDS-tiled kernel (csrc/pw_rgemm.hip)
     float* y;               // NHWC
     const float* scale;     // [Cout] or nullptr
     const float* shift;     // [Cout] or nullptr
@@ -103,6 +105,12 @@ size_t conv_packed_floats(int Cin, int Cout, int KH, int KW, int x_nchw);
 int conv_pack_weights(const float* w_oihw, float* w_packed, int Cin, int Cout, int KH, int KW,
                       int x_nchw, hipStream_t s);
 int launch_conv(const ConvDesc& d, hipStream_t s);
+// pointwise convs as a register GEMM on fragment-packed weights (csrc/pw_rgemm.hip; option conv_rgemm); launch_conv routes to it
+size_t conv_frag_floats(int Cin, int Cout, int KH, int KW, int x_nchw);  // 0: this filter has no fragment-packed form
+int conv_frag_pack_weights(const float* w_oihw, float* w_frag, int Cin, int Cout, hipStream_t s);
+bool pw_rgemm_supported(const ConvDesc& d);
+bool pw_rgemm_preferred(const ConvDesc& d);  // where it measured faster than the LDS-tiled kernel (conv_rgemm = 1)
+int launch_pw_rgemm(const ConvDesc& d, hipStream_t s);
 // narrow pointwise projections (Cout <= 32, high-resolution maps) as an HBM stream without an LDS stage for the pixels
 // (csrc/pw_narrow.hip; option pw_narrow); launch_conv routes to it
 bool pw_narrow_supported(const ConvDesc& d);

@@ -819,7 +819,10 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     ORBIT_REQUIRE(d.Cout % 4 == 0, "conv: Cout %% 4 != 0 (Cout=%d): the epilogue writes float4 rows", d.Cout);
     const bool pw = !d.x_nchw && d.KH == 1 && d.KW == 1 && d.pad_t == 0 && d.pad_l == 0;
     if (d.stats_blocks) *d.stats_blocks = 0;
+    const int rg = get_option("conv_rgemm");
+    if (rg == 2 && pw_rgemm_supported(d)) return launch_pw_rgemm(d, s);
     if (pw && !d.y_raw && pw_narrow_supported(d)) return launch_pw_narrow(d, s);
+    if (rg && pw_rgemm_supported(d) && (rg == 2 || pw_rgemm_preferred(d))) return launch_pw_rgemm(d, s);
     ORBIT_REQUIRE(!d.gate || (!d.x_nchw && !d.pool2), "conv: the squeeze-excite gate needs the NHWC path without fused pooling");
     const ConvPackGeom g = conv_pack_geom(d.Cin, d.Cout, d.KH, d.KW, d.x_nchw);
     ConvParams p;
@@ -966,11 +969,14 @@ int orbit_op_conv2d(const float* x, int x_nchw, const float* w, float* y, const 
     ORBIT_REQUIRE(KH > 0 && KW > 0 && stride > 0, "op_conv2d: bad kernel geometry");
     hipStream_t s = (hipStream_t)stream;
     float* wp = nullptr;
-    const size_t nfl = conv_packed_floats(Cin, Cout, KH, KW, x_nchw);
-    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&wp), nfl * sizeof(float), s));
+    const size_t nfl = (conv_packed_floats(Cin, Cout, KH, KW, x_nchw) + 63) & ~(size_t)63;
+    const size_t ffl = conv_frag_floats(Cin, Cout, KH, KW, x_nchw);
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&wp), (nfl + ffl) * sizeof(float), s));
     int rc = conv_pack_weights(w, wp, Cin, Cout, KH, KW, x_nchw, s);
+    if (rc == ORBIT_OK && ffl) rc = conv_frag_pack_weights(w, wp + nfl, Cin, Cout, s);
     if (rc == ORBIT_OK) {
         ConvDesc d;
+        d.w_frag = ffl ? wp + nfl : nullptr;
         d.x = x, d.w_packed = wp, d.y = y, d.scale = scale, d.shift = shift, d.residual = residual;
         d.gate = gate, d.B = B, d.H = H, d.W = W, d.Cin = Cin, d.Cout = Cout, d.KH = KH, d.KW = KW;
         d.stride = stride, d.pad_t = pad_top, d.pad_l = pad_left, d.Ho = Ho, d.Wo = Wo, d.act = act;

@@ -43,7 +43,8 @@ struct PackJob {
     const float* src;
     float* dst;
     int kind;  // 0 conv OIHW -> [cout_pad][KT] (vector mode), 1 same in stem mode, 2 depthwise [C][1][K][K] -> [K][K][C],
-               // 3 transpose [rows][cols] -> [cols][rows], 4 dgrad filter (rotated, channels swapped) -> packed
+               // 3 transpose [rows][cols] -> [cols][rows], 4 dgrad filter (rotated, channels swapped) -> packed,
+               // 5 pointwise filter [Cout][Cin] -> MFMA-fragment order [tile16][chunk16][lane][4] (csrc/pw_rgemm.hip; KT = Cin / 16)
     int Cin, Cout, KH, KW, cin_pad, KT, cout_pad;
     unsigned total;
 };
@@ -64,6 +65,12 @@ static __global__ __launch_bounds__(256) void pack_jobs_kernel(const PackJob* __
             const int r = (int)(i / (unsigned)j.Cout), c = (int)(i % (unsigned)j.Cout);
             j.dst[(size_t)c * j.Cin + r] = j.src[i];
             continue;
+        } else if (j.kind == 5) {
+            const int e = (int)(i & 3), lane = (int)((i >> 2) & 63);
+            const unsigned tc = i >> 8;
+            const int c = (int)(tc % (unsigned)j.KT), tile = (int)(tc / (unsigned)j.KT);
+            const int n = tile * 16 + (lane & 15), k = c * 16 + 4 * (lane >> 4) + e;
+            if (n < j.Cout) v = j.src[(size_t)n * j.Cin + k];
         } else {  // dgrad: n = ci (output channel of the dgrad conv), k = (tap', co)
             const int n = (int)(i / (unsigned)j.KT), k = (int)(i % (unsigned)j.KT);
             const int tap = k / j.cin_pad, co = k % j.cin_pad;
@@ -98,6 +105,7 @@ struct Op {
     int act = ORBIT_ACT_NONE, pool2 = 0, x_nchw = 0, use_gate = 0;
     int weight = -1, bias = -1, bn = -1;  // param / BN indices
     size_t packed_off = 0;                // into the packed-weight pool
+    size_t frag_off = SIZE_MAX;           // OP_CONV: the filter in MFMA-fragment order (csrc/pw_rgemm.hip) or SIZE_MAX
     int se_w1 = -1, se_b1 = -1, se_w2 = -1, se_b2 = -1, R = 0;
     // OP_MBFRONT in its stem form (csrc/mbconv.hip): frame size, stem padding, packed [mid][32] stem filter
     bool stem = false;
@@ -357,6 +365,11 @@ struct orbit_extractor {
         o.weight = index.count(wkey) ? index[wkey] : add_param(wkey, (size_t)Cout * Cin * K * K);
         o.packed_off = packed_floats;
         packed_floats += conv_packed_floats(Cin, Cout, K, K, x_nchw);
+        if (stride == 1 && pad_t == 0 && pad_l == 0 && !pool2 && conv_frag_floats(Cin, Cout, K, K, x_nchw)) {
+            packed_floats = (packed_floats + 63) & ~(size_t)63;
+            o.frag_off = packed_floats;
+            packed_floats += conv_frag_floats(Cin, Cout, K, K, x_nchw);
+        }
         const int oh = pool2 ? Ho / 2 : Ho, ow = pool2 ? Wo / 2 : Wo;
         note_buf(out, (size_t)oh * ow * Cout);
         macs += (double)(pool2 ? oh * 2 : Ho) * (pool2 ? ow * 2 : Wo) * Cout * Cin * K * K;

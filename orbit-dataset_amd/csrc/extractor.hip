@@ -456,6 +456,9 @@ int orbit_extractor_finalize(orbit_extractor_t* fe, orbit_stream_t stream) {
                 const ConvPackGeom g = conv_pack_geom(o.Cin, o.Cout, o.KH, o.KW, o.x_nchw);
                 job(o.x_nchw ? 1 : 0, fe->d_pool + fe->params[o.weight].off, fe->d_packed + o.packed_off, o.Cin, o.Cout, o.KH,
                     o.KW, g.cin_pad, g.kt, g.cout_pad, (size_t)g.cout_pad * g.kt);
+                if (o.frag_off != SIZE_MAX)
+                    job(5, fe->d_pool + fe->params[o.weight].off, fe->d_packed + o.frag_off, o.Cin, o.Cout, 1, 1, 0, o.Cin / 16,
+                        0, conv_frag_floats(o.Cin, o.Cout, 1, 1, 0));
             } else if (o.kind == OP_DWCONV) {
                 job(2, fe->d_pool + fe->params[o.weight].off, fe->d_packed + o.packed_off, o.Cin, 0, o.KH, o.KH, 0, 0, 0,
                     (size_t)o.Cin * o.KH * o.KH);
@@ -618,6 +621,7 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
                 }
                 ConvDesc d;
                 d.x = buf(o.in), d.w_packed = fe->d_packed + o.packed_off, d.y = buf(o.out);
+                d.w_frag = o.frag_off != SIZE_MAX ? fe->d_packed + o.frag_off : nullptr;
                 d.scale = o.bn >= 0 ? scale + fe->bns[o.bn].fold_off : nullptr;
                 d.shift = o.bn >= 0 ? shift + fe->bns[o.bn].fold_off : nullptr;
                 d.residual = o.res >= 0 ? buf(o.res) : nullptr;

@@ -59,6 +59,9 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"conv_stem_fast", "ORBIT_CONV_STEM_FAST", 1, false},
                              {"conv_early_sc", "ORBIT_CONV_EARLY_SC", 1, false},
                              {"conv_epi_batch", "ORBIT_CONV_EPI_BATCH", 1, false},
+                             {"conv_rgemm", "ORBIT_CONV_RGEMM", 1, false},
+                             {"conv_rgemm_t", "ORBIT_CONV_RGEMM_T", 0, false},
+                             {"conv_rgemm_wk", "ORBIT_CONV_RGEMM_WK", 0, false},
                              {"head_lds", "ORBIT_HEAD_LDS", 1, false},
                              {"head_stream", "ORBIT_HEAD_STREAM", 2, false}};
 static Option* find_option(const char* name) {

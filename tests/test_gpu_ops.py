@@ -551,6 +551,63 @@ def test_conv_pointwise_narrow(lib, device, Cin, Cout, HW, gated, res, act):
     assert torch.equal(got, igemm)
 
 
+RGEMM_CASES = [  # (Cin, Cout, (H, W), B, gated, residual, act, T, wk)   T / wk = 0: the launcher's plan
+    (80, 480, (14, 14), 5, False, False, 2, 0, 0),     # an expansion: SiLU epilogue, odd chunk count (5)
+    (480, 80, (14, 14), 5, True, True, 0, 0, 0),       # a gated projection with skip connection, Cout = 5 tiles of 16
+    (144, 40, (28, 28), 3, True, False, 0, 0, 0),      # Cout = 40: the last 16-channel tile is half full
+    (672, 112, (14, 14), 3, True, True, 0, 7, 4),      # 7 tiles per wave, four K slices (11 + 11 + 11 + 9 chunks)
+    (1152, 320, (7, 7), 7, True, False, 0, 4, 4),      # 7x7: 343 pixels = 10 tiles of 32 + 23 (ragged M, clamped rows)
+    (1152, 192, (7, 7), 2, True, True, 0, 3, 2),       # two K slices, two pixel tiles per block
+    (320, 1280, (7, 7), 3, False, False, 2, 5, 1),     # the head conv
+    (320, 1280, (7, 7), 3, False, False, 2, 8, 2),     # 8 tiles per wave (two resident waves per SIMD)
+    (16, 44, (9, 5), 2, False, False, 1, 0, 0),        # one chunk; Cout % 16 = 12
+    (32, 64, (3, 3), 1, True, False, 0, 6, 1),         # fewer pixels than one tile, two chunks
+    (160, 36, (11, 13), 4, False, True, 2, 3, 4),      # 10 chunks in four slices of one parity: 3 + 3 + 3 + 1
+]
+
+
+@pytest.mark.parametrize("case", RGEMM_CASES, ids=["%dto%d_%dx%d_t%dk%d" % (c[0], c[1], c[2][0], c[2][1], c[7], c[8]) for c in RGEMM_CASES])
+def test_conv_pointwise_register_gemm(lib, device, case):
+    """csrc/pw_rgemm.hip (pointwise convs as a barrier-free register GEMM on fragment-packed weights, transposed 16x16x4 MFMAs,
+    float4 epilogue, K slices summed in slice order) against the fp32 reference and the LDS-tiled kernel: every EfficientNet
+    epilogue form, ragged pixel counts, partly filled channel tiles, odd / even chunk counts, forced tiles-per-wave and K splits."""
+    Cin, Cout, (H, W), B, gated, res, act, T, wk = case
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    kw = dict(scale=torch.rand(Cout, generator=g) + 0.5, shift=torch.randn(Cout, generator=g) * 0.1,
+              residual=torch.randn(B, Cout, H, W, generator=g) if res else None,
+              gate=torch.rand(B, Cin, generator=g) if gated else None, act=act)
+    want = ref_conv(x.double(), w.double(), 1, 0, 0, H, W, **{k: (v.double() if torch.is_tensor(v) else v) for k, v in kw.items()})
+    prev = lib.orbit_get_option(b"conv_rgemm")
+    try:
+        lib.orbit_set_option(b"conv_rgemm", 2)
+        lib.orbit_set_option(b"conv_rgemm_t", T)
+        lib.orbit_set_option(b"conv_rgemm_wk", wk)
+        lib.orbit_prof_enable(1)
+        got = run_conv(lib, device, x, w, 1, 0, 0, H, W, **kw)
+        lib.orbit_prof_enable(0)
+        lib.orbit_prof_collect(None, None, None)
+        name = ctypes.create_string_buffer(48)
+        lib.orbit_prof_variant(0, name, None, None, None, None)
+        assert name.value.decode().startswith("conv_pw_rgemm<"), name.value  # the launch did take the register GEMM
+        if T:
+            assert name.value.decode().startswith("conv_pw_rgemm<%d," % T)
+        again = run_conv(lib, device, x, w, 1, 0, 0, H, W, **kw)
+        lib.orbit_set_option(b"conv_rgemm", 0)
+        igemm = run_conv(lib, device, x, w, 1, 0, 0, H, W, **kw)
+    finally:
+        lib.orbit_prof_enable(0)
+        lib.orbit_set_option(b"conv_rgemm", prev)
+        lib.orbit_set_option(b"conv_rgemm_t", 0)
+        lib.orbit_set_option(b"conv_rgemm_wk", 0)
+    assert not torch.isnan(got).any()
+    tol = 2e-5 * max(1.0, want.abs().max().item())
+    assert (got.double() - want).abs().max().item() < tol
+    assert (igemm.double() - want).abs().max().item() < tol
+    assert torch.equal(got, again)  # deterministic (K slices are added in slice order)
+
+
 def _conv_random_cases(lib, device, rnd):
     for case in range(40):
         Cin = rnd.choice([4, 8, 12, 16, 24, 40, 48, 64, 80, 96, 144, 160])
