@@ -231,7 +231,7 @@ class TaskPrefetcher:
     slot: they stay valid until the NEXT task is requested (then the slot is handed back: an event on the caller's stream
     makes the copy stream wait for the kernels that still read it)."""
 
-    def __init__(self, source, device, depth=3, frame_norm_method="imagenet"):
+    def __init__(self, source, device, depth=3, frame_norm_method="imagenet", consumer_streams=()):
         from .. import _lib
         _lib.require_gpu()
         self._lib = _lib
@@ -240,6 +240,10 @@ class TaskPrefetcher:
         self.depth = max(2, int(depth))
         self.slots = [_Slot() for _ in range(self.depth)]
         self.copy_stream = torch.cuda.Stream(device=self.device)
+        # further streams on which the consumer reads a slot's tensors (a recogniser in pipelined mode, overlap_query = 2, runs
+        # the query pass on its own second stream and does not join it): a slot is only refilled once EVERY such stream has
+        # passed the point at which the next task was requested. A callable is evaluated at release time.
+        self.consumer_streams = consumer_streams
         self.free, self.full = queue.Queue(), queue.Queue()
         for s in self.slots:
             self.free.put(s)
@@ -266,8 +270,8 @@ class TaskPrefetcher:
                 slot = self.free.get()
                 if slot is None:
                     return
-                if slot.released is not None:
-                    self.copy_stream.wait_event(slot.released)  # the consumer's kernels that read the slot's last task
+                for ev in slot.released or ():
+                    self.copy_stream.wait_event(ev)  # the consumer's kernels that read the slot's last task
                 out = dict(task)
                 with torch.cuda.stream(self.copy_stream):
                     for key, val in task.items():
@@ -291,8 +295,8 @@ class TaskPrefetcher:
                         if not val.is_pinned():
                             host = self._buffer(slot.pinned, key, val.shape,
                                                 lambda n: torch.empty(n, dtype=torch.uint8).pin_memory())
-                            if slot.released is not None:
-                                slot.released.synchronize()  # the previous upload from this pinned buffer has long finished;
+                            for ev in slot.released or ():
+                                ev.synchronize()             # the previous upload from this pinned buffer has long finished;
                             host.copy_(val)                  # (host-side wait only matters if the consumer never advanced)
                         u8 = self._buffer(slot.dev_u8, key, val.shape,
                                           lambda n: torch.empty(n, dtype=torch.uint8, device=self.device))
@@ -314,9 +318,13 @@ class TaskPrefetcher:
 
     def _release_current(self):
         if self.current is not None:
-            ev = torch.cuda.Event()
-            ev.record(torch.cuda.current_stream(self.device))
-            self.current.released = ev
+            extra = self.consumer_streams() if callable(self.consumer_streams) else self.consumer_streams
+            events = []
+            for st in [torch.cuda.current_stream(self.device)] + [s for s in (extra or ()) if s is not None]:
+                ev = torch.cuda.Event()
+                ev.record(st)
+                events.append(ev)
+            self.current.released = events
             self.current.task = None
             self.free.put(self.current)
             self.current = None

@@ -273,8 +273,15 @@ class GradientBucket:
             self._build()
         if self._active():
             if self.p2p is not None:
-                self.p2p.raise_on_error()  # covers the previous step's exchange (non-blocking read of a host-mapped word)
                 self.p2p(self.flat)
+                # A peer that stalls poisons this bucket with NaN and raises the error word when the kernel gives up. The
+                # word is checked AFTER the exchange has run (one event wait per optimizer step; the learner synchronises
+                # per task anyway), so a timeout is an exception here - before optimizer.step() can write NaN into the
+                # parameters and the optimizer state (round 3 only looked at the previous step's exchange at this point).
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(self.flat.device))
+                done.synchronize()
+                self.p2p.raise_on_error()
             else:
                 dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 
@@ -330,31 +337,35 @@ class RunningStatSync:
 
     def begin(self):
         self.start = [b.detach().clone() for b in self.stats]
-        self.start_count = [int(c.item()) for c in self.counters[:1]]  # all layers of a network advance together
+        # the window's first forward count stays ON the device (all layers of a network advance together): begin() and sync()
+        # run once per optimizer step inside a host-bound loop, and a .item() here was a device synchronisation each time
+        self.start_count = self.counters[0].detach().clone() if self.counters else None
 
     def sync(self):
         if not self.stats or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
             return
-        n_local = (int(self.counters[0].item()) - self.start_count[0]) if self.counters else 0
-        a = 1.0 - self.momentum
-        flat = torch.zeros(sum(b.numel() for b in self.stats) + 1, device=self.stats[0].device, dtype=torch.float32)
-        if n_local > 0:
-            an = a ** n_local
-            off = 0
-            for b, r0 in zip(self.stats, self.start):
-                k = b.numel()
-                flat[off:off + k] = ((b.reshape(-1) - an * r0.reshape(-1)) / (1.0 - an)) * n_local  # n_k * s_k
-                off += k
-            flat[-1] = n_local
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-        N = int(round(float(flat[-1].item())))
-        if N == 0:
-            return
-        aN = a ** N
+        import math
+        dev = self.stats[0].device
+        log_a = math.log(1.0 - self.momentum)
+        n = ((self.counters[0] - self.start_count).to(torch.float32) if self.counters
+             else torch.zeros((), device=dev, dtype=torch.float32)).reshape(1)            # forwards this rank ran, on the device
+        an = torch.exp(n * log_a)
+        live = n > 0
+        denom = torch.where(live, 1.0 - an, torch.ones_like(an))
+        cur = torch.cat([b.reshape(-1).to(torch.float32) for b in self.stats])
+        r0 = torch.cat([b.reshape(-1).to(torch.float32) for b in self.start])
+        s_k = torch.where(live, (cur - an * r0) / denom * n, torch.zeros_like(cur))         # n_k * s_k (0 for an idle rank)
+        flat = torch.cat([s_k, n])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)                       # ONE flat message, counters included
+        N = flat[-1:]
+        aN = torch.exp(N * log_a)
+        new = aN * r0 + (1.0 - aN) * flat[:-1] / N.clamp(min=1.0)
+        new = torch.where(N > 0, new, cur)                                                  # nobody ran a forward: unchanged
         off = 0
-        for b, r0 in zip(self.stats, self.start):
+        for b in self.stats:
             k = b.numel()
-            b.copy_((aN * r0.reshape(-1) + (1.0 - aN) * flat[off:off + k] / N).view_as(b))
+            b.copy_(new[off:off + k].view_as(b))
             off += k
+        extra = torch.round(N - n).to(torch.int64)
         for c in self.counters:
-            c += N - n_local
+            c += extra.reshape(c.shape) if c.dim() == 0 else extra

@@ -47,7 +47,8 @@ class PrototypicalClassifier(nn.Module):
     # process, guarded by a lock; entries hold the label tensor only WEAKLY (round 2 pinned up to 256 of them alive) and
     # die with it, so a recycled storage address cannot hit a stale entry
     _unique_cache = {}
-    _unique_lock = __import__("threading").Lock()
+    _unique_lock = __import__("threading").RLock()  # re-entrant: `drop` below is a weakref finaliser and may fire on the thread
+                                                    # that already holds the lock (a GC pass inside the locked section)
 
     @classmethod
     def unique_labels(cls, context_labels, device):

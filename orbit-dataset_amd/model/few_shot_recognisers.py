@@ -441,9 +441,16 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
                     logits = self.classifier.predict(self._pool_features(target_features))
                     self.logits_ready = torch.cuda.Event()
                     self.logits_ready.record(side)
-                # the class weights are dropped (and their memory handed back to the caller's stream) by _reset(): keep
-                # them alive for the kernels queued on the second stream
-                for t in (getattr(self.classifier, "weight", None), getattr(self.classifier, "bias", None)):
+                # Everything the second stream's kernels still read was allocated on the caller's stream and is dropped by
+                # _reset() / the next personalise() (or, for clips a TaskPrefetcher slot owns, handed back when the next task
+                # is requested) while those kernels may still be queued: the class weights, the FiLM vectors of this task
+                # (film_dict views and the generator's gamma / beta they are cut from) and the query clips. record_stream
+                # makes the caching allocator wait for the second stream before it reuses their memory.
+                held = [getattr(self.classifier, "weight", None), getattr(self.classifier, "bias", None), target_clips]
+                if self.film_dict:
+                    held += list(self.film_dict.values())
+                held += list(getattr(self.film_generator, "last_film", None) or ())
+                for t in held:
                     if isinstance(t, torch.Tensor) and t.is_cuda:
                         t.record_stream(side)
                 logits.record_stream(main)

@@ -305,11 +305,15 @@ def test_edge_empty_query_and_ragged_batches(device):
     assert tuple(model.predict(one["target_clips"].cuda()).shape) == (4, 1)
 
 
-def test_pipelined_overlap_is_bit_identical_over_consecutive_tasks(device):
+@pytest.mark.parametrize("adapt", [False, True])
+def test_pipelined_overlap_is_bit_identical_over_consecutive_tasks(device, adapt):
     """overlap_query = 2: extractor + head of predict() on the second stream, not joined, so the next task's personalise()
     starts while this task's query pass runs. Same kernels on the same inputs: bit-identical logits for every task of a
-    back-to-back sequence (class weights of task i must survive _reset() until the second stream has used them)."""
-    model = SingleStepFewShotRecogniser("resnet18", False, "proto", 1, 16, False, 16, 1.0)
+    back-to-back sequence. What the second stream still reads must survive _reset() / the next personalise() on the caller's
+    stream: the class weights and, with adapt_features (CNAPs / FiLM), this task's generated gamma / beta vectors - between
+    the tasks the caller's stream allocates and overwrites scratch of the same sizes, so a block handed back too early shows
+    up as different logits."""
+    model = SingleStepFewShotRecogniser("resnet18", adapt, "proto", 1, 16, False, 16, 1.0)
     synthetic.init_parameters_(model)
     model._set_device(device)
     model._send_to_device()
@@ -325,6 +329,9 @@ def test_pipelined_overlap_is_bit_identical_over_consecutive_tasks(device):
                     model.personalise(t["context_clips"], t["context_labels"])
                     outs.append(model.predict(t["target_clips"]))
                     model._reset()
+                    if mode == 2:  # churn the caller stream's allocator with blocks of the freed sizes
+                        junk = [torch.full((n,), float("nan"), device=device) for n in (64, 128, 256, 512, 5 * 512, 4800)]
+                        del junk
         torch.cuda.synchronize()
         model.overlap_query = False
         return [o.clone() for o in outs]
