@@ -70,7 +70,10 @@ def g1_head():
     cases = {}
     g = torch.Generator().manual_seed(101)
     specs = [("w5_d512", 50, 40, 512, list(range(5))), ("w10_d96", 50, 40, 96, list(range(10))),
-             ("noncontig_d96", 30, 20, 96, [3, 7, 9]), ("oneshot_d64", 5, 12, 64, list(range(5)))]
+             ("noncontig_d96", 30, 20, 96, [3, 7, 9]), ("oneshot_d64", 5, 12, 64, list(range(5))),
+             # the extractor width of the headline (efficientnet_b0: D = 1280), 5- and 10-way (BASELINE configs 3 and 5);
+             # appended so that the generator state of the four cases above, and with it their recorded values, is unchanged
+             ("w5_d1280", 50, 40, 1280, list(range(5))), ("w10_d1280", 50, 40, 1280, list(range(10)))]
     for name, N, M, D, values in specs:
         way = len(values)
         cls = torch.arange(way).repeat_interleave(N // way)[torch.randperm(N, generator=g)]

@@ -74,3 +74,23 @@ def test_bench_other_modes_run():
     assert "resnet18" in d["config"]["workload"] and d["value"] > 0 and "cpu_baseline" not in d or d["cpu_baseline"] is None
     t = _run(["--mode", "lite_train", "--workload", "resnet18_84", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"])
     assert "LITE" in t["config"]["workload"] and t["ms_per_step"] > 0
+
+
+def test_bench_config5_command_contract():
+    """BASELINE config 5 is `bench.py --gpus 8 --mode lite_train --way 10 --tasks-per-rank 8`: 10-way efficientnet_b0 @224 LITE,
+    64 tasks per optimizer step sharded over 8 ranks, one all-reduce of the flat gradient bucket per step (reference
+    single-step-learner.py:162-166,231). Eight ranks share this box's one GPU through the gloo self-test backend; the line
+    must say n_gpus 8 / tasks_per_step 64 and that the ranks shared a device (no scaling claim is made from it)."""
+    env = dict(os.environ, ORBIT_BENCH_BACKEND="gloo", ORBIT_BENCH_SETTLE="0")
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--mode", "lite_train", "--way", "10",
+                          "--tasks-per-rank", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
+                         capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["config"]["tasks_per_step"] == 64 and d["ranks_share_gpus"] is True
+    assert "10-way" in d["config"]["workload"] and "LITE" in d["config"]["workload"] and "gradient all-reduce" in d["config"]["workload"]
+    assert d["scaling"] == "weak" and d["ms_per_step"] > 0 and d["value"] > 0
+    assert 0.0 <= d["frame_accuracy"] <= 1.0

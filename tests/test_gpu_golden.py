@@ -27,7 +27,7 @@ def gold(name):
             for k, v in np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False).items()}
 
 
-@pytest.mark.parametrize("case", ["w5_d512", "w10_d96", "noncontig_d96", "oneshot_d64"])
+@pytest.mark.parametrize("case", ["w5_d512", "w10_d96", "noncontig_d96", "oneshot_d64", "w5_d1280", "w10_d1280"])
 @pytest.mark.parametrize("dist", ["euclidean", "cosine"])
 @pytest.mark.parametrize("scale", [1, 32])
 def test_G1_head(device, case, dist, scale):

@@ -19,7 +19,7 @@ def gold(name):
             for k, v in np.load(os.path.join(GOLD, name + ".npz"), allow_pickle=False).items()}
 
 
-HEAD_CASES = ["w5_d512", "w10_d96", "noncontig_d96", "oneshot_d64"]
+HEAD_CASES = ["w5_d512", "w10_d96", "noncontig_d96", "oneshot_d64", "w5_d1280", "w10_d1280"]
 
 
 @pytest.mark.parametrize("case", HEAD_CASES)
