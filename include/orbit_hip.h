@@ -111,9 +111,9 @@ int orbit_device_count(void);
  *                   epilogue scale / shift requested before the K loop; batched epilogue output pass
  *  pointwise convolution as a register GEMM (csrc/pw_rgemm.hip):
  *   "conv_rgemm"    1 (default) = the barrier-free 16x16x4-MFMA register GEMM on fragment-packed weights serves the stride-1
- *                   pointwise convs (Cin % 16 == 0) for which it is a gain inside the network: long-K projections of maps under
- *                   16 384 pixels to more than 256 channels (EfficientNet-B0's 1152 -> 320 at 7x7); 0 = never; 2 = every conv it
- *                   supports; 16 + mask = chosen classes (1 projections to <= 128 channels, 2 expansions, 4 the default class,
+ *                   pointwise convs (Cin % 16 == 0) for which it is a gain inside the network: projections of at most 8x8 maps
+ *                   from >= 512 to more than 256 channels (EfficientNet-B0's 1152 -> 320 at 7x7; a rule on the layer, not on the
+ *                   batch, so a frame's bits do not depend on the batch it arrives in); 0 = never; 2 = every conv it supports; 16 + mask = chosen classes (1 projections to <= 128 channels, 2 expansions, 4 the default class,
  *                   8 the rest) for A/B runs
  *   "conv_rgemm_t", "conv_rgemm_wk"  0 (default) = the launcher's cost model picks the 16-channel tiles per wave (3..8) and the
  *                   K slices per block (1, 2, 4); other values force them (sweeps: tools/conv_bench.py)
