@@ -388,7 +388,9 @@ __device__ __forceinline__ int head_xcd_remap(int bid, int nblk) {
 
 // (Forcing 8 waves per SIMD - launch_bounds(512, 8): 64 VGPRs, four blocks per CU = 1 024 slots for the 832 blocks of the
 // 64-task launch - spills 16 dwords per lane and measured 38.6 us against 19.5 us: the 79-register form stays.)
-template <int NW, int R, int NI>
+// LEAN: Euclidean distance, no argmax output - the per-row cosine norms and the running best class leave the register file
+// (79 -> <= 72 VGPRs: seven waves per SIMD, so four 7-wave blocks share a CU)
+template <int NW, int R, int NI, bool LEAN = false>
 __global__ __launch_bounds__(NW * 64) void proto_predict_stream_kernel(
     const float* __restrict__ Q, const float* __restrict__ W, const float* __restrict__ bias, int M, int D, int C,
     float logit_scale, int cosine, float* __restrict__ logits, int32_t* __restrict__ argmax, int blocks_per_task) {
@@ -411,7 +413,7 @@ __global__ __launch_bounds__(NW * 64) void proto_predict_stream_kernel(
     for (int i = tid * 4; i < C * D; i += NW * 256) *reinterpret_cast<float4*>(Ws + i) = *reinterpret_cast<const float4*>(Wt + i);
     __syncthreads();
     float* wn = Ws + (size_t)C * D;
-    if (cosine) {
+    if (!LEAN && cosine) {
         for (int c = wave; c < C; c += NW) {
             float s = 0.f;
             for (int d = lane * 4; d < D; d += 256) {
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(NW * 64) void proto_predict_stream_kernel(
     int best_c[R];
 #pragma unroll
     for (int r = 0; r < R; ++r) best[r] = -INFINITY, best_c[r] = 0, qn2[r] = 0.f;
-    if (cosine) {
+    if (!LEAN && cosine) {
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float qq = 0.f;
@@ -454,20 +456,20 @@ __global__ __launch_bounds__(NW * 64) void proto_predict_stream_kernel(
 #pragma unroll
             for (int r = 0; r < R; ++r) acc[r] += x[r][i].x * w.x + x[r][i].y * w.y + x[r][i].z * w.z + x[r][i].w * w.w;
         }
-        const float bj = cosine ? 0.f : bias[(size_t)task * C + c];
-        const float wnj = cosine ? wn[c] : 0.f;
+        const float bj = (!LEAN && cosine) ? 0.f : bias[(size_t)task * C + c];
+        const float wnj = (!LEAN && cosine) ? wn[c] : 0.f;
 #pragma unroll
         for (int r = 0; r < R; ++r) {
             float v = wave_sum(acc[r]);
-            if (cosine)
+            if (!LEAN && cosine)
                 v = logit_scale * (v / (fmaxf(sqrtf(qn2[r]), 1e-8f) * fmaxf(wnj, 1e-8f)));
             else
                 v = logit_scale * (v + bj);
             if (lane == 0 && row_ok[r]) logits[((size_t)task * M + m0 + r) * C + c] = v;
-            if (v > best[r]) best[r] = v, best_c[r] = c;
+            if (!LEAN && v > best[r]) best[r] = v, best_c[r] = c;
         }
     }
-    if (argmax != nullptr && lane == 0) {
+    if (!LEAN && argmax != nullptr && lane == 0) {
 #pragma unroll
         for (int r = 0; r < R; ++r)
             if (row_ok[r]) argmax[(size_t)task * M + m0 + r] = best_c[r];
@@ -610,6 +612,12 @@ int orbit_proto_predict(const float* Q, const float* W, const float* b, int n_ta
         Q, W, b, M, D, C, logit_scale, cosine, logits, argmax, cdiv(M, NW_ * R_))
             if (stream_opt == 1) { if (D == 1280) ORBIT_HEAD_STREAM(4, 4, 5); else ORBIT_HEAD_STREAM(4, 4, 2); }
             else if (stream_opt == 3) { if (D == 1280) ORBIT_HEAD_STREAM(4, 2, 5); else ORBIT_HEAD_STREAM(4, 2, 2); }
+            else if (D == 1280 && !cosine && argmax == nullptr)
+                // the lean instantiation (67 VGPRs): 18.4 against 19.3 us on the 64-task 5-way launch, 24.6 against 26.2 us 10-way
+                // (tools/head_roofline.py). A 7-wave form whose 960 blocks are all resident at once (4 x 7 waves per CU) measured
+                // 19.5 us: residency is not what bounds this launch, its ~8 us of launch + drain on a 67 MB burst is
+                proto_predict_stream_kernel<8, 2, 5, true><<<cdiv(M, 16) * n_tasks, 512, lds, s>>>(
+                    Q, W, b, M, D, C, logit_scale, cosine, logits, argmax, cdiv(M, 16));
             else { if (D == 1280) ORBIT_HEAD_STREAM(8, 2, 5); else ORBIT_HEAD_STREAM(8, 2, 2); }
 #undef ORBIT_HEAD_STREAM
             ORBIT_LAUNCH_CHECK();
