@@ -303,6 +303,19 @@ def metric_variants(model, tasks, device, steps):
         return dt
     prefetched(3)
     t_pf = prefetched(steps)
+
+    def prefetched_f32(n):  # the reference's fp32 clips (602 KB per frame) through the same pipeline: upload under compute
+        pf = TaskPrefetcher((host[i % len(host)] for i in range(n)), device, depth=3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for t in pf:
+            run_task(model, t)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        pf.close()
+        return dt
+    prefetched_f32(3)
+    t_pf32 = prefetched_f32(steps)
     # ... and a stream of NEW device-resident tasks: every task arrives with a label tensor the head has not seen, so its label
     # set is resolved inside the timed region - one torch.unique + host sync per task, what the reference's configure pays in
     # its .item() loop (model/classifier_heads.py:96-100). The headline loop cycles through resident tasks whose label sets
@@ -314,6 +327,7 @@ def metric_variants(model, tasks, device, steps):
     return {"predict_only_query_frames_per_s": NUM_QUERY * steps / t_pred,
             "new_task_labels_resolved_in_loop_query_frames_per_s": NUM_QUERY * steps / t_new,
             "h2d_inclusive_query_frames_per_s": NUM_QUERY * steps / t_h2d,
+            "h2d_inclusive_fp32_prefetched_query_frames_per_s": NUM_QUERY * steps / t_pf32,
             "h2d_inclusive_uint8_query_frames_per_s": NUM_QUERY * steps / t_pf,
             "h2d_inclusive_uint8_unpipelined_query_frames_per_s": NUM_QUERY * steps / t_h2d8,
             "note": "predict-only: predict() of 200 resident query frames after one personalise(); h2d-inclusive: whole "
@@ -321,7 +335,8 @@ def metric_variants(model, tasks, device, steps):
                     "region; the uint8 variant uploads 8-bit frames (a quarter of the bytes) and applies to_tensor + normalize on "
                     "the GPU (orbit_frames_from_uint8) - through data/pipeline.TaskPrefetcher (pinned ring, staging thread, copy "
                     "stream double-buffered against the extractor; first task's upload included), and 'unpipelined' = uploaded "
-                    "per mini-batch on the compute / query stream as in round 2; new_task_labels_resolved_in_loop: the "
+                    "per mini-batch on the compute / query stream as in round 2; fp32_prefetched: the fp32 clips of the h2d-inclusive "
+                    "variant through the same TaskPrefetcher (task i+1 uploads on the copy stream while task i runs); new_task_labels_resolved_in_loop: the "
                     "resident-input loop on tasks whose label tensors are new to the head, so the per-task label-set resolution "
                     "(torch.unique + one host sync, the reference's configure does the same) is inside the timed region"}
 

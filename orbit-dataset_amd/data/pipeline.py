@@ -223,8 +223,9 @@ class _Slot:
 
 class TaskPrefetcher:
     """Iterate over `source` (host tasks whose `*_clips` are uint8, channels last [..., H, W, 3] or channels first
-    [..., 3, H, W]); yields the same dicts with the clips replaced by normalised fp32 [..., 3, H, W] tensors RESIDENT on
-    `device`. Every other entry passes through (label tensors are moved to the device).
+    [..., 3, H, W] - or already-normalised float32 [..., 3, H, W], the reference's layout); yields the same dicts with the
+    clips replaced by normalised fp32 [..., 3, H, W] tensors RESIDENT on `device`. Every other entry passes through (label
+    tensors are moved to the device).
 
     A staging thread fills pinned slot buffers and issues, on a copy stream, the 8-bit upload and the normalisation kernel of
     task i+1 (and i+2 with depth 3) while the caller's stream runs the extractor on task i. The yielded tensors belong to the
@@ -285,8 +286,24 @@ class TaskPrefetcher:
                                 lab.copy_(val, non_blocking=True)
                                 out[key] = lab
                             continue
+                        if val.dtype == torch.float32:
+                            # already-normalised fp32 clips (the reference's own task_dict layout, data/datasets.py:584-597:
+                            # 602 KB per 224x224 frame): no transform, but the upload of task i+1 still runs on the copy stream
+                            # under the extractor's work on task i instead of in front of it
+                            host = val
+                            if not val.is_pinned():
+                                host = self._buffer(slot.pinned, (key, "f32"), val.shape,
+                                                    lambda n: torch.empty(n, dtype=torch.float32).pin_memory())
+                                for ev in slot.released or ():
+                                    ev.synchronize()
+                                host.copy_(val)
+                            f32 = self._buffer(slot.dev_f32, key, val.shape,
+                                               lambda n: torch.empty(n, dtype=torch.float32, device=self.device))
+                            f32.copy_(host, non_blocking=True)
+                            out[key] = f32
+                            continue
                         if val.dtype != torch.uint8:
-                            raise ValueError("TaskPrefetcher: %s must be uint8 frames, got %s" % (key, val.dtype))
+                            raise ValueError("TaskPrefetcher: %s must be uint8 or float32 frames, got %s" % (key, val.dtype))
                         hwc = val.shape[-1] == 3 and val.shape[-3] != 3
                         *lead, a, b, c = val.shape
                         H, W = (a, b) if hwc else (b, c)

@@ -84,6 +84,21 @@ def test_prefetcher_with_pinned_host_tasks_and_more_tasks_than_slots(device):
             model._reset()
         assert i == 6
 
+        # float32 clips (the reference's task_dict layout): uploaded on the copy stream as they are
+        tasks32 = [{"context_clips": torch.randn(12, 1, 3, 64, 64, generator=g), "context_labels": torch.arange(12) % 3,
+                    "target_clips": torch.randn(9, 1, 3, 64, 64, generator=g).pin_memory()} for _ in range(4)]
+        want32 = []
+        for t in tasks32:
+            model.personalise(t["context_clips"].to(device), t["context_labels"].to(device))
+            want32.append(model.predict(t["target_clips"].to(device)).clone())
+            model._reset()
+        for i, t in enumerate(pipeline.TaskPrefetcher(iter(tasks32), device, depth=2)):
+            assert t["context_clips"].is_cuda and t["context_clips"].dtype == torch.float32
+            model.personalise(t["context_clips"], t["context_labels"])
+            assert torch.equal(model.predict(t["target_clips"]), want32[i])
+            model._reset()
+        assert i == 3
+
     def broken():
         yield tasks[0]
         raise RuntimeError("decoder died")
