@@ -92,6 +92,14 @@ int orbit_device_count(void);
  *   "dw_lds"        depthwise kernel staging its input patch in LDS: 1 = stride-1 5x5 and small 3x3 maps (default), 0 = never,
  *                   2 = whenever the patch fits in 64 KiB
  *   "dw_pipe"       software-pipelined streaming depthwise kernel: 1 = large stride-2 layers (default), 0 = never, 2 = always
+ *   "se_fold"       the squeeze-excite gate of an MBConv block computed by the kernel that produces its pooling partials
+ *                   (row-streaming fused fronts, LDS-patch and streaming depthwise kernels): every block takes a ticket on a
+ *                   per-frame counter and the block that completes a frame runs the gate MLP for it (csrc/se_tail.h; same bits
+ *                   as the stand-alone kernel). 0 (default) = always the stand-alone gate kernel - measured faster: a frame's
+ *                   gate is a latency chain through ONE block, and behind a 35-60 us depthwise launch the last frames' chains
+ *                   are exposed at the 256-thread / low-register rate the producer can afford (dwconv_lds 36 + 10 us -> 70 us);
+ *                   1 = gates of <= 256 channels only (the row-streaming producers: break-even); 2 = every gate a producer can
+ *                   take. Read per forward
  *   "se_wide"       1 (default) = 1024-thread squeeze-excite gate blocks for C >= 1024
  *   "graph"         HIP-graph replay of extractor forwards: 0 = never, 1 = always, 2 = adaptive (default: only while an
  *                   eager kernel launch costs > ~12 us of host time on this host); read per forward

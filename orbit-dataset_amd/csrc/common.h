@@ -9,6 +9,8 @@
 
 namespace orbit {
 
+struct SeTail;  // csrc/se_tail.h
+
 // thread-local error message returned by orbit_last_error()
 char* err_buf();
 int set_err(int code, const char* fmt, ...);
@@ -125,7 +127,9 @@ int dwconv_se_chunks(int Ho);
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                      float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
                      int Wo, int act, hipStream_t s, int stats = 0, const float* in_scale = nullptr,
-                     const float* in_shift = nullptr, int in_act = 0);
+                     const float* in_shift = nullptr, int in_act = 0, struct SeTail* se = nullptr);
+// (se, in / out: the squeeze-excite gate that consumes the pooling partials, to be run by the launch itself - csrc/se_tail.h;
+// on return se->counter == nullptr means the chosen kernel could not take it and the stand-alone gate kernel must follow)
 // in_scale / in_shift (with stats): x is the RAW output of the producing conv; act(x * in_scale[c] + in_shift[c]) is applied
 // as the kernel loads it, so the activated tensor of that layer is never written (no-backward passes of the LITE step)
 // stats != 0: pool_partial receives [B * dwconv_se_chunks(Ho)][2][C] column sums / sums of squares of the outputs instead
@@ -154,14 +158,15 @@ bool mbconv_rows_supported(int H, int W, int Cin, int mid, int K, int stride);
 int mbconv_rows_tiles(int H, int W, int Cin, int mid, int K, int stride);
 int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
                        const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
-                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, int plan_tiles = 0);
+                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, int plan_tiles = 0,
+                       struct SeTail* se = nullptr);
 // (plan_tiles > 0: the tile count the caller sized `pool` and its consumer for; the launch fails if the options now differ)
 // row-streaming stem + first depthwise (csrc/mbconv_rows.hip): w1_packed = stem_pack_weights' [32][32]; pool [B][stem_rows_tiles][32]
 bool stem_rows_supported(int H, int W, int mid, int K, int stride);
 int stem_rows_tiles(int H, int W);
 int launch_stem_rows(const float* frames, const float* w1_packed, const float* sc1, const float* sh1, const float* wdw,
                      const float* sc2, const float* sh2, float* y, float* pool, int B, int FH, int FW, int spad_t,
-                     int spad_l, int H, int W, hipStream_t s, int plan_tiles = 0);
+                     int spad_l, int H, int W, hipStream_t s, int plan_tiles = 0, struct SeTail* se = nullptr);
 // stem form of the fused front kernel: conv_stem (NCHW frames, 3x3 stride 2) + BN + SiLU + depthwise 3x3/1 + BN + SiLU
 bool stem_dw_front_supported(int mid, int K, int stride);
 int stem_pack_weights(const float* w_oihw, float* w_packed, int mid, hipStream_t s);  // [mid][27] -> [mid][32]

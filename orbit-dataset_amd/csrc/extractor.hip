@@ -13,6 +13,7 @@
 #include <cstdlib>
 
 #include "extractor.h"
+#include "se_tail.h"
 
 using namespace orbit;
 
@@ -278,7 +279,7 @@ static int build_set_encoder(orbit_extractor* fe, int H, int W) {
 
 // ---- workspace layout ------------------------------------------------------------------------------
 struct WsLayout {
-    size_t buf[3], pooled, gate, fold, splitk, total;
+    size_t buf[3], pooled, gate, fold, splitk, se_counter, total;
 };
 static ConvDesc conv_shape(const Op& o, int B) {  // the fields the split-K plan looks at
     ConvDesc d;
@@ -306,6 +307,8 @@ static WsLayout ws_layout(const orbit_extractor* fe, int B) {
     for (const Op& o : fe->ops)
         if (o.kind == OP_CONV) skf = std::max(skf, conv_splitk_floats(conv_shape(o, B)));
     off += align_up(skf * sizeof(float), 256);
+    L.se_counter = off;  // per-frame tickets of the squeeze-excite gates computed by their producers (csrc/se_tail.h)
+    off += align_up((size_t)B * sizeof(unsigned), 256);
     L.total = off;
     return L;
 }
@@ -607,7 +610,29 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
         ORBIT_LAUNCH_CHECK();
         scale = fs, shift = fs + fe->fold_floats;
     }
-    for (const Op& o : fe->ops) {
+    // Squeeze-excite gates run by the kernel that produces their pooling partials (option se_fold; csrc/se_tail.h): the op
+    // that follows a depthwise / fused-front op describes the gate; the producer's launcher takes it if its kernel can.
+    const int se_fold = get_option("se_fold");  // 0 = off (default), 1 = gates of <= 256 channels, 2 = every gate a producer can take
+    unsigned* se_counter = reinterpret_cast<unsigned*>(ws + L.se_counter);
+    bool se_done = false;  // the gate of the next OP_SE was computed by its producer
+    if (se_fold) ORBIT_HIP_CHECK(hipMemsetAsync(se_counter, 0, (size_t)B * sizeof(unsigned), s));
+    auto tail_for = [&](size_t oi, int chunks) {
+        SeTail t;
+        if (!se_fold || oi + 1 >= fe->ops.size() || fe->ops[oi + 1].kind != OP_SE) return t;
+        const Op& e = fe->ops[oi + 1];
+        // a frame's partial rows must be whole 128-byte lines; the 1 024-thread stand-alone kernel (C >= 1024) groups long
+        // chunk lists differently from a 256-thread block
+        if (chunks != e.se_chunks || ((size_t)chunks * e.Cin) % 32 != 0 || (e.Cin >= 1024 && chunks > 8)) return t;
+        if (se_fold == 1 && e.Cin > 256) return t;
+        t.counter = se_counter;
+        t.w1 = fe->d_pool + fe->params[e.se_w1].off, t.b1 = fe->d_pool + fe->params[e.se_b1].off;
+        t.w2t = fe->d_packed + e.packed_off, t.b2 = fe->d_pool + fe->params[e.se_b2].off;
+        t.gate = buf(102), t.partial = buf(101);
+        t.chunks = chunks, t.C = e.Cin, t.R = e.R, t.inv_hw = 1.0f / (float)e.se_hw;
+        return t;
+    };
+    for (size_t oi = 0; oi < fe->ops.size(); ++oi) {
+        const Op& o = fe->ops[oi];
         int rc = ORBIT_OK;
         switch (o.kind) {
             case OP_CONV: {
@@ -633,18 +658,23 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
                 rc = launch_conv(d, s);
                 break;
             }
-            case OP_DWCONV:
+            case OP_DWCONV: {
+                SeTail t = o.pool_partial ? tail_for(oi, dwconv_se_chunks(o.Ho)) : SeTail{};
                 rc = launch_dwconv_se(buf(o.in), fe->d_packed + o.packed_off, buf(o.out),
                                       scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off,
                                       o.pool_partial ? buf(101) : nullptr, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t,
-                                      o.pad_l, o.Ho, o.Wo, o.act, s);
+                                      o.pad_l, o.Ho, o.Wo, o.act, s, 0, nullptr, nullptr, 0, &t);
+                se_done = t.counter != nullptr;
                 break;
+            }
             case OP_MBFRONT:
                 if (o.stem && o.rows) {
+                    SeTail t = tail_for(oi, o.se_chunks);
                     rc = launch_stem_rows(buf(o.in), fe->d_packed + o.packed_off2, scale + fe->bns[o.bn].fold_off,
                                           shift + fe->bns[o.bn].fold_off, fe->d_packed + o.packed_off,
                                           scale + fe->bns[o.bn2].fold_off, shift + fe->bns[o.bn2].fold_off, buf(o.out),
-                                          buf(101), B, o.stem_h, o.stem_w, o.stem_pt, o.stem_pl, o.H, o.W, s, o.se_chunks);
+                                          buf(101), B, o.stem_h, o.stem_w, o.stem_pt, o.stem_pl, o.H, o.W, s, o.se_chunks, &t);
+                    se_done = t.counter != nullptr;
                     break;
                 }
                 if (o.stem) {
@@ -664,11 +694,13 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
                     break;
                 }
                 if (o.rows) {
+                    SeTail t = tail_for(oi, o.se_chunks);
                     rc = launch_mbconv_rows(buf(o.in), fe->d_pool + fe->params[o.weight].off,
                                             scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off,
                                             fe->d_packed + o.packed_off, scale + fe->bns[o.bn2].fold_off,
                                             shift + fe->bns[o.bn2].fold_off, buf(o.out), buf(101), B, o.H, o.W, o.Cin,
-                                            o.Cout, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s, o.se_chunks);
+                                            o.Cout, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s, o.se_chunks, &t);
+                    se_done = t.counter != nullptr;
                     break;
                 }
                 rc = launch_mbconv_front(buf(o.in), fe->d_pool + fe->params[o.weight].off,
@@ -685,6 +717,10 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
                 rc = launch_avgpool(buf(o.in), buf(o.out), B, o.H * o.W, o.Cin, s);
                 break;
             case OP_SE:
+                if (se_done) {  // computed by the last block per frame of the launch before
+                    se_done = false;
+                    break;
+                }
                 rc = launch_se_gate2(buf(101), o.se_chunks, o.se_hw, fe->d_pool + fe->params[o.se_w1].off,
                                      fe->d_pool + fe->params[o.se_b1].off, fe->d_packed + o.packed_off,
                                      fe->d_pool + fe->params[o.se_b2].off, buf(102), B, o.Cin, o.R, s);

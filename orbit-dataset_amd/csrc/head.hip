@@ -50,6 +50,7 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"se_bn_fuse", "ORBIT_SE_BN_FUSE", 1, false},
                              {"stem_direct", "ORBIT_STEM_DIRECT", 1, false},
                              {"se_wide", "ORBIT_SE_WIDE", 1, false},
+                             {"se_fold", "ORBIT_SE_FOLD", 0, false},
                              {"conv_tile", "ORBIT_CONV_TILE", 0, false},
                              {"conv_bk", "ORBIT_CONV_BK", 0, false},
                              {"conv_bk_auto", "ORBIT_CONV_BK_AUTO", 1, false},

@@ -22,6 +22,7 @@
 // row's LDS address is linear in the tile row; the last tile is shifted back to end at the window's end (a few pixels are
 // computed by two waves - same values) instead of guarding its tail.
 #include "common.h"
+#include "se_tail.h"
 
 namespace orbit {
 
@@ -52,6 +53,7 @@ struct MbRowsParams {
     const float* sh2;
     float* y;          // [B][Ho][Wo][mid]
     float* pool;       // [B][tiles][mid] or nullptr
+    SeTail se;         // the gate that consumes the partials, run by the block that completes a frame (se_tail.h)
     int H, W, Cin, mid, pad_t, pad_l, Ho, Wo;
     int SWo, SWi, strips, band_rows, bands, nchunk, total;
 };
@@ -361,8 +363,9 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const
         if (tid < 8 && c0 + tid * 4 < p.mid) {
             v4f t4 = red[tid];
             for (int sl = 1; sl < 32; ++sl) t4 += red[sl * 8 + tid];
-            *reinterpret_cast<v4f*>(p.pool + ((size_t)b * tiles + tile) * p.mid + c0 + tid * 4) = t4;
+            se_store_partial(p.pool + ((size_t)b * tiles + tile) * p.mid + c0 + tid * 4, t4, p.se.counter != nullptr);
         }
+        se_tail_finish<2>(p.se, b, ring);
     }
 }
 
@@ -411,7 +414,7 @@ int mbconv_rows_tiles(int H, int W, int Cin, int mid, int K, int stride) {
 
 int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
                        const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
-                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, int plan_tiles) {
+                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, int plan_tiles, SeTail* se) {
     ORBIT_REQUIRE(x && w1 && sc1 && sh1 && wdw && sc2 && sh2 && y, "mbconv_rows: null pointer");
     RowsGeom g;
     ORBIT_REQUIRE(Ho == cdiv(H, stride) && Wo == cdiv(W, stride) && rows_geom(H, W, Cin, mid, K, stride, Ho, Wo, g),
@@ -430,6 +433,16 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
     const int grid = cdiv(p.total, 8) * 8;
     const int n_new = g.TO * stride * g.SWi;
     const size_t lds = (size_t)3 * n_new * ROWS_ES * sizeof(float) + (K == 3 ? 0 : (size_t)K * K * 8 * 16);
+    if (se != nullptr && se->counter != nullptr) {
+        // every block of a frame (channel chunk x strip x band) counts itself in; a chunk whose 32 channels are all beyond
+        // `mid` does not exist (nchunk = ceil(mid / 32)), so each of them writes a partial
+        if (pool != nullptr && se_tail_lds_floats(se->C, se->R) * sizeof(float) <= lds) {
+            se->expected = p.nchunk * g.strips * g.bands;
+            p.se = *se;
+        } else {
+            se->counter = nullptr;
+        }
+    }
     const double pix = (double)B * H * W;
     const int rec = prof_start("mbconv_rows", 2.0 * pix * Cin * mid + 2.0 * B * Ho * Wo * mid * K * K,
                                4.0 * (pix * Cin + (double)B * Ho * Wo * mid), s);
@@ -488,6 +501,7 @@ struct StemRowsParams {
     const float* sh2;
     float* y;             // [B][H][W][32]
     float* pool;          // [B][tiles][32] or nullptr
+    SeTail se;            // as in MbRowsParams
     int FH, FW, spad_t, spad_l, H, W;  // (H, W) = stem output grid = depthwise grid
     int SWo, SWi, strips, band_rows, bands, total;
 };
@@ -731,8 +745,9 @@ __global__ __launch_bounds__(256, 3) void stem_rows_kernel(const StemRowsParams 
         if (tid < 8) {
             v4f t4 = red[tid];
             for (int sl = 1; sl < 32; ++sl) t4 += red[sl * 8 + tid];
-            *reinterpret_cast<v4f*>(p.pool + ((size_t)b * tiles + tile) * 32 + tid * 4) = t4;
+            se_store_partial(p.pool + ((size_t)b * tiles + tile) * 32 + tid * 4, t4, p.se.counter != nullptr);
         }
+        se_tail_finish<2>(p.se, b, ring);
     }
 }
 
@@ -763,7 +778,7 @@ int stem_rows_tiles(int H, int W) {
 
 int launch_stem_rows(const float* frames, const float* w1_packed, const float* sc1, const float* sh1, const float* wdw,
                      const float* sc2, const float* sh2, float* y, float* pool, int B, int FH, int FW, int spad_t,
-                     int spad_l, int H, int W, hipStream_t s, int plan_tiles) {
+                     int spad_l, int H, int W, hipStream_t s, int plan_tiles, SeTail* se) {
     ORBIT_REQUIRE(frames && w1_packed && sc1 && sh1 && wdw && sc2 && sh2 && y, "stem_rows: null pointer");
     StemRowsGeom g;
     ORBIT_REQUIRE(stem_rows_geom(H, W, 32, 3, 1, g), "stem_rows: unsupported shape (H=%d W=%d)", H, W);
@@ -777,6 +792,14 @@ int launch_stem_rows(const float* frames, const float* w1_packed, const float* s
     p.total = g.strips * g.bands * B;
     const int grid = cdiv(p.total, 8) * 8;
     const size_t lds = ((size_t)3 * 2 * g.SWi * ROWS_ES + 2 * 3 * 5 * STEM_PW + 14 * 64) * sizeof(float);
+    if (se != nullptr && se->counter != nullptr) {
+        if (pool != nullptr && se_tail_lds_floats(se->C, se->R) * sizeof(float) <= lds) {
+            se->expected = g.strips * g.bands;
+            p.se = *se;
+        } else {
+            se->counter = nullptr;
+        }
+    }
     const double pix = (double)B * H * W;
     const int rec = prof_start("stem_rows", 2.0 * pix * 32 * 27 + 2.0 * pix * 32 * 9,
                                4.0 * ((double)B * 3 * FH * FW + pix * 32), s);

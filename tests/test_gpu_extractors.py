@@ -153,6 +153,45 @@ def test_largest_forward_of_the_reference_configuration(device):
     assert torch.isfinite(big).all() and torch.equal(big, small)
 
 
+@pytest.mark.parametrize("B", [1, 7, 200])
+def test_squeeze_excite_gate_computed_by_the_producer_kernel(device, B):
+    """se_fold (csrc/se_tail.h; opt-in - it measured slower than the stand-alone gate kernel): the last block per frame of the depthwise / fused-front launch runs the squeeze-excite gate MLP
+    (tickets on a per-frame counter, write-through partials, one agent-scope acquire) instead of a separate gate kernel. Same
+    arithmetic in the same order: features BIT-IDENTICAL to the stand-alone kernel - checked over repeated forwards while a
+    second stream keeps the chip busy with another forward (a stale partial or an early ticket shows up as different bits only
+    under uneven load), with and without graph replay."""
+    from orbit_dataset_amd import _lib
+    lib = _lib.load()
+    fe, _ = create_feature_extractor("efficientnet_b0", True, False, False)
+    synthetic.init_parameters_(fe)
+    fe = fe.cuda().eval()
+    other, _ = create_feature_extractor("efficientnet_b0", True, False, False)
+    synthetic.init_parameters_(other, seed=3)
+    other = other.cuda().eval()
+    g = torch.Generator(device=device).manual_seed(B)
+    xs = [torch.randn(B, 3, 224, 224, device=device, generator=g) for _ in range(3)]
+    noise = torch.randn(64, 3, 224, 224, device=device, generator=g)
+    side = torch.cuda.Stream()
+    prev_fold, prev_graph = lib.orbit_get_option(b"se_fold"), lib.orbit_get_option(b"graph")
+    try:
+        with torch.no_grad():
+            lib.orbit_set_option(b"se_fold", 0)
+            want = [fe(x).clone() for x in xs]
+            lib.orbit_set_option(b"se_fold", 2)  # every producer that can take a gate
+            for graph in (0, 1):
+                lib.orbit_set_option(b"graph", graph)
+                for rep in range(6):
+                    with torch.cuda.stream(side):
+                        other(noise)
+                    for x, w in zip(xs, want):
+                        got = fe(x)
+                        assert torch.equal(got, w), "rep %d graph %d: max diff %g" % (rep, graph, (got - w).abs().max().item())
+            torch.cuda.synchronize()
+    finally:
+        lib.orbit_set_option(b"se_fold", prev_fold)
+        lib.orbit_set_option(b"graph", prev_graph)
+
+
 def test_row_streaming_plan_refuses_a_changed_band_option(device):
     """`mbrows_band` is read when a plan is built (it sizes the squeeze-excite pooling partials) and again at
     launch. Changing it in between must fail loudly instead of writing a different number of partials than the gate sums."""
