@@ -50,7 +50,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
     f = glob.glob("%s/pmc_%s/*/*counter_collection.csv" % (out, c))[0]
     n, v = 0, 0.0
     for r in csv.DictReader(open(f)):
-        if r.get("Counter_Name") == c and "conv_igemm_kernel" in r["Kernel_Name"]:
+        if r.get("Counter_Name") == c and ("conv_igemm_kernel" in r["Kernel_Name"] or "pw_rgemm_kernel" in r["Kernel_Name"]):
             n += 1
             v += float(r["Counter_Value"])
     tot[c] = (n, v)
@@ -60,7 +60,7 @@ write = tot["WRITE_SIZE"][1] * 1024 / max(tot["WRITE_SIZE"][0], 1)
 import subprocess
 sha = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; print(bench.kernel_sources_sha16())" % os.environ.get("GRAFT_REPO_ROOT", ".")],
                      capture_output=True, text=True).stdout.strip().splitlines()[-1]
-print(json.dumps({"workload": "efficientnet_b0_224", "kernel": "orbit::conv_igemm_kernel (all instantiations)",
+print(json.dumps({"workload": "efficientnet_b0_224", "kernel": "orbit::conv_igemm_kernel (all instantiations) + orbit::pw_rgemm_kernel",
                   "kernel_sources_sha16": sha,
                   "launches_profiled": launches, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                   "traffic_bytes_per_launch": fetch + write,
@@ -87,10 +87,20 @@ fetch = 2.0 * 1024 * sum(tot["FETCH_SIZE"]) / max(len(tot["FETCH_SIZE"]), 1)
 write = 1024 * sum(tot["WRITE_SIZE"]) / max(len(tot["WRITE_SIZE"]), 1)
 sha = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; print(bench.kernel_sources_sha16())" % os.environ.get("GRAFT_REPO_ROOT", ".")],
                      capture_output=True, text=True).stdout.strip().splitlines()[-1]
-print(json.dumps({"kernel": "orbit::proto_predict_stream_kernel<8, 2, 5> (64 tasks x 200 x 1280, 5-way)", "kernel_sources_sha16": sha,
+print(json.dumps({"kernel": "orbit::proto_predict_stream_kernel<8, 2, 5, lean> (64 tasks x 200 x 1280, 5-way)", "kernel_sources_sha16": sha,
                   "launches_profiled": len(tot["FETCH_SIZE"]), "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                   "traffic_bytes_per_launch": fetch + write, "algorithmic_bytes_per_launch": 4.0 * (200 * 1280 + 5 * 1280 + 5 + 200 * 5) * 64,
                   "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of tools/head_roofline.py quick; "
                             "FETCH_SIZE x2 (gfx950 wide-load correction), WRITE_SIZE as reported"}))
 PY
+# ---- SQ counters of the dense-conv kernels per layer shape, and of the pointwise register GEMM (own passes) ----------------
+cd $R
+bash tools/conv_pmc.sh $OUT/convpmc effnet_224 > /dev/null 2>&1; cp $O/convpmc/summary.txt $O/${TAG}_conv_sq_counters.txt 2>/dev/null
+bash tools/kernel_pmc.sh $OUT/rgemmpmc pw_rgemm python tools/rgemm_bench.py > /dev/null 2>&1; cp $O/rgemmpmc/summary.txt $O/${TAG}_rgemm_sq_counters.txt 2>/dev/null
+if [ -x tools/dispatch_probe.bin ]; then
+  { echo "# tools/dispatch_probe.bin <blocks> <dynamic LDS bytes>: how the dispatcher spreads co-resident 256-thread blocks over the CUs";
+    tools/dispatch_probe.bin 770 36864; tools/dispatch_probe.bin 1535 0; tools/dispatch_probe.bin 1535 20480; tools/dispatch_probe.bin 3080 36864; } > $O/${TAG}_dispatch_probe.txt 2>&1
+fi
+# raw rocprofv3 output stays on the box: only the summaries travel back (gpurun merges at most 64 MiB)
+rm -rf $O/stats_* $O/pmc_* $O/convpmc/pass* $O/rgemmpmc/pass*
 ls -la $O | head -60
