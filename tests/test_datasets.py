@@ -142,3 +142,28 @@ def test_clip_sampling_edges():
     with pytest.raises(NotImplementedError):
         datasets.ORBITDataset(".", "max", 15, ("max", "max"), (5, 2), ("clean", "clutter"), 30, ("max", "max"), 1, 16, "imagenet",
                               annotations_to_load=["object_bounding_box"])
+
+
+def test_dataset_task_source_layout(g14, tree):
+    """data/pipeline.DatasetTaskSource: the host-task layout TaskPrefetcher uploads - a test-mode target set (a list of videos)
+    becomes one uint8 tensor [M, 1, H, W, 3] + row ranges + one label per frame; a train-mode target set passes through."""
+    from orbit_dataset_amd.data import pipeline
+    ds = build(tree, CASES["test_default"], frames="uint8")
+    random.seed(5)
+    want = ds[1]
+    random.seed(5)
+    (task,) = list(pipeline.DatasetTaskSource(ds, [1]))
+    assert task["task_id"] == ds.users[1] and task["object_list"] == want["object_list"]
+    assert task["context_clips"].dtype == torch.uint8 and torch.equal(task["context_clips"], want["context_clips"])
+    lens = [len(v) for v in want["target_clips"]]
+    assert task["target_videos"] == [(sum(lens[:i]), sum(lens[:i + 1])) for i in range(len(lens))]
+    assert task["target_clips"].shape == (sum(lens), 1, 16, 16, 3)
+    for (lo, hi), frames, lab in zip(task["target_videos"], want["target_clips"], want["target_labels"]):
+        assert torch.equal(task["target_clips"][lo:hi, 0], frames)
+        assert task["target_labels"][lo:hi].tolist() == [int(lab)] * (hi - lo)
+    train = build(tree, CASES["train_random"], frames="uint8")
+    random.seed(6)
+    (t2,) = list(pipeline.DatasetTaskSource(train, [0]))
+    assert t2["target_clips"].dim() == 5 and "target_videos" not in t2 and len(t2["target_labels"]) == len(t2["target_clips"])
+    with pytest.raises(ValueError):
+        pipeline.DatasetTaskSource(build(tree, CASES["train_random"], frames="float"))
