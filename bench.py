@@ -737,6 +737,48 @@ def main():
     out["head_roofline"] = head_roofline(device)
     if not train and world == 1:
         out["variants_of_the_metric"] = metric_variants(model, tasks, device, min(args.steps, 20))
+    bf3 = None
+    if not train and world == 1 and args.workload.startswith("efficientnet") and os.environ.get("ORBIT_BENCH_BF3", "1") != "0":
+        # OPT-IN alternative, never `value`: the 14x14 / 7x7 pointwise convs with both operands split three
+        # ways into bf16 and six products per fp32 product on the bf16 matrix cores (csrc/conv_bf3.hip, option conv_bf3). The
+        # same timed loop, then the serial leg with per-launch events; its logit error against the pinned oracle is added
+        # below from the cpu_baseline task.
+        lib.orbit_set_option(b"conv_bf3", 1)
+        try:
+            loop(3)
+            el3, _, _ = loop(args.steps)
+            ov = getattr(model, "overlap_query", False)
+            model.overlap_query = False
+            loop(2)
+            off3, _, _ = loop(args.steps)
+            lib.orbit_prof_enable(1)
+            loop(args.steps)
+            lib.orbit_prof_enable(0)
+            model.overlap_query = ov
+            ms3, fl3, n3 = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+            lib.orbit_prof_collect(ctypes.byref(ms3), ctypes.byref(fl3), ctypes.byref(n3))
+            split_ms = split_fl = 0.0
+            for i in range(lib.orbit_prof_num_variants()):
+                nm = ctypes.create_string_buffer(48)
+                vms, vfl = ctypes.c_double(), ctypes.c_double()
+                lib.orbit_prof_variant(i, nm, None, ctypes.byref(vms), ctypes.byref(vfl), None)
+                if nm.value.decode().startswith("conv_bf3<"):
+                    split_ms += vms.value
+                    split_fl += vfl.value
+            bf3 = {"option": "conv_bf3 = 1 (default 0)", "ms_per_step": 1e3 * el3 / args.steps,
+                   "query_frames_per_s": NUM_QUERY * args.steps * per_step / el3,
+                   "query_frames_per_s_overlap_off": NUM_QUERY * args.steps * per_step / off3,
+                   "conv_tflops_all_dense_conv_launches": fl3.value / ms3.value / 1e9 if ms3.value else None,
+                   "conv_frac_of_fp32_mfma_peak": fl3.value / ms3.value / 1e9 / PEAK_FP32_MFMA_TFLOPS if ms3.value else None,
+                   "split_kernel_share_of_conv_flops": split_fl / fl3.value if fl3.value else None,
+                   "split_kernel_tflops": split_fl / split_ms / 1e9 if split_ms else None,
+                   "note": "fp32 operands split x = x0 + x1 + x2 (bf16, round to nearest, 24 significand bits), products "
+                           "x0w0 + x0w1 + x1w0 + x1w1 + x0w2 + x2w0 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the fraction "
+                           "is quoted against the fp32-MFMA peak the default path is priced on (FLOPs of the fp32 problem)"}
+        finally:
+            lib.orbit_prof_enable(0)
+            lib.orbit_set_option(b"conv_bf3", 0)
+    out["opt_in_conv_bf3"] = bf3
     if not args.no_cpu_baseline and world == 1:
         sd_before = {k: v.clone() for k, v in model.state_dict().items()} if train else None
         base, task, want = cpu_baseline(args.workload, model, train=train, way=way, template=template)
@@ -751,6 +793,16 @@ def main():
         base["frame_accuracy_gpu"] = float((got.argmax(1) == task["target_labels"]).float().mean())
         base["frame_accuracy_oracle"] = float((want.argmax(1) == task["target_labels"]).float().mean())
         out["cpu_baseline"] = base
+        if bf3 is not None:  # the opt-in path's logits on the same task against the same oracle logits
+            lib.orbit_set_option(b"conv_bf3", 1)
+            try:
+                got3 = run_step(model, {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in task.items()}).cpu()
+            finally:
+                lib.orbit_set_option(b"conv_bf3", 0)
+            bf3["max_abs_dlogit_vs_oracle"] = float((got3 - want).abs().max().item())
+            bf3["argmax_identical_to_oracle"] = bool(torch.equal(got3.argmax(1), want.argmax(1)))
+            bf3["max_abs_dlogit_vs_default_path"] = float((got3 - got).abs().max().item())
+            bf3["default_path_max_abs_dlogit_vs_oracle"] = base["max_abs_dlogit_vs_gpu"]
         # parity gate (no timing is reported for a path that does not reproduce the reference's logits)
         if not (base["max_abs_dlogit_vs_gpu"] <= 1e-3 and base["argmax_identical"]):
             print("PARITY GATE FAILED, no timing reported: " + json.dumps(base), file=sys.stderr)

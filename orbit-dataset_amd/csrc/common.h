@@ -16,6 +16,7 @@ char* err_buf();
 int set_err(int code, const char* fmt, ...);
 // tuning switches (orbit_set_option / ORBIT_* environment): "dw_window", "mbconv_fusion", "graph"
 int get_option(const char* name);
+int option_epoch();  // changes whenever orbit_set_option changed a value (key of captured launch sequences)
 
 #define ORBIT_HIP_CHECK(expr)                                                                  \
     do {                                                                                       \
@@ -111,6 +112,9 @@ int launch_conv(const ConvDesc& d, hipStream_t s);
 size_t conv_frag_floats(int Cin, int Cout, int KH, int KW, int x_nchw);  // 0: this filter has no fragment-packed form
 int conv_frag_pack_weights(const float* w_oihw, float* w_frag, int Cin, int Cout, hipStream_t s);
 bool pw_rgemm_supported(const ConvDesc& d);
+// pointwise convs on the bf16 matrix cores with both operands split three ways (csrc/conv_bf3.hip; option conv_bf3, opt-in)
+bool conv_bf3_supported(const ConvDesc& d);
+int launch_conv_bf3(const ConvDesc& d, hipStream_t s);
 bool pw_rgemm_preferred(const ConvDesc& d);  // where it measured faster than the LDS-tiled kernel (conv_rgemm = 1)
 int launch_pw_rgemm(const ConvDesc& d, hipStream_t s);
 // narrow pointwise projections (Cout <= 32, high-resolution maps) as an HBM stream without an LDS stage for the pixels

@@ -1,0 +1,357 @@
+// Pointwise convolution with fp32 operands split three ways into bf16 and multiplied on the bf16 matrix cores
+// (`conv_bf3` option, OPT-IN: the default path multiplies fp32 operands on v_mfma_f32_32x32x2_f32).
+//
+//   x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)      (round to nearest even; the two
+//   subtractions are exact in fp32, the three pieces carry 24 significand bits)
+//   x * w  ~=  x0 w0 + (x0 w1 + x1 w0) + (x1 w1 + x0 w2 + x2 w0)                      six of the nine products; the three
+//   dropped ones are <= 2^-24 |x w| each. Every bf16 x bf16 product is exact in fp32 and the MFMA accumulates in fp32.
+//
+// A v_mfma_f32_32x32x16_bf16 does 8x the multiply-adds of a v_mfma_f32_32x32x2_f32 in half its cycles: six of them per
+// 16 k replace eight fp32 ones per 16 k at 3/8 of the matrix-pipe time. The split itself costs ~5.5 VALU instructions per
+// staged element (operands are split when a tile is written to LDS: once per block and K-tile, not once per MFMA).
+// The five small products accumulate in their own register tile and are added to the x0 w0 sums once, in the epilogue.
+//
+// Structure: csrc/conv_igemm.hip's pointwise / unpredicated form (same tiling, same global -> register -> LDS pipeline one
+// K-tile ahead, same epilogue), with LDS tiles that hold three bf16 planes per operand. Rows are 2 BK bytes, 16-byte chunks
+// XOR-swizzled by row so that the ds_read_b128 fragment reads of 16-lane groups are conflict-free without padding.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+
+#include "common.h"
+
+namespace orbit {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct Bf3Params {
+    const float* x;
+    const float* w;       // conv_pack_weights layout [cout_pad][KT], KT = Cin here
+    float* y;
+    const float* scale;
+    const float* shift;
+    const float* residual;
+    const float* gate;
+    int M, Cin, Cout, act;
+    int m_tiles, n_tiles;
+    FastDiv fd_per;  // / (H*W): frame of a row (gate)
+};
+
+__device__ __forceinline__ float bf3_act(float v, int act) {
+    if (act == ORBIT_ACT_RELU) return fmaxf(v, 0.f);
+    if (act == ORBIT_ACT_SILU) return v * __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+    return v;
+}
+
+__device__ __forceinline__ int bf3_xcd_remap(int bid, int nblk) {  // as conv_igemm.hip: contiguous tile runs per XCD
+    const int q = nblk >> 3, r = nblk & 7;
+    const int xcd = bid & 7, slot = bid >> 3;
+    const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return start + slot;
+}
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
+    const f32x2 v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+__device__ __forceinline__ float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
+__device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
+
+// four fp32 values -> three planes of four bf16 (two dwords each)
+__device__ __forceinline__ void split3(const f32x4 v, uint2& p0, uint2& p1, uint2& p2) {
+    p0.x = pk_bf16(v[0], v[1]), p0.y = pk_bf16(v[2], v[3]);
+    const float r0 = v[0] - bf_lo(p0.x), r1 = v[1] - bf_hi(p0.x), r2 = v[2] - bf_lo(p0.y), r3 = v[3] - bf_hi(p0.y);
+    p1.x = pk_bf16(r0, r1), p1.y = pk_bf16(r2, r3);
+    p2.x = pk_bf16(r0 - bf_lo(p1.x), r1 - bf_hi(p1.x)), p2.y = pk_bf16(r2 - bf_lo(p1.y), r3 - bf_hi(p1.y));
+}
+
+template <int BM, int BN, int WGM, int WGN, int BK, bool GATE, int PF, bool ODD>
+__global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
+    static_assert(WGM * WGN == 4, "4 waves per block");
+    static_assert(BK == 16 || BK == 32, "BK");
+    constexpr int WM = BM / WGM, WN = BN / WGN;
+    constexpr int TM = WM / 32, TN = WN / 32;
+    static_assert(TM >= 1 && TN >= 1, "wave tile");
+    constexpr int TPR = BK / 4;              // threads (float4 columns) per tile row
+    constexpr int RPP = 256 / TPR;           // rows per pass
+    constexpr int AR = BM / RPP, BR = (BN + RPP - 1) / RPP;
+    static_assert(AR >= 1 && BM % RPP == 0 && (BN % RPP == 0 || BN < RPP), "tile rows per pass");
+    constexpr int ROWB = BK * 2;             // bytes per plane row
+    constexpr int APL = BM * ROWB, BPL = BN * ROWB;  // bytes per plane
+    constexpr int BUF = 3 * (APL + BPL);     // bytes per pipeline buffer
+    constexpr int KS = BK / 16;              // MFMA k-steps per K-tile
+
+    extern __shared__ __attribute__((aligned(16))) char smem_c[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, lh = lane >> 5;
+    const int wm = (wave / WGN) * WM, wn = (wave % WGN) * WN;
+    const int ntiles = p.m_tiles * p.n_tiles;
+    const int tile = bf3_xcd_remap(blockIdx.x, ntiles);
+    const int m0 = (tile / p.n_tiles) * BM, n0 = (tile % p.n_tiles) * BN;
+
+    auto sw = [](int r) { return BK == 32 ? ((r >> 2) & 3) : ((r >> 3) & 1); };
+
+    const int c4 = tid % TPR, lrow = tid / TPR;
+    const float* a_ptr[AR];
+    const float* g_ptr[GATE ? AR : 1];
+#pragma unroll
+    for (int i = 0; i < AR; ++i) {
+        const int m = min(m0 + lrow + RPP * i, p.M - 1);  // rows beyond M are clamped: computed, never stored
+        a_ptr[i] = p.x + (size_t)m * p.Cin + c4 * 4;
+        if (GATE) g_ptr[i] = p.gate + (size_t)fdiv((unsigned)m, p.fd_per) * p.Cin + c4 * 4;
+    }
+    const bool b_row_ok = BN % RPP == 0 || lrow < BN;  // 128x32 tiles at BK = 16: half of the threads stage B
+    const float* b_ptr = p.w + (size_t)(n0 + (b_row_ok ? lrow : 0)) * p.Cin + c4 * 4;
+    // byte offset of this thread's 8-byte slot inside a plane row block (same for A and B: both tiles are staged by row)
+    int st_off[AR > BR ? AR : BR];
+#pragma unroll
+    for (int i = 0; i < (AR > BR ? AR : BR); ++i) {
+        const int r = lrow + RPP * i;
+        st_off[i] = r * ROWB + (((c4 >> 1) ^ sw(r)) << 4) + ((c4 & 1) << 3);
+    }
+
+    // PF = staged K-tiles in flight (1 or 2). The K loop of this kernel is short on matrix time (12 MFMAs of 32 cycles per wave
+    // and 32 k), so with one tile in flight a block sits out most of every global-load round trip
+    struct Stage {
+        f32x4 a[AR], b[BR], g[GATE ? AR : 1];
+    };
+    int ld_k = 0;
+    auto load_tile = [&](Stage& st) {
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            st.a[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + ld_k);
+            if (GATE) st.g[i] = *reinterpret_cast<const f32x4*>(g_ptr[i] + ld_k);
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) st.b[j] = *reinterpret_cast<const f32x4*>(b_ptr + (size_t)(RPP * j) * p.Cin + ld_k);
+        ld_k += BK;
+    };
+    auto store_tile = [&](const Stage& st, int buf) {
+        char* A = smem_c + buf * BUF;
+        char* Bq = A + 3 * APL;
+#pragma unroll
+        for (int i = 0; i < AR; ++i) {
+            uint2 q0, q1, q2;
+            split3(GATE ? st.a[i] * st.g[i] : st.a[i], q0, q1, q2);
+            *reinterpret_cast<uint2*>(A + st_off[i]) = q0;
+            *reinterpret_cast<uint2*>(A + APL + st_off[i]) = q1;
+            *reinterpret_cast<uint2*>(A + 2 * APL + st_off[i]) = q2;
+        }
+#pragma unroll
+        for (int j = 0; j < BR; ++j) {
+            if (!b_row_ok) break;
+            uint2 q0, q1, q2;
+            split3(st.b[j], q0, q1, q2);
+            *reinterpret_cast<uint2*>(Bq + st_off[j]) = q0;
+            *reinterpret_cast<uint2*>(Bq + BPL + st_off[j]) = q1;
+            *reinterpret_cast<uint2*>(Bq + 2 * BPL + st_off[j]) = q2;
+        }
+    };
+
+    // three accumulator tiles: x0 w0 / the two first-order products / the three second-order products. They are added once, in
+    // the epilogue (small sums first), and give the MFMA sequence below no two dependent instructions back to back.
+    f32x16 acc[TM][TN], c1[TM][TN], c2[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f, c1[i][j][r] = 0.f, c2[i][j][r] = 0.f;
+
+    // fragment read offsets: lane (row l31, k-half lh) reads the 16-byte chunk 2 ks + lh of its row
+    int a_off[TM][KS], b_off[TN][KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int r = wm + i * 32 + l31;
+            a_off[i][ks] = r * ROWB + (((2 * ks + lh) ^ sw(r)) << 4);
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int r = wn + j * 32 + l31;
+            b_off[j][ks] = r * ROWB + (((2 * ks + lh) ^ sw(r)) << 4);
+        }
+    }
+
+    auto compute_tile = [&](int cur) {
+        const char* A = smem_c + cur * BUF;
+        const char* Bq = A + 3 * APL;
+        bf16x8 af[2][3][TM], bf[2][3][TN];  // register double buffer over the k-steps of a K-tile
+        auto read_frags = [&](int set, int ks) {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) af[set][q][i] = *reinterpret_cast<const bf16x8*>(A + q * APL + a_off[i][ks]);
+#pragma unroll
+                for (int j = 0; j < TN; ++j) bf[set][q][j] = *reinterpret_cast<const bf16x8*>(Bq + q * BPL + b_off[j][ks]);
+            }
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int s = ks & 1;
+            if (ks + 1 < KS) read_frags(s ^ 1, ks + 1);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    c2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][2][i], bf[s][0][j], c2[i][j], 0, 0, 0);
+                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1][i], bf[s][0][j], c1[i][j], 0, 0, 0);
+                    c2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0][i], bf[s][2][j], c2[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0][i], bf[s][0][j], acc[i][j], 0, 0, 0);
+                    c2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1][i], bf[s][1][j], c2[i][j], 0, 0, 0);
+                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0][i], bf[s][1][j], c1[i][j], 0, 0, 0);
+                }
+        }
+        // pin the issue order spelled out above (0x100 = DS read, 0x008 = MFMA): all reads of a k-step ahead of its MFMAs, the
+        // next k-step's reads spread between this one's MFMAs
+        constexpr int NR = 3 * (TM + TN), NM = 6 * TM * TN;
+        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            if (ks + 1 < KS) {
+#pragma unroll
+                for (int q = 0; q < NM; ++q) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, (NR + NM - 1) / NM, 0);
+                }
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+            }
+        }
+    };
+
+    const int nk = p.Cin / BK;
+    if constexpr (PF == 1) {
+        Stage s0;
+        load_tile(s0);
+        store_tile(s0, 0);
+        __syncthreads();
+        for (int kt = 0; kt < nk; ++kt) {
+            const int cur = kt & 1;
+            if (kt + 1 < nk) load_tile(s0);
+            compute_tile(cur);
+            if (kt + 1 < nk) store_tile(s0, cur ^ 1);
+            __syncthreads();
+        }
+    } else {
+        // tile t travels through stage set t & 1 into LDS buffer t & 1; its loads were issued two iterations before its store.
+        // ODD (the parity of the K-tile count) is a template parameter: a run-time exit between the two halves of the loop
+        // body makes hipcc keep two accumulator sets and copy between them (288 v_accvgpr moves, 220 registers)
+        Stage s0, s1;
+        load_tile(s0);
+        if (nk > 1) load_tile(s1);
+        store_tile(s0, 0);
+        __syncthreads();
+        for (int kt = 0; kt + 1 < nk; kt += 2) {
+            if (kt + 2 < nk) load_tile(s0);
+            compute_tile(0);
+            store_tile(s1, 1);
+            __syncthreads();
+            if (kt + 3 < nk) load_tile(s1);
+            compute_tile(1);
+            if (kt + 2 < nk) store_tile(s0, 0);
+            __syncthreads();
+        }
+        if constexpr (ODD) {
+            compute_tile(0);
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue (conv_igemm.hip's batched form): C tile through LDS, float4 rows out --------------------------------
+    float* Cs = reinterpret_cast<float*>(smem_c);  // [BM][BN]
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn + j * 32 + l31;
+        const bool n_ok = n < p.Cout;
+        const float sc = (n_ok && p.scale) ? p.scale[n] : 1.0f;
+        const float sh = (n_ok && p.shift) ? p.shift[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int rowl = wm + i * 32 + 8 * rq + 4 * lh;
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    Cs[(rowl + r) * BN + wn + j * 32 + l31] = (acc[i][j][rq * 4 + r] + (c1[i][j][rq * 4 + r] + c2[i][j][rq * 4 + r])) * sc + sh;
+            }
+    }
+    __syncthreads();
+    constexpr int TPO = BN / 4, RPO = 256 / TPO, ITER = BM / RPO;
+    const int oc = (tid % TPO) * 4, n = n0 + oc;
+    if (n < p.Cout) {
+        f32x4 v[ITER], res[ITER];
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int r = tid / TPO + it * RPO;
+            const bool ok = m0 + r < p.M;
+            v[it] = *reinterpret_cast<const f32x4*>(Cs + r * BN + oc);
+            res[it] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (p.residual) res[it] = *reinterpret_cast<const f32x4*>(p.residual + (size_t)(ok ? m0 + r : 0) * p.Cout + n);
+        }
+#pragma unroll
+        for (int it = 0; it < ITER; ++it) {
+            const int r = tid / TPO + it * RPO;
+            if (m0 + r < p.M) {
+                f32x4 o = v[it] + res[it];
+                o[0] = bf3_act(o[0], p.act), o[1] = bf3_act(o[1], p.act), o[2] = bf3_act(o[2], p.act), o[3] = bf3_act(o[3], p.act);
+                *reinterpret_cast<f32x4*>(p.y + (size_t)(m0 + r) * p.Cout + n) = o;
+            }
+        }
+    }
+}
+
+bool conv_bf3_supported(const ConvDesc& d) {
+    const bool pw = !d.x_nchw && d.KH == 1 && d.KW == 1 && d.pad_t == 0 && d.pad_l == 0 && d.stride == 1;
+    return pw && !d.pool2 && !d.y_raw && !d.stats && d.Cin % 16 == 0 && d.Cout % 4 == 0 && d.Cin >= 64 && d.Cout >= 40;
+}
+
+template <int BM, int BN, int WGM, int WGN, int BK>
+static int bf3_launch(Bf3Params& p, const ConvDesc& d, hipStream_t s) {
+    p.m_tiles = cdiv(p.M, BM), p.n_tiles = cdiv(p.Cout, BN);
+    const size_t pipe = (size_t)2 * 3 * (BM + BN) * BK * 2, epi = (size_t)BM * BN * 4;
+    const size_t lds = pipe > epi ? pipe : epi;
+    const int grid = p.m_tiles * p.n_tiles;
+    char name[48];
+    snprintf(name, sizeof(name), "conv_bf3<%d,%d,%d%s%s>", BM, BN, BK, d.gate ? ",gate" : "", get_option("conv_bf3_pf") == 1 ? ",pf1" : "");
+    const double pix = (double)p.M;
+    const int rec = prof_start(name, 2.0 * pix * d.Cout * d.Cin * d.prof_flop_scale,
+                               4.0 * (pix * d.Cin + pix * d.Cout * (d.residual ? 2.0 : 1.0) + (double)d.Cout * d.Cin), s);
+    const bool odd = ((p.Cin / BK) & 1) != 0;
+    if (get_option("conv_bf3_pf") == 1) {
+        if (d.gate) conv_bf3_kernel<BM, BN, WGM, WGN, BK, true, 1, false><<<grid, 256, lds, s>>>(p);
+        else conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 1, false><<<grid, 256, lds, s>>>(p);
+    } else if (odd) {
+        if (d.gate) conv_bf3_kernel<BM, BN, WGM, WGN, BK, true, 2, true><<<grid, 256, lds, s>>>(p);
+        else conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 2, true><<<grid, 256, lds, s>>>(p);
+    } else {
+        if (d.gate) conv_bf3_kernel<BM, BN, WGM, WGN, BK, true, 2, false><<<grid, 256, lds, s>>>(p);
+        else conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 2, false><<<grid, 256, lds, s>>>(p);
+    }
+    prof_stop(rec, s);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int launch_conv_bf3(const ConvDesc& d, hipStream_t s) {
+    ORBIT_REQUIRE(conv_bf3_supported(d), "conv_bf3: unsupported convolution");
+    Bf3Params p;
+    p.x = d.x, p.w = d.w_packed, p.y = d.y, p.scale = d.scale, p.shift = d.shift, p.residual = d.residual, p.gate = d.gate;
+    p.M = d.B * d.H * d.W, p.Cin = d.Cin, p.Cout = d.Cout, p.act = d.act;
+    p.fd_per = make_fastdiv((unsigned)(d.H * d.W));
+    // tiles as conv_igemm.hip chooses them: 128x32 where a 64-wide last column tile would be mostly padding
+    const double waste64 = (double)(cdiv(d.Cout, 64) * 64 - d.Cout) / d.Cout;
+    const double waste32 = (double)(cdiv(d.Cout, 32) * 32 - d.Cout) / d.Cout;
+    const bool narrow = waste64 - waste32 >= 0.15;
+    const int bk = (d.Cin % 32 == 0 && get_option("conv_bf3_bk") != 16) ? 32 : 16;
+    if (narrow) return bk == 32 ? bf3_launch<128, 32, 4, 1, 32>(p, d, s) : bf3_launch<128, 32, 4, 1, 16>(p, d, s);
+    return bk == 32 ? bf3_launch<64, 64, 2, 2, 32>(p, d, s) : bf3_launch<64, 64, 2, 2, 16>(p, d, s);
+}
+
+}  // namespace orbit

@@ -819,6 +819,9 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     ORBIT_REQUIRE(d.Cout % 4 == 0, "conv: Cout %% 4 != 0 (Cout=%d): the epilogue writes float4 rows", d.Cout);
     const bool pw = !d.x_nchw && d.KH == 1 && d.KW == 1 && d.pad_t == 0 && d.pad_l == 0;
     if (d.stats_blocks) *d.stats_blocks = 0;
+    // opt-in: three-way bf16 split of both operands on the bf16 matrix cores (a function of the layer only, like every routing
+    // rule here: a frame's bits do not depend on its batch)
+    if (get_option("conv_bf3") && conv_bf3_supported(d)) return launch_conv_bf3(d, s);
     const int rg = get_option("conv_rgemm");
     if (rg == 2 && pw_rgemm_supported(d)) return launch_pw_rgemm(d, s);
     if (pw && !d.y_raw && pw_narrow_supported(d)) return launch_pw_narrow(d, s);

@@ -184,9 +184,10 @@ struct orbit_extractor {
     struct GraphKey {
         const void *frames, *gamma, *beta, *feats, *ws, *stream;
         int B;
+        int epoch;  // option_epoch() at capture: runtime options choose kernels
         bool operator==(const GraphKey& o) const {
             return frames == o.frames && gamma == o.gamma && beta == o.beta && feats == o.feats && ws == o.ws &&
-                   stream == o.stream && B == o.B;
+                   stream == o.stream && B == o.B && epoch == o.epoch;
         }
     };
     struct GraphEntry {
@@ -214,7 +215,7 @@ struct orbit_extractor {
     // addresses step after step (torch's caching allocator in a steady-state training loop) replay; others stay eager.
     struct TrainGraphKey {
         const void* p[10];
-        long v[4];
+        long v[5];  // v[4] = option_epoch() (set by run_train_graphed)
         bool operator==(const TrainGraphKey& o) const { return memcmp(this, &o, sizeof(*this)) == 0; }
     };
     struct TrainGraphEntry {
@@ -240,6 +241,7 @@ struct orbit_extractor {
             ++train_graph_eager;
             return run(s);
         }
+        key.v[4] = option_epoch();
         TrainGraphEntry* hit = nullptr;
         for (auto& g : train_graphs)
             if (g.key == key) hit = &g;

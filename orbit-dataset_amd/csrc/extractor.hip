@@ -541,7 +541,7 @@ int orbit_extractor_forward(orbit_extractor_t* fe, const float* frames, int B, c
 
     // graph path: 1st sight of a pointer tuple runs eagerly (also performs one-time kernel attribute setup), the 2nd
     // captures + instantiates, later ones replay
-    const orbit_extractor::GraphKey key{frames, film_gamma, film_beta, feats, workspace, nullptr, B};
+    const orbit_extractor::GraphKey key{frames, film_gamma, film_beta, feats, workspace, nullptr, B, option_epoch()};
     orbit_extractor::GraphEntry* hit = nullptr;
     for (auto& g : fe->graphs)
         if (g.key == key) hit = &g;

@@ -63,6 +63,9 @@ static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
                              {"conv_rgemm", "ORBIT_CONV_RGEMM", 1, false},
                              {"conv_rgemm_t", "ORBIT_CONV_RGEMM_T", 0, false},
                              {"conv_rgemm_wk", "ORBIT_CONV_RGEMM_WK", 0, false},
+                             {"conv_bf3", "ORBIT_CONV_BF3", 0, false},
+                             {"conv_bf3_bk", "ORBIT_CONV_BF3_BK", 0, false},
+                             {"conv_bf3_pf", "ORBIT_CONV_BF3_PF", 0, false},
                              {"head_lds", "ORBIT_HEAD_LDS", 1, false},
                              {"head_stream", "ORBIT_HEAD_STREAM", 2, false}};
 static Option* find_option(const char* name) {
@@ -81,6 +84,10 @@ int get_option(const char* name) {
     Option* o = find_option(name);
     return o ? o->value : 0;
 }
+// bumped by every orbit_set_option that changes a value: captured launch sequences (csrc/extractor.hip, extractor.h) carry the
+// epoch they were recorded under in their key, so a graph never replays kernels chosen under other option values
+static int g_option_epoch = 0;
+int option_epoch() { return g_option_epoch; }
 
 // wave64 sum on the VALU with DPP lane permutes (quad swaps, half-row / row mirrors, then row broadcasts), result
 // broadcast from lane 63. __shfl_xor lowers to ds_bpermute_b32, an LDS-pipe round trip per step: with 20 reductions per
@@ -548,6 +555,7 @@ int orbit_set_option(const char* name, int value) {
     ORBIT_REQUIRE(name, "set_option: null name");
     Option* o = find_option(name);
     ORBIT_REQUIRE(o != nullptr, "set_option: unknown option '%s'", name);
+    if (o->value != value) ++g_option_epoch;
     o->value = value;
     return ORBIT_OK;
 }

@@ -192,6 +192,37 @@ def test_squeeze_excite_gate_computed_by_the_producer_kernel(device, B):
         lib.orbit_set_option(b"graph", prev_graph)
 
 
+@pytest.mark.parametrize("graph", [0, 1])
+def test_extractor_with_bf16x3_pointwise_convs_matches_oracle(device, graph):
+    """`conv_bf3` (opt-in, csrc/conv_bf3.hip): EfficientNet-B0's 14x14 / 7x7 pointwise convs on the bf16 matrix cores with three-way
+    split operands. Same oracle, same bound as the default path (FEAT_TOL); the features differ from the default path's (another
+    summation), and an option change re-captures a replayed launch sequence (the option epoch is part of the graph key)."""
+    from orbit_dataset_amd import _lib
+    lib = _lib.load()
+    ref, fe, _ = _pair("efficientnet_b0")
+    x = _frames(4, 224)
+    with torch.no_grad():
+        want = ref(x)
+    xd = x.to(device)
+    prev, prev_graph = lib.orbit_get_option(b"conv_bf3"), lib.orbit_get_option(b"graph")
+    try:
+        lib.orbit_set_option(b"graph", graph)
+        lib.orbit_set_option(b"conv_bf3", 0)
+        out = torch.empty(4, fe.output_size, device=device)
+        base = [fe(xd, out=out).clone() for _ in range(3)][-1]  # eager, capture, replay
+        lib.orbit_set_option(b"conv_bf3", 1)
+        got = [fe(xd, out=out).clone() for _ in range(3)]
+        lib.orbit_set_option(b"conv_bf3", 0)
+        back = fe(xd, out=out).clone()
+    finally:
+        lib.orbit_set_option(b"conv_bf3", prev)
+        lib.orbit_set_option(b"graph", prev_graph)
+    assert feat_err(base.cpu(), want) < FEAT_TOL
+    assert all(torch.equal(got[0], g_) for g_ in got) and not torch.equal(got[0], base)  # the split kernels did run
+    assert feat_err(got[0].cpu(), want) < FEAT_TOL
+    assert torch.equal(back, base)
+
+
 def test_row_streaming_plan_refuses_a_changed_band_option(device):
     """`mbrows_band` is read when a plan is built (it sizes the squeeze-excite pooling partials) and again at
     launch. Changing it in between must fail loudly instead of writing a different number of partials than the gate sums."""

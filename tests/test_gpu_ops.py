@@ -608,6 +608,63 @@ def test_conv_pointwise_register_gemm(lib, device, case):
     assert torch.equal(got, again)  # deterministic (K slices are added in slice order)
 
 
+BF3_CASES = [  # Cin, Cout, (H, W), B, gated, residual, act, forced K-tile (0 = the launcher's)
+    (144, 40, (28, 28), 3, True, False, 0, 0),       # 64x64 tiles, K-tile 16, 9 K-tiles (odd), ragged last column tile
+    (240, 80, (14, 14), 5, True, False, 0, 0),       # 128x32 tiles, K-tile 16, 15 K-tiles
+    (80, 480, (14, 14), 2, False, False, 2, 0),      # expansion: 5 K-tiles of 16, SiLU epilogue
+    (480, 80, (14, 14), 3, True, True, 0, 0),        # 128x32 tiles, K-tile 32, residual
+    (672, 112, (14, 14), 2, True, True, 0, 0),       # 21 K-tiles of 32 (odd)
+    (672, 112, (14, 14), 2, True, True, 0, 16),      # the same layer forced to 42 K-tiles of 16
+    (1152, 320, (7, 7), 7, True, False, 0, 0),       # 343 rows = 5 tiles of 64 + 23 (clamped rows), 36 K-tiles
+    (320, 1280, (7, 7), 3, False, False, 2, 0),      # the head conv
+    (64, 40, (3, 3), 1, False, False, 1, 0),         # fewer rows than one tile, two K-tiles, ReLU
+    (96, 44, (9, 5), 2, False, True, 0, 0),          # Cout % 16 = 12, three K-tiles (odd count at K-tile 32)
+]
+
+
+@pytest.mark.parametrize("case", BF3_CASES, ids=["%dto%d_%dx%d_bk%d" % (c[0], c[1], c[2][0], c[2][1], c[7]) for c in BF3_CASES])
+def test_conv_pointwise_bf16x3(lib, device, case):
+    """csrc/conv_bf3.hip (opt-in `conv_bf3`): both operands split three ways into bf16, six bf16 x bf16 products per fp32 product
+    on v_mfma_f32_32x32x16_bf16, fp32 accumulation. Against the fp64 evaluation of the same layer it must be AT LEAST as close as
+    the default fp32-MFMA kernel (same 2e-5 bound, and an error no larger than 1.5x the fp32 kernel's + 1e-7), for every
+    EfficientNet epilogue form, ragged row counts, both tile shapes, both K-tile widths, odd / even K-tile counts; deterministic."""
+    Cin, Cout, (H, W), B, gated, res, act, bk = case
+    g = torch.Generator().manual_seed(Cin * 5 + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5
+    kw = dict(scale=torch.rand(Cout, generator=g) + 0.5, shift=torch.randn(Cout, generator=g) * 0.1,
+              residual=torch.randn(B, Cout, H, W, generator=g) if res else None,
+              gate=torch.rand(B, Cin, generator=g) if gated else None, act=act)
+    want = ref_conv(x.double(), w.double(), 1, 0, 0, H, W, **{k: (v.double() if torch.is_tensor(v) else v) for k, v in kw.items()})
+    prev = lib.orbit_get_option(b"conv_bf3")
+    try:
+        lib.orbit_set_option(b"conv_bf3", 0)
+        fp32 = run_conv(lib, device, x, w, 1, 0, 0, H, W, **kw)
+        lib.orbit_set_option(b"conv_bf3", 1)
+        lib.orbit_set_option(b"conv_bf3_bk", bk)
+        lib.orbit_prof_enable(1)
+        got = run_conv(lib, device, x, w, 1, 0, 0, H, W, **kw)
+        lib.orbit_prof_enable(0)
+        lib.orbit_prof_collect(None, None, None)
+        name = ctypes.create_string_buffer(48)
+        lib.orbit_prof_variant(0, name, None, None, None, None)
+        assert name.value.decode().startswith("conv_bf3<"), name.value  # the launch did take the split kernel
+        again = run_conv(lib, device, x, w, 1, 0, 0, H, W, **kw)
+        lib.orbit_set_option(b"conv_bf3_pf", 1)  # one staged K-tile in flight instead of two: the same sums
+        pf1 = run_conv(lib, device, x, w, 1, 0, 0, H, W, **kw)
+    finally:
+        lib.orbit_prof_enable(0)
+        lib.orbit_set_option(b"conv_bf3", prev)
+        lib.orbit_set_option(b"conv_bf3_bk", 0)
+        lib.orbit_set_option(b"conv_bf3_pf", 0)
+    assert not torch.isnan(got).any()
+    scale = max(1.0, want.abs().max().item())
+    e_bf3, e_fp32 = (got.double() - want).abs().max().item(), (fp32.double() - want).abs().max().item()
+    assert e_bf3 < 2e-5 * scale and e_fp32 < 2e-5 * scale
+    assert e_bf3 <= 1.5 * e_fp32 + 1e-7 * scale, (e_bf3, e_fp32)
+    assert torch.equal(got, again) and torch.equal(got, pf1)
+
+
 def _conv_random_cases(lib, device, rnd):
     for case in range(40):
         Cin = rnd.choice([4, 8, 12, 16, 24, 40, 48, 64, 80, 96, 144, 160])
