@@ -131,7 +131,7 @@ int orbit_device_count(void);
  *                   v_mfma_f32_32x32x16_bf16 (csrc/conv_bf3.hip): the dropped terms are <= 3 x 2^-24 of a product. NOT the
  *                   reference's arithmetic bit for bit - a measured alternative, never the default, never part of bench.py's value
  *   "conv_bf3_bk"   0 (default) = K-tile 32 where Cin % 32 == 0, else 16; 16 = always 16 (A/B)
- *   "conv_bf3_pf"   0 (default) = two staged K-tiles in flight per block; 1 = one (A/B; the same sums)
+ *   "conv_bf3_pf"   0 (default) = one staged K-tile in flight per block; 2 = two (A/B; the same sums, no measured gain)
  *  prototype head (csrc/head.hip):
  *   "head_stream"   2 (default) = the streaming distance kernel (rows requested before the weight staging, 8 waves x 2 rows)
  *                   for launches with >= 64 query rows, 1 = always, 0 = never

@@ -114,8 +114,7 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
         st_off[i] = r * ROWB + (((c4 >> 1) ^ sw(r)) << 4) + ((c4 & 1) << 3);
     }
 
-    // PF = staged K-tiles in flight (1 or 2). The K loop of this kernel is short on matrix time (12 MFMAs of 32 cycles per wave
-    // and 32 k), so with one tile in flight a block sits out most of every global-load round trip
+    // PF = staged K-tiles in flight: 1 (default) or 2 (`conv_bf3_pf` = 2; measured: no gain, 16-36 more registers)
     struct Stage {
         f32x4 a[AR], b[BR], g[GATE ? AR : 1];
     };
@@ -152,15 +151,15 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
         }
     };
 
-    // three accumulator tiles: x0 w0 / the two first-order products / the three second-order products. They are added once, in
-    // the epilogue (small sums first), and give the MFMA sequence below no two dependent instructions back to back.
-    f32x16 acc[TM][TN], c1[TM][TN], c2[TM][TN];
+    // two accumulator tiles: the x0 w0 sums (kept by VALU adds, see compute_tile) and the five small products, which are
+    // 2^-8 .. 2^-16 of the former and accumulate on the matrix cores. They are added once, in the epilogue.
+    f32x16 acc[TM][TN], c1[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f, c1[i][j][r] = 0.f, c2[i][j][r] = 0.f;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f, c1[i][j][r] = 0.f;
 
     // fragment read offsets: lane (row l31, k-half lh) reads the 16-byte chunk 2 ks + lh of its row
     int a_off[TM][KS], b_off[TN][KS];
@@ -191,6 +190,19 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
                 for (int j = 0; j < TN; ++j) bf[set][q][j] = *reinterpret_cast<const bf16x8*>(Bq + q * BPL + b_off[j][ks]);
             }
         };
+        // The x0 w0 products of this K-tile are summed in a FRESH register tile and added to the running sums with fp32 VALU
+        // adds (round to nearest even). Measured (tools/mfma_round_probe.hip): the bf16 MFMA aligns its 16 products and C to
+        // the largest exponent among them and drops what falls more than ~3 bits below that term's ulp, without rounding - fed
+        // a large running sum as C it loses up to ~1 ulp of the SUM per instruction, always toward zero: over the 36-72
+        // instructions of a layer that is a systematic 1e-6 relative error, 4e-5 on the task's logits (30x the fp32 path).
+        // With C = 0 the loss is relative to the largest PRODUCT of a 16-group instead.
+        f32x16 t[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t[i][j][r] = 0.f;
         read_frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -200,14 +212,19 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    c2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][2][i], bf[s][0][j], c2[i][j], 0, 0, 0);
+                    // smallest products first
+                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][2][i], bf[s][0][j], c1[i][j], 0, 0, 0);
+                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0][i], bf[s][2][j], c1[i][j], 0, 0, 0);
+                    t[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0][i], bf[s][0][j], t[i][j], 0, 0, 0);
+                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1][i], bf[s][1][j], c1[i][j], 0, 0, 0);
                     c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1][i], bf[s][0][j], c1[i][j], 0, 0, 0);
-                    c2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0][i], bf[s][2][j], c2[i][j], 0, 0, 0);
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0][i], bf[s][0][j], acc[i][j], 0, 0, 0);
-                    c2[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1][i], bf[s][1][j], c2[i][j], 0, 0, 0);
                     c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0][i], bf[s][1][j], c1[i][j], 0, 0, 0);
                 }
         }
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) acc[i][j] += t[i][j];
         // pin the issue order spelled out above (0x100 = DS read, 0x008 = MFMA): all reads of a k-step ahead of its MFMAs, the
         // next k-step's reads spread between this one's MFMAs
         constexpr int NR = 3 * (TM + TN), NM = 6 * TM * TN;
@@ -279,7 +296,7 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
                 const int rowl = wm + i * 32 + 8 * rq + 4 * lh;
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
-                    Cs[(rowl + r) * BN + wn + j * 32 + l31] = (acc[i][j][rq * 4 + r] + (c1[i][j][rq * 4 + r] + c2[i][j][rq * 4 + r])) * sc + sh;
+                    Cs[(rowl + r) * BN + wn + j * 32 + l31] = (acc[i][j][rq * 4 + r] + c1[i][j][rq * 4 + r]) * sc + sh;
             }
     }
     __syncthreads();
@@ -319,12 +336,12 @@ static int bf3_launch(Bf3Params& p, const ConvDesc& d, hipStream_t s) {
     const size_t lds = pipe > epi ? pipe : epi;
     const int grid = p.m_tiles * p.n_tiles;
     char name[48];
-    snprintf(name, sizeof(name), "conv_bf3<%d,%d,%d%s%s>", BM, BN, BK, d.gate ? ",gate" : "", get_option("conv_bf3_pf") == 1 ? ",pf1" : "");
+    snprintf(name, sizeof(name), "conv_bf3<%d,%d,%d%s%s>", BM, BN, BK, d.gate ? ",gate" : "", get_option("conv_bf3_pf") == 2 ? ",pf2" : "");
     const double pix = (double)p.M;
     const int rec = prof_start(name, 2.0 * pix * d.Cout * d.Cin * d.prof_flop_scale,
                                4.0 * (pix * d.Cin + pix * d.Cout * (d.residual ? 2.0 : 1.0) + (double)d.Cout * d.Cin), s);
     const bool odd = ((p.Cin / BK) & 1) != 0;
-    if (get_option("conv_bf3_pf") == 1) {
+    if (get_option("conv_bf3_pf") != 2) {
         if (d.gate) conv_bf3_kernel<BM, BN, WGM, WGN, BK, true, 1, false><<<grid, 256, lds, s>>>(p);
         else conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 1, false><<<grid, 256, lds, s>>>(p);
     } else if (odd) {

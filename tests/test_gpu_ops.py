@@ -650,7 +650,7 @@ def test_conv_pointwise_bf16x3(lib, device, case):
         lib.orbit_prof_variant(0, name, None, None, None, None)
         assert name.value.decode().startswith("conv_bf3<"), name.value  # the launch did take the split kernel
         again = run_conv(lib, device, x, w, 1, 0, 0, H, W, **kw)
-        lib.orbit_set_option(b"conv_bf3_pf", 1)  # one staged K-tile in flight instead of two: the same sums
+        lib.orbit_set_option(b"conv_bf3_pf", 2)  # two staged K-tiles in flight instead of one: the same sums
         pf1 = run_conv(lib, device, x, w, 1, 0, 0, H, W, **kw)
     finally:
         lib.orbit_prof_enable(0)
@@ -662,7 +662,7 @@ def test_conv_pointwise_bf16x3(lib, device, case):
     e_bf3, e_fp32 = (got.double() - want).abs().max().item(), (fp32.double() - want).abs().max().item()
     assert e_bf3 < 2e-5 * scale and e_fp32 < 2e-5 * scale
     assert e_bf3 <= 1.5 * e_fp32 + 1e-7 * scale, (e_bf3, e_fp32)
-    assert torch.equal(got, again) and torch.equal(got, pf1)
+    assert torch.equal(got, again) and torch.equal(got, pf1)  # (pf1: the other prefetch depth)
 
 
 def _conv_random_cases(lib, device, rnd):
