@@ -738,7 +738,7 @@ def main():
     if not train and world == 1:
         out["variants_of_the_metric"] = metric_variants(model, tasks, device, min(args.steps, 20))
     bf3 = None
-    if not train and world == 1 and args.workload.startswith("efficientnet") and os.environ.get("ORBIT_BENCH_BF3", "1") != "0":
+    if not train and world == 1 and os.environ.get("ORBIT_BENCH_BF3", "1") != "0":
         # OPT-IN alternative, never `value`: the 14x14 / 7x7 pointwise convs with both operands split three
         # ways into bf16 and six products per fp32 product on the bf16 matrix cores (csrc/conv_bf3.hip, option conv_bf3). The
         # same timed loop, then the serial leg with per-launch events; its logit error against the pinned oracle is added

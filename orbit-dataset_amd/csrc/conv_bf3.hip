@@ -38,7 +38,10 @@ struct Bf3Params {
     const float* gate;
     int M, Cin, Cout, act;
     int m_tiles, n_tiles;
-    FastDiv fd_per;  // / (H*W): frame of a row (gate)
+    FastDiv fd_per;  // / (Ho*Wo): frame of a row (gate; row decode of the general form)
+    // general (non-pointwise) form: NHWC input, taps walked as in conv_igemm.hip (k = (kh*KW + kw)*Cin + ci, Cin % BK == 0)
+    int H, W, KH, KW, stride, pad_t, pad_l, Ho, Wo, KT;
+    FastDiv fd_wo;
 };
 
 __device__ __forceinline__ float bf3_act(float v, int act) {
@@ -69,10 +72,11 @@ __device__ __forceinline__ void split3(const f32x4 v, uint2& p0, uint2& p1, uint
     p2.x = pk_bf16(r0 - bf_lo(p1.x), r1 - bf_hi(p1.x)), p2.y = pk_bf16(r2 - bf_lo(p1.y), r3 - bf_hi(p1.y));
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK, bool GATE, int PF, bool ODD>
+template <int BM, int BN, int WGM, int WGN, int BK, bool GATE, int PF, bool ODD, bool PW>
 __global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
     static_assert(WGM * WGN == 4, "4 waves per block");
     static_assert(BK == 16 || BK == 32, "BK");
+    static_assert(PW || !GATE, "the squeeze-excite gate prologue belongs to the pointwise form");
     constexpr int WM = BM / WGM, WN = BN / WGN;
     constexpr int TM = WM / 32, TN = WN / 32;
     static_assert(TM >= 1 && TN >= 1, "wave tile");
@@ -98,14 +102,28 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
     const int c4 = tid % TPR, lrow = tid / TPR;
     const float* a_ptr[AR];
     const float* g_ptr[GATE ? AR : 1];
+    int a_hi0[PW ? 1 : AR], a_wi0[PW ? 1 : AR];  // general form: top-left input coordinate of the row's receptive field
 #pragma unroll
     for (int i = 0; i < AR; ++i) {
-        const int m = min(m0 + lrow + RPP * i, p.M - 1);  // rows beyond M are clamped: computed, never stored
-        a_ptr[i] = p.x + (size_t)m * p.Cin + c4 * 4;
-        if (GATE) g_ptr[i] = p.gate + (size_t)fdiv((unsigned)m, p.fd_per) * p.Cin + c4 * 4;
+        if (PW) {
+            const int m = min(m0 + lrow + RPP * i, p.M - 1);  // rows beyond M are clamped: computed, never stored
+            a_ptr[i] = p.x + (size_t)m * p.Cin + c4 * 4;
+            if (GATE) g_ptr[i] = p.gate + (size_t)fdiv((unsigned)m, p.fd_per) * p.Cin + c4 * 4;
+        } else {
+            const int m = m0 + lrow + RPP * i;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int b = (int)fdiv((unsigned)mm, p.fd_per), r = mm - b * (p.Ho * p.Wo);
+            const int ho = (int)fdiv((unsigned)r, p.fd_wo), wo = r - ho * p.Wo;
+            const int hi0 = ho * p.stride - p.pad_t, wi0 = wo * p.stride - p.pad_l;
+            // (the pointer may lie outside the tensor for padded rows: it is only used where the bounds test passes)
+            a_ptr[i] = p.x + (((long)b * p.H + hi0) * p.W + wi0) * p.Cin + c4 * 4;
+            a_hi0[i] = ok ? hi0 : -(1 << 28);  // rows beyond M fail every bounds test
+            a_wi0[i] = wi0;
+        }
     }
     const bool b_row_ok = BN % RPP == 0 || lrow < BN;  // 128x32 tiles at BK = 16: half of the threads stage B
-    const float* b_ptr = p.w + (size_t)(n0 + (b_row_ok ? lrow : 0)) * p.Cin + c4 * 4;
+    const float* b_ptr = p.w + (size_t)(n0 + (b_row_ok ? lrow : 0)) * p.KT + c4 * 4;
     // byte offset of this thread's 8-byte slot inside a plane row block (same for A and B: both tiles are staged by row)
     int st_off[AR > BR ? AR : BR];
 #pragma unroll
@@ -117,16 +135,35 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
     // PF = staged K-tiles in flight: 1 (default) or 2 (`conv_bf3_pf` = 2; measured: no gain, 16-36 more registers)
     struct Stage {
         f32x4 a[AR], b[BR], g[GATE ? AR : 1];
+        unsigned mask;  // general form: bit i = row i's element of this tap lies inside the image
     };
     int ld_k = 0;
+    int ld_ci = 0, ld_kh = 0, ld_kw = 0, ld_tap = 0;  // wave-uniform tap walk of the general form (conv_igemm.hip)
     auto load_tile = [&](Stage& st) {
+        if (PW) {
 #pragma unroll
-        for (int i = 0; i < AR; ++i) {
-            st.a[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + ld_k);
-            if (GATE) st.g[i] = *reinterpret_cast<const f32x4*>(g_ptr[i] + ld_k);
+            for (int i = 0; i < AR; ++i) {
+                st.a[i] = *reinterpret_cast<const f32x4*>(a_ptr[i] + ld_k);
+                if (GATE) st.g[i] = *reinterpret_cast<const f32x4*>(g_ptr[i] + ld_k);
+            }
+        } else {
+            unsigned mask = 0;
+            const long koff = (long)ld_tap + ld_ci;
+#pragma unroll
+            for (int i = 0; i < AR; ++i) {
+                const bool ok = (unsigned)(a_hi0[i] + ld_kh) < (unsigned)p.H && (unsigned)(a_wi0[i] + ld_kw) < (unsigned)p.W;
+                st.a[i] = *reinterpret_cast<const f32x4*>(ok ? a_ptr[i] + koff : p.x);  // unconditional load, zeroed at the store
+                mask |= (ok ? 1u : 0u) << i;
+            }
+            st.mask = mask;
+            ld_ci += BK;
+            if (ld_ci >= p.Cin) {
+                ld_ci = 0, ld_tap += p.Cin;
+                if (++ld_kw == p.KW) ld_kw = 0, ++ld_kh, ld_tap += (p.W - p.KW) * p.Cin;
+            }
         }
 #pragma unroll
-        for (int j = 0; j < BR; ++j) st.b[j] = *reinterpret_cast<const f32x4*>(b_ptr + (size_t)(RPP * j) * p.Cin + ld_k);
+        for (int j = 0; j < BR; ++j) st.b[j] = *reinterpret_cast<const f32x4*>(b_ptr + (size_t)(RPP * j) * p.KT + ld_k);
         ld_k += BK;
     };
     auto store_tile = [&](const Stage& st, int buf) {
@@ -135,7 +172,8 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
 #pragma unroll
         for (int i = 0; i < AR; ++i) {
             uint2 q0, q1, q2;
-            split3(GATE ? st.a[i] * st.g[i] : st.a[i], q0, q1, q2);
+            const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+            split3(GATE ? st.a[i] * st.g[i] : (PW || ((st.mask >> i) & 1u)) ? st.a[i] : zero, q0, q1, q2);
             *reinterpret_cast<uint2*>(A + st_off[i]) = q0;
             *reinterpret_cast<uint2*>(A + APL + st_off[i]) = q1;
             *reinterpret_cast<uint2*>(A + 2 * APL + st_off[i]) = q2;
@@ -243,7 +281,7 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
         }
     };
 
-    const int nk = p.Cin / BK;
+    const int nk = p.KT / BK;
     if constexpr (PF == 1) {
         Stage s0;
         load_tile(s0);
@@ -325,50 +363,67 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
 }
 
 bool conv_bf3_supported(const ConvDesc& d) {
-    const bool pw = !d.x_nchw && d.KH == 1 && d.KW == 1 && d.pad_t == 0 && d.pad_l == 0 && d.stride == 1;
-    return pw && !d.pool2 && !d.y_raw && !d.stats && d.Cin % 16 == 0 && d.Cout % 4 == 0 && d.Cin >= 64 && d.Cout >= 40;
+    if (d.x_nchw || d.pool2 || d.y_raw || d.stats) return false;
+    if (d.Cin % 16 != 0 || d.Cout % 4 != 0 || d.Cin < 64 || d.Cout < 40) return false;
+    const bool pw = d.KH == 1 && d.KW == 1 && d.pad_t == 0 && d.pad_l == 0 && d.stride == 1;
+    return pw || d.gate == nullptr;  // the general form (taps, stride, padding) has no squeeze-excite prologue
 }
 
-template <int BM, int BN, int WGM, int WGN, int BK>
+template <int BM, int BN, int WGM, int WGN, int BK, bool PW>
 static int bf3_launch(Bf3Params& p, const ConvDesc& d, hipStream_t s) {
     p.m_tiles = cdiv(p.M, BM), p.n_tiles = cdiv(p.Cout, BN);
     const size_t pipe = (size_t)2 * 3 * (BM + BN) * BK * 2, epi = (size_t)BM * BN * 4;
     const size_t lds = pipe > epi ? pipe : epi;
     const int grid = p.m_tiles * p.n_tiles;
+    const bool pf2 = get_option("conv_bf3_pf") == 2;
     char name[48];
-    snprintf(name, sizeof(name), "conv_bf3<%d,%d,%d%s%s>", BM, BN, BK, d.gate ? ",gate" : "", get_option("conv_bf3_pf") == 2 ? ",pf2" : "");
+    snprintf(name, sizeof(name), "conv_bf3<%d,%d,%d%s%s%s>", BM, BN, BK, d.gate ? ",gate" : "", PW ? ",pw" : "", pf2 ? ",pf2" : "");
     const double pix = (double)p.M;
-    const int rec = prof_start(name, 2.0 * pix * d.Cout * d.Cin * d.prof_flop_scale,
-                               4.0 * (pix * d.Cin + pix * d.Cout * (d.residual ? 2.0 : 1.0) + (double)d.Cout * d.Cin), s);
-    const bool odd = ((p.Cin / BK) & 1) != 0;
-    if (get_option("conv_bf3_pf") != 2) {
-        if (d.gate) conv_bf3_kernel<BM, BN, WGM, WGN, BK, true, 1, false><<<grid, 256, lds, s>>>(p);
-        else conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 1, false><<<grid, 256, lds, s>>>(p);
-    } else if (odd) {
-        if (d.gate) conv_bf3_kernel<BM, BN, WGM, WGN, BK, true, 2, true><<<grid, 256, lds, s>>>(p);
-        else conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 2, true><<<grid, 256, lds, s>>>(p);
+    const int rec = prof_start(name, 2.0 * pix * d.Cout * d.KH * d.KW * d.Cin * d.prof_flop_scale,
+                               4.0 * ((double)d.B * d.H * d.W * d.Cin + pix * d.Cout * (d.residual ? 2.0 : 1.0) +
+                                      (double)d.Cout * d.KH * d.KW * d.Cin), s);
+    const bool odd = ((p.KT / BK) & 1) != 0;
+    if constexpr (PW) {
+        if (!pf2) {
+            if (d.gate) conv_bf3_kernel<BM, BN, WGM, WGN, BK, true, 1, false, true><<<grid, 256, lds, s>>>(p);
+            else conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 1, false, true><<<grid, 256, lds, s>>>(p);
+        } else if (odd) {
+            if (d.gate) conv_bf3_kernel<BM, BN, WGM, WGN, BK, true, 2, true, true><<<grid, 256, lds, s>>>(p);
+            else conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 2, true, true><<<grid, 256, lds, s>>>(p);
+        } else {
+            if (d.gate) conv_bf3_kernel<BM, BN, WGM, WGN, BK, true, 2, false, true><<<grid, 256, lds, s>>>(p);
+            else conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 2, false, true><<<grid, 256, lds, s>>>(p);
+        }
     } else {
-        if (d.gate) conv_bf3_kernel<BM, BN, WGM, WGN, BK, true, 2, false><<<grid, 256, lds, s>>>(p);
-        else conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 2, false><<<grid, 256, lds, s>>>(p);
+        conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 1, false, false><<<grid, 256, lds, s>>>(p);
     }
     prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
 
-int launch_conv_bf3(const ConvDesc& d, hipStream_t s) {
-    ORBIT_REQUIRE(conv_bf3_supported(d), "conv_bf3: unsupported convolution");
-    Bf3Params p;
-    p.x = d.x, p.w = d.w_packed, p.y = d.y, p.scale = d.scale, p.shift = d.shift, p.residual = d.residual, p.gate = d.gate;
-    p.M = d.B * d.H * d.W, p.Cin = d.Cin, p.Cout = d.Cout, p.act = d.act;
-    p.fd_per = make_fastdiv((unsigned)(d.H * d.W));
+template <bool PW>
+static int bf3_dispatch(Bf3Params& p, const ConvDesc& d, hipStream_t s) {
     // tiles as conv_igemm.hip chooses them: 128x32 where a 64-wide last column tile would be mostly padding
     const double waste64 = (double)(cdiv(d.Cout, 64) * 64 - d.Cout) / d.Cout;
     const double waste32 = (double)(cdiv(d.Cout, 32) * 32 - d.Cout) / d.Cout;
     const bool narrow = waste64 - waste32 >= 0.15;
     const int bk = (d.Cin % 32 == 0 && get_option("conv_bf3_bk") != 16) ? 32 : 16;
-    if (narrow) return bk == 32 ? bf3_launch<128, 32, 4, 1, 32>(p, d, s) : bf3_launch<128, 32, 4, 1, 16>(p, d, s);
-    return bk == 32 ? bf3_launch<64, 64, 2, 2, 32>(p, d, s) : bf3_launch<64, 64, 2, 2, 16>(p, d, s);
+    if (narrow) return bk == 32 ? bf3_launch<128, 32, 4, 1, 32, PW>(p, d, s) : bf3_launch<128, 32, 4, 1, 16, PW>(p, d, s);
+    return bk == 32 ? bf3_launch<64, 64, 2, 2, 32, PW>(p, d, s) : bf3_launch<64, 64, 2, 2, 16, PW>(p, d, s);
+}
+
+int launch_conv_bf3(const ConvDesc& d, hipStream_t s) {
+    ORBIT_REQUIRE(conv_bf3_supported(d), "conv_bf3: unsupported convolution");
+    Bf3Params p;
+    p.x = d.x, p.w = d.w_packed, p.y = d.y, p.scale = d.scale, p.shift = d.shift, p.residual = d.residual, p.gate = d.gate;
+    p.M = d.B * d.Ho * d.Wo, p.Cin = d.Cin, p.Cout = d.Cout, p.act = d.act;
+    p.H = d.H, p.W = d.W, p.KH = d.KH, p.KW = d.KW, p.stride = d.stride, p.pad_t = d.pad_t, p.pad_l = d.pad_l;
+    p.Ho = d.Ho, p.Wo = d.Wo, p.KT = d.KH * d.KW * d.Cin;  // (Cin % 16 == 0: conv_pack_weights pads nothing)
+    p.fd_per = make_fastdiv((unsigned)(d.Ho * d.Wo)), p.fd_wo = make_fastdiv((unsigned)d.Wo);
+    ORBIT_REQUIRE((long long)d.B * d.H * d.W * d.Cin < (1ll << 40) && p.M > 0, "conv_bf3: tensor too large");
+    const bool pw = d.KH == 1 && d.KW == 1 && d.pad_t == 0 && d.pad_l == 0 && d.stride == 1;
+    return pw ? bf3_dispatch<true>(p, d, s) : bf3_dispatch<false>(p, d, s);
 }
 
 }  // namespace orbit

@@ -665,6 +665,59 @@ def test_conv_pointwise_bf16x3(lib, device, case):
     assert torch.equal(got, again) and torch.equal(got, pf1)  # (pf1: the other prefetch depth)
 
 
+BF3_GENERAL_CASES = [  # Cin, Cout, K, stride, (H, W), B, residual, act, TF-SAME padding
+    (64, 64, 3, 1, (14, 14), 3, True, 1, False),      # resnet basic block conv2: residual + ReLU
+    (64, 128, 3, 2, (15, 13), 2, False, 1, False),    # stride 2, odd map: partial windows at the borders
+    (64, 128, 1, 2, (14, 14), 2, False, 0, False),    # the 1x1 stride-2 shortcut
+    (128, 128, 3, 1, (7, 9), 5, True, 1, False),      # 315 rows: ragged last row tile
+    (256, 44, 3, 1, (5, 5), 2, False, 0, False),      # 128x32 tiles, Cout % 16 = 12
+    (80, 48, 5, 2, (12, 12), 2, False, 2, True),      # 5x5 stride 2 with TF-SAME (asymmetric) padding, K-tile 16
+    (512, 512, 3, 1, (7, 7), 2, True, 1, False),      # layer4: 144 K-tiles
+]
+
+
+@pytest.mark.parametrize("case", BF3_GENERAL_CASES, ids=["%dto%d_k%ds%d_%dx%d" % (c[0], c[1], c[2], c[3], c[4][0], c[4][1]) for c in BF3_GENERAL_CASES])
+def test_conv_general_bf16x3(lib, device, case):
+    """csrc/conv_bf3.hip, general form (opt-in `conv_bf3`): KxK taps, stride, zero / TF-SAME padding on the bf16 matrix cores with
+    three-way split operands - resnet18's 3x3 and shortcut convs. Against the fp64 evaluation: the default kernel's bound, and an
+    error no larger than 1.5x the default fp32-MFMA kernel's + 1e-7."""
+    Cin, Cout, K, stride, (H, W), B, res, act, same = case
+    if same:
+        Ho, Wo = -(-H // stride), -(-W // stride)
+        pt, pl = max((Ho - 1) * stride + K - H, 0) // 2, max((Wo - 1) * stride + K - W, 0) // 2
+    else:
+        pt = pl = K // 2
+        Ho, Wo = (H + 2 * pt - K) // stride + 1, (W + 2 * pl - K) // stride + 1
+    g = torch.Generator().manual_seed(Cin + 3 * Cout + K + H)
+    x = torch.randn(B, Cin, H, W, generator=g).abs()  # (post-ReLU-like, non-zero mean)
+    w = torch.randn(Cout, Cin, K, K, generator=g) / (Cin * K * K) ** 0.5
+    kw = dict(scale=torch.rand(Cout, generator=g) + 0.5, shift=torch.randn(Cout, generator=g) * 0.1,
+              residual=torch.randn(B, Cout, Ho, Wo, generator=g) if res else None, act=act)
+    want = ref_conv(x.double(), w.double(), stride, pt, pl, Ho, Wo, **{k: (v.double() if torch.is_tensor(v) else v) for k, v in kw.items()})
+    prev = lib.orbit_get_option(b"conv_bf3")
+    try:
+        lib.orbit_set_option(b"conv_bf3", 0)
+        fp32 = run_conv(lib, device, x, w, stride, pt, pl, Ho, Wo, **kw)
+        lib.orbit_set_option(b"conv_bf3", 1)
+        lib.orbit_prof_enable(1)
+        got = run_conv(lib, device, x, w, stride, pt, pl, Ho, Wo, **kw)
+        lib.orbit_prof_enable(0)
+        lib.orbit_prof_collect(None, None, None)
+        name = ctypes.create_string_buffer(48)
+        lib.orbit_prof_variant(0, name, None, None, None, None)
+        assert name.value.decode().startswith("conv_bf3<") and ",pw" not in name.value.decode(), name.value
+        again = run_conv(lib, device, x, w, stride, pt, pl, Ho, Wo, **kw)
+    finally:
+        lib.orbit_prof_enable(0)
+        lib.orbit_set_option(b"conv_bf3", prev)
+    assert not torch.isnan(got).any()
+    scale = max(1.0, want.abs().max().item())
+    e_bf3, e_fp32 = (got.double() - want).abs().max().item(), (fp32.double() - want).abs().max().item()
+    assert e_bf3 < 2e-5 * scale and e_fp32 < 2e-5 * scale
+    assert e_bf3 <= 1.5 * e_fp32 + 1e-7 * scale, (e_bf3, e_fp32)
+    assert torch.equal(got, again)
+
+
 def _conv_random_cases(lib, device, rnd):
     for case in range(40):
         Cin = rnd.choice([4, 8, 12, 16, 24, 40, 48, 64, 80, 96, 144, 160])

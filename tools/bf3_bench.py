@@ -69,6 +69,58 @@ def main():
         tot[0] += t[0][0]
         tot[1] += t[1][0]
     print("sum: fp32 %.1f us  bf3 %.1f us" % (tot[0], tot[1]))
+    if len(sys.argv) > 1 and sys.argv[1] == "resnet":
+        resnet(lib, dev, B)
+
+
+def resnet(lib, dev, B):
+    """resnet18 @224 3x3 and shortcut layers (NHWC, ReLU epilogue), default fp32-MFMA kernel against conv_bf3's general form."""
+    tot = [0.0, 0.0]
+    for name, H, Cin, Cout, K, stride, n in (("l1 3x3", 56, 64, 64, 3, 1, 4), ("l2 3x3/2", 56, 64, 128, 3, 2, 1), ("l2 1x1/2", 56, 64, 128, 1, 2, 1),
+                                             ("l2 3x3", 28, 128, 128, 3, 1, 3), ("l3 3x3/2", 28, 128, 256, 3, 2, 1), ("l3 3x3", 14, 256, 256, 3, 1, 3),
+                                             ("l4 3x3/2", 14, 256, 512, 3, 2, 1), ("l4 3x3", 7, 512, 512, 3, 1, 3)):
+        pad = K // 2
+        Ho = (H + 2 * pad - K) // stride + 1
+        x = torch.randn(B, H, H, Cin, device=dev).abs()
+        w = torch.randn(Cout, Cin, K, K, device=dev) / (Cin * K * K) ** 0.5
+        sc, sh = torch.rand(Cout, device=dev) + 0.5, torch.randn(Cout, device=dev)
+
+        def run(y):
+            _lib.check(lib.orbit_op_conv2d(_lib.dptr(x), 0, _lib.dptr(w), _lib.dptr(y), _lib.dptr(sc), _lib.dptr(sh), None, None,
+                                           B, H, H, Cin, Cout, K, K, stride, pad, pad, Ho, Ho, 1, 0, _lib.stream_handle()))
+
+        def measure(y, reps=6):
+            for _ in range(2):
+                run(y)
+            lib.orbit_prof_enable(1)
+            for _ in range(reps):
+                run(y)
+            torch.cuda.synchronize()
+            lib.orbit_prof_enable(0)
+            ms, fl, n_ = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
+            lib.orbit_prof_collect(ctypes.byref(ms), ctypes.byref(fl), ctypes.byref(n_))
+            nm = ctypes.create_string_buffer(48)
+            lib.orbit_prof_variant(0, nm, None, None, None, None)
+            return 1e3 * ms.value / reps, nm.value.decode()
+
+        ys, t = {}, {}
+        for rep in range(2):
+            for opt in (0, 1):
+                lib.orbit_set_option(b"conv_bf3", opt)
+                ys[opt] = torch.empty(B, Ho, Ho, Cout, device=dev)
+                us, nm = measure(ys[opt])
+                t[opt] = (min(us, t.get(opt, (1e9, ""))[0]), nm)
+        lib.orbit_set_option(b"conv_bf3", 0)
+        ref = torch.nn.functional.conv2d(x[:8].permute(0, 3, 1, 2).double(), w.double(), None, stride, pad).permute(0, 2, 3, 1)
+        ref = torch.relu(ref * sc.double() + sh.double())
+        err = [(ys[o][:8].double() - ref).abs().max().item() / ref.abs().max().item() for o in (0, 1)]
+        fl = 2.0 * B * Ho * Ho * Cin * Cout * K * K
+        print("%-9s x%d  %3d->%3d @%2d  fp32 %7.1f us %5.1f TF (%s)   bf3 %7.1f us %5.1f TF (%s) %+5.0f%%   err max %.1e / %.1e"
+              % (name, n, Cin, Cout, H, t[0][0], fl / t[0][0] / 1e6, t[0][1], t[1][0], fl / t[1][0] / 1e6, t[1][1],
+                 100 * (t[0][0] / t[1][0] - 1), err[0], err[1]), flush=True)
+        tot[0] += n * t[0][0]
+        tot[1] += n * t[1][0]
+    print("resnet18 @224 dense convs without the stem, per %d-frame pass: fp32 %.1f us  bf3 %.1f us" % (B, tot[0], tot[1]))
 
 
 if __name__ == "__main__":

@@ -12,6 +12,11 @@ done
 for w in cnaps_versa_resnet18_224 simple_cnaps_resnet18_224; do python bench.py --workload $w --no-cpu-baseline > $O/full_$w.json 2> $O/full_$w.err; done
 python bench.py --workload efficientnet_b0_224 --way 10 --no-cpu-baseline > $O/full_efficientnet_b0_224_10way.json 2> $O/full_10way.err
 python bench.py --mode lite_train --workload efficientnet_b0_224 --way 10 --tasks-per-rank 8 --steps 10 --warmup 3 --no-cpu-baseline > $O/lite_config5_10way_8tasks.json 2> $O/lite_config5.err
+# round 4: the opt-in bf16x3 conv path (per layer, logits against the fp64 oracle, the MFMA rounding probe) and the vendor GEMM beside ours
+timeout 400 python tools/bf3_bench.py resnet > $O/bf3_bench.txt 2>&1
+timeout 800 python tools/bf3_logit_error.py 200 > $O/bf3_logit_error.txt 2>&1
+tools/mfma_round_probe.bin > $O/mfma_round_probe.txt 2>&1
+timeout 400 python tools/blas_compare.py conv3x3 > $O/blas_compare.txt 2>&1
 python - "$O" <<'PY'
 import json, glob, os, sys
 for f in sorted(glob.glob(sys.argv[1] + '/*.json')):
@@ -21,6 +26,10 @@ for f in sorted(glob.glob(sys.argv[1] + '/*.json')):
         print(os.path.basename(f), round(d['value']), round(d['ms_per_step'], 2), 'frac', round(d['roofline']['frac'], 3), 'share',
               round(d['roofline'].get('kernel_time_share', 0), 2), 'host', round(d.get('host_enqueue_ms_per_step', 0), 2), 'acc',
               round(d.get('frame_accuracy', 0), 3), 'cpu', cb.get('value'), cb.get('cores'), cb.get('max_abs_dlogit_vs_gpu'), cb.get('argmax_identical'))
+        b = d.get('opt_in_conv_bf3')
+        if b:
+            print('    opt-in conv_bf3:', round(b['query_frames_per_s']), round(b['ms_per_step'], 2), 'frac', round(b['conv_frac_of_fp32_mfma_peak'], 3),
+                  'dlogit vs oracle', b.get('max_abs_dlogit_vs_oracle'), b.get('argmax_identical_to_oracle'))
     except Exception as e:
         print(f, 'ERR', e)
 PY
