@@ -743,7 +743,7 @@ def main():
         # ways into bf16 and six products per fp32 product on the bf16 matrix cores (csrc/conv_bf3.hip, option conv_bf3). The
         # same timed loop, then the serial leg with per-launch events; its logit error against the pinned oracle is added
         # below from the cpu_baseline task.
-        lib.orbit_set_option(b"conv_bf3", 1)
+        lib.orbit_set_option(b"conv_bf3", 3)
         try:
             loop(3)
             el3, _, _ = loop(args.steps)
@@ -765,7 +765,7 @@ def main():
                 if nm.value.decode().startswith("conv_bf3<"):
                     split_ms += vms.value
                     split_fl += vfl.value
-            bf3 = {"option": "conv_bf3 = 1 (default 0)", "ms_per_step": 1e3 * el3 / args.steps,
+            bf3 = {"option": "conv_bf3 = 3 (default 0): dense convs + the expand stage of the row-streaming fused fronts", "ms_per_step": 1e3 * el3 / args.steps,
                    "query_frames_per_s": NUM_QUERY * args.steps * per_step / el3,
                    "query_frames_per_s_overlap_off": NUM_QUERY * args.steps * per_step / off3,
                    "conv_tflops_all_dense_conv_launches": fl3.value / ms3.value / 1e9 if ms3.value else None,
@@ -794,9 +794,17 @@ def main():
         base["frame_accuracy_oracle"] = float((want.argmax(1) == task["target_labels"]).float().mean())
         out["cpu_baseline"] = base
         if bf3 is not None:  # the opt-in path's logits on the same task against the same oracle logits
-            lib.orbit_set_option(b"conv_bf3", 1)
+            lib.orbit_set_option(b"conv_bf3", 3)
             try:
                 got3 = run_step(model, {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in task.items()}).cpu()
+            finally:
+                lib.orbit_set_option(b"conv_bf3", 0)
+            # the same task twice more under the stream overlap: the path must be repeatable bit for bit (an earlier form of the
+            # kernel was not - an LDS return overwrote operands of queued bf16 MFMAs when another stream's kernels were on the chip)
+            lib.orbit_set_option(b"conv_bf3", 3)
+            try:
+                dev_task = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in task.items()}
+                bf3["bitwise_repeatable_under_overlap"] = all(bool(torch.equal(run_step(model, dev_task).cpu(), got3)) for _ in range(3))
             finally:
                 lib.orbit_set_option(b"conv_bf3", 0)
             bf3["max_abs_dlogit_vs_oracle"] = float((got3 - want).abs().max().item())

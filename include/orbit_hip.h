@@ -125,10 +125,12 @@ int orbit_device_count(void);
  *                   8 the rest) for A/B runs
  *   "conv_rgemm_t", "conv_rgemm_wk"  0 (default) = the launcher's cost model picks the 16-channel tiles per wave (3..8) and the
  *                   K slices per block (1, 2, 4); other values force them (sweeps: tools/conv_bench.py)
- *   "conv_bf3"      0 (default) = every product is an fp32 x fp32 MFMA; 1 = OPT-IN: stride-1 pointwise convs with Cin % 16 == 0,
- *                   Cin >= 64, Cout >= 40 split both operands three ways into bf16 (x = x0 + x1 + x2, 24 significand bits) and
- *                   sum six of the nine bf16 x bf16 products (each exact in fp32, fp32 accumulation) on
- *                   v_mfma_f32_32x32x16_bf16 (csrc/conv_bf3.hip): the dropped terms are <= 3 x 2^-24 of a product. NOT the
+ *   "conv_bf3"      0 (default) = every product is an fp32 x fp32 MFMA. OPT-IN bits: 1 = dense convs (stride-1 pointwise, and un-gated
+ *                   KxK / strided convs) with Cin % 16 == 0, Cin >= 64, Cout >= 40 split both operands three ways into bf16
+ *                   (x = x0 + x1 + x2, 24 significand bits) and sum six of the nine bf16 x bf16 products (each exact in fp32) on
+ *                   v_mfma_f32_32x32x16_bf16 (csrc/conv_bf3.hip); 2 = the expand GEMM of the row-streaming fused MBConv fronts does
+ *                   the same (csrc/mbconv_rows.hip); 3 = both. Dropped terms <= 2^-26 of a product; the x0 w0 sums are kept by
+ *                   fp32 VALU adds because the bf16 MFMA does not round its accumulator. NOT the
  *                   reference's arithmetic bit for bit - a measured alternative, never the default, never part of bench.py's value
  *   "conv_bf3_bk"   0 (default) = K-tile 32 where Cin % 32 == 0, else 16; 16 = always 16 (A/B)
  *   "conv_bf3_pf"   0 (default) = one staged K-tile in flight per block; 2 = two (A/B; the same sums, no measured gain)

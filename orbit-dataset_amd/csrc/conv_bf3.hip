@@ -18,13 +18,11 @@
 
 #include <cstdio>
 
+#include "bf3.h"
 #include "common.h"
 
 namespace orbit {
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -55,21 +53,6 @@ __device__ __forceinline__ int bf3_xcd_remap(int bid, int nblk) {  // as conv_ig
     const int xcd = bid & 7, slot = bid >> 3;
     const int start = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
     return start + slot;
-}
-
-__device__ __forceinline__ unsigned pk_bf16(float a, float b) {  // v_cvt_pk_bf16_f32 (round to nearest even)
-    const f32x2 v = {a, b};
-    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
-}
-__device__ __forceinline__ float bf_lo(unsigned p) { return __uint_as_float(p << 16); }
-__device__ __forceinline__ float bf_hi(unsigned p) { return __uint_as_float(p & 0xffff0000u); }
-
-// four fp32 values -> three planes of four bf16 (two dwords each)
-__device__ __forceinline__ void split3(const f32x4 v, uint2& p0, uint2& p1, uint2& p2) {
-    p0.x = pk_bf16(v[0], v[1]), p0.y = pk_bf16(v[2], v[3]);
-    const float r0 = v[0] - bf_lo(p0.x), r1 = v[1] - bf_hi(p0.x), r2 = v[2] - bf_lo(p0.y), r3 = v[3] - bf_hi(p0.y);
-    p1.x = pk_bf16(r0, r1), p1.y = pk_bf16(r2, r3);
-    p2.x = pk_bf16(r0 - bf_lo(p1.x), r1 - bf_hi(p1.x)), p2.y = pk_bf16(r2 - bf_lo(p1.y), r3 - bf_hi(p1.y));
 }
 
 template <int BM, int BN, int WGM, int WGN, int BK, bool GATE, int PF, bool ODD, bool PW>
@@ -218,16 +201,23 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
     auto compute_tile = [&](int cur) {
         const char* A = smem_c + cur * BUF;
         const char* Bq = A + 3 * APL;
-        bf16x8 af[2][3][TM], bf[2][3][TN];  // register double buffer over the k-steps of a K-tile
-        auto read_frags = [&](int set, int ks) {
+        // EVERY fragment of the K-tile is read into registers before its first MFMA, and no fragment register is written again
+        // before the tile's last MFMA result has been read. The form that fetched k-step 1's fragments between k-step 0's MFMAs
+        // (into the registers k-step 0's operands had used, as csrc/conv_igemm.hip does for the fp32 MFMAs) was correct alone
+        // and WRONG with another stream's kernels on the chip: the task's logits moved by up to 0.26 from run to run
+        // (tools/bf3_race_probe3.py: two independent models on two streams; hipcc's own schedule of the same loop showed it too,
+        // K-tile 16 - one k-step, nothing to overwrite - did not). An issued v_mfma_f32_32x32x16_bf16 that waits behind other
+        // waves' matrix instructions evidently has not read its A / B registers yet when an LDS return overwrites them.
+        bf16x8 af[KS][3][TM], bf[KS][3][TN];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int q = 0; q < 3; ++q) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i) af[set][q][i] = *reinterpret_cast<const bf16x8*>(A + q * APL + a_off[i][ks]);
+                for (int i = 0; i < TM; ++i) af[ks][q][i] = *reinterpret_cast<const bf16x8*>(A + q * APL + a_off[i][ks]);
 #pragma unroll
-                for (int j = 0; j < TN; ++j) bf[set][q][j] = *reinterpret_cast<const bf16x8*>(Bq + q * BPL + b_off[j][ks]);
+                for (int j = 0; j < TN; ++j) bf[ks][q][j] = *reinterpret_cast<const bf16x8*>(Bq + q * BPL + b_off[j][ks]);
             }
-        };
         // The x0 w0 products of this K-tile are summed in a FRESH register tile and added to the running sums with fp32 VALU
         // adds (round to nearest even). Measured (tools/mfma_round_probe.hip): the bf16 MFMA aligns its 16 products and C to
         // the largest exponent among them and drops what falls more than ~3 bits below that term's ulp, without rounding - fed
@@ -241,44 +231,27 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
             for (int j = 0; j < TN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) t[i][j][r] = 0.f;
-        read_frags(0, 0);
+        __builtin_amdgcn_sched_barrier(0);  // (the reads above stay above: see the note on this lambda)
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            const int s = ks & 1;
-            if (ks + 1 < KS) read_frags(s ^ 1, ks + 1);
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j) {
-                    // smallest products first
-                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][2][i], bf[s][0][j], c1[i][j], 0, 0, 0);
-                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0][i], bf[s][2][j], c1[i][j], 0, 0, 0);
-                    t[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0][i], bf[s][0][j], t[i][j], 0, 0, 0);
-                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1][i], bf[s][1][j], c1[i][j], 0, 0, 0);
-                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][1][i], bf[s][0][j], c1[i][j], 0, 0, 0);
-                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s][0][i], bf[s][1][j], c1[i][j], 0, 0, 0);
+                    // smallest products first; the x0 w0 product LAST: its result is read by the adds below, and the matrix
+                    // pipe runs in order, so by then every MFMA of the tile has consumed its operands
+                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][2][i], bf[ks][0][j], c1[i][j], 0, 0, 0);
+                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bf[ks][2][j], c1[i][j], 0, 0, 0);
+                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1][i], bf[ks][1][j], c1[i][j], 0, 0, 0);
+                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][1][i], bf[ks][0][j], c1[i][j], 0, 0, 0);
+                    c1[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bf[ks][1][j], c1[i][j], 0, 0, 0);
+                    t[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[ks][0][i], bf[ks][0][j], t[i][j], 0, 0, 0);
                 }
-        }
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
             for (int j = 0; j < TN; ++j) acc[i][j] += t[i][j];
-        // pin the issue order spelled out above (0x100 = DS read, 0x008 = MFMA): all reads of a k-step ahead of its MFMAs, the
-        // next k-step's reads spread between this one's MFMAs
-        constexpr int NR = 3 * (TM + TN), NM = 6 * TM * TN;
-        __builtin_amdgcn_sched_group_barrier(0x100, NR, 0);
-#pragma unroll
-        for (int ks = 0; ks < KS; ++ks) {
-            if (ks + 1 < KS) {
-#pragma unroll
-                for (int q = 0; q < NM; ++q) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, (NR + NM - 1) / NM, 0);
-                }
-            } else {
-                __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
-            }
-        }
+        __builtin_amdgcn_sched_barrier(0);  // (nothing of the next stage moves above the adds)
     };
 
     const int nk = p.KT / BK;

@@ -821,8 +821,10 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     if (d.stats_blocks) *d.stats_blocks = 0;
     // opt-in: three-way bf16 split of both operands on the bf16 matrix cores (a function of the layer only, like every routing
     // rule here: a frame's bits do not depend on its batch)
-    if (get_option("conv_bf3") && conv_bf3_supported(d)) return launch_conv_bf3(d, s);
     const int rg = get_option("conv_rgemm");
+    if ((get_option("conv_bf3") & 1) && conv_bf3_supported(d) &&
+        !(rg == 1 && pw_rgemm_supported(d) && pw_rgemm_preferred(d)))  // (1152 -> 320 @7x7: 770 tiles on 768 slots - the register GEMM's 1 535 blocks win)
+        return launch_conv_bf3(d, s);
     if (rg == 2 && pw_rgemm_supported(d)) return launch_pw_rgemm(d, s);
     if (pw && !d.y_raw && pw_narrow_supported(d)) return launch_pw_narrow(d, s);
     if (rg && pw_rgemm_supported(d) && (rg == 2 || pw_rgemm_preferred(d))) return launch_pw_rgemm(d, s);

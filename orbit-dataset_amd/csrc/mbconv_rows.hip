@@ -21,6 +21,7 @@
 // Pixels of a window are enumerated in ring-memory order (pad columns included and forced to zero), so an accumulator
 // row's LDS address is linear in the tile row; the last tile is shifted back to end at the window's end (a few pixels are
 // computed by two waves - same values) instead of guarding its tail.
+#include "bf3.h"
 #include "common.h"
 #include "se_tail.h"
 
@@ -79,7 +80,11 @@ constexpr int ROWS_ES = 36;  // ring pixel stride (floats): 32 channels + 4
 // step never changes); the output address is `scalar row pointer + per-lane constant`; and the lane -> (slot, channel quad)
 // map puts slots u and u + 4 (288 floats = 32 banks apart) with both channel halves into each ds_read_b128 service group,
 // which makes the reads conflict-free at the same 36-float stride.
-template <int K, int S, int TO, int NOUT, int NG, int SPR, bool EXACT>
+// BF3 (opt-in `conv_bf3`, csrc/conv_bf3.hip): the expand GEMM on v_mfma_f32_32x32x16_bf16 with both operands split three ways
+// (six products per fp32 product; a k-step of 16 = two of this kernel's 8-deep k-groups, the odd last group paired with zeros):
+// 6 / 12 / 18 MFMAs of 32 cycles for Cin = 16 / 24 / 40 instead of 8 / 12 / 20 of 64 cycles; the window's x quads are split as
+// they arrive (~22 VALU instructions per quad), the chunk's filter quads once per block. Not bit-identical to the unfused pair.
+template <int K, int S, int TO, int NOUT, int NG, int SPR, bool EXACT, bool BF3>
 __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const MbRowsParams p) {
     constexpr int NEW = TO * S;
     constexpr int NCOL = (NOUT - 1) * S + K;
@@ -146,6 +151,11 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const
         }
         if (ch < p.mid) s1 = p.sc1[ch], h1 = p.sh1[ch];
     }
+    uint2 wq[BF3 ? 3 : 1][BF3 ? NG : 1];  // BF3: the filter quads' three bf16 planes
+    if constexpr (BF3) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g) split3(wb[g], wq[0][g], wq[1][g], wq[2][g]);
+    }
     const float* xb = p.x + (size_t)b * p.H * p.W * p.Cin;
     v4f xa[NG];
     auto load_x = [&](int w) {
@@ -169,10 +179,35 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[r] = 0.f;
         if (rowmask != 0) {  // (a window entirely above / below the image is zeros: no arithmetic)
+            if constexpr (BF3) {
+                const uint2 z2 = {0u, 0u};
 #pragma unroll
-            for (int g = 0; g < NG; ++g)
+                for (int g = 0; g < NG; g += 2) {
+                    uint2 xq[3][2];
+                    split3(xa[g], xq[0][0], xq[1][0], xq[2][0]);
+                    if (g + 1 < NG) split3(xa[g + 1], xq[0][1], xq[1][1], xq[2][1]);
+                    else xq[0][1] = xq[1][1] = xq[2][1] = z2;
+                    bf16x8 af[3], bf[3];
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[g][kk], wb[g][kk], acc, 0, 0, 0);
+                    for (int q = 0; q < 3; ++q) {
+                        af[q] = bf3_frag(xq[q][0], xq[q][1]);
+                        bf[q] = bf3_frag(wq[q][g], g + 1 < NG ? wq[q][g + 1] : z2);
+                    }
+                    // smallest products first; K <= 48, so the sums stay on the matrix cores (csrc/conv_bf3.hip keeps long sums
+                    // out of the bf16 MFMA's accumulator)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], bf[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[0], acc, 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < NG; ++g)
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[g][kk], wb[g][kk], acc, 0, 0, 0);
+            }
         }
         load_x(w + 1 <= NI ? w + 1 : NI);  // the last call re-requests window NI (unused)
         unsigned okbits = 0;
@@ -446,9 +481,9 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
     const double pix = (double)B * H * W;
     const int rec = prof_start("mbconv_rows", 2.0 * pix * Cin * mid + 2.0 * B * Ho * Wo * mid * K * K,
                                4.0 * (pix * Cin + (double)B * Ho * Wo * mid), s);
-#define ORBIT_MBR3(KK, SS, TO_, NOUT_, NG_, SPR_, EX_)                                                         \
+#define ORBIT_MBR3(KK, SS, TO_, NOUT_, NG_, SPR_, EX_, BF_)                                                       \
     do {                                                                                                \
-        auto kern = mbconv_rows3_kernel<KK, SS, TO_, NOUT_, NG_, SPR_, EX_>;                                     \
+        auto kern = mbconv_rows3_kernel<KK, SS, TO_, NOUT_, NG_, SPR_, EX_, BF_>;                                \
         static bool attr_set = false;                                                                   \
         if (!attr_set) {                                                                                \
             ORBIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),                    \
@@ -462,16 +497,19 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
     // chunk is full or exactly half full (a missing quad duplicates the quad 16 channels below)
     const bool exact = g.strips * g.SWo == Wo && Ho % g.TO == 0 && g.band_rows % g.TO == 0 && (mid % 32 == 0 || mid % 32 == 16) &&
                        g.SWo % g.NOUT == 0 && get_option("mbrows_exact") != 0;
+    const bool bf3 = (get_option("conv_bf3") & 2) != 0;  // (opt-in bit 2; the exact-tiling instantiations only)
 #define ORBIT_MBR3X(KK, SS, TO_, NOUT_, NG_, SPR_)                    \
     do {                                                              \
-        if (exact) ORBIT_MBR3(KK, SS, TO_, NOUT_, NG_, SPR_, true);   \
-        else ORBIT_MBR3(KK, SS, TO_, NOUT_, NG_, SPR_, false);        \
+        if (exact && bf3) ORBIT_MBR3(KK, SS, TO_, NOUT_, NG_, SPR_, true, true);   \
+        else if (exact) ORBIT_MBR3(KK, SS, TO_, NOUT_, NG_, SPR_, true, false);    \
+        else ORBIT_MBR3(KK, SS, TO_, NOUT_, NG_, SPR_, false, false);              \
     } while (0)
     if (K == 3 && stride == 2 && ng == 2) ORBIT_MBR3X(3, 2, 1, 1, 2, 32);  // the (TO, NOUT) of rows_geom; SPR >= SWo / NOUT
     else if (K == 3 && stride == 1 && ng == 3) ORBIT_MBR3X(3, 1, 2, 2, 3, 32);
     else if (K == 5 && stride == 2 && ng == 3) ORBIT_MBR3X(5, 2, 2, 1, 3, 16);
     else if (K == 5 && stride == 1 && ng == 5) ORBIT_MBR3X(5, 1, 4, 4, 5, 8);
-    else ORBIT_MBR3X(3, 2, 2, 1, 5, 16);
+    else if (exact) ORBIT_MBR3(3, 2, 2, 1, 5, 16, true, false);  // (its BF3 form needs 11 more registers than 3 waves per SIMD leave)
+    else ORBIT_MBR3(3, 2, 2, 1, 5, 16, false, false);
 #undef ORBIT_MBR3X
 #undef ORBIT_MBR3
     prof_stop(rec, s);

@@ -210,7 +210,7 @@ def test_extractor_with_bf16x3_pointwise_convs_matches_oracle(device, graph):
         lib.orbit_set_option(b"conv_bf3", 0)
         out = torch.empty(4, fe.output_size, device=device)
         base = [fe(xd, out=out).clone() for _ in range(3)][-1]  # eager, capture, replay
-        lib.orbit_set_option(b"conv_bf3", 1)
+        lib.orbit_set_option(b"conv_bf3", 3)  # dense convs (bit 1) and the expand stage of the row-streaming fronts (bit 2)
         got = [fe(xd, out=out).clone() for _ in range(3)]
         lib.orbit_set_option(b"conv_bf3", 0)
         back = fe(xd, out=out).clone()
@@ -221,6 +221,43 @@ def test_extractor_with_bf16x3_pointwise_convs_matches_oracle(device, graph):
     assert all(torch.equal(got[0], g_) for g_ in got) and not torch.equal(got[0], base)  # the split kernels did run
     assert feat_err(got[0].cpu(), want) < FEAT_TOL
     assert torch.equal(back, base)
+
+
+@pytest.mark.parametrize("opt", [0, 3])
+def test_two_extractors_on_two_streams_repeat_their_solo_results(device, opt):
+    """Two independent plans, each on its own stream, issued back to back so their kernels share the chip: every forward must
+    return the bits of its solo run. With `conv_bf3` this caught a kernel that was correct alone: fragment reads of the next
+    k-step overwrote the operand registers of issued-but-queued v_mfma_f32_32x32x16_bf16 instructions when another stream's
+    matrix instructions delayed them (features off by up to 1e-2 from run to run; csrc/conv_bf3.hip reads every fragment of a
+    K-tile before its first MFMA since)."""
+    from orbit_dataset_amd import _lib
+    lib = _lib.load()
+    fes = []
+    for seed in (0, 3):
+        fe, _ = create_feature_extractor("efficientnet_b0", True, False, False)
+        synthetic.init_parameters_(fe, seed=seed)
+        fes.append(fe.cuda().eval())
+    g = torch.Generator(device=device).manual_seed(7)
+    xs = [torch.randn(160, 3, 224, 224, device=device, generator=g) for _ in range(2)]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    prev, prev_graph = lib.orbit_get_option(b"conv_bf3"), lib.orbit_get_option(b"graph")
+    try:
+        lib.orbit_set_option(b"conv_bf3", opt)
+        lib.orbit_set_option(b"graph", 0)
+        with torch.no_grad():
+            solo = [fes[i](xs[i]).clone() for i in range(2)]
+            torch.cuda.synchronize()
+            for rep in range(8):
+                outs = []
+                for i in range(2):
+                    with torch.cuda.stream(streams[i]):
+                        outs.append(fes[i](xs[i]))
+                torch.cuda.synchronize()
+                for i in range(2):
+                    assert torch.equal(outs[i], solo[i]), "rep %d plan %d: max diff %g" % (rep, i, (outs[i] - solo[i]).abs().max().item())
+    finally:
+        lib.orbit_set_option(b"conv_bf3", prev)
+        lib.orbit_set_option(b"graph", prev_graph)
 
 
 def test_row_streaming_plan_refuses_a_changed_band_option(device):

@@ -334,6 +334,54 @@ def test_mbconv_front_row_streaming(lib, device, Cin, mid, K, stride, H, W, band
     assert torch.equal(y.cpu(), y2.cpu())
 
 
+@pytest.mark.parametrize("Cin,mid,K,stride,H,W", MBROWS_CASES[:5])
+def test_mbconv_front_row_streaming_bf16x3(lib, device, Cin, mid, K, stride, H, W):
+    """Opt-in `conv_bf3` inside the row-streaming fused front: the expand GEMM on the bf16 matrix cores with three-way split operands
+    (exact-tiling instantiations; the 40 -> 240 3x3 / 2 shape keeps the fp32 form - register budget). Against the fp64 evaluation
+    of the block front: the default kernel's bound, and an error no larger than 1.5x the default kernel's + 1e-6."""
+    g = torch.Generator().manual_seed(Cin * 1000 + mid + K + stride + H)
+    B = 2
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w1 = torch.randn(mid, Cin, 1, 1, generator=g) / Cin ** 0.5
+    wd = torch.randn(mid, 1, K, K, generator=g) / K
+    s1, h1 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.3
+    s2, h2 = torch.rand(mid, generator=g) + 0.5, torch.randn(mid, generator=g) * 0.1
+    Ho, Wo = -(-H // stride), -(-W // stride)
+    ph, pw = max((Ho - 1) * stride + K - H, 0), max((Wo - 1) * stride + K - W, 0)
+    d = lambda t: t.double()
+    e = F.silu(F.conv2d(d(x), d(w1)) * d(s1)[None, :, None, None] + d(h1)[None, :, None, None])
+    ep = F.pad(e, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
+    want = F.silu(F.conv2d(ep, d(wd), None, stride, 0, 1, mid) * d(s2)[None, :, None, None] + d(h2)[None, :, None, None])
+    dev = [t.to(device).contiguous() for t in (nhwc(x), w1, s1, h1, wd, s2, h2)]
+    prev, prev3 = lib.orbit_get_option(b"mbconv_rows"), lib.orbit_get_option(b"conv_bf3")
+    lib.orbit_set_option(b"mbconv_rows", 1)
+    out = {}
+    try:
+        tiles = lib.orbit_op_mbconv_front_partials(H, W, Cin, mid, K, stride)
+        for opt in (0, 2):  # bit 2 of the option = this kernel family
+            lib.orbit_set_option(b"conv_bf3", opt)
+            y = torch.full((B, Ho, Wo, mid), float("nan"), device=device)
+            pool = torch.full((B, tiles, mid), float("nan"), device=device)
+            _lib.check(lib.orbit_op_mbconv_front(*[_lib.dptr(t) for t in dev], _lib.dptr(y), _lib.dptr(pool), B, H, W, Cin, mid,
+                                                 K, stride, ph // 2, pw // 2, Ho, Wo, _st()), "mbconv_front (rows)")
+            torch.cuda.synchronize()
+            out[opt] = (nchw(y.cpu()), pool.cpu())
+    finally:
+        lib.orbit_set_option(b"conv_bf3", prev3)
+        lib.orbit_set_option(b"mbconv_rows", prev)
+    (y0, p0), (y1, p1) = out[0], out[2]
+    assert not torch.isnan(y1).any() and not torch.isnan(p1).any()
+    e0, e1 = (y0.double() - want).abs().max().item(), (y1.double() - want).abs().max().item()
+    scale = max(1.0, want.abs().max().item())
+    assert e0 < 5e-5 * scale and e1 < 5e-5 * scale
+    assert e1 <= 1.5 * e0 + 1e-6 * scale, (e1, e0)
+    if (Cin, K, stride) == (40, 3, 2):
+        assert torch.equal(y0, y1)      # this shape keeps the fp32 expand
+    else:
+        assert not torch.equal(y0, y1)  # the split form did run
+    assert (p1.double().sum(1) - want.sum((2, 3))).abs().max().item() < 2e-3 * max(1.0, want.sum((2, 3)).abs().max().item())
+
+
 MBMAP_CASES = [  # Cin, K, stride, HW : every whole-map shape of efficientnet_b0 @224 (blocks 3.1 .. 6.0)
     (80, 3, 1, 14), (80, 5, 1, 14), (112, 5, 1, 14), (112, 5, 2, 14), (192, 5, 1, 7), (192, 3, 1, 7)]
 

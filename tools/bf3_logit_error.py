@@ -18,11 +18,14 @@ def main():
     torch.manual_seed(0)
     lib = _lib.load()
     device = torch.device("cuda", 0)
+    trained = len(sys.argv) > 2 and sys.argv[2] == "trained"  # the meta-trained checkpoint + the "blobs" task family of bench.py
     model = bench.build_model("efficientnet_b0_224", device)
+    if trained:
+        bench.load_trained_checkpoint(model, bench.trained_checkpoint("efficientnet_b0_224"))
     ref = OracleRecogniser("efficientnet_b0", False, "proto", 1, 256, num_lite_samples=bench.NUM_LITE)
     sd = {k: v.cpu() for k, v in model.state_dict().items()}
     ref.fe.load_state_dict({k[len("feature_extractor."):]: v for k, v in sd.items() if k.startswith("feature_extractor.")})
-    task = synthetic.make_task(0, 5, 1, n // 5, n, 224)
+    task = synthetic.make_task(0, 5, 1, n // 5, n, 224, template="blobs" if trained else "noise")
     torch.set_num_threads(min(32, os.cpu_count() or 1))
     with torch.no_grad():
         ref.personalise(task["context_clips"], task["context_labels"])
@@ -32,12 +35,12 @@ def main():
         l64 = ref.predict(task["target_clips"].double())
         dev = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in task.items()}
         out = {}
-        for opt in (0, 1):
+        for opt in (0, 3):
             lib.orbit_set_option(b"conv_bf3", opt)
-            out[opt] = bench.run_task(model, dev).double().cpu()
+            out[1 if opt else 0] = bench.run_task(model, dev).double().cpu()
         lib.orbit_set_option(b"conv_bf3", 0)
     d = lambda a, b: (a - b).abs().max().item()
-    print("frames per set %d, |logit| max %.1f, mean %.1f" % (n, l64.abs().max().item(), l64.abs().mean().item()))
+    print("%s weights, frames per set %d, |logit| max %.1f, mean %.1f" % ("meta-trained" if trained else "synthetic", n, l64.abs().max().item(), l64.abs().mean().item()))
     print("max |logit - fp64 oracle|:  fp32 oracle %.3e   GPU default (fp32 MFMA) %.3e   GPU conv_bf3 %.3e" % (d(l32, l64), d(out[0], l64), d(out[1], l64)))
     print("max |logit - fp32 oracle|:  GPU default %.3e   GPU conv_bf3 %.3e" % (d(out[0], l32), d(out[1], l32)))
     print("argmax equal to the fp64 oracle's:  fp32 oracle %s  default %s  conv_bf3 %s" % tuple(
