@@ -684,8 +684,9 @@ def test_conv_pointwise_bf16x3(lib, device, case):
               residual=torch.randn(B, Cout, H, W, generator=g) if res else None,
               gate=torch.rand(B, Cin, generator=g) if gated else None, act=act)
     want = ref_conv(x.double(), w.double(), 1, 0, 0, H, W, **{k: (v.double() if torch.is_tensor(v) else v) for k, v in kw.items()})
-    prev = lib.orbit_get_option(b"conv_bf3")
+    prev, prev_rg = lib.orbit_get_option(b"conv_bf3"), lib.orbit_get_option(b"conv_rgemm")
     try:
+        lib.orbit_set_option(b"conv_rgemm", 0)  # (its default class, 1152 -> 320 at 7x7, would keep that layer)
         lib.orbit_set_option(b"conv_bf3", 0)
         fp32 = run_conv(lib, device, x, w, 1, 0, 0, H, W, **kw)
         lib.orbit_set_option(b"conv_bf3", 1)
@@ -703,6 +704,7 @@ def test_conv_pointwise_bf16x3(lib, device, case):
     finally:
         lib.orbit_prof_enable(0)
         lib.orbit_set_option(b"conv_bf3", prev)
+        lib.orbit_set_option(b"conv_rgemm", prev_rg)
         lib.orbit_set_option(b"conv_bf3_bk", 0)
         lib.orbit_set_option(b"conv_bf3_pf", 0)
     assert not torch.isnan(got).any()
