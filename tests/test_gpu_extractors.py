@@ -223,8 +223,8 @@ def test_extractor_with_bf16x3_pointwise_convs_matches_oracle(device, graph):
     assert torch.equal(back, base)
 
 
-@pytest.mark.parametrize("opt", [0, 3])
-def test_two_extractors_on_two_streams_repeat_their_solo_results(device, opt):
+@pytest.mark.parametrize("name,frames,opt", [("efficientnet_b0", 160, 0), ("efficientnet_b0", 160, 3), ("resnet18", 96, 0), ("resnet18", 96, 1)])
+def test_two_extractors_on_two_streams_repeat_their_solo_results(device, name, frames, opt):
     """Two independent plans, each on its own stream, issued back to back so their kernels share the chip: every forward must
     return the bits of its solo run. With `conv_bf3` this caught a kernel that was correct alone: fragment reads of the next
     k-step overwrote the operand registers of issued-but-queued v_mfma_f32_32x32x16_bf16 instructions when another stream's
@@ -234,11 +234,11 @@ def test_two_extractors_on_two_streams_repeat_their_solo_results(device, opt):
     lib = _lib.load()
     fes = []
     for seed in (0, 3):
-        fe, _ = create_feature_extractor("efficientnet_b0", True, False, False)
+        fe, _ = create_feature_extractor(name, True, False, False)
         synthetic.init_parameters_(fe, seed=seed)
         fes.append(fe.cuda().eval())
     g = torch.Generator(device=device).manual_seed(7)
-    xs = [torch.randn(160, 3, 224, 224, device=device, generator=g) for _ in range(2)]
+    xs = [torch.randn(frames, 3, 224, 224, device=device, generator=g) for _ in range(2)]
     streams = [torch.cuda.Stream(), torch.cuda.Stream()]
     prev, prev_graph = lib.orbit_get_option(b"conv_bf3"), lib.orbit_get_option(b"graph")
     try:

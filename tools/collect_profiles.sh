@@ -97,10 +97,11 @@ PY
 cd $R
 bash tools/conv_pmc.sh $OUT/convpmc effnet_224 > /dev/null 2>&1; cp $O/convpmc/summary.txt $O/${TAG}_conv_sq_counters.txt 2>/dev/null
 bash tools/kernel_pmc.sh $OUT/rgemmpmc pw_rgemm python tools/rgemm_bench.py > /dev/null 2>&1; cp $O/rgemmpmc/summary.txt $O/${TAG}_rgemm_sq_counters.txt 2>/dev/null
+bash tools/kernel_pmc.sh $OUT/bf3pmc conv_bf3_kernel python tools/bf3_bench.py > /dev/null 2>&1; cp $O/bf3pmc/summary.txt $O/${TAG}_bf3_sq_counters.txt 2>/dev/null
 if [ -x tools/dispatch_probe.bin ]; then
   { echo "# tools/dispatch_probe.bin <blocks> <dynamic LDS bytes>: how the dispatcher spreads co-resident 256-thread blocks over the CUs";
     tools/dispatch_probe.bin 770 36864; tools/dispatch_probe.bin 1535 0; tools/dispatch_probe.bin 1535 20480; tools/dispatch_probe.bin 3080 36864; } > $O/${TAG}_dispatch_probe.txt 2>&1
 fi
 # raw rocprofv3 output stays on the box: only the summaries travel back (gpurun merges at most 64 MiB)
-rm -rf $O/stats_* $O/pmc_* $O/convpmc/pass* $O/rgemmpmc/pass*
+rm -rf $O/stats_* $O/pmc_* $O/convpmc/pass* $O/rgemmpmc/pass* $O/bf3pmc/pass*
 ls -la $O | head -60
