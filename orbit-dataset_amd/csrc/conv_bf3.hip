@@ -1,19 +1,22 @@
-// Pointwise convolution with fp32 operands split three ways into bf16 and multiplied on the bf16 matrix cores
-// (`conv_bf3` option, OPT-IN: the default path multiplies fp32 operands on v_mfma_f32_32x32x2_f32).
+// Dense convolutions with fp32 operands split three ways into bf16 and multiplied on the bf16 matrix cores
+// (`conv_bf3` option bit 1, OPT-IN: the default path multiplies fp32 operands on v_mfma_f32_32x32x2_f32). Stride-1 pointwise
+// convs (with the squeeze-excite gate prologue) and the general form (KxK taps, stride, zero / TF-SAME padding).
 //
 //   x = x0 + x1 + x2,  x0 = bf16(x), x1 = bf16(x - x0), x2 = bf16(x - x0 - x1)      (round to nearest even; the two
-//   subtractions are exact in fp32, the three pieces carry 24 significand bits)
+//   subtractions are exact in fp32, the three pieces carry 24 significand bits; csrc/bf3.h)
 //   x * w  ~=  x0 w0 + (x0 w1 + x1 w0) + (x1 w1 + x0 w2 + x2 w0)                      six of the nine products; the three
-//   dropped ones are <= 2^-24 |x w| each. Every bf16 x bf16 product is exact in fp32 and the MFMA accumulates in fp32.
+//   dropped ones are <= 2^-26 |x w| together. Every bf16 x bf16 product is exact in fp32.
 //
 // A v_mfma_f32_32x32x16_bf16 does 8x the multiply-adds of a v_mfma_f32_32x32x2_f32 in half its cycles: six of them per
 // 16 k replace eight fp32 ones per 16 k at 3/8 of the matrix-pipe time. The split itself costs ~5.5 VALU instructions per
 // staged element (operands are split when a tile is written to LDS: once per block and K-tile, not once per MFMA).
-// The five small products accumulate in their own register tile and are added to the x0 w0 sums once, in the epilogue.
+// Two properties of the hardware shape the K loop (both measured; see compute_tile): the bf16 MFMA
+// does not round its accumulator, so the x0 w0 sums of a K-tile start from zero and join the running sums through fp32 VALU
+// adds; and operand registers of issued bf16 MFMAs must not be rewritten until the tile's last MFMA result has been read.
 //
-// Structure: csrc/conv_igemm.hip's pointwise / unpredicated form (same tiling, same global -> register -> LDS pipeline one
-// K-tile ahead, same epilogue), with LDS tiles that hold three bf16 planes per operand. Rows are 2 BK bytes, 16-byte chunks
-// XOR-swizzled by row so that the ds_read_b128 fragment reads of 16-lane groups are conflict-free without padding.
+// Structure: csrc/conv_igemm.hip's unpredicated form (same tiling, same global -> register -> LDS pipeline one K-tile ahead,
+// same epilogue), with LDS tiles that hold three bf16 planes per operand. Rows are 2 BK bytes, 16-byte chunks XOR-swizzled by
+// row so that the ds_read_b128 fragment reads of 16-lane groups are conflict-free without padding.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -28,7 +31,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 struct Bf3Params {
     const float* x;
-    const float* w;       // conv_pack_weights layout [cout_pad][KT], KT = Cin here
+    const float* w;       // conv_pack_weights layout [cout_pad][KT], KT = KH * KW * Cin (Cin % 16 == 0: no padding inside a tap)
     float* y;
     const float* scale;
     const float* shift;
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_bf3_kernel(const Bf3Params p) {
     };
 
     // two accumulator tiles: the x0 w0 sums (kept by VALU adds, see compute_tile) and the five small products, which are
-    // 2^-8 .. 2^-16 of the former and accumulate on the matrix cores. They are added once, in the epilogue.
+    // 2^-8 .. 2^-16 of the former and accumulate on the matrix cores. The two are added once, in the epilogue.
     f32x16 acc[TM][TN], c1[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
