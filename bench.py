@@ -757,14 +757,18 @@ def main():
             model.overlap_query = ov
             ms3, fl3, n3 = ctypes.c_double(), ctypes.c_double(), ctypes.c_long()
             lib.orbit_prof_collect(ctypes.byref(ms3), ctypes.byref(fl3), ctypes.byref(n3))
-            split_ms = split_fl = 0.0
+            split_ms = split_fl = conv_ms3 = conv_fl3 = 0.0
             for i in range(lib.orbit_prof_num_variants()):
                 nm = ctypes.create_string_buffer(48)
                 vms, vfl = ctypes.c_double(), ctypes.c_double()
                 lib.orbit_prof_variant(i, nm, None, ctypes.byref(vms), ctypes.byref(vfl), None)
+                if nm.value.decode().startswith("conv"):  # as `roofline`: the dense conv kernels, not the fused fronts
+                    conv_ms3 += vms.value
+                    conv_fl3 += vfl.value
                 if nm.value.decode().startswith("conv_bf3<"):
                     split_ms += vms.value
                     split_fl += vfl.value
+            ms3.value, fl3.value = conv_ms3, conv_fl3
             bf3 = {"option": "conv_bf3 = 3 (default 0): dense convs + the expand stage of the row-streaming fused fronts", "ms_per_step": 1e3 * el3 / args.steps,
                    "query_frames_per_s": NUM_QUERY * args.steps * per_step / el3,
                    "query_frames_per_s_overlap_off": NUM_QUERY * args.steps * per_step / off3,
