@@ -743,6 +743,7 @@ def main():
         # ways into bf16 and six products per fp32 product on the bf16 matrix cores (csrc/conv_bf3.hip, option conv_bf3). The
         # same timed loop, then the serial leg with per-launch events; its logit error against the pinned oracle is added
         # below from the cpu_baseline task.
+        bf3_prev = lib.orbit_get_option(b"conv_bf3")  # (0 unless ORBIT_CONV_BF3 was set for an A/B run)
         lib.orbit_set_option(b"conv_bf3", 3)
         try:
             loop(3)
@@ -781,7 +782,7 @@ def main():
                            "is quoted against the fp32-MFMA peak the default path is priced on (FLOPs of the fp32 problem)"}
         finally:
             lib.orbit_prof_enable(0)
-            lib.orbit_set_option(b"conv_bf3", 0)
+            lib.orbit_set_option(b"conv_bf3", bf3_prev)
     out["opt_in_conv_bf3"] = bf3
     if not args.no_cpu_baseline and world == 1:
         sd_before = {k: v.clone() for k, v in model.state_dict().items()} if train else None
@@ -802,7 +803,7 @@ def main():
             try:
                 got3 = run_step(model, {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in task.items()}).cpu()
             finally:
-                lib.orbit_set_option(b"conv_bf3", 0)
+                lib.orbit_set_option(b"conv_bf3", bf3_prev)
             # the same task twice more under the stream overlap: the path must be repeatable bit for bit (an earlier form of the
             # kernel was not - an LDS return overwrote operands of queued bf16 MFMAs when another stream's kernels were on the chip)
             lib.orbit_set_option(b"conv_bf3", 3)
@@ -810,7 +811,7 @@ def main():
                 dev_task = {k: (v.to(device) if isinstance(v, torch.Tensor) else v) for k, v in task.items()}
                 bf3["bitwise_repeatable_under_overlap"] = all(bool(torch.equal(run_step(model, dev_task).cpu(), got3)) for _ in range(3))
             finally:
-                lib.orbit_set_option(b"conv_bf3", 0)
+                lib.orbit_set_option(b"conv_bf3", bf3_prev)
             bf3["max_abs_dlogit_vs_oracle"] = float((got3 - want).abs().max().item())
             bf3["argmax_identical_to_oracle"] = bool(torch.equal(got3.argmax(1), want.argmax(1)))
             bf3["max_abs_dlogit_vs_default_path"] = float((got3 - got).abs().max().item())
