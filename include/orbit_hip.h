@@ -129,7 +129,7 @@ int orbit_device_count(void);
  *                   KxK / strided convs) with Cin % 16 == 0, Cin >= 64, Cout >= 40 split both operands three ways into bf16
  *                   (x = x0 + x1 + x2, 24 significand bits) and sum six of the nine bf16 x bf16 products (each exact in fp32) on
  *                   v_mfma_f32_32x32x16_bf16 (csrc/conv_bf3.hip); 2 = the expand GEMM of the row-streaming fused MBConv fronts does
- *                   the same (csrc/mbconv_rows.hip); 3 = both. Dropped terms <= 2^-26 of a product; the x0 w0 sums are kept by
+ *                   the same (csrc/mbconv_rows.hip); 3 = both. Dropped terms <= 2^-24 of a product each (median 2^-29); the x0 w0 sums are kept by
  *                   fp32 VALU adds because the bf16 MFMA does not round its accumulator. NOT the
  *                   reference's arithmetic bit for bit - a measured alternative, never the default, never part of bench.py's value
  *   "conv_bf3_bk"   0 (default) = K-tile 32 where Cin % 32 == 0, else 16; 16 = always 16 (A/B)
