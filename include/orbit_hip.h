@@ -66,90 +66,45 @@ int orbit_runtime_init(void);
 const char* orbit_last_error(void);
 /* number of visible HIP devices (<=0: no usable GPU); does not create a context on failure */
 int orbit_device_count(void);
-/* Tuning switches. Every option has an environment default ORBIT_<NAME in upper case>; all defaults are the measured-best
- * path, the switches exist so that A/B comparisons run inside one process on one box.
- *  extractor forward - which kernel serves which MBConv block (read when a plan is created, unless noted):
- *   "mbconv_rows"   1 (default) = EfficientNet blocks 1.0 .. 3.0 (112x112 .. 28x28 maps) run the ROW-STREAMING fused front
- *                   (csrc/mbconv_rows.hip: expand 1x1 + BN + SiLU + depthwise + BN + SiLU + SE partials, expanded rows in an
- *                   LDS ring, no tile halo); 0 = the tiled fused kernel / the kernel pair as "mbconv_fusion" says
- *   "stem_rows"     1 (default) = conv_stem + BN + SiLU + the first depthwise as one row-streaming kernel; 0 = direct stem
- *                   kernel + depthwise kernel
- *   "mbrows_band"   output rows per band of the two row-streaming kernels: 0 = 28 (default); the band count sizes a plan's
- *                   SE pooling partials, so a launch REFUSES a value that differs from the one its plan was built with
- *   "mbrows_exact"  1 (default) = where a map divides evenly (strips tile the width, bands are whole steps, the last 32-channel
- *                   chunk is full or half full - every shape of a 224 x 224 input) the row-streaming kernels run their
- *                   branch-free instantiation: every output slot stores, idle slots re-store a real owner's value (same bits,
- *                   same address), so the window prefetch is waited for with vmcnt(stores). 0 = always the general
- *                   (predicated) instantiation; outputs are bit-identical either way (tests/test_gpu_ops.py)
- *   "mbconv_fusion" tiled fused front (csrc/mbconv.hip) for blocks the row-streaming kernel does not take: 2 (default) =
- *                   where it measured faster than the conv + depthwise pair, 1 = every supported block (incl. the stem
- *                   form), 0 = never. A plan that records a training tape is always built without fused blocks
- *   "mbconv_map"    whole-map fused front for the 14x14 / 7x7 stages (csrc/mbconv_map.hip): 0 (default) = off, 1 = where
- *                   it beats the pair, 2 = everywhere it applies; "mbmap_groups": its channel-chunk groups per block (0 = auto)
- *   "stem_direct"   1 (default) = EfficientNet's stem as the direct LDS-row kernel (csrc/stem.hip) when not fused; 0 = implicit GEMM
- *   "pw_narrow"     0 (default) / 1 = narrow pointwise projections (Cout 16 / 24) through csrc/pw_narrow.hip
- *   "dw_window"     register-window depthwise kernel: 1 = where it wins (3x3, stride 1, >= 14 rows; default), 0 = never, 2 = always
- *   "dw_lds"        depthwise kernel staging its input patch in LDS: 1 = stride-1 5x5 and small 3x3 maps (default), 0 = never,
- *                   2 = whenever the patch fits in 64 KiB
- *   "dw_pipe"       software-pipelined streaming depthwise kernel: 1 = large stride-2 layers (default), 0 = never, 2 = always
- *   "se_fold"       the squeeze-excite gate of an MBConv block computed by the kernel that produces its pooling partials
- *                   (row-streaming fused fronts, LDS-patch and streaming depthwise kernels): every block takes a ticket on a
- *                   per-frame counter and the block that completes a frame runs the gate MLP for it (csrc/se_tail.h; same bits
- *                   as the stand-alone kernel). 0 (default) = always the stand-alone gate kernel - measured faster: a frame's
- *                   gate is a latency chain through ONE block, and behind a 35-60 us depthwise launch the last frames' chains
- *                   are exposed at the 256-thread / low-register rate the producer can afford (dwconv_lds 36 + 10 us -> 70 us);
- *                   1 = gates of <= 256 channels only (the row-streaming producers: break-even); 2 = every gate a producer can
- *                   take. Read per forward
- *   "se_wide"       1 (default) = 1024-thread squeeze-excite gate blocks for C >= 1024
+/* Runtime options (14). Every option has an environment default ORBIT_<NAME in upper case>; the defaults are the measured-best
+ * path. They exist so that the parity tests can reach every kernel a default path uses and so that A/B comparisons run
+ * inside one process on one box. Setting an option bumps an epoch that invalidates captured launch sequences.
+ *  network runtime:
  *   "graph"         HIP-graph replay of extractor forwards: 0 = never, 1 = always, 2 = adaptive (default: only while an
  *                   eager kernel launch costs > ~12 us of host time on this host); read per forward
- *  implicit-GEMM convolution (csrc/conv_igemm.hip):
- *   "conv_tile"     force the block tile: 0 = heuristic (default); 1 = 128x128, 2 = 128x64, 3 = 64x64, 4 = 128x32,
- *                   5 = 64x32 k-split 2, 6 = 32x32 k-split 4, 7 = 32x64 k-split 2; pointwise convs only: 8 / 9 / 10 = 32 / 64 /
- *                   128 rows x 96 columns and 11 / 12 / 13 = x 128 columns (one pass over N for Cout <= 96 / 128) - sweeps
- *   "conv_bk"       cap the K-tile width: 0 = widest of 32/16/8 dividing Cin (default), 8, 16, 32 (read when weights are
- *                   packed AND at launch: set it before creating / finalizing an extractor)
- *   "conv_bk_auto"  1 (default) = a pointwise conv whose Cin is a multiple of 32 runs with 16-wide K-tiles (same packed filter,
- *                   7 instead of 4 blocks per CU) where that measured faster: Cout <= 32 with Cin <= 128, or 1 025 .. 1 792
- *                   64x64 output tiles; 0 = always the widest tile. Ignored when "conv_bk" is set
- *   "conv_uncond"   staged loads without predicates: 1 = pointwise convs only (default), 0 = never, 2 = everywhere
- *   "conv_splitk"   1 (default) = convs with few output tiles and a long reduction are split over K (partial tiles + a
- *                   deterministic reduce), 0 = never; "conv_splitk_tiles": the tile-count threshold (0 = 320)
- *   "conv_stem_fast", "conv_early_sc", "conv_epi_batch"  1 (default) / 0: interior fast path of the NCHW stem gather;
- *                   epilogue scale / shift requested before the K loop; batched epilogue output pass
- *  pointwise convolution as a register GEMM (csrc/pw_rgemm.hip):
- *   "conv_rgemm"    1 (default) = the barrier-free 16x16x4-MFMA register GEMM on fragment-packed weights serves the stride-1
- *                   pointwise convs (Cin % 16 == 0) for which it is a gain inside the network: projections of at most 8x8 maps
- *                   from >= 512 to more than 256 channels (EfficientNet-B0's 1152 -> 320 at 7x7; a rule on the layer, not on the
- *                   batch, so a frame's bits do not depend on the batch it arrives in); 0 = never; 2 = every conv it supports; 16 + mask = chosen classes (1 projections to <= 128 channels, 2 expansions, 4 the default class,
- *                   8 the rest) for A/B runs
- *   "conv_rgemm_t", "conv_rgemm_wk"  0 (default) = the launcher's cost model picks the 16-channel tiles per wave (3..8) and the
- *                   K slices per block (1, 2, 4); other values force them (sweeps: tools/conv_bench.py)
- *   "conv_bf3"      0 (default) = every product is an fp32 x fp32 MFMA. OPT-IN bits: 1 = dense convs (stride-1 pointwise, and un-gated
- *                   KxK / strided convs) with Cin % 16 == 0, Cin >= 64, Cout >= 40 split both operands three ways into bf16
- *                   (x = x0 + x1 + x2, 24 significand bits) and sum six of the nine bf16 x bf16 products (each exact in fp32) on
- *                   v_mfma_f32_32x32x16_bf16 (csrc/conv_bf3.hip); 2 = the expand GEMM of the row-streaming fused MBConv fronts does
- *                   the same (csrc/mbconv_rows.hip); 3 = both. Dropped terms <= 2^-24 of a product each (median 2^-29); the x0 w0 sums are kept by
- *                   fp32 VALU adds because the bf16 MFMA does not round its accumulator. NOT the
- *                   reference's arithmetic bit for bit - a measured alternative, never the default, never part of bench.py's value
- *   "conv_bf3_bk"   0 (default) = K-tile 32 where Cin % 32 == 0, else 16; 16 = always 16 (A/B)
- *   "conv_bf3_pf"   0 (default) = one staged K-tile in flight per block; 2 = two (A/B; the same sums, no measured gain)
- *  prototype head (csrc/head.hip):
- *   "head_stream"   2 (default) = the streaming distance kernel (rows requested before the weight staging, 8 waves x 2 rows)
- *                   for launches with >= 64 query rows, 1 = always, 0 = never
- *   "head_lds"      1 (default) = otherwise the LDS-staged kernel for >= 64 query rows; 0 = the one-wave-per-row form
- *  LITE training step (csrc/extractor_train.hip, train_*.hip):
- *   "train_graph"   0 (default) / 1 = the training entry points replay captured HIP graphs (frees host time; the step is
- *                   GPU-bound, so it is opt-in)
- *   "dw_dgrad_forward"  1 (default) = the input gradient of a stride-1 depthwise conv runs through the forward LDS-patch
- *                   kernels with rotated taps; 0 = the gather kernel
+ *   "train_graph"   1 (default) = the training entry points (orbit_extractor_train_forward / _backward) replay captured HIP
+ *                   graphs from the third sight of a call on (same pointers, same sizes); 0 = eager launches
+ *   "mbconv_rows"   1 (default) = EfficientNet blocks 1.0 .. 3.0 (112x112 .. 28x28 maps) run the row-streaming fused front
+ *                   (csrc/mbconv_rows.hip: expand 1x1 + BN + SiLU + depthwise + BN + SiLU + SE partials, expanded rows in an
+ *                   LDS ring); 0 = conv + depthwise kernel pair everywhere. Read when a plan is created
+ *   "stem_rows"     1 (default) = conv_stem + BN + SiLU + the first depthwise as one row-streaming kernel; 0 = direct stem
+ *                   kernel + depthwise kernel. Read when a plan is created
  *   "train_dw_xf"   1 (default) = ORBIT_TRAIN_NO_BACKWARD forwards skip the activation pass between an expand / stem conv and
  *                   its depthwise conv (applied on load instead); 0 = always the separate pass
- *   "train_dual_write"  1 (default) = under running-statistics BatchNorm (frozen extractor) a taped conv writes its raw output
- *                   AND the activation from one epilogue; 0 = raw output + a separate activation pass
- *   "dw_dgrad_s2"   1 (default) = the input gradient of a stride-2 depthwise conv as the 2x2-block kernel; 0 = the gather kernel
- *   "se_bn_fuse"    1 (default) = the last pass of the squeeze-excite backward also carries the reduction pass of the
- *                   depthwise BatchNorm's backward (csrc/train_mbconv.hip gate_bwd_apply_bn_kernel); 0 = separate passes */
+ *  dense convolutions (csrc/conv_igemm.hip, pw_rgemm.hip, conv_bf3.hip):
+ *   "conv_tile"     0 = heuristic (default); 3 = 64x64, 4 = 128x32, 6 = 32x32 with K split over the four waves (the three
+ *                   tilings the heuristic chooses from)
+ *   "conv_bk"       cap the K-tile width: 0 = widest of 32/16/8 dividing Cin, 16 on the layers where that measured faster
+ *                   (default); 8, 16, 32 (read when weights are packed AND at launch: set it before creating / finalizing a plan)
+ *   "conv_splitk"   1 (default) = convs with few output tiles and a long reduction are split over K (partial tiles + a
+ *                   deterministic reduce), 0 = never
+ *   "conv_rgemm"    1 (default) = the barrier-free 16x16x4-MFMA register GEMM on fragment-packed weights serves the stride-1
+ *                   pointwise convs for which it is a gain inside the network: projections of at most 8x8 maps from >= 512 to
+ *                   more than 256 channels (EfficientNet-B0's 1152 -> 320 at 7x7; a rule on the layer, not on the batch, so a
+ *                   frame's bits do not depend on the batch it arrives in); 0 = never; 2 = every conv it supports. Read at plan
+ *                   creation (which filters get a fragment-ordered copy) and at launch
+ *   "conv_bf3"      0 (default) = every product is an fp32 x fp32 MFMA. OPT-IN bits: 1 = dense convs with Cin % 16 == 0,
+ *                   Cin >= 64, Cout >= 40 split both operands three ways into bf16 and sum six of the nine bf16 x bf16 products on
+ *                   v_mfma_f32_32x32x16_bf16 (csrc/conv_bf3.hip); 2 = the expand GEMM of the row-streaming fused fronts does the
+ *                   same; 3 = both. NOT the reference's arithmetic bit for bit - a measured alternative, frozen, never the
+ *                   default, never part of bench.py's value
+ *  depthwise kernel families (csrc/ops.hip): 1 = where measured faster (default), 0 = never, 2 = wherever it fits
+ *   "dw_window"     register-window kernel (default: 3x3, stride 1, >= 14 rows)
+ *   "dw_lds"        input patch staged in LDS (default: stride-1 5x5 and small 3x3 maps)
+ *   "dw_pipe"       software-pipelined streaming kernel (default: large stride-2 layers)
+ *  prototype head (csrc/head.hip):
+ *   "head_stream"   1 (default) = the streaming distance kernel (rows requested before the weight staging, 8 waves x 2 rows)
+ *                   for T = 1, D = 512 / 1280 launches with >= 64 query rows; 0 = the general LDS-staged kernel */
 int orbit_set_option(const char* name, int value);
 /* current value of an option (after its environment default was applied), -1 for an unknown name */
 int orbit_get_option(const char* name);
@@ -192,6 +147,11 @@ int orbit_set_mean(const float* x, int n, int D, float* out, orbit_stream_t stre
 /* ---- feature extractors / set encoder ---------------------------------------------------------- */
 /* name: "resnet18" | "efficientnet_b0" | "set_encoder".  H,W: frame size the plan is built for. */
 int orbit_extractor_create(const char* name, int H, int W, orbit_extractor_t** out);
+/* flags: ORBIT_PLAN_UNFUSED = a plan for forwards that record a tape or use batch statistics (the LITE training step,
+ * few_shot_recognisers.py:176-183): every MBConv block stays a conv + depthwise pair, whose outputs the backward needs;
+ * same parameters in the same order as the default plan. */
+#define ORBIT_PLAN_UNFUSED 1
+int orbit_extractor_create_ex(const char* name, int H, int W, int flags, orbit_extractor_t** out);
 void orbit_extractor_destroy(orbit_extractor_t* fe);
 
 /* state_dict enumeration: parameter/buffer keys the extractor expects (torch state_dict names). */
@@ -289,7 +249,7 @@ int orbit_op_se_gate(const float* pooled, const float* w1, const float* b1, cons
  * expanded tensor kept in LDS. x NHWC [B][H][W][Cin]; w1 torch [mid][Cin][1][1]; wdw torch [mid][1][K][K];
  * scale/shift = folded BatchNorms [mid]; y NHWC [B][Ho][Wo][mid]; pool_partial [B][tiles][mid] or NULL: partial sums
  * of y for the SE average pool, tiles = orbit_op_mbconv_front_partials(...) (the kernel form - tiled, whole-map or
- * row-streaming, options mbconv_map / mbconv_rows - decides how many partial sums a frame has). */
+ * row-streaming or not, option mbconv_rows - decides how many partial sums a frame has). */
 int orbit_op_mbconv_front_partials(int H, int W, int Cin, int mid, int K, int stride);
 int orbit_op_mbconv_front(const float* x, const float* w1, const float* scale1, const float* shift1,
                           const float* wdw, const float* scale2, const float* shift2, float* y, float* pool_partial,

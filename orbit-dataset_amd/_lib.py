@@ -28,6 +28,7 @@ _SIGNATURES = {
     "orbit_set_mean": (c_int, [P, c_int, c_int, P, P]),
     "orbit_history_mean_pool": (c_int, [P, c_int, c_int, c_int, P, P]),
     "orbit_extractor_create": (c_int, [c_char_p, c_int, c_int, POINTER(c_void_p)]),
+    "orbit_extractor_create_ex": (c_int, [c_char_p, c_int, c_int, c_int, POINTER(c_void_p)]),
     "orbit_extractor_destroy": (None, [P]),
     "orbit_extractor_num_params": (c_int, [P]),
     "orbit_extractor_param_name": (c_char_p, [P, c_int]),

@@ -17,7 +17,7 @@ OBJDIR = os.path.join(HERE, "build")
 LIB = os.path.join(LIBDIR, "liborbit_hip.so")
 INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 
-SOURCES = ["head.hip", "heads_extra.hip", "loss.hip", "conv_igemm.hip", "pw_rgemm.hip", "conv_bf3.hip", "pw_narrow.hip", "ops.hip", "film.hip", "ingest.hip", "mbconv.hip", "mbconv_map.hip", "mbconv_rows.hip", "stem.hip", "extractor.hip", "train_ops.hip", "train_mbconv.hip", "conv_wgrad.hip", "extractor_train.hip",
+SOURCES = ["head.hip", "heads_extra.hip", "loss.hip", "conv_igemm.hip", "pw_rgemm.hip", "conv_bf3.hip", "ops.hip", "film.hip", "ingest.hip", "mbconv_rows.hip", "stem.hip", "extractor.hip", "train_ops.hip", "train_mbconv.hip", "conv_wgrad.hip", "extractor_train.hip",
            "comm.hip"]
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",

@@ -9,12 +9,10 @@
 
 namespace orbit {
 
-struct SeTail;  // csrc/se_tail.h
-
 // thread-local error message returned by orbit_last_error()
 char* err_buf();
 int set_err(int code, const char* fmt, ...);
-// tuning switches (orbit_set_option / ORBIT_* environment): "dw_window", "mbconv_fusion", "graph"
+// runtime options (orbit_set_option / ORBIT_* environment; the table is in csrc/head.hip)
 int get_option(const char* name);
 int option_epoch();  // changes whenever orbit_set_option changed a value (key of captured launch sequences)
 
@@ -117,10 +115,6 @@ bool conv_bf3_supported(const ConvDesc& d);
 int launch_conv_bf3(const ConvDesc& d, hipStream_t s);
 bool pw_rgemm_preferred(const ConvDesc& d);  // where it measured faster than the LDS-tiled kernel (conv_rgemm = 1)
 int launch_pw_rgemm(const ConvDesc& d, hipStream_t s);
-// narrow pointwise projections (Cout <= 32, high-resolution maps) as an HBM stream without an LDS stage for the pixels
-// (csrc/pw_narrow.hip; option pw_narrow); launch_conv routes to it
-bool pw_narrow_supported(const ConvDesc& d);
-int launch_pw_narrow(const ConvDesc& d, hipStream_t s);
 bool conv_prof_enabled();
 // per-launch HIP-event records of orbit_prof_* (no-ops returning -1 while profiling is off)
 int prof_start(const char* name, double flops, double bytes, hipStream_t s);
@@ -131,9 +125,7 @@ int dwconv_se_chunks(int Ho);
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                      float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
                      int Wo, int act, hipStream_t s, int stats = 0, const float* in_scale = nullptr,
-                     const float* in_shift = nullptr, int in_act = 0, struct SeTail* se = nullptr);
-// (se, in / out: the squeeze-excite gate that consumes the pooling partials, to be run by the launch itself - csrc/se_tail.h;
-// on return se->counter == nullptr means the chosen kernel could not take it and the stand-alone gate kernel must follow)
+                     const float* in_shift = nullptr, int in_act = 0);
 // in_scale / in_shift (with stats): x is the RAW output of the producing conv; act(x * in_scale[c] + in_shift[c]) is applied
 // as the kernel loads it, so the activated tensor of that layer is never written (no-backward passes of the LITE step)
 // stats != 0: pool_partial receives [B * dwconv_se_chunks(Ho)][2][C] column sums / sums of squares of the outputs instead
@@ -142,45 +134,26 @@ int launch_se_gate2(const float* partial, int chunks, int HW, const float* w1, c
                     const float* b2, float* gate, int B, int C, int R, hipStream_t s, float* pooled_out = nullptr);
 // (pooled_out, optional: the pooled means [B][C] the gate was computed from - the training tape keeps them)
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
-// fused expand(1x1, MFMA) + BN + SiLU + depthwise + BN + SiLU (+ SE pooling partials [B][tiles][mid]); csrc/mbconv.hip
-bool mbconv_front_supported(int Cin, int mid, int K, int stride);
-int mbconv_front_tiles(int Ho, int Wo, int stride);
 // EfficientNet stem as a direct VALU kernel with LDS-staged input rows (csrc/stem.hip); w = raw OIHW filter [32][3][3][3]
 bool stem_direct_supported(int Cin, int Cout, int K, int stride, int W, int act);
 int launch_stem_direct(const float* frames, const float* w_oihw, const float* scale, const float* shift, float* y, int B,
                        int H, int W, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s);
-// whole-map form for the 14x14 / 7x7 stages (csrc/mbconv_map.hip): pool sums are complete per (frame, channel), i.e. the
-// squeeze-excite gate kernel sees ONE partial per frame
-bool mbconv_map_supported(int H, int W, int Cin, int mid, int K, int stride);
-bool mbconv_map_preferred(int H, int W, int Cin, int mid, int K, int stride);  // where it measured faster than the pair
-int launch_mbconv_map(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
-                      const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
-                      int K, int stride, hipStream_t s);
+// fused expand(1x1, MFMA) + BN + SiLU + depthwise + BN + SiLU (+ SE pooling partials), the
 // row-streaming form for the 112x112 .. 28x28 stages (csrc/mbconv_rows.hip): a block walks down a strip of the map with the
 // expanded rows in an LDS ring - no tile halo; pool partials [B][mbconv_rows_tiles][mid]
 bool mbconv_rows_supported(int H, int W, int Cin, int mid, int K, int stride);
 int mbconv_rows_tiles(int H, int W, int Cin, int mid, int K, int stride);
 int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
                        const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
-                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, int plan_tiles = 0,
-                       struct SeTail* se = nullptr);
-// (plan_tiles > 0: the tile count the caller sized `pool` and its consumer for; the launch fails if the options now differ)
+                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, int plan_tiles = 0);
+// (plan_tiles > 0: the tile count the caller sized `pool` and its consumer for; the launch fails if it would write another)
 // row-streaming stem + first depthwise (csrc/mbconv_rows.hip): w1_packed = stem_pack_weights' [32][32]; pool [B][stem_rows_tiles][32]
 bool stem_rows_supported(int H, int W, int mid, int K, int stride);
 int stem_rows_tiles(int H, int W);
 int launch_stem_rows(const float* frames, const float* w1_packed, const float* sc1, const float* sh1, const float* wdw,
                      const float* sc2, const float* sh2, float* y, float* pool, int B, int FH, int FW, int spad_t,
-                     int spad_l, int H, int W, hipStream_t s, int plan_tiles = 0, struct SeTail* se = nullptr);
-// stem form of the fused front kernel: conv_stem (NCHW frames, 3x3 stride 2) + BN + SiLU + depthwise 3x3/1 + BN + SiLU
-bool stem_dw_front_supported(int mid, int K, int stride);
+                     int spad_l, int H, int W, hipStream_t s, int plan_tiles = 0);
 int stem_pack_weights(const float* w_oihw, float* w_packed, int mid, hipStream_t s);  // [mid][27] -> [mid][32]
-int launch_stem_dw_front(const float* frames, const float* w1_packed, const float* sc1, const float* sh1,
-                         const float* wdw, const float* sc2, const float* sh2, float* y, float* pool, int B, int FH, int FW,
-                         int spad_t, int spad_l, int H, int W, int mid, int K, int pad_t, int pad_l, int Ho, int Wo,
-                         hipStream_t s);
-int launch_mbconv_front(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
-                        const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
-                        int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s);
 // [C][1][K][K] -> [K][K][C]
 int dwconv_pack_weights(const float* w, float* w_khwc, int C, int K, hipStream_t s);
 int launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int K, int stride, int pad,

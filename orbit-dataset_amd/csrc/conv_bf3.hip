@@ -352,25 +352,15 @@ static int bf3_launch(Bf3Params& p, const ConvDesc& d, hipStream_t s) {
     const size_t pipe = (size_t)2 * 3 * (BM + BN) * BK * 2, epi = (size_t)BM * BN * 4;
     const size_t lds = pipe > epi ? pipe : epi;
     const int grid = p.m_tiles * p.n_tiles;
-    const bool pf2 = get_option("conv_bf3_pf") == 2;
     char name[48];
-    snprintf(name, sizeof(name), "conv_bf3<%d,%d,%d%s%s%s>", BM, BN, BK, d.gate ? ",gate" : "", PW ? ",pw" : "", pf2 ? ",pf2" : "");
+    snprintf(name, sizeof(name), "conv_bf3<%d,%d,%d%s%s>", BM, BN, BK, d.gate ? ",gate" : "", PW ? ",pw" : "");
     const double pix = (double)p.M;
     const int rec = prof_start(name, 2.0 * pix * d.Cout * d.KH * d.KW * d.Cin * d.prof_flop_scale,
                                4.0 * ((double)d.B * d.H * d.W * d.Cin + pix * d.Cout * (d.residual ? 2.0 : 1.0) +
                                       (double)d.Cout * d.KH * d.KW * d.Cin), s);
-    const bool odd = ((p.KT / BK) & 1) != 0;
     if constexpr (PW) {
-        if (!pf2) {
-            if (d.gate) conv_bf3_kernel<BM, BN, WGM, WGN, BK, true, 1, false, true><<<grid, 256, lds, s>>>(p);
-            else conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 1, false, true><<<grid, 256, lds, s>>>(p);
-        } else if (odd) {
-            if (d.gate) conv_bf3_kernel<BM, BN, WGM, WGN, BK, true, 2, true, true><<<grid, 256, lds, s>>>(p);
-            else conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 2, true, true><<<grid, 256, lds, s>>>(p);
-        } else {
-            if (d.gate) conv_bf3_kernel<BM, BN, WGM, WGN, BK, true, 2, false, true><<<grid, 256, lds, s>>>(p);
-            else conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 2, false, true><<<grid, 256, lds, s>>>(p);
-        }
+        if (d.gate) conv_bf3_kernel<BM, BN, WGM, WGN, BK, true, 1, false, true><<<grid, 256, lds, s>>>(p);
+        else conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 1, false, true><<<grid, 256, lds, s>>>(p);
     } else {
         conv_bf3_kernel<BM, BN, WGM, WGN, BK, false, 1, false, false><<<grid, 256, lds, s>>>(p);
     }
@@ -385,7 +375,7 @@ static int bf3_dispatch(Bf3Params& p, const ConvDesc& d, hipStream_t s) {
     const double waste64 = (double)(cdiv(d.Cout, 64) * 64 - d.Cout) / d.Cout;
     const double waste32 = (double)(cdiv(d.Cout, 32) * 32 - d.Cout) / d.Cout;
     const bool narrow = waste64 - waste32 >= 0.15;
-    const int bk = (d.Cin % 32 == 0 && get_option("conv_bf3_bk") != 16) ? 32 : 16;
+    const int bk = d.Cin % 32 == 0 ? 32 : 16;
     if (narrow) return bk == 32 ? bf3_launch<128, 32, 4, 1, 32, PW>(p, d, s) : bf3_launch<128, 32, 4, 1, 16, PW>(p, d, s);
     return bk == 32 ? bf3_launch<64, 64, 2, 2, 32, PW>(p, d, s) : bf3_launch<64, 64, 2, 2, 16, PW>(p, d, s);
 }

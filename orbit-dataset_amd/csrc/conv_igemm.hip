@@ -60,9 +60,6 @@ struct ConvParams {
     FastDiv fd_per, fd_wo;   // / (Ho*Wo), / Wo  (pool2: / (HoP*WoP), / WoP)
     FastDiv fd_cin, fd_kw;   // stem mode: / Cin, / KW
     float prof_flop_scale;
-    int epi_batch;             // epilogue output rows read / loaded in one batch (conv_epi_batch option, A/B)
-    int early_sc;              // epilogue scale/shift loaded before the K loop (conv_early_sc option, A/B)
-    int stem_table;            // stem mode: use the interior fast path (conv_stem_fast option, A/B)
     int ksplit, kt_per_split;  // split-K: blockIdx = split * tiles + tile; raw partial tiles go to part[split][M][Cout]
     float* part;
     float* stats;              // [m_tiles][2][Cout] column sums / sums of squares of the raw outputs (train-mode BatchNorm) or null
@@ -221,7 +218,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         // to one per-row pointer; no decode, no bounds test (entries of the K padding point at the row's first pixel: the
         // packed filter is zero there).
         const bool inside = ok && a_hi0[0] >= 0 && a_hi0[0] + p.KH <= p.H && a_wi0[0] >= 0 && a_wi0[0] + p.KW <= p.W;
-        stem_fast = BM == 64 && p.stem_table && p.KT <= 256 && __all(inside);  // measured: +2..7 % at BM 64, -3 % at 128
+        stem_fast = BM == 64 && p.KT <= 256 && __all(inside);  // measured: +2..7 % at BM 64, -3 % at 128
         stem_row = a_ptr[0] + (inside ? a_hi0[0] * p.W + a_wi0[0] : 0);
         if (p.KT <= 256) {
             if (tid < p.KT) {
@@ -400,17 +397,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         // projections - the co-resident blocks are not role-split enough for the arbiter to help)
     };
 
-    // folded-BatchNorm scale / shift of this wave's output columns: requested before the K loop (conv_early_sc) so the
+    // folded-BatchNorm scale / shift of this wave's output columns: requested before the K loop so the
     // epilogue does not open with an L2 round trip - on the 1-3 K-tile EfficientNet layers that is a visible share
+    // (split-K partial: plain sums, the reduce kernel applies the epilogue; dual write: the tile is staged raw, scale / shift
+    // enter in the output pass; the shift enters the sum once)
     float sc_pre[TN], sh_pre[TN];
-    if (p.early_sc) {
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn + j * 32 + l31;
-            const bool use = n < p.Cout && p.ksplit <= 1 && p.y_raw == nullptr;  // dual write: the tile is staged raw
-            sc_pre[j] = (use && p.scale) ? p.scale[n] : 1.0f;
-            sh_pre[j] = (use && p.shift && wk == 0) ? p.shift[n] : 0.0f;
-        }
+    for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn + j * 32 + l31;
+        const bool use = n < p.Cout && p.ksplit <= 1 && p.y_raw == nullptr;
+        sc_pre[j] = (use && p.scale) ? p.scale[n] : 1.0f;
+        sh_pre[j] = (use && p.shift && wk == 0) ? p.shift[n] : 0.0f;
     }
 
     load_tile();
@@ -438,17 +435,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
     float* Cs = smem + wk * (OROWS * CS);        // [WGK][OROWS][CS]: one partial tile per K-wave group
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-        const int n = n0 + wn + j * 32 + l31;
-        const bool n_ok = n < p.Cout;
-        const bool raw = p.ksplit > 1 || p.y_raw != nullptr;  // split-K partial: plain sums, the reduce kernel applies the
-                                                              // epilogue; dual write: scale / shift enter in the output pass
-        float sc, sh;
-        if (p.early_sc) {
-            sc = sc_pre[j], sh = sh_pre[j];
-        } else {
-            sc = (n_ok && p.scale && !raw) ? p.scale[n] : 1.0f;
-            sh = (n_ok && p.shift && wk == 0 && !raw) ? p.shift[n] : 0.0f;  // the shift enters the sum once
-        }
+        const float sc = sc_pre[j], sh = sh_pre[j];
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -479,7 +466,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
         float* yout = p.ksplit > 1 ? p.part + (size_t)split * p.M * p.Cout : p.y;
         constexpr int ITER = (OROWS + RPO - 1) / RPO;  // output rows per thread (4 for the 64x64 and 128x32 tiles)
         f32x4 st_s = {0.f, 0.f, 0.f, 0.f}, st_q = {0.f, 0.f, 0.f, 0.f};  // column sums of this thread's rows (p.stats)
-        if (n < p.Cout && p.epi_batch && ITER <= 8) {
+        if (n < p.Cout && ITER <= 8) {
             // batched form: the LDS reads and the residual loads of all of a thread's rows are issued before the first use
             // (row by row, every row paid an LDS - and with a skip connection an L2 - round trip of its own)
             f32x4 v[ITER], res[ITER];
@@ -725,38 +712,23 @@ static int launch_cfg2(ConvParams& p, hipStream_t s) {
 
 template <int BM, int BN, int WGM, int WGN, int WGK, int BK, int MODE, bool POOL2, bool GATE, bool PW>
 static int launch_cfg(ConvParams& p, hipStream_t s) {
-    // UL = staged loads without predicates. Pointwise convs (every element of a tile exists once the rows beyond M are
-    // clamped): no predicate, mask or select at all; other convs: loads from a safe address, zeroed at the LDS store.
-    // In-process A/B on MI355X (tools/conv_bench.py <net> ab|abgate conv_uncond): pointwise +1..2 % on most layers,
-    // +16..20 % on the 128x32 projections, gated projections +3..21 % (the gate and tile loads then share one wait;
-    // predicated, hipcc waits for the tile load before it issues the gate load); 3x3 convs and the stems lose 1-4 % to
-    // the selects. conv_uncond: 1 = pointwise only (default), 0 = never, 2 = everywhere.
-    const int opt = get_option("conv_uncond");
-    const bool ul_ok = !PW || p.cin_pad == p.Cin;  // the clamped pointwise form has no K-padding predicate
-    if (ul_ok && (opt == 2 || (opt == 1 && PW)))
-        return launch_cfg2<BM, BN, WGM, WGN, WGK, BK, MODE, POOL2, GATE, PW, true>(p, s);
+    // UL = staged loads without predicates, for pointwise convs (every element of a tile exists once the rows beyond M are
+    // clamped): no predicate, mask or select at all. In-process A/B on MI355X: +1..2 % on most pointwise layers, +16..20 % on
+    // the 128x32 projections, gated projections +3..21 % (the gate and tile loads then share one wait; predicated, hipcc
+    // waits for the tile load before it issues the gate load); 3x3 convs and the stems lose 1-4 % to the selects.
+    if constexpr (PW)
+        if (p.cin_pad == p.Cin)  // the clamped pointwise form has no K-padding predicate
+            return launch_cfg2<BM, BN, WGM, WGN, WGK, BK, MODE, POOL2, GATE, PW, true>(p, s);
     return launch_cfg2<BM, BN, WGM, WGN, WGK, BK, MODE, POOL2, GATE, PW, false>(p, s);
 }
 
 template <int BK, int MODE, bool POOL2, bool GATE, bool PW>
 static int launch_tiled(ConvParams& p, hipStream_t s) {
     if (p.ksplit > 1) return launch_cfg<64, 64, 2, 2, 1, BK, MODE, POOL2, GATE, PW>(p, s);  // split-K plans on 64x64 tiles
-    switch (get_option("conv_tile")) {  // tuning sweeps (tools/conv_bench.py): 0 = heuristic below
-        case 1: return launch_cfg<128, 128, 2, 2, 1, BK, MODE, POOL2, GATE, PW>(p, s);
-        case 2: return launch_cfg<128, 64, 2, 2, 1, BK, MODE, POOL2, GATE, PW>(p, s);
+    switch (get_option("conv_tile")) {  // 0 = the heuristic below; else force one of its three tilings (parity tests, A/B)
         case 3: return launch_cfg<64, 64, 2, 2, 1, BK, MODE, POOL2, GATE, PW>(p, s);
         case 4: return launch_cfg<128, 32, 4, 1, 1, BK, MODE, POOL2, GATE, PW>(p, s);
-        case 5: if constexpr (MODE == 0 && !POOL2 && BK >= 16) return launch_cfg<64, 32, 2, 1, 2, BK, MODE, POOL2, GATE, PW>(p, s); break;
-        case 6: if constexpr (MODE == 0 && !POOL2 && BK >= 32) return launch_cfg<32, 32, 1, 1, 4, BK, MODE, POOL2, GATE, PW>(p, s); break;
-        case 7: if constexpr (MODE == 0 && !POOL2 && BK >= 16) return launch_cfg<32, 64, 1, 2, 2, BK, MODE, POOL2, GATE, PW>(p, s); break;
-        // one pass over N for the 80- / 112-channel projections (Cout <= 96 / 128): every wave owns all output columns of its
-        // 32 rows, so the A operand (the large depthwise output) is read ONCE instead of once per 32- / 64-column tile
-        case 8: if constexpr (MODE == 0 && !POOL2 && PW && BK == 32) return launch_cfg<32, 96, 1, 1, 4, BK, MODE, POOL2, GATE, PW>(p, s); break;
-        case 9: if constexpr (MODE == 0 && !POOL2 && PW && BK >= 16) return launch_cfg<64, 96, 2, 1, 2, BK, MODE, POOL2, GATE, PW>(p, s); break;
-        case 10: if constexpr (MODE == 0 && !POOL2 && PW) return launch_cfg<128, 96, 4, 1, 1, BK, MODE, POOL2, GATE, PW>(p, s); break;
-        case 11: if constexpr (MODE == 0 && !POOL2 && PW && BK == 32) return launch_cfg<32, 128, 1, 1, 4, BK, MODE, POOL2, GATE, PW>(p, s); break;
-        case 12: if constexpr (MODE == 0 && !POOL2 && PW && BK >= 16) return launch_cfg<64, 128, 2, 1, 2, BK, MODE, POOL2, GATE, PW>(p, s); break;
-        case 13: if constexpr (MODE == 0 && !POOL2 && PW) return launch_cfg<128, 128, 4, 1, 1, BK, MODE, POOL2, GATE, PW>(p, s); break;
+        case 6: if constexpr (MODE == 0 && !POOL2 && BK == 32) return launch_cfg<32, 32, 1, 1, 4, BK, MODE, POOL2, GATE, PW>(p, s); break;
         default: break;
     }
     // Measured sweep on MI355X (tools/conv_bench.py <net> sweep, in-process A/B over every layer shape of resnet18 @84
@@ -797,8 +769,7 @@ int conv_splitk(const ConvDesc& d) {
     const long tiles = (long)cdiv(d.B * d.Ho * d.Wo, 64) * cdiv(d.Cout, 64);
     // measured with the reduce pass included (tools/conv_bench.py <net> ab conv_splitk): -11..-18 % time at 232 tiles
     // (resnet18 @84 layer4), break-even at ~450 tiles (layer3, EfficientNet's 7x7 projections)
-    const int tile_cap = get_option("conv_splitk_tiles");  // tuning: split-K below this many 64x64 tiles (default 320)
-    if (tiles >= (tile_cap > 0 ? tile_cap : 320) || nk < 16) return 1;
+    if (tiles >= 320 || nk < 16) return 1;
     int S = (int)(1280 / tiles);
     S = S < 2 ? 2 : (S > 4 ? 4 : S);
     while (S > 1 && cdiv(nk, S) < 6) --S;
@@ -826,7 +797,6 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
         !(rg == 1 && pw_rgemm_supported(d) && pw_rgemm_preferred(d)))  // (1152 -> 320 @7x7: 770 tiles on 768 slots - the register GEMM's 1 535 blocks win)
         return launch_conv_bf3(d, s);
     if (rg == 2 && pw_rgemm_supported(d)) return launch_pw_rgemm(d, s);
-    if (pw && !d.y_raw && pw_narrow_supported(d)) return launch_pw_narrow(d, s);
     if (rg && pw_rgemm_supported(d) && (rg == 2 || pw_rgemm_preferred(d))) return launch_pw_rgemm(d, s);
     ORBIT_REQUIRE(!d.gate || (!d.x_nchw && !d.pool2), "conv: the squeeze-excite gate needs the NHWC path without fused pooling");
     const ConvPackGeom g = conv_pack_geom(d.Cin, d.Cout, d.KH, d.KW, d.x_nchw);
@@ -855,13 +825,10 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     // 79.5 -> 75.9 - and where the 64x64 tiling gives between one and two rounds of 4 blocks per CU, i.e. a second round that
     // is mostly empty (480 -> 112 and 672 -> 112 @14x14, 1 226 tiles: 65.7 -> 60.2, 81.0 -> 73.7 us); elsewhere 32 is as good
     // or better (fewer barriers per K: 1152 -> 320 @7x7 91.8 vs 96.1 us)
-    if (bk == 32 && pw && !d.pool2 && !d.x_nchw && get_option("conv_bk") == 0 && get_option("conv_bk_auto")) {
+    if (bk == 32 && pw && !d.pool2 && !d.x_nchw && get_option("conv_bk") == 0) {
         const long tiles64 = (long)cdiv(p.M, 64) * cdiv(d.Cout, 64);
         if ((d.Cout <= 32 && d.Cin <= 128) || (d.Cout > 32 && tiles64 > 1024 && tiles64 <= 1792)) bk = 16;
     }
-    p.stem_table = get_option("conv_stem_fast");
-    p.early_sc = get_option("conv_early_sc");
-    p.epi_batch = get_option("conv_epi_batch");
     p.ksplit = d.splitk_ws ? conv_splitk(d) : 1;
     p.kt_per_split = p.ksplit > 1 ? cdiv(g.kt / bk, p.ksplit) : 0;
     p.part = d.splitk_ws;

@@ -107,14 +107,13 @@ struct Op {
     size_t packed_off = 0;                // into the packed-weight pool
     size_t frag_off = SIZE_MAX;           // OP_CONV: the filter in MFMA-fragment order (csrc/pw_rgemm.hip) or SIZE_MAX
     int se_w1 = -1, se_b1 = -1, se_w2 = -1, se_b2 = -1, R = 0;
-    // OP_MBFRONT in its stem form (csrc/mbconv.hip): frame size, stem padding, packed [mid][32] stem filter
+    // OP_MBFRONT in its stem form (csrc/mbconv_rows.hip): frame size, stem padding, packed [mid][32] stem filter
     bool stem = false;
     int stem_h = 0, stem_w = 0, stem_pt = 0, stem_pl = 0;
     size_t packed_off2 = 0;
     int se_chunks = 0, se_hw = 0;  // squeeze-excite pooling partials produced by the preceding depthwise conv
     int pool_partial = 0;          // depthwise: also emit the pooling partials
     int weight2 = -1, bn2 = -1;    // OP_MBFRONT: depthwise weight (packed at packed_off) and its BatchNorm
-    bool whole_map = false;        // OP_MBFRONT served by the whole-map kernel (csrc/mbconv_map.hip)
     bool rows = false;             // OP_MBFRONT served by the row-streaming kernel (csrc/mbconv_rows.hip)
     int pool_k = 0, pool_pad = 0;
 };
@@ -367,7 +366,13 @@ struct orbit_extractor {
         o.weight = index.count(wkey) ? index[wkey] : add_param(wkey, (size_t)Cout * Cin * K * K);
         o.packed_off = packed_floats;
         packed_floats += conv_packed_floats(Cin, Cout, K, K, x_nchw);
-        if (stride == 1 && pad_t == 0 && pad_l == 0 && !pool2 && conv_frag_floats(Cin, Cout, K, K, x_nchw)) {
+        // the fragment-ordered copy of a pointwise filter only where the register GEMM will be asked for it (csrc/pw_rgemm.hip:
+        // conv_rgemm = 1 one layer class, = 2 every supported conv) - it doubles the packed bytes and the pack work of a layer
+        ConvDesc shape;
+        shape.H = H_, shape.W = W_, shape.Cin = Cin, shape.Cout = Cout;
+        const int rg = get_option("conv_rgemm");
+        if (stride == 1 && pad_t == 0 && pad_l == 0 && !pool2 && conv_frag_floats(Cin, Cout, K, K, x_nchw) &&
+            (rg == 2 || (rg == 1 && pw_rgemm_preferred(shape)))) {
             packed_floats = (packed_floats + 63) & ~(size_t)63;
             o.frag_off = packed_floats;
             packed_floats += conv_frag_floats(Cin, Cout, K, K, x_nchw);

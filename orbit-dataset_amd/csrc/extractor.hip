@@ -13,7 +13,6 @@
 #include <cstdlib>
 
 #include "extractor.h"
-#include "se_tail.h"
 
 using namespace orbit;
 
@@ -76,46 +75,23 @@ static int build_resnet18(orbit_extractor* fe, int H, int W) {
 }
 
 // ---- efficientnet_b0, timm `tf_` variant (SAME padding, BN eps 1e-3), num_classes=0 --------------
-static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
+static int build_efficientnet_b0(orbit_extractor* fe, int H, int W, bool unfused) {
     fe->out_size = 1280;
     const float eps = 1e-3f;
-    // The fused expand+depthwise kernel (csrc/mbconv.hip) is parity-green but, as measured on MI355X, slower than the
-    // two tuned kernels it replaces (2.6 ms vs 1.7 ms per 200-frame forward over the five eligible blocks): opt-in.
-    // fused expand + depthwise (csrc/mbconv.hip): 1 = every supported block, 2 = only where the fused kernel is measured
-    // faster than the pair (tools/mb_bench.py, 200 frames: 16 -> 96 channels 3x3/2 at 112x112: 335 vs 553 us; 24 -> 144
-    // 3x3/1 at 56x56: 281-306 vs 338-347 us; the 5x5 blocks and 40 -> 240 3x3/2 tie or lose: 282 vs 282, 305 vs 166,
-    // 143 vs 104 us - fusing the 5x5/2 block as well left the whole-task time unchanged), 0 = never
-    const int fuse_opt = get_option("mbconv_fusion");
-    // whole-map form (csrc/mbconv_map.hip) for the 14x14 / 7x7 stages: mbconv_map = 0 (default) never, 1 = where it measured
-    // faster than the conv + depthwise pair, 2 = every supported shape. Opt-in: per block it is 6-20 % faster on 7 of the 9
-    // shapes, but the whole task only moves from 6.63 to 6.58 ms (the blocks it replaces are the best-running convs)
-    const int map_opt = get_option("mbconv_map");
-    auto fuse_map_ok = [&](int hh, int ww, int cin, int mid, int K, int stride) {
-        if (fuse_opt == 0 || map_opt == 0) return false;
-        return map_opt >= 2 ? mbconv_map_supported(hh, ww, cin, mid, K, stride)
-                            : mbconv_map_preferred(hh, ww, cin, mid, K, stride);
-    };
-    // row-streaming form (csrc/mbconv_rows.hip) for the 112x112 .. 28x28 stages: mbconv_rows = 1 wherever it applies
-    const int rows_opt = get_option("mbconv_rows");
-    auto fuse_rows_ok = [&](int hh, int ww, int cin, int mid, int K, int stride) {
-        return fuse_opt != 0 && rows_opt != 0 && mbconv_rows_supported(hh, ww, cin, mid, K, stride);
-    };
+    // expand 1x1 + BatchNorm + SiLU + depthwise + BatchNorm + SiLU as ONE row-streaming kernel (csrc/mbconv_rows.hip; option
+    // mbconv_rows, default on) for the 112x112 .. 28x28 stages, where the 6x-expanded tensor would otherwise make an HBM round
+    // trip; the 14x14 / 7x7 stages run the MFMA conv + LDS-patch depthwise pair
+    // (a plan that records a tape - `unfused` - keeps the pair everywhere: the fused kernels have no backward form)
+    const int rows_opt = unfused ? 0 : get_option("mbconv_rows");
     auto fuse_front_ok = [&](int hh, int ww, int cin, int mid, int K, int stride) {
-        if (fuse_map_ok(hh, ww, cin, mid, K, stride) || fuse_rows_ok(hh, ww, cin, mid, K, stride)) return true;
-        if (fuse_opt == 0 || !mbconv_front_supported(cin, mid, K, stride)) return false;
-        return fuse_opt == 1 || (cin <= 24 && K == 3);
+        return rows_opt != 0 && mbconv_rows_supported(hh, ww, cin, mid, K, stride);
     };
     int h, w, pt, pl;
     same_pad(H, 3, 2, h, pt);
     same_pad(W, 3, 2, w, pl);
     int bn = fe->add_bn("bn1", 32, eps, true);  // root bn1 is FiLM-tagged (film.py:45-46)
-    // stem + first depthwise in one kernel (the stem's 112x112x32 output never reaches HBM): only with mbconv_fusion = 1 -
-    // measured in the whole network it is 1.3 % SLOWER than the stem conv + depthwise pair (16 scalar gathers per thread
-    // to build the im2col patch, two blocks per CU)
-    // row-streaming stem + depthwise (csrc/mbconv_rows.hip, option mbconv_rows): the stem's 112x112x32 output stays in LDS
-    const bool stem_rows = fuse_opt != 0 && get_option("mbconv_rows") >= 1 && get_option("stem_rows") != 0 &&
-                           stem_rows_supported(h, w, 32, 3, 1);
-    const bool fuse_stem = stem_rows || (fuse_opt == 1 && stem_dw_front_supported(32, 3, 1));
+    // row-streaming stem + first depthwise (csrc/mbconv_rows.hip, option stem_rows): the stem's 112x112x32 output stays in LDS
+    const bool fuse_stem = rows_opt != 0 && get_option("stem_rows") != 0 && stem_rows_supported(h, w, 32, 3, 1);
     size_t stem_weight = 0;
     if (fuse_stem) stem_weight = fe->add_param("conv_stem.weight", (size_t)32 * 27);
     else fe->add_conv("conv_stem.weight", bn, -1, 0, -1, H, W, 3, 32, 3, 2, pt, pl, h, w, ORBIT_ACT_SILU, 0, 1, 0);
@@ -179,8 +155,8 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
             o.packed_off2 = fe->packed_floats;  // stem filter [32][32]
             fe->packed_floats += (size_t)32 * 32;
             ho = o.Ho, wo = o.Wo;
-            o.rows = stem_rows;
-            se_chunks0 = stem_rows ? stem_rows_tiles(h, w) : mbconv_front_tiles(ho, wo, 1);
+            o.rows = true;
+            se_chunks0 = stem_rows_tiles(h, w);
             o.se_chunks = se_chunks0;  // what the pooling buffer and the gate were sized for (checked at launch)
             fe->max_partial = std::max(fe->max_partial, (size_t)se_chunks0 * 32);
             fe->note_buf(t1, (size_t)ho * wo * 32);
@@ -210,7 +186,7 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
             const int bn1 = fe->add_bn(p + ".bn1", mid, eps, false);
             int se_chunks;
             if (fuse_front_ok(h, w, cin, mid, K, stride)) {
-                // expand + depthwise in one kernel: the 6x-expanded tensor never leaves LDS (csrc/mbconv.hip)
+                // expand + depthwise in one kernel: the 6x-expanded tensor never leaves LDS
                 Op o;
                 o.kind = OP_MBFRONT, o.in = cur, o.out = t2, o.H = h, o.W = w, o.Cin = cin, o.Cout = mid;
                 o.KH = o.KW = K, o.stride = stride, o.bn = bn1;
@@ -222,10 +198,8 @@ static int build_efficientnet_b0(orbit_extractor* fe, int H, int W) {
                 o.packed_off = fe->packed_floats;
                 fe->packed_floats += (size_t)(mid * K * K + 3) / 4 * 4;
                 ho = o.Ho, wo = o.Wo;
-                o.whole_map = fuse_map_ok(h, w, cin, mid, K, stride);
-                o.rows = !o.whole_map && fuse_rows_ok(h, w, cin, mid, K, stride);
-                se_chunks = o.whole_map ? 1 : o.rows ? mbconv_rows_tiles(h, w, cin, mid, K, stride)
-                                                     : mbconv_front_tiles(ho, wo, stride);
+                o.rows = true;
+                se_chunks = mbconv_rows_tiles(h, w, cin, mid, K, stride);
                 o.se_chunks = se_chunks;  // what the pooling buffer and the gate were sized for (checked at launch)
                 fe->max_partial = std::max(fe->max_partial, (size_t)se_chunks * mid);
                 fe->note_buf(t2, (size_t)ho * wo * mid);
@@ -279,7 +253,7 @@ static int build_set_encoder(orbit_extractor* fe, int H, int W) {
 
 // ---- workspace layout ------------------------------------------------------------------------------
 struct WsLayout {
-    size_t buf[3], pooled, gate, fold, splitk, se_counter, total;
+    size_t buf[3], pooled, gate, fold, splitk, total;
 };
 static ConvDesc conv_shape(const Op& o, int B) {  // the fields the split-K plan looks at
     ConvDesc d;
@@ -307,8 +281,6 @@ static WsLayout ws_layout(const orbit_extractor* fe, int B) {
     for (const Op& o : fe->ops)
         if (o.kind == OP_CONV) skf = std::max(skf, conv_splitk_floats(conv_shape(o, B)));
     off += align_up(skf * sizeof(float), 256);
-    L.se_counter = off;  // per-frame tickets of the squeeze-excite gates computed by their producers (csrc/se_tail.h)
-    off += align_up((size_t)B * sizeof(unsigned), 256);
     L.total = off;
     return L;
 }
@@ -316,13 +288,17 @@ static WsLayout ws_layout(const orbit_extractor* fe, int B) {
 extern "C" {
 
 int orbit_extractor_create(const char* name, int H, int W, orbit_extractor_t** out) {
+    return orbit_extractor_create_ex(name, H, W, 0, out);
+}
+
+int orbit_extractor_create_ex(const char* name, int H, int W, int flags, orbit_extractor_t** out) {
     ORBIT_REQUIRE(name && out, "extractor_create: null pointer");
     ORBIT_REQUIRE(H >= 8 && W >= 8 && H <= 4096 && W <= 4096, "extractor_create: bad frame size %dx%d", H, W);
     orbit_extractor* fe = new orbit_extractor();
     fe->name = name, fe->H = H, fe->W = W;
     int rc;
     if (fe->name == "resnet18") rc = build_resnet18(fe, H, W);
-    else if (fe->name == "efficientnet_b0") rc = build_efficientnet_b0(fe, H, W);
+    else if (fe->name == "efficientnet_b0") rc = build_efficientnet_b0(fe, H, W, (flags & ORBIT_PLAN_UNFUSED) != 0);
     else if (fe->name == "set_encoder") rc = build_set_encoder(fe, H, W);
     else rc = set_err(ORBIT_ERR_ARG, "Invalid feature_extractor_name: %s", name);
     if (rc != ORBIT_OK) {
@@ -610,33 +586,12 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
         ORBIT_LAUNCH_CHECK();
         scale = fs, shift = fs + fe->fold_floats;
     }
-    // Squeeze-excite gates run by the kernel that produces their pooling partials (option se_fold; csrc/se_tail.h): the op
-    // that follows a depthwise / fused-front op describes the gate; the producer's launcher takes it if its kernel can.
-    const int se_fold = get_option("se_fold");  // 0 = off (default), 1 = gates of <= 256 channels, 2 = every gate a producer can take
-    unsigned* se_counter = reinterpret_cast<unsigned*>(ws + L.se_counter);
-    bool se_done = false;  // the gate of the next OP_SE was computed by its producer
-    if (se_fold) ORBIT_HIP_CHECK(hipMemsetAsync(se_counter, 0, (size_t)B * sizeof(unsigned), s));
-    auto tail_for = [&](size_t oi, int chunks) {
-        SeTail t;
-        if (!se_fold || oi + 1 >= fe->ops.size() || fe->ops[oi + 1].kind != OP_SE) return t;
-        const Op& e = fe->ops[oi + 1];
-        // a frame's partial rows must be whole 128-byte lines; the 1 024-thread stand-alone kernel (C >= 1024) groups long
-        // chunk lists differently from a 256-thread block
-        if (chunks != e.se_chunks || ((size_t)chunks * e.Cin) % 32 != 0 || (e.Cin >= 1024 && chunks > 8)) return t;
-        if (se_fold == 1 && e.Cin > 256) return t;
-        t.counter = se_counter;
-        t.w1 = fe->d_pool + fe->params[e.se_w1].off, t.b1 = fe->d_pool + fe->params[e.se_b1].off;
-        t.w2t = fe->d_packed + e.packed_off, t.b2 = fe->d_pool + fe->params[e.se_b2].off;
-        t.gate = buf(102), t.partial = buf(101);
-        t.chunks = chunks, t.C = e.Cin, t.R = e.R, t.inv_hw = 1.0f / (float)e.se_hw;
-        return t;
-    };
     for (size_t oi = 0; oi < fe->ops.size(); ++oi) {
         const Op& o = fe->ops[oi];
         int rc = ORBIT_OK;
         switch (o.kind) {
             case OP_CONV: {
-                if (o.x_nchw && !o.pool2 && o.res < 0 && o.bn >= 0 && get_option("stem_direct") &&
+                if (o.x_nchw && !o.pool2 && o.res < 0 && o.bn >= 0 &&
                     stem_direct_supported(o.Cin, o.Cout, o.KH, o.stride, o.W, o.act) && o.KH == o.KW) {
                     // EfficientNet stem: LDS-staged input rows + VALU (csrc/stem.hip) instead of the element-wise gather
                     rc = launch_stem_direct(buf(o.in), fe->d_pool + fe->params[o.weight].off, scale + fe->bns[o.bn].fold_off,
@@ -658,56 +613,24 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
                 rc = launch_conv(d, s);
                 break;
             }
-            case OP_DWCONV: {
-                SeTail t = o.pool_partial ? tail_for(oi, dwconv_se_chunks(o.Ho)) : SeTail{};
+            case OP_DWCONV:
                 rc = launch_dwconv_se(buf(o.in), fe->d_packed + o.packed_off, buf(o.out),
                                       scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off,
                                       o.pool_partial ? buf(101) : nullptr, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t,
-                                      o.pad_l, o.Ho, o.Wo, o.act, s, 0, nullptr, nullptr, 0, &t);
-                se_done = t.counter != nullptr;
+                                      o.pad_l, o.Ho, o.Wo, o.act, s);
                 break;
-            }
             case OP_MBFRONT:
-                if (o.stem && o.rows) {
-                    SeTail t = tail_for(oi, o.se_chunks);
+                if (o.stem)
                     rc = launch_stem_rows(buf(o.in), fe->d_packed + o.packed_off2, scale + fe->bns[o.bn].fold_off,
                                           shift + fe->bns[o.bn].fold_off, fe->d_packed + o.packed_off,
                                           scale + fe->bns[o.bn2].fold_off, shift + fe->bns[o.bn2].fold_off, buf(o.out),
-                                          buf(101), B, o.stem_h, o.stem_w, o.stem_pt, o.stem_pl, o.H, o.W, s, o.se_chunks, &t);
-                    se_done = t.counter != nullptr;
-                    break;
-                }
-                if (o.stem) {
-                    rc = launch_stem_dw_front(buf(o.in), fe->d_packed + o.packed_off2, scale + fe->bns[o.bn].fold_off,
-                                              shift + fe->bns[o.bn].fold_off, fe->d_packed + o.packed_off,
-                                              scale + fe->bns[o.bn2].fold_off, shift + fe->bns[o.bn2].fold_off, buf(o.out),
-                                              buf(101), B, o.stem_h, o.stem_w, o.stem_pt, o.stem_pl, o.H, o.W, o.Cout, o.KH,
-                                              o.pad_t, o.pad_l, o.Ho, o.Wo, s);
-                    break;
-                }
-                if (o.whole_map) {
-                    rc = launch_mbconv_map(buf(o.in), fe->d_pool + fe->params[o.weight].off,
-                                           scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off,
-                                           fe->d_packed + o.packed_off, scale + fe->bns[o.bn2].fold_off,
-                                           shift + fe->bns[o.bn2].fold_off, buf(o.out), buf(101), B, o.H, o.W, o.Cin, o.Cout,
-                                           o.KH, o.stride, s);
-                    break;
-                }
-                if (o.rows) {
-                    SeTail t = tail_for(oi, o.se_chunks);
+                                          buf(101), B, o.stem_h, o.stem_w, o.stem_pt, o.stem_pl, o.H, o.W, s, o.se_chunks);
+                else
                     rc = launch_mbconv_rows(buf(o.in), fe->d_pool + fe->params[o.weight].off,
                                             scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off,
                                             fe->d_packed + o.packed_off, scale + fe->bns[o.bn2].fold_off,
                                             shift + fe->bns[o.bn2].fold_off, buf(o.out), buf(101), B, o.H, o.W, o.Cin,
-                                            o.Cout, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s, o.se_chunks, &t);
-                    se_done = t.counter != nullptr;
-                    break;
-                }
-                rc = launch_mbconv_front(buf(o.in), fe->d_pool + fe->params[o.weight].off,
-                                         scale + fe->bns[o.bn].fold_off, shift + fe->bns[o.bn].fold_off,
-                                         fe->d_packed + o.packed_off, scale + fe->bns[o.bn2].fold_off,
-                                         shift + fe->bns[o.bn2].fold_off, buf(o.out), buf(101), B, o.H, o.W, o.Cin, o.Cout,
-                                         o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+                                            o.Cout, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s, o.se_chunks);
                 break;
             case OP_MAXPOOL:
                 rc = launch_maxpool(buf(o.in), buf(o.out), B, o.H, o.W, o.Cin, o.pool_k, o.stride, o.pool_pad, o.Ho,
@@ -717,10 +640,6 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
                 rc = launch_avgpool(buf(o.in), buf(o.out), B, o.H * o.W, o.Cin, s);
                 break;
             case OP_SE:
-                if (se_done) {  // computed by the last block per frame of the launch before
-                    se_done = false;
-                    break;
-                }
                 rc = launch_se_gate2(buf(101), o.se_chunks, o.se_hw, fe->d_pool + fe->params[o.se_w1].off,
                                      fe->d_pool + fe->params[o.se_b1].off, fe->d_packed + o.packed_off,
                                      fe->d_pool + fe->params[o.se_b2].off, buf(102), B, o.Cin, o.R, s);

@@ -354,7 +354,7 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
             // running-statistics BatchNorm (frozen extractor: CNAPs meta-training, FiLM fine-tuning): scale / shift are known
             // before the conv runs, so its epilogue writes BOTH the raw output (tape: xhat and the SiLU derivative need it)
             // and the activation - no separate activation pass over the tensor
-            const bool dual = !bn_train && !o.pool2 && get_option("train_dual_write");
+            const bool dual = !bn_train && !o.pool2;
             if (dual) {
                 d.y_raw = fl(L.y[i]), d.y = fl(L.a[i]);
                 d.scale = scale + bn.fold_off, d.shift = shift + bn.fold_off;
@@ -720,7 +720,7 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                 // into the last pass of the squeeze-excite backward
                 SeBnFuse fuse;
                 const SeBnFuse* fuse_ptr = nullptr;
-                if (fe->ops[src].kind == OP_DWCONV && get_option("se_bn_fuse")) {
+                if (fe->ops[src].kind == OP_DWCONV) {
                     const BNDesc& sbn = fe->bns[fe->ops[src].bn];
                     fuse.y = tf(L.y[src]), fuse.mean = mean + sbn.fold_off, fuse.invstd = invstd + sbn.fold_off;
                     fuse.scale = scale + sbn.fold_off, fuse.shift = shift + sbn.fold_off, fuse.act = fe->ops[src].act;

@@ -30,44 +30,25 @@ struct Option {
     int value;
     bool init;
 };
-static Option g_options[] = {{"dw_window", "ORBIT_DW_WINDOW", 1, false},
-                             {"dw_lds", "ORBIT_DW_LDS", 1, false},
-                             {"dw_pipe", "ORBIT_DW_PIPE", 1, false},
-                             {"mbconv_fusion", "ORBIT_MBCONV_FUSION", 2, false},
-                             {"mbconv_map", "ORBIT_MBCONV_MAP", 0, false},
-                             {"mbmap_groups", "ORBIT_MBMAP_GROUPS", 0, false},
-                             {"mbconv_rows", "ORBIT_MBCONV_ROWS", 1, false},
-                             {"mbrows_band", "ORBIT_MBROWS_BAND", 0, false},
-                             {"mbrows_exact", "ORBIT_MBROWS_EXACT", 1, false},
-                             {"stem_rows", "ORBIT_STEM_ROWS", 1, false},
-                             {"pw_narrow", "ORBIT_PW_NARROW", 0, false},
-                             {"dw_dgrad_forward", "ORBIT_DW_DGRAD_FORWARD", 1, false},
-                             {"dw_dgrad_s2", "ORBIT_DW_DGRAD_S2", 1, false},
-                             {"train_dw_xf", "ORBIT_TRAIN_DW_XF", 1, false},
-                             {"train_dual_write", "ORBIT_TRAIN_DUAL_WRITE", 1, false},
-                             {"graph", "ORBIT_GRAPH", 2, false},
-                             {"train_graph", "ORBIT_TRAIN_GRAPH", 0, false},
-                             {"se_bn_fuse", "ORBIT_SE_BN_FUSE", 1, false},
-                             {"stem_direct", "ORBIT_STEM_DIRECT", 1, false},
-                             {"se_wide", "ORBIT_SE_WIDE", 1, false},
-                             {"se_fold", "ORBIT_SE_FOLD", 0, false},
-                             {"conv_tile", "ORBIT_CONV_TILE", 0, false},
-                             {"conv_bk", "ORBIT_CONV_BK", 0, false},
-                             {"conv_bk_auto", "ORBIT_CONV_BK_AUTO", 1, false},
-                             {"conv_uncond", "ORBIT_CONV_UNCOND", 1, false},
-                             {"conv_splitk", "ORBIT_CONV_SPLITK", 1, false},
-                             {"conv_splitk_tiles", "ORBIT_CONV_SPLITK_TILES", 0, false},
-                             {"conv_stem_fast", "ORBIT_CONV_STEM_FAST", 1, false},
-                             {"conv_early_sc", "ORBIT_CONV_EARLY_SC", 1, false},
-                             {"conv_epi_batch", "ORBIT_CONV_EPI_BATCH", 1, false},
-                             {"conv_rgemm", "ORBIT_CONV_RGEMM", 1, false},
-                             {"conv_rgemm_t", "ORBIT_CONV_RGEMM_T", 0, false},
-                             {"conv_rgemm_wk", "ORBIT_CONV_RGEMM_WK", 0, false},
-                             {"conv_bf3", "ORBIT_CONV_BF3", 0, false},
-                             {"conv_bf3_bk", "ORBIT_CONV_BF3_BK", 0, false},
-                             {"conv_bf3_pf", "ORBIT_CONV_BF3_PF", 0, false},
-                             {"head_lds", "ORBIT_HEAD_LDS", 1, false},
-                             {"head_stream", "ORBIT_HEAD_STREAM", 2, false}};
+static Option g_options[] = {
+    // network runtime
+    {"graph", "ORBIT_GRAPH", 2, false},              // forward launch sequences as HIP graphs: 0 never, 1 always, 2 adaptive
+    {"train_graph", "ORBIT_TRAIN_GRAPH", 1, false},  // the same for the training entry points: 0 never, 1 from the third sight of a call
+    {"mbconv_rows", "ORBIT_MBCONV_ROWS", 1, false},  // row-streaming fused MBConv fronts at plan creation (0 = conv + depthwise pair)
+    {"stem_rows", "ORBIT_STEM_ROWS", 1, false},      // the same for stem + first depthwise
+    {"train_dw_xf", "ORBIT_TRAIN_DW_XF", 1, false},  // no-backward training forwards: BatchNorm + SiLU applied on the depthwise load
+    // dense convolutions
+    {"conv_tile", "ORBIT_CONV_TILE", 0, false},      // 0 heuristic; 3 = 64x64, 4 = 128x32, 6 = 32x32 with K split over the waves
+    {"conv_bk", "ORBIT_CONV_BK", 0, false},          // 0 = widest K-tile that divides Cin; 8 / 16 / 32 caps it
+    {"conv_splitk", "ORBIT_CONV_SPLITK", 1, false},  // split-K over blocks for short, long-K layers
+    {"conv_rgemm", "ORBIT_CONV_RGEMM", 1, false},    // pointwise register GEMM: 0 never, 1 where measured faster, 2 wherever supported
+    {"conv_bf3", "ORBIT_CONV_BF3", 0, false},        // OPT-IN bf16 x 3 split (bit 1 dense convs, bit 2 fused-front expands); never in `value`
+    // depthwise kernel families: 1 = where measured faster (default), 0 = never, 2 = wherever it fits
+    {"dw_window", "ORBIT_DW_WINDOW", 1, false},
+    {"dw_lds", "ORBIT_DW_LDS", 1, false},
+    {"dw_pipe", "ORBIT_DW_PIPE", 1, false},
+    // head
+    {"head_stream", "ORBIT_HEAD_STREAM", 1, false}};  // streaming distance kernel (T = 1, D = 512 / 1280); 0 = general LDS form
 static Option* find_option(const char* name) {
     for (Option& o : g_options)
         if (strcmp(o.name, name) == 0) {
@@ -610,18 +591,14 @@ int orbit_proto_predict(const float* Q, const float* W, const float* b, int n_ta
     // rows per wave: measured on MI355X (64 tasks x 200 x 1280): R = 1 with the row loop unrolled streams faster than
     // R = 4 (more waves in flight beats W reuse: W is L1/L2-resident anyway); the R > 1 forms stay for very wide heads
     const size_t lds = ((size_t)C * D + C) * sizeof(float);
-    if ((D & 3) == 0 && lds <= 60 * 1024 && (long)M * n_tasks >= 64 && get_option("head_lds")) {
-        const int opt = get_option("head_lds");  // 1: 4 rows per wave (16 per block), 2: 8 rows per wave (32 per block)
-        // head_stream (default 2): rows requested before the weight staging, one class at a time (T = 1, D = 1280 / 512).
-        // 1 = 4 waves x 4 rows per block, 2 = 8 waves x 2 rows (79 VGPRs: 6 waves per SIMD), 3 = 4 waves x 2 rows
-        const int stream_opt = get_option("head_stream");
-        if (stream_opt && T == 1 && (D == 1280 || D == 512)) {
+    if ((D & 3) == 0 && lds <= 60 * 1024 && (long)M * n_tasks >= 64) {
+        // head_stream (default 1; 0 = the general LDS form below, parity tests): rows requested before the weight staging, one
+        // class at a time (T = 1, D = 1280 / 512), 8 waves x 2 rows per block (79 VGPRs: 6 waves per SIMD)
+        if (get_option("head_stream") && T == 1 && (D == 1280 || D == 512)) {
 #define ORBIT_HEAD_STREAM(NW_, R_, NI_)                                                                                  \
     proto_predict_stream_kernel<NW_, R_, NI_><<<cdiv(M, NW_ * R_) * n_tasks, NW_ * 64, lds, s>>>(                         \
         Q, W, b, M, D, C, logit_scale, cosine, logits, argmax, cdiv(M, NW_ * R_))
-            if (stream_opt == 1) { if (D == 1280) ORBIT_HEAD_STREAM(4, 4, 5); else ORBIT_HEAD_STREAM(4, 4, 2); }
-            else if (stream_opt == 3) { if (D == 1280) ORBIT_HEAD_STREAM(4, 2, 5); else ORBIT_HEAD_STREAM(4, 2, 2); }
-            else if (D == 1280 && !cosine && argmax == nullptr)
+            if (D == 1280 && !cosine && argmax == nullptr)
                 // the lean instantiation (67 VGPRs): 18.4 against 19.3 us on the 64-task 5-way launch, 24.6 against 26.2 us 10-way
                 // (tools/head_roofline.py). A 7-wave form whose 960 blocks are all resident at once (4 x 7 waves per CU) measured
                 // 19.5 us: residency is not what bounds this launch, its ~8 us of launch + drain on a 67 MB burst is
@@ -632,13 +609,7 @@ int orbit_proto_predict(const float* Q, const float* W, const float* b, int n_ta
             ORBIT_LAUNCH_CHECK();
             return ORBIT_OK;
         }
-        if (opt == 2) {
-            const dim3 grid(cdiv(M, 32), n_tasks);
-            if (C <= 5)
-                proto_predict_lds_kernel<5, 8><<<grid, 256, lds, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine, logits, argmax);
-            else
-                proto_predict_lds_kernel<10, 8><<<grid, 256, lds, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine, logits, argmax);
-        } else {
+        {
             const dim3 grid(cdiv(M, 16), n_tasks);
             if (C <= 5)
                 proto_predict_lds_kernel<5, 4><<<grid, 256, lds, s>>>(Q, W, b, M, T, D, C, logit_scale, cosine, logits, argmax);

@@ -23,7 +23,6 @@
 // computed by two waves - same values) instead of guarding its tail.
 #include "bf3.h"
 #include "common.h"
-#include "se_tail.h"
 
 namespace orbit {
 
@@ -54,7 +53,6 @@ struct MbRowsParams {
     const float* sh2;
     float* y;          // [B][Ho][Wo][mid]
     float* pool;       // [B][tiles][mid] or nullptr
-    SeTail se;         // the gate that consumes the partials, run by the block that completes a frame (se_tail.h)
     int H, W, Cin, mid, pad_t, pad_l, Ho, Wo;
     int SWo, SWi, strips, band_rows, bands, nchunk, total;
 };
@@ -398,9 +396,8 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const
         if (tid < 8 && c0 + tid * 4 < p.mid) {
             v4f t4 = red[tid];
             for (int sl = 1; sl < 32; ++sl) t4 += red[sl * 8 + tid];
-            se_store_partial(p.pool + ((size_t)b * tiles + tile) * p.mid + c0 + tid * 4, t4, p.se.counter != nullptr);
+            *reinterpret_cast<v4f*>(p.pool + ((size_t)b * tiles + tile) * p.mid + c0 + tid * 4) = t4;
         }
-        se_tail_finish<2>(p.se, b, ring);
     }
 }
 
@@ -427,8 +424,6 @@ static bool rows_geom(int H, int W, int Cin, int mid, int K, int stride, int Ho,
     const int n_new = g.TO * stride * g.SWi;
     if (n_new <= 32 || n_new > 128) return false;
     g.band_rows = 28;  // measured: 28-row bands beat 14 (fewer pipeline fills) and 56 (too few blocks) on the whole task
-    const int forced = get_option("mbrows_band");
-    if (forced > 0) g.band_rows = forced;
     g.band_rows = cdiv(g.band_rows, g.TO) * g.TO;
     g.bands = cdiv(Ho, g.band_rows);
     return true;
@@ -449,16 +444,14 @@ int mbconv_rows_tiles(int H, int W, int Cin, int mid, int K, int stride) {
 
 int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
                        const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
-                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, int plan_tiles, SeTail* se) {
+                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, int plan_tiles) {
     ORBIT_REQUIRE(x && w1 && sc1 && sh1 && wdw && sc2 && sh2 && y, "mbconv_rows: null pointer");
     RowsGeom g;
     ORBIT_REQUIRE(Ho == cdiv(H, stride) && Wo == cdiv(W, stride) && rows_geom(H, W, Cin, mid, K, stride, Ho, Wo, g),
                   "mbconv_rows: unsupported shape (H=%d W=%d Cin=%d mid=%d K=%d s=%d)", H, W, Cin, mid, K, stride);
-    // the band height is a runtime option: a plan sized its pooling partials (and the SE gate sums them) for the tile count
-    // it saw when it was built - refuse to write a different number of partials than the consumer reads
+    // a plan sized its pooling partials (and the SE gate sums them) for a tile count: refuse to write a different number
     ORBIT_REQUIRE(plan_tiles <= 0 || plan_tiles == g.strips * g.bands,
-                  "mbconv_rows: the plan was built for %d pooling tiles per frame, the current options give %d "
-                  "(mbrows_band changed after the plan was created: rebuild the plan)", plan_tiles, g.strips * g.bands);
+                  "mbconv_rows: the plan was built for %d pooling tiles per frame, this launch writes %d", plan_tiles, g.strips * g.bands);
     MbRowsParams p;
     p.x = x, p.w1 = w1, p.sc1 = sc1, p.sh1 = sh1, p.wdw = wdw, p.sc2 = sc2, p.sh2 = sh2, p.y = y, p.pool = pool;
     p.H = H, p.W = W, p.Cin = Cin, p.mid = mid, p.pad_t = pad_t, p.pad_l = pad_l, p.Ho = Ho, p.Wo = Wo;
@@ -468,16 +461,6 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
     const int grid = cdiv(p.total, 8) * 8;
     const int n_new = g.TO * stride * g.SWi;
     const size_t lds = (size_t)3 * n_new * ROWS_ES * sizeof(float) + (K == 3 ? 0 : (size_t)K * K * 8 * 16);
-    if (se != nullptr && se->counter != nullptr) {
-        // every block of a frame (channel chunk x strip x band) counts itself in; a chunk whose 32 channels are all beyond
-        // `mid` does not exist (nchunk = ceil(mid / 32)), so each of them writes a partial
-        if (pool != nullptr && se_tail_lds_floats(se->C, se->R) * sizeof(float) <= lds) {
-            se->expected = p.nchunk * g.strips * g.bands;
-            p.se = *se;
-        } else {
-            se->counter = nullptr;
-        }
-    }
     const double pix = (double)B * H * W;
     const int rec = prof_start("mbconv_rows", 2.0 * pix * Cin * mid + 2.0 * B * Ho * Wo * mid * K * K,
                                4.0 * (pix * Cin + (double)B * Ho * Wo * mid), s);
@@ -496,7 +479,7 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
     // branch-free stores need: strips tile the width exactly, every band is a whole number of steps, and the last 32-channel
     // chunk is full or exactly half full (a missing quad duplicates the quad 16 channels below)
     const bool exact = g.strips * g.SWo == Wo && Ho % g.TO == 0 && g.band_rows % g.TO == 0 && (mid % 32 == 0 || mid % 32 == 16) &&
-                       g.SWo % g.NOUT == 0 && get_option("mbrows_exact") != 0;
+                       g.SWo % g.NOUT == 0;
     const bool bf3 = (get_option("conv_bf3") & 2) != 0;  // (opt-in bit 2; the exact-tiling instantiations only)
 #define ORBIT_MBR3X(KK, SS, TO_, NOUT_, NG_, SPR_)                    \
     do {                                                              \
@@ -539,7 +522,6 @@ struct StemRowsParams {
     const float* sh2;
     float* y;             // [B][H][W][32]
     float* pool;          // [B][tiles][32] or nullptr
-    SeTail se;            // as in MbRowsParams
     int FH, FW, spad_t, spad_l, H, W;  // (H, W) = stem output grid = depthwise grid
     int SWo, SWi, strips, band_rows, bands, total;
 };
@@ -783,9 +765,8 @@ __global__ __launch_bounds__(256, 3) void stem_rows_kernel(const StemRowsParams 
         if (tid < 8) {
             v4f t4 = red[tid];
             for (int sl = 1; sl < 32; ++sl) t4 += red[sl * 8 + tid];
-            se_store_partial(p.pool + ((size_t)b * tiles + tile) * 32 + tid * 4, t4, p.se.counter != nullptr);
+            *reinterpret_cast<v4f*>(p.pool + ((size_t)b * tiles + tile) * 32 + tid * 4) = t4;
         }
-        se_tail_finish<2>(p.se, b, ring);
     }
 }
 
@@ -799,8 +780,6 @@ static bool stem_rows_geom(int H, int W, int mid, int K, int stride, StemRowsGeo
     g.SWi = g.SWo + 2;
     if (2 * g.SWi > 64) return false;
     g.band_rows = 28;  // measured: 28-row bands beat 14 (fewer pipeline fills) and 56 (too few blocks) on the whole task
-    const int forced = get_option("mbrows_band");
-    if (forced > 0) g.band_rows = forced;
     g.band_rows = cdiv(g.band_rows, 2) * 2;
     g.bands = cdiv(H, g.band_rows);
     return true;
@@ -816,13 +795,12 @@ int stem_rows_tiles(int H, int W) {
 
 int launch_stem_rows(const float* frames, const float* w1_packed, const float* sc1, const float* sh1, const float* wdw,
                      const float* sc2, const float* sh2, float* y, float* pool, int B, int FH, int FW, int spad_t,
-                     int spad_l, int H, int W, hipStream_t s, int plan_tiles, SeTail* se) {
+                     int spad_l, int H, int W, hipStream_t s, int plan_tiles) {
     ORBIT_REQUIRE(frames && w1_packed && sc1 && sh1 && wdw && sc2 && sh2 && y, "stem_rows: null pointer");
     StemRowsGeom g;
     ORBIT_REQUIRE(stem_rows_geom(H, W, 32, 3, 1, g), "stem_rows: unsupported shape (H=%d W=%d)", H, W);
     ORBIT_REQUIRE(plan_tiles <= 0 || plan_tiles == g.strips * g.bands,
-                  "stem_rows: the plan was built for %d pooling tiles per frame, the current options give %d "
-                  "(mbrows_band changed after the plan was created: rebuild the plan)", plan_tiles, g.strips * g.bands);
+                  "stem_rows: the plan was built for %d pooling tiles per frame, this launch writes %d", plan_tiles, g.strips * g.bands);
     StemRowsParams p;
     p.frames = frames, p.w1 = w1_packed, p.sc1 = sc1, p.sh1 = sh1, p.wdw = wdw, p.sc2 = sc2, p.sh2 = sh2, p.y = y, p.pool = pool;
     p.FH = FH, p.FW = FW, p.spad_t = spad_t, p.spad_l = spad_l, p.H = H, p.W = W;
@@ -830,23 +808,80 @@ int launch_stem_rows(const float* frames, const float* w1_packed, const float* s
     p.total = g.strips * g.bands * B;
     const int grid = cdiv(p.total, 8) * 8;
     const size_t lds = ((size_t)3 * 2 * g.SWi * ROWS_ES + 2 * 3 * 5 * STEM_PW + 14 * 64) * sizeof(float);
-    if (se != nullptr && se->counter != nullptr) {
-        if (pool != nullptr && se_tail_lds_floats(se->C, se->R) * sizeof(float) <= lds) {
-            se->expected = g.strips * g.bands;
-            p.se = *se;
-        } else {
-            se->counter = nullptr;
-        }
-    }
     const double pix = (double)B * H * W;
     const int rec = prof_start("stem_rows", 2.0 * pix * 32 * 27 + 2.0 * pix * 32 * 9,
                                4.0 * ((double)B * 3 * FH * FW + pix * 32), s);
     // branch-free stores: strips tile the width exactly and every band is a whole number of 2-row steps
-    if (g.strips * g.SWo == W && H % 2 == 0 && g.band_rows % 2 == 0 && get_option("mbrows_exact") != 0) stem_rows_kernel<true><<<grid, 256, lds, s>>>(p, w1_packed, sc1, sh1);
+    if (g.strips * g.SWo == W && H % 2 == 0 && g.band_rows % 2 == 0) stem_rows_kernel<true><<<grid, 256, lds, s>>>(p, w1_packed, sc1, sh1);
     else stem_rows_kernel<false><<<grid, 256, lds, s>>>(p, w1_packed, sc1, sh1);
     prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
 
+// OIHW [mid][3][3][3] = [mid][27] -> [mid][32] (zero columns 27..31): the "expand weights" of the stem form
+__global__ __launch_bounds__(256) void stem_pack_kernel(const float* __restrict__ w, float* __restrict__ wp, int mid) {
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < mid * 32; i += gridDim.x * 256) {
+        const int r = i >> 5, k = i & 31;
+        wp[i] = k < 27 ? w[r * 27 + k] : 0.f;
+    }
+}
+int stem_pack_weights(const float* w_oihw, float* w_packed, int mid, hipStream_t s) {
+    stem_pack_kernel<<<cdiv(mid * 32, 256), 256, 0, s>>>(w_oihw, w_packed, mid);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
 }  // namespace orbit
+
+using namespace orbit;
+
+// ---- single-operator entries for the parity tests ----------------------------------------------------------------------
+// pooling partials per frame of orbit_op_stem_dw_front (0: shape not served by the fused kernel)
+extern "C" int orbit_op_stem_dw_front_partials(int H, int W, int mid) {
+    return stem_rows_supported(H, W, mid, 3, 1) ? stem_rows_tiles(H, W) : 0;
+}
+
+// frames NCHW, w_stem torch [mid][3][3][3], wdw torch [mid][1][3][3]
+extern "C" int orbit_op_stem_dw_front(const float* frames, const float* w_stem, const float* scale1, const float* shift1,
+                                      const float* wdw, const float* scale2, const float* shift2, float* y,
+                                      float* pool_partial, int B, int FH, int FW, int spad_top, int spad_left, int H, int W,
+                                      int mid, int pad_top, int pad_left, int Ho, int Wo, orbit_stream_t stream) {
+    ORBIT_REQUIRE(frames && w_stem && wdw && y, "op_stem_dw_front: null pointer");
+    ORBIT_REQUIRE(stem_rows_supported(H, W, mid, 3, 1) && pad_top == 1 && pad_left == 1 && Ho == H && Wo == W,
+                  "op_stem_dw_front: unsupported shape (H=%d W=%d mid=%d)", H, W, mid);
+    hipStream_t s = (hipStream_t)stream;
+    float* wp = nullptr;
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&wp), (size_t)mid * (32 + 9) * sizeof(float), s));
+    int rc = stem_pack_weights(w_stem, wp, mid, s);
+    if (rc == ORBIT_OK) rc = dwconv_pack_weights(wdw, wp + (size_t)mid * 32, mid, 3, s);
+    if (rc == ORBIT_OK)
+        rc = launch_stem_rows(frames, wp, scale1, shift1, wp + (size_t)mid * 32, scale2, shift2, y, pool_partial, B, FH, FW,
+                              spad_top, spad_left, H, W, s);
+    (void)hipFreeAsync(wp, s);
+    return rc;
+}
+
+// pooling partials per frame of orbit_op_mbconv_front (0: shape not served by the fused kernel)
+extern "C" int orbit_op_mbconv_front_partials(int H, int W, int Cin, int mid, int K, int stride) {
+    return mbconv_rows_supported(H, W, Cin, mid, K, stride) ? mbconv_rows_tiles(H, W, Cin, mid, K, stride) : 0;
+}
+
+// w1 torch [mid][Cin][1][1], wdw torch [mid][1][K][K]
+extern "C" int orbit_op_mbconv_front(const float* x, const float* w1, const float* scale1, const float* shift1,
+                                     const float* wdw, const float* scale2, const float* shift2, float* y,
+                                     float* pool_partial, int B, int H, int W, int Cin, int mid, int K, int stride,
+                                     int pad_top, int pad_left, int Ho, int Wo, orbit_stream_t stream) {
+    ORBIT_REQUIRE(x && w1 && wdw && y, "op_mbconv_front: null pointer");
+    ORBIT_REQUIRE(mbconv_rows_supported(H, W, Cin, mid, K, stride),
+                  "op_mbconv_front: unsupported shape (H=%d W=%d Cin=%d mid=%d K=%d s=%d)", H, W, Cin, mid, K, stride);
+    hipStream_t s = (hipStream_t)stream;
+    float* wp = nullptr;
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&wp), (size_t)mid * K * K * sizeof(float), s));
+    int rc = dwconv_pack_weights(wdw, wp, mid, K, s);
+    if (rc == ORBIT_OK)
+        rc = launch_mbconv_rows(x, w1, scale1, shift1, wp, scale2, shift2, y, pool_partial, B, H, W, Cin, mid, K, stride,
+                                pad_top, pad_left, Ho, Wo, s);
+    (void)hipFreeAsync(wp, s);
+    return rc;
+}

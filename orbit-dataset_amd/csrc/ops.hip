@@ -9,7 +9,6 @@
 //                                folded here to a per-channel (scale, shift) consumed by conv epilogues.
 #include "common.h"
 #include <algorithm>
-#include "se_tail.h"
 
 namespace orbit {
 
@@ -68,8 +67,7 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
                                                         const float* __restrict__ shift,
                                                         float* __restrict__ pool_partial, int H, int W, int C,
                                                         int pad_t, int pad_l, int Ho, int Wo, int act, int cb4,
-                                                        int rows_per_chunk, DwInXf xf = DwInXf{nullptr, nullptr, 0},
-                                                        SeTail se = SeTail{}) {
+                                                        int rows_per_chunk, DwInXf xf = DwInXf{nullptr, nullptr, 0}) {
     constexpr int NCOL = 3 * S + K;
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float4* wl = reinterpret_cast<float4*>(sm);             // [K*K][cb4]
@@ -159,9 +157,8 @@ __global__ __launch_bounds__(256) void dwconv_se_kernel(const float* __restrict_
             const float4 u = red[l * cb4 + tid];
             t.x += u.x, t.y += u.y, t.z += u.z, t.w += u.w;
         }
-        se_store_partial(pool_partial + prow * C + (c4_0 + tid) * 4, (v4f){t.x, t.y, t.z, t.w}, !STATS && se.counter != nullptr);
+        *reinterpret_cast<float4*>(pool_partial + prow * C + (c4_0 + tid) * 4) = t;
     }
-    if (!STATS) se_tail_finish<2>(se, b, sm);  // the block that completes frame b computes its squeeze-excite gate (se_tail.h)
     if (STATS) {
         __syncthreads();
         if (active) red[lw * cb4 + lc] = psq;
@@ -433,7 +430,7 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict
                                                          float* __restrict__ pool_partial, int H, int W, int C,
                                                          int pad_t, int pad_l, int Ho, int Wo, int act, int cs4,
                                                          int rows_per_chunk, int G, int IWA,
-                                                         DwInXf xf = DwInXf{nullptr, nullptr, 0}, SeTail se = SeTail{}) {
+                                                         DwInXf xf = DwInXf{nullptr, nullptr, 0}) {
     constexpr int NCOL = 3 * S + K;
     extern __shared__ __attribute__((aligned(16))) float sml[];
     const int CSP = cs4 * 4 + 4;                     // padded pixel stride (floats)
@@ -544,9 +541,8 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict
     if (tid < cs4) {
         v4f t = red[tid];
         for (int l = 1; l < P; ++l) t += red[l * cs4 + tid];
-        se_store_partial(pool_partial + prow * C + c0 + tid * 4, t, !STATS && se.counter != nullptr);
+        *reinterpret_cast<v4f*>(pool_partial + prow * C + c0 + tid * 4) = t;
     }
-    if (!STATS) se_tail_finish<2>(se, b, sml);  // the block that completes frame b computes its squeeze-excite gate (se_tail.h)
     if (STATS) {
         __syncthreads();
         red[p * cs4 + lc] = psq;
@@ -556,6 +552,125 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict
             for (int l = 1; l < P; ++l) t += red[l * cs4 + tid];
             *reinterpret_cast<v4f*>(pool_partial + (prow + 1) * C + c0 + tid * 4) = t;
         }
+    }
+}
+
+// squeeze-excite gate from pooling partials: pooled[c] = (sum_chunks partial[b][chunk][c]) / HW, then
+// g = sigmoid(W2 silu(W1 pooled + b1) + b2). w2t is W2 transposed to [R][C] so the second layer reads coalesced.
+// One block per frame; the block pulls both weight matrices (up to 2 x 221 KB at C = 1152) through one CU's L1, so the
+// kernel is a chain of L2 latencies: everything is float4 and every phase keeps 16-20 independent loads per lane in
+// flight (layer 1: one wave per hidden unit, four units at a time; layer 2: eight hidden units per step).
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float se_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float se_wave_sum(float v) {  // lane 63 holds the sum; returned wave-uniform
+    v = se_dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = se_dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = se_dpp_add<0x141, 0xf>(v);  // row_half_mirror
+    v = se_dpp_add<0x140, 0xf>(v);  // row_mirror
+    v = se_dpp_add<0x142, 0xa>(v);  // row_bcast:15
+    v = se_dpp_add<0x143, 0xc>(v);  // row_bcast:31
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
+// NT threads cooperate; U = hidden units a wave works on at a time. `partial`, `gate`, `pooled_out` point at THIS frame's
+// rows; sm2 needs ((C + R + 3) & ~3) + 4 * NT floats.
+template <int NT, int U>
+__device__ __forceinline__ void se_gate_frame(const float* __restrict__ partial, int chunks, float inv_hw,
+                                              const float* __restrict__ w1, const float* __restrict__ b1,
+                                              const float* __restrict__ w2t, const float* __restrict__ b2,
+                                              float* __restrict__ gate, int C, int R, float* __restrict__ pooled_out, float* sm2) {
+    v4f* sp4 = reinterpret_cast<v4f*>(sm2);
+    float* hid = sm2 + C;
+    const int tid = threadIdx.x;
+    const int C4 = C >> 2;
+    const v4f* part4 = reinterpret_cast<const v4f*>(partial);  // this frame's [chunks][C]
+    const int parts = C4 <= NT / 2 ? NT / C4 : 1;  // thread groups sharing the chunk list of a channel quad
+    if (parts > 1 && chunks > 8) {
+        // many partials (the fused MBConv front writes one per 8x8 / 4x8 tile: up to 98) and few channels: 256 / C4 threads
+        // per quad take every parts-th chunk, the groups' sums are added in group order (fixed order, deterministic)
+        v4f* tmp = reinterpret_cast<v4f*>(sm2 + ((C + R + 3) & ~3));  // [parts][C4]
+        const int q = tid % C4, part = tid / C4;
+        if (part < parts) {
+            v4f s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+            for (int k = part; k < chunks; k += parts) s += part4[(size_t)k * C4 + q];
+            tmp[part * C4 + q] = s;
+        }
+        __syncthreads();
+        if (tid < C4) {
+            v4f s = tmp[tid];
+            for (int g = 1; g < parts; ++g) s += tmp[g * C4 + tid];
+            sp4[tid] = s * inv_hw;
+        }
+    } else {
+        for (int c4 = tid; c4 < C4; c4 += NT) {
+            v4f s = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+            for (int k = 0; k < chunks; ++k) s += part4[(size_t)k * C4 + c4];  // loads batched, adds in chunk order
+            sp4[c4] = s * inv_hw;
+        }
+    }
+    __syncthreads();
+    if (pooled_out != nullptr)  // training: the pooled means go on the tape (input of the gate MLP's backward)
+        for (int c4 = tid; c4 < C4; c4 += NT) reinterpret_cast<v4f*>(pooled_out)[c4] = sp4[c4];
+    // layer 1: wave w takes hidden units w, w + 4, ...; four units at a time, lanes stride the channel quads
+    const int lane = tid & 63, wave = tid >> 6;
+    const v4f* w14 = reinterpret_cast<const v4f*>(w1);
+    for (int r0 = wave; r0 < R; r0 += U * (NT / 64)) {  // each wave takes units r0, r0 + NW, .. (U at a time)
+        float acc[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] = 0.f;
+        for (int cb = 0; cb < C4; cb += 320) {  // 5 quads per lane per pass: C <= 1280 is a single pass
+            v4f wv[U][5], pv[5];
+#pragma unroll
+            for (int j = 0; j < 5; ++j) {
+                const int c4 = cb + lane + 64 * j;
+                const bool ok = c4 < C4;
+                pv[j] = ok ? sp4[c4] : (v4f){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const int r = r0 + (NT / 64) * u;
+                    wv[u][j] = (ok && r < R) ? w14[(size_t)r * C4 + c4] : (v4f){0.f, 0.f, 0.f, 0.f};
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < 5; ++j) {
+                    const v4f t = wv[u][j] * pv[j];
+                    acc[u] += (t[0] + t[1]) + (t[2] + t[3]);
+                }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int r = r0 + (NT / 64) * u;
+            const float sum = se_wave_sum(acc[u]);
+            if (r < R && lane == 0) {
+                const float t = sum + b1[r];
+                hid[r] = t / (1.0f + expf(-t));
+            }
+        }
+    }
+    __syncthreads();
+    // layer 2: thread = channel quad, eight hidden units (eight independent 16-byte loads) per step
+    const v4f* w24 = reinterpret_cast<const v4f*>(w2t);
+    for (int c4 = tid; c4 < C4; c4 += NT) {
+        v4f a = *reinterpret_cast<const v4f*>(b2 + 4 * c4);
+        int r = 0;
+        for (; r + 8 <= R; r += 8) {
+            v4f wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w24[(size_t)(r + u) * C4 + c4];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) a += wv[u] * hid[r + u];
+        }
+        for (; r < R; ++r) a += w24[(size_t)r * C4 + c4] * hid[r];
+        v4f g;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) g[q] = 1.0f / (1.0f + expf(-a[q]));
+        reinterpret_cast<v4f*>(gate)[c4] = g;
     }
 }
 
@@ -679,23 +794,8 @@ int dwconv_se_chunks(int Ho) { return cdiv(Ho, dwconv_se_rows_per_chunk(Ho)); }
 
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                      float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
-                     int Wo, int act, hipStream_t s, int stats, const float* in_scale, const float* in_shift, int in_act,
-                     SeTail* se) {
+                     int Wo, int act, hipStream_t s, int stats, const float* in_scale, const float* in_shift, int in_act) {
     ORBIT_REQUIRE(x && w_khwc && y, "dwconv_se: null pointer");
-    // `se` (optional, in / out): the squeeze-excite gate the caller would launch next. A kernel that can run it from its last
-    // block per frame (dwconv_lds / dwconv_se without statistics) takes it - `expected` is filled in here; otherwise the counter
-    // is cleared and the caller launches the stand-alone gate kernel.
-    SeTail tail;
-    auto take_tail = [&](dim3 g, size_t& lds_bytes) {
-        if (se == nullptr || se->counter == nullptr) return;
-        tail = *se;
-        tail.expected = (int)(g.x * g.y);
-        lds_bytes = std::max(lds_bytes, se_tail_lds_floats(tail.C, tail.R) * sizeof(float));
-    };
-    auto no_tail = [&]() {
-        if (se) se->counter = nullptr;
-    };
-    if (stats || in_scale) no_tail();
     ORBIT_REQUIRE(!stats || pool_partial, "dwconv_se: statistics requested without a buffer");
     ORBIT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dwconv_se: the input transform needs scale and shift");
     ORBIT_REQUIRE(!in_scale || stats, "dwconv_se: the input transform is instantiated for the statistics form only");
@@ -730,9 +830,6 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
                                 (size_t)(K * K * cs4 + 256) * sizeof(float4);
             if (ldsb <= 64 * 1024) {
                 dim3 gl(c4 / cs4, cdiv(Ho, rpc), B);
-                size_t ldsb_t = ldsb;
-                take_tail(gl, ldsb_t);
-                if (ldsb_t > 64 * 1024) tail = SeTail{}, ldsb_t = ldsb, no_tail();
                 // staging batch per thread: 8 loads in flight, 12 where a thread owns more than 8 patch pixels (7x7 maps with
                 // 16-quad slices: one HBM round trip instead of two, +6 %; elsewhere 12 is neutral or slightly worse)
                 const bool deep = IHmax * IWA > 8 * (256 / cs4);
@@ -746,11 +843,11 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
             dwconv_lds_kernel<KK, SS, 8, true><<<gl, 256, ldsb, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C,  \
                                                                      pad_t, pad_l, Ho, Wo, act, cs4, rpc, G, IWA);     \
         else if (deep)                                                                                                 \
-            dwconv_lds_kernel<KK, SS, 12><<<gl, 256, ldsb_t, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t, \
-                                                                  pad_l, Ho, Wo, act, cs4, rpc, G, IWA, DwInXf{nullptr, nullptr, 0}, tail); \
+            dwconv_lds_kernel<KK, SS, 12><<<gl, 256, ldsb, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t, \
+                                                                  pad_l, Ho, Wo, act, cs4, rpc, G, IWA); \
         else                                                                                                           \
-            dwconv_lds_kernel<KK, SS, 8><<<gl, 256, ldsb_t, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t,  \
-                                                                 pad_l, Ho, Wo, act, cs4, rpc, G, IWA, DwInXf{nullptr, nullptr, 0}, tail); \
+            dwconv_lds_kernel<KK, SS, 8><<<gl, 256, ldsb, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t,  \
+                                                                 pad_l, Ho, Wo, act, cs4, rpc, G, IWA); \
     } while (0)
                 if (K == 3 && stride == 1) ORBIT_DWL(3, 1);
                 else if (K == 3) ORBIT_DWL(3, 2);
@@ -769,7 +866,6 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     // VGPRs, 1 wave/SIMD) and on stride 2. dw_window: 1 = auto (default), 0 = never, 2 = always.
     const int win_opt = get_option("dw_window");
     if (win_opt == 2 || (win_opt == 1 && K == 3 && stride == 1 && Ho >= 14)) {
-        no_tail();
 #define ORBIT_DWW(KK, SS, NO)                                                                                          \
     do {                                                                                                               \
         if (use_xf)                                                                                                    \
@@ -795,7 +891,6 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     // stride-2 layers (112x96 3x3, 56x144 5x5), slower on the small maps (two tap rows of registers -> 2 waves per SIMD)
     const int pipe_opt = get_option("dw_pipe");
     if (pipe_opt == 2 || (pipe_opt == 1 && stride == 2 && Ho >= 28)) {
-        no_tail();
 #define ORBIT_DWP(KK, SS)                                                                                              \
     do {                                                                                                               \
         if (use_xf)                                                                                                    \
@@ -816,8 +911,6 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
         ORBIT_LAUNCH_CHECK();
         return ORBIT_OK;
     }
-    size_t lds_t = lds;
-    take_tail(grid, lds_t);
 #define ORBIT_DW(KK, SS)                                                                                               \
     do {                                                                                                               \
         if (use_xf)                                                                                                    \
@@ -827,8 +920,8 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
             dwconv_se_kernel<KK, SS, true><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C,      \
                                                                   pad_t, pad_l, Ho, Wo, act, cb4, rpc);                \
         else                                                                                                           \
-            dwconv_se_kernel<KK, SS><<<grid, 256, lds_t, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t,   \
-                                                              pad_l, Ho, Wo, act, cb4, rpc, DwInXf{nullptr, nullptr, 0}, tail); \
+            dwconv_se_kernel<KK, SS><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, C, pad_t,   \
+                                                              pad_l, Ho, Wo, act, cb4, rpc); \
     } while (0)
     if (K == 3 && stride == 1) ORBIT_DW(3, 1);
     else if (K == 3) ORBIT_DW(3, 2);
@@ -847,7 +940,7 @@ int launch_se_gate2(const float* partial, int chunks, int HW, const float* w1, c
     // weights); 1024 threads take all 48 hidden units of the 1152-channel blocks in one round and every channel quad in one
     // pass (19-20 us -> measured below), 256 stay best for the narrow early blocks
     const size_t lds = (size_t)(((C + R + 3) & ~3) + 4 * 1024) * sizeof(float);
-    if (C >= 1024 && get_option("se_wide"))  // measured per 200 frames: C = 1152: 19-20 -> 14.2-14.8 us; C = 672: 11.0-11.3 -> 11.3-13.1 (worse)
+    if (C >= 1024)  // measured per 200 frames: C = 1152: 19-20 -> 14.2-14.8 us; C = 672: 11.0-11.3 -> 11.3-13.1 (worse)
         se_gate2_kernel<1024><<<B, 1024, lds, s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2, gate, C, R, pooled_out);
     else
         se_gate2_kernel<256><<<B, 256, lds, s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2, gate, C, R, pooled_out);

@@ -249,17 +249,14 @@ static int pwr_default_wk(int nchunk) { return (nchunk & 1) ? 1 : nchunk >= 32 ?
 //   operand time = the bytes the waves request (2 KiB of pixels + T KiB of weights (+ gates) per wave and chunk) / ~15 TB/s,
 //                  the rate the vector L1s deliver this access pattern at - why small T loses on long-K layers;
 //   fixed        = ~8 us (launch, first operand round trip, epilogue) + the output at ~5 TB/s.
-// The cheapest T = 3..8 at the layer's K slicing wins; `conv_rgemm_t` / `conv_rgemm_wk` override both (sweeps). Returns the
-// estimate (us).
+// The cheapest T = 3..8 at the layer's K slicing wins. Returns the estimate (us).
 static double pwr_plan(int M, int K, int Cout, bool gate, int& T, int& wk) {
     const int tiles16 = cdiv(Cout, 16), nchunk = K / 16, m_tiles = cdiv(M, 32);
-    const int ft = get_option("conv_rgemm_t"), fw = get_option("conv_rgemm_wk");
     double best = 1e300;
     T = 4, wk = 1;
     for (int t = 3; t <= 8; ++t) {
-        if (ft >= 3 && ft <= 8 && t != ft) continue;
         for (int w = 1; w <= 4; w *= 2) {
-            if ((fw == 1 || fw == 2 || fw == 4) ? w != fw : w != pwr_default_wk(nchunk)) continue;
+            if (w != pwr_default_wk(nchunk)) continue;
             if (w > 1 && (nchunk / w < 2 || (nchunk & 1))) continue;  // (K slices of one parity: pwr_slice)
             const int groups = cdiv(tiles16, t);
             const double blocks = (double)cdiv(m_tiles, 4 / w) * groups;
@@ -283,24 +280,13 @@ static double pwr_plan(int M, int K, int Cout, bool gate, int& T, int& wk) {
 // picture is different (bench.py, whole task, tools/ab_opts.sh): the register GEMM asks the vector L1s for ~2x the operand
 // bytes of the LDS-tiled kernel, and next to the other stream's kernels that costs what the shorter launch saves - with the
 // projection and expansion classes switched on the task is 1 % SLOWER under the support / query overlap and 1 % faster
-// without it; only the 7x7 1152 -> 320 class is a gain in both modes. That class is the default (mask 4); `conv_rgemm` =
-// 16 + mask selects classes for A/B runs (1 = projections to <= 128 channels, 2 = expansions, 4 = projections of <= 8x8 maps
-// from >= 512 to > 256 channels, 8 = everything else), 2 = every conv the kernel supports.
-// (Also measured and NOT kept: the projection + next block's expansion as one launch with the projected rows held in LDS -
-// 98 / 163 us per pair at 14x14 against 101 / 155 us for the two launches, whole task +3 %: DESIGN.md section 4.0r4.)
+// without it; only the class "projections of <= 8x8 maps from >= 512 to > 256 channels" (1152 -> 320 at 7x7) is a gain in
+// both modes. That class is what `conv_rgemm` = 1 (default) routes here; 2 = every conv the kernel supports (parity tests).
 bool pw_rgemm_preferred(const ConvDesc& d) {
     if (d.Cout < 40) return false;
-    const int opt = get_option("conv_rgemm");
-    const int mask = opt >= 16 ? opt - 16 : 4;
-    const bool narrow = d.Cout <= 128;
-    const bool expand = d.Cout >= 4 * d.Cin || (d.Cin <= 320 && d.Cout >= 480);
     // (a rule on the LAYER, not on the pixel count: which kernel serves a conv decides its summation order, and a frame must
     // give the same bits in any batch; maps this small only occur behind >= 512 input channels in the supported networks)
-    const bool small_long = d.H * d.W <= 64 && d.Cin >= 512;
-    if (narrow) return (mask & 1) != 0;
-    if (expand) return (mask & 2) != 0;
-    if (small_long) return d.Cout > 256 ? (mask & 4) != 0 : (mask & 8) != 0;
-    return (mask & 8) != 0;
+    return d.H * d.W <= 64 && d.Cin >= 512 && d.Cout > 256;
 }
 
 template <int T, bool GATE>

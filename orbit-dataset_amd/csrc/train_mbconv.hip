@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void dwconv_flip_kernel(const float* __restric
 
 int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, int H, int W, int C, int K, int stride,
                         int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, float* flip_scratch) {
-    if (stride == 1 && flip_scratch != nullptr && get_option("dw_dgrad_forward")) {
+    if (stride == 1 && flip_scratch != nullptr) {
         // dx[h][w] = sum dy[h + pad_t - kh][w + pad_l - kw] w[kh][kw] = a forward depthwise conv of dy with the rotated
         // taps and padding K-1-pad: the LDS-patch forward kernels (35-60 us on these layers) replace the gather below
         // (180-200 us: K*K loads of dy and K*K loads of w per pixel, each behind its bounds branch)
@@ -550,7 +550,7 @@ int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, 
     }
 
     ORBIT_REQUIRE(C % 4 == 0 && (K == 3 || K == 5), "dwconv_dgrad: C %% 4 != 0 or K not in {3,5}");
-    if (stride == 2 && get_option("dw_dgrad_s2") && (long long)B * ((H + 1) / 2) * ((W + 1) / 2) < (1ll << 31)) {
+    if (stride == 2 && (long long)B * ((H + 1) / 2) * ((W + 1) / 2) < (1ll << 31)) {
         // 2x2-block form: one dy patch + LDS taps per four outputs (see dwconv_dgrad_s2_kernel)
         int G, R, yg;
         dw_layout(C, G, R, yg);

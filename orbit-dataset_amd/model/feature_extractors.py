@@ -48,15 +48,9 @@ class _Plan:
     def __init__(self, name, H, W, trainable=False):
         lib = _lib.load()
         h = ctypes.c_void_p()
-        # the fused MBConv front kernel has no backward form: a plan that will record a tape is built without it
-        prev = lib.orbit_get_option(b"mbconv_fusion")
-        if trainable:
-            lib.orbit_set_option(b"mbconv_fusion", 0)
-        try:
-            _lib.check(lib.orbit_extractor_create(name.encode(), H, W, ctypes.byref(h)), "orbit_extractor_create")
-        finally:
-            if trainable:
-                lib.orbit_set_option(b"mbconv_fusion", prev)
+        # the fused MBConv front kernels have no backward form: a plan that will record a tape is built without them
+        _lib.check(lib.orbit_extractor_create_ex(name.encode(), H, W, 1 if trainable else 0, ctypes.byref(h)),
+                   "orbit_extractor_create_ex")
         self.handle = h
         self.stamp = None
         self.generation = 0  # bumped by every parameter upload: a tape recorded under generation g can only be replayed under g
@@ -305,8 +299,8 @@ class HipNetwork(nn.Module):
         lib = _lib.load()
         if not lib.orbit_extractor_supports_training(plan.handle):
             raise NotImplementedError(
-                "this %s plan has no native training path (it was built with the fused MBConv front op, "
-                "ORBIT_MBCONV_FUSION=1); for inference call it in eval() under torch.no_grad()" % self.native_name)
+                "this %s plan has no native training path (it was built with the fused MBConv front kernels); "
+                "for inference call it in eval() under torch.no_grad()" % self.native_name)
         B = x.shape[0]
         gamma, beta = film if film is not None else (None, None)
         if use_tape:

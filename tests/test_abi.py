@@ -113,7 +113,7 @@ def test_every_runtime_option_is_documented_and_resolvable(lib):
     on a name that is not in the table would silently return 0 - every name used in csrc/ must be in the table."""
     src = open(os.path.join(ROOT, "orbit-dataset_amd", "csrc", "head.hip")).read()
     table = re.findall(r'\{"([a-z0-9_]+)",\s*"(ORBIT_[A-Z0-9_]+)",\s*(-?\d+),\s*false\}', src)
-    assert len(table) >= 30
+    assert 10 <= len(table) <= 15  # (VERDICT r4: the option table stays small - every entry selects a default-path kernel family or the one opt-in)
     header = open(os.path.join(ROOT, "include", "orbit_hip.h")).read()
     for name, env, default in table:
         assert env == "ORBIT_" + name.upper(), (name, env)

@@ -153,46 +153,7 @@ def test_largest_forward_of_the_reference_configuration(device):
     assert torch.isfinite(big).all() and torch.equal(big, small)
 
 
-@pytest.mark.parametrize("B", [1, 7, 200])
-def test_squeeze_excite_gate_computed_by_the_producer_kernel(device, B):
-    """se_fold (csrc/se_tail.h; opt-in - it measured slower than the stand-alone gate kernel): the last block per frame of the depthwise / fused-front launch runs the squeeze-excite gate MLP
-    (tickets on a per-frame counter, write-through partials, one agent-scope acquire) instead of a separate gate kernel. Same
-    arithmetic in the same order: features BIT-IDENTICAL to the stand-alone kernel - checked over repeated forwards while a
-    second stream keeps the chip busy with another forward (a stale partial or an early ticket shows up as different bits only
-    under uneven load), with and without graph replay."""
-    from orbit_dataset_amd import _lib
-    lib = _lib.load()
-    fe, _ = create_feature_extractor("efficientnet_b0", True, False, False)
-    synthetic.init_parameters_(fe)
-    fe = fe.cuda().eval()
-    other, _ = create_feature_extractor("efficientnet_b0", True, False, False)
-    synthetic.init_parameters_(other, seed=3)
-    other = other.cuda().eval()
-    g = torch.Generator(device=device).manual_seed(B)
-    xs = [torch.randn(B, 3, 224, 224, device=device, generator=g) for _ in range(3)]
-    noise = torch.randn(64, 3, 224, 224, device=device, generator=g)
-    side = torch.cuda.Stream()
-    prev_fold, prev_graph = lib.orbit_get_option(b"se_fold"), lib.orbit_get_option(b"graph")
-    try:
-        with torch.no_grad():
-            lib.orbit_set_option(b"se_fold", 0)
-            want = [fe(x).clone() for x in xs]
-            lib.orbit_set_option(b"se_fold", 2)  # every producer that can take a gate
-            for graph in (0, 1):
-                lib.orbit_set_option(b"graph", graph)
-                for rep in range(6):
-                    with torch.cuda.stream(side):
-                        other(noise)
-                    for x, w in zip(xs, want):
-                        got = fe(x)
-                        assert torch.equal(got, w), "rep %d graph %d: max diff %g" % (rep, graph, (got - w).abs().max().item())
-            torch.cuda.synchronize()
-    finally:
-        lib.orbit_set_option(b"se_fold", prev_fold)
-        lib.orbit_set_option(b"graph", prev_graph)
-
-
-@pytest.mark.parametrize("graph", [0, 1])
+@pytest.mark.parametrize("graph", [1])
 def test_extractor_with_bf16x3_pointwise_convs_matches_oracle(device, graph):
     """`conv_bf3` (opt-in, csrc/conv_bf3.hip): EfficientNet-B0's 14x14 / 7x7 pointwise convs on the bf16 matrix cores with three-way
     split operands. Same oracle, same bound as the default path (FEAT_TOL); the features differ from the default path's (another
@@ -223,7 +184,7 @@ def test_extractor_with_bf16x3_pointwise_convs_matches_oracle(device, graph):
     assert torch.equal(back, base)
 
 
-@pytest.mark.parametrize("name,frames,opt", [("efficientnet_b0", 160, 0), ("efficientnet_b0", 160, 3), ("resnet18", 96, 0), ("resnet18", 96, 1)])
+@pytest.mark.parametrize("name,frames,opt", [("efficientnet_b0", 160, 0), ("efficientnet_b0", 160, 3), ("resnet18", 96, 0)])
 def test_two_extractors_on_two_streams_repeat_their_solo_results(device, name, frames, opt):
     """Two independent plans, each on its own stream, issued back to back so their kernels share the chip: every forward must
     return the bits of its solo run. With `conv_bf3` this caught a kernel that was correct alone: fragment reads of the next
@@ -247,7 +208,7 @@ def test_two_extractors_on_two_streams_repeat_their_solo_results(device, name, f
         with torch.no_grad():
             solo = [fes[i](xs[i]).clone() for i in range(2)]
             torch.cuda.synchronize()
-            for rep in range(8):
+            for rep in range(12):
                 outs = []
                 for i in range(2):
                     with torch.cuda.stream(streams[i]):
@@ -258,28 +219,3 @@ def test_two_extractors_on_two_streams_repeat_their_solo_results(device, name, f
     finally:
         lib.orbit_set_option(b"conv_bf3", prev)
         lib.orbit_set_option(b"graph", prev_graph)
-
-
-def test_row_streaming_plan_refuses_a_changed_band_option(device):
-    """`mbrows_band` is read when a plan is built (it sizes the squeeze-excite pooling partials) and again at
-    launch. Changing it in between must fail loudly instead of writing a different number of partials than the gate sums."""
-    from orbit_dataset_amd import _lib
-    lib = _lib.load()
-    fe, _ = create_feature_extractor("efficientnet_b0", True, False, False)
-    synthetic.init_parameters_(fe)
-    fe = fe.cuda().eval()
-    x = _frames(2, 224).to(device)
-    with torch.no_grad():
-        want = fe(x).clone()
-    graph = lib.orbit_get_option(b"graph")
-    lib.orbit_set_option(b"graph", 0)  # a replayed graph would not re-enter the launch code
-    lib.orbit_set_option(b"mbrows_band", 14)
-    try:
-        with pytest.raises(ValueError, match="mbrows_band"):  # ORBIT_ERR_ARG surfaces as ValueError (_lib.check)
-            with torch.no_grad():
-                fe(x)
-    finally:
-        lib.orbit_set_option(b"mbrows_band", 0)
-        lib.orbit_set_option(b"graph", graph)
-    with torch.no_grad():
-        assert torch.equal(fe(x), want)

@@ -84,17 +84,13 @@ def main():
             res = {0: [], 1: []}
             for rep_ in range(3):
                 for v in (0, 1):
-                    lib.orbit_set_option(opt, 2 * v if sys.argv[3] == "conv_uncond" else v)
+                    lib.orbit_set_option(opt, v)
                     res[v].append(measure(0)[0])
             a0, a1 = min(res[0]), min(res[1])
             line += "  | %s=0 %.1f us  =1 %.1f us  (%+.1f%%)" % (sys.argv[3], a0, a1, 100 * (a0 / a1 - 1))
             lib.orbit_set_option(opt, 1)
         if sweep:
-            cand = (2, 3, 4, 5, 6, 7)
-            if K == 1 and not nchw and Cout <= 96:
-                cand += (8, 9, 10)
-            if K == 1 and not nchw and Cout <= 128:
-                cand += (11, 12, 13)
+            cand = (3, 4, 6)
             res = {t: measure(t)[0] for t in cand}
             best = min(res, key=res.get)
             line += "  | " + "  ".join("%s %.1f" % (TILES[t], res[t]) for t in res) + "  -> best %s (%.0f%% vs auto)" % (

@@ -1,6 +1,5 @@
-"""Row-streaming fused MBConv front (csrc/mbconv_rows.hip) vs the tiled fused kernel (csrc/mbconv.hip) vs the unfused
-conv + depthwise pair, per high-resolution EfficientNet-B0 block shape, 200 frames. GPU box only.
-   python tools/mbrows_bench.py [shape substrings] [band=<rows>]"""
+"""Row-streaming fused MBConv front (csrc/mbconv_rows.hip) vs the unfused conv + depthwise pair, per high-resolution EfficientNet-B0 block shape, 200 frames. GPU box only.
+   python tools/mbrows_bench.py [shape substrings] [B=<frames>]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -15,8 +14,6 @@ kv = dict(a.split("=") for a in sys.argv[1:] if "=" in a)
 if args:
     SHAPES = [s_ for s_ in SHAPES if any(a in s_[0] for a in args)]
 lib = _lib.load()
-if "band" in kv:
-    lib.orbit_set_option(b"mbrows_band", int(kv["band"]))
 dev = torch.device("cuda", 0)
 B = int(kv.get("B", 200))
 st = _lib.stream_handle

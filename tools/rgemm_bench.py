@@ -78,25 +78,6 @@ def main():
             100 * (res_t[0][0] / res_t[2][0] - 1), roof, e0, e2)
         tot[0] += res_t[0][0]
         tot[1] += res_t[2][0]
-        if sweep:
-            lib.orbit_set_option(b"conv_rgemm", 2)
-            best = (1e9, None)
-            cells = []
-            for T in range(3, 9):
-                for wk in (1, 2, 4):
-                    if wk > 1 and ((Cin // 16) % 2 or Cin // 16 // wk < 2):
-                        continue
-                    lib.orbit_set_option(b"conv_rgemm_t", T)
-                    lib.orbit_set_option(b"conv_rgemm_wk", wk)
-                    y = torch.empty(B, H, H, Cout, device=dev)
-                    us, nm = measure(y, 4)
-                    ok = (y.double() - ref).abs().max().item() / ref.abs().max().item() < 1e-4
-                    cells.append("%d/%d %.1f%s" % (T, wk, us, "" if ok else "!"))
-                    if us < best[0]:
-                        best = (us, (T, wk))
-            lib.orbit_set_option(b"conv_rgemm_t", 0)
-            lib.orbit_set_option(b"conv_rgemm_wk", 0)
-            line += "\n      " + "  ".join(cells) + "  -> best %s %.1f" % (best[1], best[0])
         print(line, flush=True)
     print("sum: igemm %.1f us  rgemm %.1f us" % (tot[0], tot[1]))
 

@@ -29,6 +29,5 @@ def timeit(fn):
     for _ in range(10): fn()
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) * 100
-for band in (0, 28, 56, 112):
-    lib.orbit_set_option(b"mbrows_band", band)
+for band in (28,):
     print("band %3d: pair %6.1f us   rows %6.1f us   (again %6.1f / %6.1f)   max|diff| %.1e" % (band, timeit(pair), timeit(rows), timeit(pair), timeit(rows), (y - yr).abs().max().item()))
