@@ -316,16 +316,7 @@ def metric_variants(model, tasks, device, steps):
         return dt
     prefetched_f32(3)
     t_pf32 = prefetched_f32(steps)
-    # ... and a stream of NEW device-resident tasks: every task arrives with a label tensor the head has not seen, so its label
-    # set is resolved inside the timed region - one torch.unique + host sync per task, what the reference's configure pays in
-    # its .item() loop (model/classifier_heads.py:96-100). The headline loop cycles through resident tasks whose label sets
-    # were resolved (and memoised per label tensor) before the clock started.
-    fresh = [dict(tasks[i % len(tasks)], context_labels=tasks[i % len(tasks)]["context_labels"].clone()) for i in range(steps + 3)]
-    newt = lambda i: run_task(model, fresh[i])
-    timed(newt, 3)
-    t_new = timed(lambda i: run_task(model, fresh[i + 3]), steps)
     return {"predict_only_query_frames_per_s": NUM_QUERY * steps / t_pred,
-            "new_task_labels_resolved_in_loop_query_frames_per_s": NUM_QUERY * steps / t_new,
             "h2d_inclusive_query_frames_per_s": NUM_QUERY * steps / t_h2d,
             "h2d_inclusive_fp32_prefetched_query_frames_per_s": NUM_QUERY * steps / t_pf32,
             "h2d_inclusive_uint8_query_frames_per_s": NUM_QUERY * steps / t_pf,
@@ -336,13 +327,23 @@ def metric_variants(model, tasks, device, steps):
                     "the GPU (orbit_frames_from_uint8) - through data/pipeline.TaskPrefetcher (pinned ring, staging thread, copy "
                     "stream double-buffered against the extractor; first task's upload included), and 'unpipelined' = uploaded "
                     "per mini-batch on the compute / query stream as in round 2; fp32_prefetched: the fp32 clips of the h2d-inclusive "
-                    "variant through the same TaskPrefetcher (task i+1 uploads on the copy stream while task i runs); new_task_labels_resolved_in_loop: the "
-                    "resident-input loop on tasks whose label tensors are new to the head, so the per-task label-set resolution "
-                    "(torch.unique + one host sync, the reference's configure does the same) is inside the timed region"}
+                    "variant through the same TaskPrefetcher (task i+1 uploads on the copy stream while task i runs)"}
+
+
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(workload, model, train=False, way=WAY, template="noise"):
-    """The oracle (CPU restatement of the reference path) on ONE task of the same workload, all host cores."""
+    """The oracle (CPU restatement of the reference path) on a bounded sample of the same workload - the median of 3 tasks
+    at 224x224, of 5 at 84x84 (ORBIT_BENCH_CPU_TASKS overrides the count) - on the host cores."""
     from oracle.recogniser import OracleRecogniser
     fe_name, adapt, size = WORKLOADS[workload]
     ref = OracleRecogniser(fe_name, adapt, HEADS.get(workload, "proto"), 1, 256, num_lite_samples=NUM_LITE)
@@ -356,7 +357,12 @@ def cpu_baseline(workload, model, train=False, way=WAY, template="noise"):
         ref.set_encoder.load_state_dict({k[len("set_encoder."):]: v for k, v in sd.items() if k.startswith("set_encoder.")})
         ref.build_film_generator().load_state_dict(
             {k[len("film_generator."):]: v for k, v in sd.items() if k.startswith("film_generator.")})
-    task = synthetic.make_task(0, way, 1, WAY * SHOTS * FRAMES_PER_SHOT // way, NUM_QUERY, size, template=template)
+    n_tasks = int(os.environ.get("ORBIT_BENCH_CPU_TASKS", "3" if size >= 224 else "5"))
+    if train:
+        n_tasks = 1  # (the parity leg replays this one training step on the GPU from the same weights)
+    cpu_tasks = [synthetic.make_task(i, way, 1, WAY * SHOTS * FRAMES_PER_SHOT // way, NUM_QUERY, size, template=template)
+                 for i in range(max(1, n_tasks))]
+    task = cpu_tasks[0]
     # Thread count: BASELINE.md asks for os.cpu_count(); PyTorch-CPU gets SLOWER past the point where the small
     # convolutions stop scaling, so every candidate up to and including os.cpu_count() is timed on a probe with the batch
     # shape of the real task (one 64-frame extractor batch + one 64-frame query batch; the round-1 probe used 32 frames,
@@ -364,7 +370,8 @@ def cpu_baseline(workload, model, train=False, way=WAY, template="noise"):
     ncpu = os.cpu_count() or 1
     warm = synthetic.make_task(1, WAY, 1, 12, 64, size)
     probe = {}
-    for nt in sorted({min(c, ncpu) for c in (8, 16, 32, 64, 128, ncpu)}):
+    candidates = [int(c) for c in os.environ.get("ORBIT_BENCH_CPU_THREADS", "8,16,32,64,128,%d" % ncpu).split(",")]
+    for nt in sorted({min(c, ncpu) for c in candidates}):
         torch.set_num_threads(nt)
         if not probe:
             ref.personalise(warm["context_clips"][:8], warm["context_labels"][:8])  # first-call set-up, untimed
@@ -385,17 +392,24 @@ def cpu_baseline(workload, model, train=False, way=WAY, template="noise"):
                                                         task["target_clips"], task["target_labels"])
         dt = time.perf_counter() - t0
         what = "1 LITE training task (200 support + 200 query frames, H=%d, forward + backward)" % NUM_LITE
+        per_task = [dt]
     else:
-        t0 = time.perf_counter()
-        ref.personalise(task["context_clips"], task["context_labels"])
-        logits = ref.predict(task["target_clips"])
-        dt = time.perf_counter() - t0
-        what = "1 task (200 support + 200 query frames"
-        what += ")"
+        per_task, logits = [], None
+        for t in cpu_tasks:
+            t0 = time.perf_counter()
+            ref.personalise(t["context_clips"], t["context_labels"])
+            lg = ref.predict(t["target_clips"])
+            per_task.append(time.perf_counter() - t0)
+            if logits is None:
+                logits = lg  # the parity leg compares the GPU path on the FIRST task
+        dt = sorted(per_task)[len(per_task) // 2]
+        what = "median of %d tasks (200 support + 200 query frames each)" % len(per_task)
     return {"value": NUM_QUERY / dt, "unit": "query frames/s", "cores": cores, "kind": "port",
-            "host_cpus": os.cpu_count(),
-            "sample": "%s, %dx%d, PyTorch-CPU oracle, %d threads (fastest of %s on a 60+64-frame probe), "
-                      "%.1f s" % (what, size, size, cores, "/".join(str(k) for k in sorted(probe)), dt),
+            "host_cpus": os.cpu_count(), "cpu_model": cpu_model_name(),
+            "per_task_seconds": [round(x, 2) for x in per_task],
+            "sample": "%s, %dx%d, PyTorch-CPU oracle on %s, %d threads (fastest of %s on a 60+64-frame probe), "
+                      "%.1f s per task, %.0f s of CPU work" % (what, size, size, cpu_model_name(), cores,
+                                                              "/".join(str(k) for k in sorted(probe)), dt, sum(per_task)),
             "thread_probe_frames_per_s": {str(k): round(124 / v, 1) for k, v in sorted(probe.items())},
             }, task, logits
 
@@ -436,6 +450,44 @@ def _rccl_check(lib, rank, world, dist, device):
     if lo != hi or lo != float(world):
         raise SystemExit("bench.py: orbit_allreduce_sum over %d ranks returned [%g, %g], expected %d" % (world, lo, hi, world))
     return int(lo)
+
+
+def per_rank_report(rank, world, dist, device, elapsed, issued, steps, train_step):
+    """What a SCALE record needs to be read: every rank's own step time and host enqueue time, and - for
+    the training form - the gradient bucket's size and the time of ONE all-reduce of it, alone on the chip, through the
+    backend (RCCL ring under `nccl`) and through the direct reduce-scatter + all-gather over the P2P inboxes
+    (csrc/comm.hip). Collective: every rank calls it; the list is gathered on all ranks."""
+    info = {"rank": rank, "ms_per_step": 1e3 * elapsed / steps, "host_enqueue_ms_per_step": 1e3 * issued / steps}
+    bucket = getattr(train_step, "bucket", None)
+    if bucket is not None and getattr(bucket, "flat", None) is not None:
+        from orbit_dataset_amd import dist as odist
+        n = bucket.flat.numel()
+        info["gradient_bucket_bytes"] = 4 * n
+        scratch = torch.zeros_like(bucket.flat)
+
+        def timed(fn, reps=5):
+            fn()
+            torch.cuda.synchronize()
+            dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                fn()
+            torch.cuda.synchronize()
+            return 1e6 * (time.perf_counter() - t0) / reps
+        info["allreduce_us_backend"] = timed(lambda: dist.all_reduce(scratch, op=dist.ReduceOp.SUM))
+        info["allreduce_algbw_GBps_backend"] = 4e-3 * n / info["allreduce_us_backend"]
+        if os.environ.get("ORBIT_BENCH_P2P_PROBE", "1") != "0":
+            try:
+                p2p = odist.P2PAllReduce(rank, world, odist.P2PAllReduce.floats_for_bucket(n, world))
+                info["allreduce_us_p2p"] = timed(lambda: p2p(scratch))
+                info["allreduce_algbw_GBps_p2p"] = 4e-3 * n / info["allreduce_us_p2p"]
+                p2p.raise_on_error()
+                p2p.close()
+            except Exception as e:  # (IPC mapping unavailable: report, do not fail the line)
+                info["allreduce_p2p_error"] = repr(e)[:200]
+    gathered = [None] * world
+    dist.all_gather_object(gathered, info)
+    return gathered
 
 
 def main():
@@ -509,12 +561,17 @@ def main():
     tasks = [synthetic.make_task_on_device(rank + world * i, way, 1, frames_per_class, NUM_QUERY, size, 1, device,
                                            template=template)
              for i in range(max(1, args.distinct_tasks))]
-    # label sets of the resident tasks are resolved here (memoised per label tensor, classifier_heads.unique_labels): the
-    # one device sync torch.unique needs per NEW task otherwise lands in the timed region for every task the warm-up
-    # did not touch, and drains the whole launch queue there
-    for t in tasks:
-        model.classifier.unique_labels(t["context_labels"], device)
+    # Every step of every loop below runs on a task whose LABEL TENSOR the head has never seen (a clone made before the clock
+    # starts): the per-task label-set resolution - what the reference's configure pays as torch.unique + .item() per task,
+    # model/classifier_heads.py:96-100,246-248 - is inside the timed region of `value`. (Round 4 resolved the label sets of
+    # the resident tasks before the clock and memoised them; that variant is now reported as `value_memoised_labels`.)
+    fresh_labels = True
     lib = _lib.load()
+
+    def stream_of_tasks(n):
+        if not fresh_labels:
+            return [tasks[i % len(tasks)] for i in range(n)]
+        return [dict(tasks[i % len(tasks)], context_labels=tasks[i % len(tasks)]["context_labels"].clone()) for i in range(n)]
     # long-lived objects (torch, the model, the resident tasks) leave the cyclic collector's working set: a full
     # collection otherwise walks ~1e6 objects every few steps (measured: 19.7 -> 12.3 ms per LITE step at 84x84)
     import gc
@@ -528,11 +585,12 @@ def main():
         torch.cuda.synchronize()
 
     def loop(steps):
+        todo = stream_of_tasks(steps * per_step)
         barrier()
         t0 = time.perf_counter()
         outs = []
         for i in range(steps * per_step):
-            outs.append(run_step(model, tasks[i % len(tasks)]))  # logits stay on the device; scored after the clock stops
+            outs.append(run_step(model, todo[i]))  # logits stay on the device; scored after the clock stops
         issued = time.perf_counter() - t0  # host time to enqueue everything (diagnostic: host- vs device-bound)
         barrier()
         elapsed = time.perf_counter() - t0
@@ -547,15 +605,16 @@ def main():
     # Settling (untimed, before the W warm-up steps): on a fresh box the container image is paged in lazily, and the FIRST
     # process that runs this path stays 25-40 % slower on the host side for its whole life unless the code pages it
     # needs have been touched (measured: first process 17.8 k, every later one 22.3 k query frames/s on the same box).
-    # Run chunks of 10 steps until a chunk is no faster than the one before (at most 20 chunks).
+    # Two chunks of 10 steps at most (capped at 20; the second only if it is still getting faster).
     settling = 0
     if os.environ.get("ORBIT_BENCH_SETTLE", "1") != "0":
         prev = None
-        for _ in range(20):
+        for _ in range(2):
+            todo = stream_of_tasks(10 * per_step)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for i in range(10 * per_step):
-                run_step(model, tasks[i % len(tasks)])
+                run_step(model, todo[i])
             torch.cuda.synchronize()
             dt = time.perf_counter() - t0
             settling += 10
@@ -569,21 +628,32 @@ def main():
             if done:
                 break
             prev = dt
+    todo = stream_of_tasks(args.warmup * per_step)
     for i in range(args.warmup * per_step):
-        run_step(model, tasks[i % len(tasks)])
+        run_step(model, todo[i])
     elapsed, correct, issued = loop(args.steps)  # the timed region behind `value`
+    value_memoised = None
+    if not train:  # round 4's form: label sets of the resident tasks resolved and memoised before the clock
+        fresh_labels = False
+        for t in tasks:
+            model.classifier.unique_labels(t["context_labels"], device)
+        loop(2)
+        m_elapsed, _, _ = loop(args.steps)
+        value_memoised = NUM_QUERY * args.steps * per_step / m_elapsed
+        fresh_labels = True
     if train and getattr(run_step.bucket, "p2p", None) is not None:
         run_step.bucket.p2p.raise_on_error()  # (the loop ended on a barrier + synchronize: every exchange has completed)
 
     def per_task_events(steps):
         """SURVEY §8(d): per-task HIP-event time (events on the caller's stream before personalise() and after predict();
         the query stream joins it before the head kernel), median over the tasks of a repeat of the timed steps."""
+        todo = stream_of_tasks(steps * per_step)
         barrier()
         evs = []
         for i in range(steps * per_step):
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-            run_step(model, tasks[i % len(tasks)])
+            run_step(model, todo[i])
             e1.record()
             evs.append((e0, e1))
         barrier()
@@ -614,7 +684,9 @@ def main():
     elapsed_prof, _, _ = loop(args.steps)
     lib.orbit_prof_enable(0)
     model.overlap_query = overlap
+    per_rank = None
     if dist is not None:
+        per_rank = per_rank_report(rank, world, dist, device, elapsed, issued, args.steps, run_step if train else None)
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -682,6 +754,7 @@ def main():
         "unit": "query frames/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "rccl_ranks": rccl_ranks, "ranks_share_gpus": bool(world > torch.cuda.device_count()),
+        "per_rank": per_rank,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
@@ -703,6 +776,10 @@ def main():
         "frame_accuracy": float(correct[0].item() / max(correct[1].item(), 1)),
         "train_graph_calls_replayed_eager": list(model.feature_extractor.train_graph_stats()) if train else None,
         "median_task_ms": median_task_ms,
+        "labels": "every timed task carries a label tensor new to the head: its label set is resolved inside the timed region "
+                  "(orbit_label_set on a side stream, class count waited for at the head kernel)",
+        # this rank's rate with the label sets of the resident tasks resolved and memoised before the clock (round 4's `value`)
+        "value_memoised_labels": value_memoised,
         "value_overlap_off": value_overlap_off,
         # the library's default mode (overlap_query = False: no assumption about when the query clips become ready)
         "value_default_mode": value_overlap_off if bool(timed_mode) else NUM_QUERY * args.steps * per_step * world / elapsed,
@@ -738,7 +815,7 @@ def main():
     if not train and world == 1:
         out["variants_of_the_metric"] = metric_variants(model, tasks, device, min(args.steps, 20))
     bf3 = None
-    if not train and world == 1 and os.environ.get("ORBIT_BENCH_BF3", "1") != "0":
+    if not train and world == 1 and os.environ.get("ORBIT_BENCH_BF3", "0") == "1":  # (frozen opt-in path: off unless asked for)
         # OPT-IN alternative, never `value`: the 14x14 / 7x7 pointwise convs with both operands split three
         # ways into bf16 and six products per fp32 product on the bf16 matrix cores (csrc/conv_bf3.hip, option conv_bf3). The
         # same timed loop, then the serial leg with per-launch events; its logit error against the pinned oracle is added
@@ -780,6 +857,9 @@ def main():
                    "note": "fp32 operands split x = x0 + x1 + x2 (bf16, round to nearest, 24 significand bits), products "
                            "x0w0 + x0w1 + x1w0 + x1w1 + x0w2 + x2w0 on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; the fraction "
                            "is quoted against the fp32-MFMA peak the default path is priced on (FLOPs of the fp32 problem)"}
+        except Exception as e:  # the experimental leg must never cost the default path its line
+            bf3 = None
+            out["opt_in_conv_bf3_error"] = repr(e)[:300]
         finally:
             lib.orbit_prof_enable(0)
             lib.orbit_set_option(b"conv_bf3", bf3_prev)

@@ -21,6 +21,7 @@ _SIGNATURES = {
     "orbit_device_count": (c_int, []),
     "orbit_set_option": (c_int, [c_char_p, c_int]),
     "orbit_get_option": (c_int, [c_char_p]),
+    "orbit_label_set": (c_int, [P, c_int, P, c_int, P, P]),
     "orbit_proto_configure": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, P, P, P]),
     "orbit_proto_finalize": (c_int, [P, P, c_int, c_int, c_int, c_int, P, P, P]),
     "orbit_proto_predict": (c_int, [P, P, P, c_int, c_int, c_int, c_int, c_int, c_float, c_int, P, P, P]),

@@ -122,6 +122,41 @@ __global__ __launch_bounds__(256) void proto_configure_kernel(
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[(size_t)task * C + c] = (float)cnt;
 }
 
+// ---- label set: the ascending unique values of labels[N] (what torch.unique gives the reference's configure, reference
+// model/classifier_heads.py:96-100,246-248) WITHOUT a host round trip: class_ids[0 .. cap) receives them (slots beyond the
+// count repeat the last value, so every slot is a real class and kernels launched over `cap` slots compute finite rows),
+// *count the number found, or cap + 1 when there are more than `cap`. One wave: selection by repeated minimum - the label
+// sets of a task are 5..20 values over a few hundred clips.
+__global__ __launch_bounds__(64) void label_set_kernel(const int64_t* __restrict__ labels, int N,
+                                                       int64_t* __restrict__ class_ids, int cap, int32_t* __restrict__ count) {
+    const int lane = threadIdx.x;
+    long long last = 0;
+    bool have = false;
+    int found = 0;
+    for (;;) {
+        long long best = 0;
+        int any = 0;
+        for (int i = lane; i < N; i += 64) {
+            const long long v = labels[i];
+            if ((!have || v > last) && (!any || v < best)) best = v, any = 1;
+        }
+#pragma unroll
+        for (int off = 32; off; off >>= 1) {
+            const long long ob = __shfl_xor(best, off);
+            const int oa = __shfl_xor(any, off);
+            if (oa && (!any || ob < best)) best = ob, any = 1;
+        }
+        if (!any) break;
+        if (found < cap && lane == 0) class_ids[found] = best;
+        ++found, last = best, have = true;
+        if (found > cap) break;
+    }
+    if (lane == 0) {
+        *count = found;
+        for (int i = found; i < cap; ++i) class_ids[i] = have ? last : 0;
+    }
+}
+
 // ---- finalize: W = 2 mu, b = -mu.mu ------------------------------------------------------------
 // grid (C, n_tasks), block 256
 __global__ __launch_bounds__(256) void proto_finalize_kernel(const float* __restrict__ sums,
@@ -566,6 +601,14 @@ int orbit_proto_configure(const float* feats, const int64_t* labels, const int64
     dim3 grid(cdiv(D, 256), C, n_tasks);
     proto_configure_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(feats, labels, class_ids, N, T, D, C,
                                                                   sums, counts);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+int orbit_label_set(const int64_t* labels, int N, int64_t* class_ids, int cap, int32_t* count, orbit_stream_t stream) {
+    ORBIT_REQUIRE(labels && class_ids && count, "label_set: null pointer");
+    ORBIT_REQUIRE(N >= 0 && cap > 0, "label_set: bad sizes");
+    label_set_kernel<<<1, 64, 0, (hipStream_t)stream>>>(labels, N, class_ids, cap, count);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }

@@ -346,10 +346,17 @@ class RunningStatSync:
             return
         import math
         dev = self.stats[0].device
-        log_a = math.log(1.0 - self.momentum)
+        # a^n in float64 on the device (a^n enters (cur - a^n r0) / (1 - a^n): an fp32 exp costs digits there); momentum >= 1
+        # means a = 0: a^n = 0 for every n > 0 (and log(0) must not be taken - ADVICE r4)
+        a = max(1.0 - self.momentum, 0.0)
         n = ((self.counters[0] - self.start_count).to(torch.float32) if self.counters
              else torch.zeros((), device=dev, dtype=torch.float32)).reshape(1)            # forwards this rank ran, on the device
-        an = torch.exp(n * log_a)
+
+        def a_pow(k):
+            if a <= 0.0:
+                return torch.where(k > 0, torch.zeros_like(k), torch.ones_like(k))
+            return torch.exp(k.to(torch.float64) * math.log(a)).to(torch.float32)
+        an = a_pow(n)
         live = n > 0
         denom = torch.where(live, 1.0 - an, torch.ones_like(an))
         cur = torch.cat([b.reshape(-1).to(torch.float32) for b in self.stats])
@@ -358,7 +365,7 @@ class RunningStatSync:
         flat = torch.cat([s_k, n])
         dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)                       # ONE flat message, counters included
         N = flat[-1:]
-        aN = torch.exp(N * log_a)
+        aN = a_pow(N)
         new = aN * r0 + (1.0 - aN) * flat[:-1] / N.clamp(min=1.0)
         new = torch.where(N > 0, new, cur)                                                  # nobody ran a forward: unchanged
         off = 0

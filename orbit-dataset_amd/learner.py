@@ -100,6 +100,8 @@ def build_parser():
     p.add_argument("--subsample_factor", type=int, default=30)
     p.add_argument("--test_context_clip_method", default="uniform", choices=["random", "random_200", "max", "uniform"])
     p.add_argument("--test_target_clip_method", default="random_200", choices=["random", "random_200", "max"])
+    p.add_argument("--max_test_tasks", type=int, default=None,
+                   help="with --data_root: evaluate only the first N tasks of the user-major order (default: all users)")
     p.add_argument("--num_test_tasks_per_user", type=int, default=1,
                    help="with --data_root: tasks sampled per test user (reference --num_test_tasks, utils/args.py)")
     p.add_argument("--num_workers", type=int, default=4, help="decode threads (reference data/queues.py:34: 4 in test mode)")
@@ -123,9 +125,14 @@ def frame_accuracy(logits, label):
 def mean_ci(values):
     """mean and 95 % confidence half-width, as the reference's evaluators report (utils/eval_metrics.py:24-25)."""
     v = np.asarray(values, dtype=np.float64)
-    if len(v) == 0:  # a rank (or a run) that saw no task: no statistic, not a numpy warning
-        return float("nan"), 0.0
+    if len(v) == 0:  # a rank (or a run) that saw no task: no statistic (None: json.dump would write a bare NaN, invalid JSON)
+        return None, 0.0
     return float(v.mean()), float(1.96 * v.std() / math.sqrt(len(v))) if len(v) > 1 else 0.0
+
+
+def _shown(stat):
+    """(mean, ci) for a print statement: NaN where mean_ci had no data"""
+    return (float("nan") if stat[0] is None else stat[0]), stat[1]
 
 
 class Learner:
@@ -328,8 +335,17 @@ class Learner:
             (a.test_context_clip_method, a.test_target_clip_method), a.clip_length, a.frame_size, a.frame_norm_method, [],
             ([], []), True, False, False, None, frames="uint8", rng=random.Random(a.seed + self.rank), decode_pool=pool)
         # TaskSampler order (data/samplers.py:24-30, no shuffle): user 0 x num_tasks, user 1 x num_tasks, ...; dealt to ranks
+        # - EVERY user x num_test_tasks_per_user, as the reference's loop visits them (single-step-learner.py:313-314). An
+        # optional total cap (--max_test_tasks; default none) is applied BEFORE the tasks are dealt, so the evaluated set does
+        # not depend on the world size, and is announced when it truncates the user list
         order = [u for u in range(len(dataset)) for _ in range(a.num_test_tasks_per_user)]
-        source = DatasetTaskSource(dataset, order[self.rank::self.world][:a.num_test_tasks])
+        cap = getattr(a, "max_test_tasks", None)
+        if cap is not None and cap < len(order):
+            if self.rank == 0:
+                print("test (%s): --max_test_tasks %d truncates %d tasks (%d users x %d) - NOT the full test set"
+                      % (a.data_root, cap, len(order), len(dataset), a.num_test_tasks_per_user))
+            order = order[:cap]
+        source = DatasetTaskSource(dataset, order[self.rank::self.world])
         task_acc, personalise_ms, inference_ms, frames = [], [], [], 0
         t_all = time.perf_counter()
         prefetch = TaskPrefetcher(source, self.device, depth=3, frame_norm_method=a.frame_norm_method)
@@ -369,8 +385,8 @@ class Learner:
         if self.rank == 0:
             print("test (%s): frame_acc %.2f (%.2f) %% | time to personalise %.2f (%.2f) ms | inference %.4f (%.4f) ms/frame "
                   "| %d tasks, %d target frames in %.1f s incl. JPEG decode (%d threads)"
-                  % (a.data_root, 100 * stats["frame_acc"][0], 100 * stats["frame_acc"][1], *stats["personalise_ms"],
-                     *stats["inference_ms_per_frame"], stats["num_tasks"], frames, wall, a.num_workers))
+                  % (a.data_root, 100 * _shown(stats["frame_acc"])[0], 100 * stats["frame_acc"][1], *_shown(stats["personalise_ms"]),
+                     *_shown(stats["inference_ms_per_frame"]), stats["num_tasks"], frames, wall, a.num_workers))
             if a.results_path:
                 with open(a.results_path, "w") as f:
                     json.dump(stats, f)
@@ -415,8 +431,8 @@ class Learner:
                  "inference_ms_per_frame": mean_ci(inference_ms), "num_tasks": len(task_acc), "world_size": self.world}
         if self.rank == 0:
             print("test: frame_acc %.2f (%.2f) %% | time to personalise %.2f (%.2f) ms | inference %.4f (%.4f) ms/frame "
-                  "| %d tasks on %d GPU(s)" % (100 * stats["frame_acc"][0], 100 * stats["frame_acc"][1],
-                                               *stats["personalise_ms"], *stats["inference_ms_per_frame"],
+                  "| %d tasks on %d GPU(s)" % (100 * _shown(stats["frame_acc"])[0], 100 * stats["frame_acc"][1],
+                                               *_shown(stats["personalise_ms"]), *_shown(stats["inference_ms_per_frame"]),
                                                stats["num_tasks"], self.world))
             if a.results_path:
                 with open(a.results_path, "w") as f:
@@ -480,9 +496,9 @@ class MultiStepLearner(Learner):
                  "inference_ms_per_frame": mean_ci(inference_ms), "num_tasks": len(task_acc), "world_size": self.world}
         if self.rank == 0:
             print("finetuner test: frame_acc %.2f (%.2f) %% | time to personalise %.2f (%.2f) ms (%d steps) | inference "
-                  "%.4f (%.4f) ms/frame | %d tasks" % (100 * stats["frame_acc"][0], 100 * stats["frame_acc"][1],
-                                                       *stats["personalise_ms"], a.personalize_num_grad_steps,
-                                                       *stats["inference_ms_per_frame"], stats["num_tasks"]))
+                  "%.4f (%.4f) ms/frame | %d tasks" % (100 * _shown(stats["frame_acc"])[0], 100 * stats["frame_acc"][1],
+                                                       *_shown(stats["personalise_ms"]), a.personalize_num_grad_steps,
+                                                       *_shown(stats["inference_ms_per_frame"]), stats["num_tasks"]))
         return stats
 
 

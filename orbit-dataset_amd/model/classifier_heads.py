@@ -15,10 +15,75 @@ The 'proto' / 'proto_cosine' heads are the hot path named by BASELINE.json. 'ver
 CNAPs), the other two single-step recipes of the reference README, are built on csrc/heads_extra.hip (SURVEY §8f rank 2);
 'linear' is the head of the multi-step finetuner (MultiStepFewShotRecogniser).
 """
+import ctypes
+
 import torch
 import torch.nn as nn
 
 from .. import _lib
+
+
+class PendingLabelSet:
+    """The label set of a task (ascending unique values = logit column order) being resolved on the device WITHOUT a host
+    sync: `orbit_label_set` runs on a side stream as soon as the labels are ready and its count travels to a pinned host
+    slot; the host only waits (on that side stream's event, not on the compute queue) when it first needs the NUMBER of
+    classes - to shape the logits, i.e. at the head kernel of predict(), after both extractor passes are queued.
+    The reference pays a `torch.unique` + `.item()` loop inside configure (model/classifier_heads.py:96-100,246-248), which
+    on a GPU drains the launch queue once per task."""
+
+    CAP = 32  # class slots the head kernels are launched over until the count is known (ORBIT users own <= ~20 objects)
+    _slots = None  # pinned ring of counts, shared by the process
+    _next = 0
+
+    def __init__(self, labels, device):
+        cls = PendingLabelSet
+        if cls._slots is None:
+            cls._slots = torch.zeros(64, dtype=torch.int32).pin_memory()
+        self.labels = labels
+        self.slot = cls._next % 64
+        cls._next += 1
+        lab = labels.to(torch.int64).contiguous()
+        self.ids = torch.empty(self.CAP, dtype=torch.int64, device=device)
+        self.count_dev = torch.empty(1, dtype=torch.int32, device=device)
+        main = torch.cuda.current_stream(device)
+        side = _label_stream(device)
+        ready = torch.cuda.Event()
+        ready.record(main)          # the labels may still be in flight on the caller's stream
+        side.wait_event(ready)
+        _lib.check(_lib.load().orbit_label_set(_lib.dptr(lab, torch.int64), lab.numel(), _lib.dptr(self.ids, torch.int64),
+                                               self.CAP, _lib.dptr(self.count_dev, torch.int32),
+                                               ctypes.c_void_p(side.cuda_stream)), "orbit_label_set")
+        with torch.cuda.stream(side):
+            cls._slots[self.slot:self.slot + 1].copy_(self.count_dev, non_blocking=True)
+        self.done = torch.cuda.Event()
+        self.done.record(side)
+        for t in (lab, self.ids, self.count_dev):
+            t.record_stream(side)
+        self._resolved = None
+
+    def wait_on(self, stream):
+        """device-side: `stream` may read `ids` after this"""
+        stream.wait_event(self.done)
+
+    def resolve(self):
+        """host-side: the exact class ids [C] (or None when the task has more than CAP classes: the caller then takes the
+        exact path). Blocks only until the side stream's kernel + 4-byte copy are done."""
+        if self._resolved is None:
+            self.done.synchronize()
+            c = int(PendingLabelSet._slots[self.slot])
+            self._resolved = (self.ids[:c] if c <= self.CAP else None,)
+        return self._resolved[0]
+
+
+_label_streams = {}
+
+
+def _label_stream(device):
+    key = str(device)
+    st = _label_streams.get(key)
+    if st is None:
+        st = _label_streams[key] = torch.cuda.Stream(device=device)
+    return st
 
 
 class PrototypicalClassifier(nn.Module):
@@ -34,10 +99,37 @@ class PrototypicalClassifier(nn.Module):
         self.reset()
 
     def reset(self):
+        self._pending = None
         self.weight = None
         self.class_ids = None
         if self.distance_fn == "euclidean":
             self.bias = None
+
+    # weight [C, D], bias [C], class_ids [C]: the head state the reference exposes (classifier_heads.py:261-263). When
+    # configure() ran on a PendingLabelSet they are views of the CAP-slot buffers, cut to the true class count on first access
+    def _resolve(self):
+        pend = self.__dict__.get("_pending")
+        if pend is None:
+            return
+        self.__dict__["_pending"] = None
+        pending, w_full, b_full, redo = pend
+        ids = pending.resolve()
+        if ids is None:  # more classes than slots: the exact path, now that a sync has happened anyway
+            redo()
+            return
+        C = int(ids.numel())
+        self.__dict__["_weight"], self.__dict__["_class_ids"] = w_full[:C], ids
+        if b_full is not None:
+            self.__dict__["_bias"] = b_full[:C]
+        self._memoise(pending.labels, ids)
+
+    def _get(self, name):
+        self._resolve()
+        return self.__dict__.get(name)
+
+    weight = property(lambda self: self._get("_weight"), lambda self, v: self.__dict__.__setitem__("_weight", v))
+    bias = property(lambda self: self._get("_bias"), lambda self, v: self.__dict__.__setitem__("_bias", v))
+    class_ids = property(lambda self: self._get("_class_ids"), lambda self, v: self.__dict__.__setitem__("_class_ids", v))
 
     @property
     def _cosine(self):
@@ -57,7 +149,6 @@ class PrototypicalClassifier(nn.Module):
         count, exactly like the reference's torch.unique(...).item() loop (:96-100). The result is memoised per
         label tensor (storage address + version counter): LITE re-personalises the same task once per query batch
         (single-step-learner.py:220-222), and a resident task set is re-used across epochs."""
-        import weakref
         key = (context_labels.data_ptr(), context_labels._version, context_labels.numel(), str(context_labels.device))
         with cls._unique_lock:
             hit = cls._unique_cache.get(key)
@@ -67,6 +158,26 @@ class PrototypicalClassifier(nn.Module):
             ids = torch.unique(context_labels.to(torch.int64))
         else:
             ids = torch.unique(context_labels.to(torch.int64)).to(device, non_blocking=True)
+        cls._memoise(context_labels, ids)
+        return ids
+
+    @classmethod
+    def label_set(cls, context_labels, device):
+        """`unique_labels` that never blocks the host: the memoised / host-side result when there is one, otherwise a
+        PendingLabelSet (device labels the head has not seen: resolved on a side stream, waited for at the head kernel)."""
+        if not context_labels.is_cuda:
+            return cls.unique_labels(context_labels, device)
+        key = (context_labels.data_ptr(), context_labels._version, context_labels.numel(), str(context_labels.device))
+        with cls._unique_lock:
+            hit = cls._unique_cache.get(key)
+            if hit is not None and hit[0]() is context_labels:
+                return hit[1]
+        return PendingLabelSet(context_labels, device)
+
+    @classmethod
+    def _memoise(cls, context_labels, ids):
+        import weakref
+        key = (context_labels.data_ptr(), context_labels._version, context_labels.numel(), str(context_labels.device))
         cache, lock = cls._unique_cache, cls._unique_lock
 
         def drop(ref, key=key):  # the label tensor died: its address may be handed out again
@@ -77,7 +188,6 @@ class PrototypicalClassifier(nn.Module):
             if len(cache) > 256:
                 cache.clear()
             cache[key] = (weakref.ref(context_labels, drop), ids)
-        return ids
 
     def configure(self, context_features, context_labels, ops_counter=None, frames_per_clip: int = 1,
                   class_ids=None):
@@ -93,6 +203,15 @@ class PrototypicalClassifier(nn.Module):
         labels = context_labels.to(device=dev, dtype=torch.int64).contiguous()
         if class_ids is None:
             class_ids = self.unique_labels(labels, dev)
+        pending = None
+        if isinstance(class_ids, PendingLabelSet):
+            if self.partial_reduce is not None or feats.shape[0] == 0:  # the sharded exchange needs the exact payload
+                ids = class_ids.resolve()
+                class_ids = ids if ids is not None else self.unique_labels(labels, dev)
+            else:
+                pending = class_ids
+                pending.wait_on(torch.cuda.current_stream(dev))
+                class_ids = pending.ids  # CAP slots; the true count is read when weight / bias are first used
         C, (NT, D) = int(class_ids.numel()), feats.shape
         N = NT // T
         payload = torch.empty(C * D + C, device=dev, dtype=torch.float32)
@@ -110,6 +229,11 @@ class PrototypicalClassifier(nn.Module):
         bias = None if self._cosine else torch.empty(C, device=dev, dtype=torch.float32)
         _lib.check(lib.orbit_proto_finalize(_lib.dptr(sums), _lib.dptr(counts), 1, C, D, self._cosine,
                                             _lib.dptr(weight), _lib.dptr(bias), st), "orbit_proto_finalize")
+        if pending is not None:
+            def redo(feats=feats, labels=labels, T=T):
+                self.configure(feats, labels, frames_per_clip=T, class_ids=self.unique_labels(labels, dev))
+            self.__dict__["_pending"] = (pending, weight, bias, redo)
+            return
         self.weight = weight
         self.class_ids = class_ids
         if not self._cosine:

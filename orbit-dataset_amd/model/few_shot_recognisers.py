@@ -304,9 +304,11 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
     # ---- personalise ---------------------------------------------------------------------------------
     def personalise(self, context_clips, context_labels, ops_counter=None):
         self._set_batch_norm_state()
-        # the label set does not depend on the features: resolve it (and its one possible sync) before the
-        # extractor work is queued, so nothing below waits on the device
-        class_ids = self.classifier.unique_labels(context_labels, self.device)
+        # the label set does not depend on the features: its resolution is started here, on a side stream, and the host only
+        # waits for the class COUNT when the head kernel of predict() is launched - after both extractor passes are queued
+        # (classifier_heads.PendingLabelSet; the reference's torch.unique + .item() loop, classifier_heads.py:96-100, would
+        # drain the launch queue once per task). Heads that size workspaces by the class count take the blocking form.
+        class_ids = self._label_set(context_labels)
         task_embedding = self._get_task_embedding_in_batches(context_clips, ops_counter)
         self.film_dict = self._generate_film_params(task_embedding, ops_counter)
         if self.overlap_query:
@@ -326,14 +328,20 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
             self._configured = torch.cuda.Event()
             self._configured.record(torch.cuda.current_stream(self.device))
 
+    def _label_set(self, context_labels):
+        get = getattr(self.classifier, "label_set", None)
+        if get is not None and context_labels.is_cuda:
+            return get(context_labels, self.device)
+        return self.classifier.unique_labels(context_labels, self.device)
+
     def personalise_with_lite(self, context_clips, context_labels):
         """LITE forward (reference :328-343): a random subset of `num_lite_samples` clips is re-encoded on
         every call, the rest comes from the per-task caches; features/labels are reordered by the permutation.
         The permutation comes from np.random, exactly as in the reference (seed numpy to reproduce)."""
         self._set_batch_norm_state()
-        # the label SET is permutation-invariant: resolve it from the task's own label tensor (memoised per task, so the
-        # one device sync it may need happens once per task and not once per query batch)
-        class_ids = self.classifier.unique_labels(context_labels, self.device)
+        # the label SET is permutation-invariant: resolve it from the task's own label tensor (memoised per task; the first
+        # query batch of a task resolves it on a side stream, see personalise)
+        class_ids = self._label_set(context_labels)
         shuffled_idxs = np.random.permutation(len(context_clips))
         grad_idxs = shuffled_idxs[0:self.num_lite_samples]
         no_grad_idxs = shuffled_idxs[self.num_lite_samples:]

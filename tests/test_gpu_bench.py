@@ -12,9 +12,14 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+# the contract is about the LINE: the long legs of a real run are cut short (no settling chunks, one CPU-oracle task on two
+# thread settings instead of the median of three on six)
+FAST = dict(ORBIT_BENCH_SETTLE="0", ORBIT_BENCH_CPU_TASKS="1", ORBIT_BENCH_CPU_THREADS="16,32")
+
+
 def _run(args, timeout=900):
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True,
-                         timeout=timeout, cwd=ROOT)
+                         timeout=timeout, cwd=ROOT, env=dict(os.environ, **FAST))
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
     assert len(lines) == 1, "bench.py must print exactly one line on stdout, got %d" % len(lines)
@@ -41,6 +46,9 @@ def test_bench_line_contract():
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and cb["sample"]
     assert cb["max_abs_dlogit_vs_gpu"] <= 1e-3 and cb["argmax_identical"] is True
     assert d["median_task_ms"] > 0 and d["value_overlap_off"] > 0
+    # `value` is measured on tasks whose label tensors are new to the head; the memoised form is a separate field
+    assert "new to the head" in d["labels"] and d["value_memoised_labels"] > 0
+    assert "median of 1 tasks" in cb["sample"] and cb["cpu_model"]
     # the C-ABI's RCCL communicator ran (one rank here): all-reduce of ones == world
     assert d["rccl_ranks"] == 1 and d["ranks_share_gpus"] is False
     v = d["variants_of_the_metric"]
@@ -51,7 +59,7 @@ def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus N` without a launcher re-executes itself under torch.distributed.run (it used to
     run one rank and print n_gpus 1). Two ranks share this box's GPU through the gloo self-test backend; with the RCCL
     backend (one rank per GPU) the same command must refuse instead of printing a line with the wrong n_gpus."""
-    env = dict(os.environ, ORBIT_BENCH_BACKEND="gloo")
+    env = dict(os.environ, ORBIT_BENCH_BACKEND="gloo", **FAST)
     env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
                           "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
@@ -61,6 +69,7 @@ def test_bench_launches_its_own_ranks():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["tasks_per_step"] == 2 and d["ranks_share_gpus"] is True
     assert d["rccl_ranks"] is None  # RCCL refuses two ranks on one device: only checked one rank per GPU
+    assert [r["rank"] for r in d["per_rank"]] == [0, 1] and all(r["ms_per_step"] > 0 for r in d["per_rank"])
     import torch
     if torch.cuda.device_count() < 2:
         env.pop("ORBIT_BENCH_BACKEND")

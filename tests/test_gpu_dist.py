@@ -1,4 +1,4 @@
-"""The product's multi-rank forms executed by 2 / 4 / 8 processes on hardware (all ranks on GPU 0, gloo backend - the GPU
+"""The product's multi-rank forms executed by 2 and 8 processes on hardware (all ranks on GPU 0, gloo backend - the GPU
 box has one device and RCCL refuses two ranks on it; the exchange steps are the same torch.distributed calls the nccl
 backend serves on a multi-GPU node; the peer-to-peer kernels of csrc/comm.hip run at the node's real world size, 8):
   * dist.personalise_support_sharded + dist.predict_query_sharded: each rank extracts features for ITS slice of the
@@ -66,11 +66,10 @@ def _single_process_reference(device, fe, adapt, way, per_class, nq, values):
     return model.classifier.weight.detach().cpu(), want
 
 
-@pytest.mark.parametrize("world,adapt,case", [(2, False, "resnet4"), (2, True, "resnet4"), (4, True, "resnet4"),
-                                              (4, False, "effnet10"), (8, False, "effnet10"), (8, True, "resnet4")])
+@pytest.mark.parametrize("world,adapt,case", [(2, False, "resnet4"), (2, True, "resnet4"), (8, False, "effnet10")])
 def test_support_and_query_sharded_on_ranks(device, world, adapt, case, tmp_path):
-    """dist.personalise_support_sharded / predict_query_sharded on 2, 4 and 8 ranks (BASELINE config 5 splits 8 ways):
-    ragged support slices (20 clips over 8 ranks; 40 over 8), the 10-way D = 1280 prototype payload, prototypes
+    """dist.personalise_support_sharded / predict_query_sharded on 2 and 8 ranks (BASELINE config 5 splits 8 ways):
+    ragged support slices (40 clips over 8 ranks), the 10-way D = 1280 prototype payload, prototypes
     bit-identical on all ranks and equal (fp32 rounding of a different summation order) to the single-process run."""
     out = str(tmp_path / "sh")
     _launch(world, ["sharded", out, "1" if adapt else "0", case])
@@ -163,9 +162,11 @@ def test_task_parallel_training_step_equals_single_process(device, recipe, tmp_p
         assert torch.equal(b[k], init_sd[k].to(b[k].dtype)), k
 
 
-# ---- BASELINE config 5's split: 10-way tasks, tasks_per_batch 16, on 2 / 4 / 8 ranks, against one rank AND the oracle --------
+# ---- BASELINE config 5's split: 10-way tasks, one optimizer step per window of tasks_per_batch tasks dealt over the ranks, on 2 / 8
+# ranks, against one rank AND the oracle. (Round 4 ran 20 tasks / windows of 16 on 2, 4 and 8 ranks: 117 s of CPU-oracle replay +
+# 95 s of launches; 10 tasks / windows of 8 keep one full window - one task per rank at world 8 - and a ragged one.) --------
 C5 = dict(way=10, frames_per_shot=2, num_query_videos=2, frames_per_video=5, frame_size=64, batch_size=8, num_lite=4,
-          num_train_tasks=20, tasks_per_batch=16, lr=0.002, weight_decay=0.1)
+          num_train_tasks=10, tasks_per_batch=8, lr=0.002, weight_decay=0.1)
 C5_ARGS = ["--mode", "train", "--with_lite", "--num_lite_samples", str(C5["num_lite"]), "--frame_size", str(C5["frame_size"]),
            "--way", str(C5["way"]), "--shots", "1", "--frames_per_shot", str(C5["frames_per_shot"]), "--num_query_videos",
            str(C5["num_query_videos"]), "--frames_per_video", str(C5["frames_per_video"]), "--batch_size", str(C5["batch_size"]),
@@ -176,7 +177,7 @@ C5_RECIPE = ["--feature_extractor", "efficientnet_b0", "--learn_extractor"]
 
 
 def _oracle_config5_training():
-    """The same 20 tasks / 2 optimizer steps through oracle/training.py (PyTorch-CPU autograd restatement of
+    """The same 10 tasks / 2 optimizer steps through oracle/training.py (PyTorch-CPU autograd restatement of
     single-step-learner.py:212-243, pinned by goldens G6 / G8 / G9): same initial weights, tasks, LITE permutations
     (np.random seeded per task as learner.py does), loss scaling, SGD. Returns the trained extractor's state_dict."""
     import numpy as np
@@ -214,16 +215,20 @@ def _oracle_test_logits(fe_state):
 
 @pytest.fixture(scope="module")
 def config5_single(tmp_path_factory):
+    from concurrent.futures import ThreadPoolExecutor
     out = str(tmp_path_factory.mktemp("c5") / "w1")
-    _launch(1, ["train", out] + C5_ARGS)
-    return torch.load(out + ".model.pt"), _oracle_config5_training()
+    with ThreadPoolExecutor(1) as ex:  # the one-rank GPU run (a subprocess) beside the CPU oracle's replay
+        run = ex.submit(_launch, 1, ["train", out] + C5_ARGS)
+        oracle = _oracle_config5_training()
+        run.result()
+    return torch.load(out + ".model.pt"), oracle
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 8])
 def test_task_parallel_training_config5_split(device, world, config5_single, tmp_path):
     """BASELINE config 5's partitioning (reference single-step-learner.py:162-166,231: an optimizer step every tasks_per_batch
-    = 16 tasks, 10-way tasks) on 2, 4 and 8 ranks: 20 tasks = one full window (16: two tasks per rank at world 8) and a ragged
-    one (4 tasks: at world 8 ranks 4-7 run NOTHING in it, 20 % 8 != 0) - gradients all-reduced per step, BatchNorm running
+    = 8 tasks, 10-way tasks) on 2 and 8 ranks: 10 tasks = one full window (8: one task per rank at world 8) and a ragged
+    one (2 tasks: at world 8 ranks 2-7 run NOTHING in it, 10 % 8 != 0) - gradients all-reduced per step, BatchNorm running
     statistics combined over ranks that ran 0, 1 or 2 forwards. efficientnet_b0 at a learning rate at which the trained
     model stays finite (round 3's lr 0.05 sent its test-mode features to inf), so the comparison reaches the MODEL: parameters
     N ranks vs one, test-mode logits N ranks vs one, and both against the same training replayed through the CPU oracle."""
@@ -280,7 +285,7 @@ def test_task_parallel_training_config5_split(device, world, config5_single, tmp
     assert (la.argmax(1) == lo.argmax(1)).float().mean().item() >= 0.95
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 8])
 def test_one_shot_p2p_allreduce(device, world, tmp_path):
     """csrc/comm.hip orbit_p2p_*: `world` processes map each other's inbox through HIP IPC (all on GPU 0 here; over xGMI on
     a multi-GPU node), push + flag + rank-order sum. The results are BIT-IDENTICAL on every rank and equal, bit for bit, to
@@ -304,7 +309,7 @@ def test_one_shot_p2p_allreduce(device, world, tmp_path):
           % (world, " / ".join("%.1f" % r["us_per_allreduce"] for r in rs)))
 
 
-@pytest.mark.parametrize("world", [2, 4, 8])
+@pytest.mark.parametrize("world", [2, 8])
 def test_sharded_p2p_allreduce_of_gradient_buckets(device, world, tmp_path):
     """csrc/comm.hip orbit_p2p_allreduce_sum_sharded (direct reduce-scatter + all-gather): vectors of the
     gradient bucket's size (21 MB) and ragged lengths (n % world != 0, last shard / last slice short, shards shorter than

@@ -255,8 +255,7 @@ def _seeded_check(run, tap, seeds=5, exact=2e-5):
     return report
 
 
-@pytest.mark.parametrize("bn_train", [True, False])
-@pytest.mark.parametrize("size,B", [(64, 6), (33, 4)])
+@pytest.mark.parametrize("size,B,bn_train", [(64, 6, True), (33, 4, True), (33, 4, False)])
 def test_resnet18_backward_matches_autograd(device, bn_train, size, B):
     ref, nat = _oracle_and_native("resnet18", device)
     ref = ref.double()
@@ -391,8 +390,7 @@ def test_backward_is_deterministic(device):
     assert torch.equal(grads[0], grads[1])
 
 
-@pytest.mark.parametrize("bn_train", [True, False])
-@pytest.mark.parametrize("size,B", [(64, 4), (96, 3)])
+@pytest.mark.parametrize("size,B,bn_train", [(64, 4, True), (96, 3, False)])
 def test_efficientnet_backward_matches_autograd(device, bn_train, size, B):
     """Depthwise / squeeze-excite / SiLU backward through the whole tf_efficientnet_b0 plan. No ReLU here, so there
     are no mask flips: every seed has to be close to fp32-exact (the fast exp/rcp of SiLU and sigmoid costs a little)."""
