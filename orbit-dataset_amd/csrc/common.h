@@ -213,7 +213,8 @@ struct SeBnFuse {
 int launch_se_gate_backward(const float* dxg, const float* x, const float* pooled, const float* gate, const float* w1,
                             const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1,
                             float* dw2, float* db2, float* scratch, int B, int HW, int C, int R, hipStream_t s,
-                            const SeBnFuse* bn = nullptr);
+                            const SeBnFuse* bn = nullptr, const float* w2t = nullptr);
+// (w2t, optional: W2 transposed to [R][C] - the plan's packed copy; the MLP backward then reads W2 contiguously)
 // BatchNorm backward whose reduction pass already ran (g = dout * act'(.) in `g`, [nblk][2][C] sums of g and g * xhat in
 // `partial`): finalize + apply only. coef: 3*C floats
 int launch_bn_backward_reduced(const float* g, const float* y, const float* mean, const float* invstd, const float* gamma,
@@ -225,7 +226,9 @@ int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, 
                         int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, float* flip_scratch = nullptr);
 size_t dwconv_wgrad_scratch_floats(int B, int Ho, int Wo, int C, int K);
 int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int C, int K,
-                        int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s);
+                        int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, const float* in_scale = nullptr,
+                        const float* in_shift = nullptr, int in_act = 0);
+// (in_scale / in_shift: x is the RAW output of the producing conv; act(x * in_scale[c] + in_shift[c]) is applied on load)
 size_t conv_wgrad_scratch_floats(int B, int Cin, int Cout, int KH, int KW, int Ho, int Wo);
 int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
                       int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float* scratch, hipStream_t s,

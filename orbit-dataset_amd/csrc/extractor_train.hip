@@ -55,6 +55,25 @@ static bool plan_trainable(const orbit_extractor* fe) {
 
 static bool has_bn(const Op& o) { return o.kind == OP_CONV || o.kind == OP_DWCONV; }
 
+// A batch-statistics conv whose activated output is read by ONE consumer, the depthwise conv that follows (EfficientNet's
+// expansion convs and stem): that consumer applies the conv's BatchNorm + SiLU as it loads the RAW output (DwInXf in
+// csrc/ops.hip; the depthwise filter gradient does the same, csrc/train_mbconv.hip), so the activated 6x-expanded tensor is
+// never written - on forwards that run no backward (round 3) and, since round 5, on taped ones: its only other reader would
+// be a ReLU mask, so the activation must not be ReLU there. Forward and backward evaluate this on the same plan; the option
+// is read by both (do not flip train_dw_xf between a forward and its backward).
+static bool conv_feeds_dw_raw(const orbit_extractor* fe, size_t i, int bn_train, bool no_backward) {
+    const Op& o = fe->ops[i];
+    if (o.kind != OP_CONV || !bn_train || !get_option("train_dw_xf") || o.pool2 || o.res >= 0 || o.Cout % 4 != 0) return false;
+    if (i + 1 >= fe->ops.size() || fe->ops[i + 1].kind != OP_DWCONV || fe->ops[i + 1].in != o.out) return false;
+    if (!no_backward && o.act != ORBIT_ACT_SILU && o.act != ORBIT_ACT_NONE) return false;
+    for (size_t j = i + 2; j < fe->ops.size(); ++j) {  // no later reader of the buffer before it is written again
+        const Op& q = fe->ops[j];
+        if (q.in == o.out || q.res == o.out) return false;
+        if (q.out == o.out) break;
+    }
+    return true;
+}
+
 static size_t max_bn_partial_floats(const orbit_extractor* fe, int B) {
     size_t m = 4;
     for (const Op& o : fe->ops)
@@ -385,12 +404,9 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
                                          fl(L.partial), s);
                 if (rc != ORBIT_OK) return rc;
             }
-            // No backward will read this tape (a cache pass under torch.no_grad(), ORBIT_TRAIN_NO_BACKWARD) and the only
-            // consumer is the depthwise conv that follows: it applies this BatchNorm + activation as it loads the raw output
-            // (DwInXf, csrc/ops.hip), so the activated 6x-expanded tensor is neither written nor read back
-            dw_in_raw = no_backward && bn_train && get_option("train_dw_xf") && !o.pool2 && o.res < 0 &&
-                        i + 1 < fe->ops.size() && fe->ops[i + 1].kind == OP_DWCONV && fe->ops[i + 1].in == o.out &&
-                        o.Cout % 4 == 0;
+            // the only consumer is the depthwise conv that follows: it applies this BatchNorm + activation as it loads the raw
+            // output (conv_feeds_dw_raw above), so the activated 6x-expanded tensor is neither written nor read back
+            dw_in_raw = conv_feeds_dw_raw(fe, i, bn_train, no_backward);
             if (dw_in_raw) {
                 cur[o.out] = d.y;
                 dw_in_bn = o.bn, dw_in_act = o.act;
@@ -631,8 +647,16 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
             if (rc != ORBIT_OK) return rc;
             release(g), grad_slot[i] = -1;
             if (wg) {
-                rc = launch_dwconv_wgrad(out_tensor(src), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
-                                         wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+                if (src >= 0 && conv_feeds_dw_raw(fe, (size_t)src, bn_train, false)) {
+                    // the forward never wrote this layer's input: rebuild it from the producing conv's raw output on load
+                    const BNDesc& sbn = fe->bns[fe->ops[src].bn];
+                    rc = launch_dwconv_wgrad(tf(L.y[src]), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
+                                             wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s,
+                                             scale + sbn.fold_off, shift + sbn.fold_off, fe->ops[src].act);
+                } else {
+                    rc = launch_dwconv_wgrad(out_tensor(src), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
+                                             wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+                }
                 if (rc != ORBIT_OK) return rc;
             }
             if (need_dx) {
@@ -735,7 +759,7 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                                              pg ? pg + fe->params[so.se_b1].off : nullptr,
                                              pg ? pg + fe->params[so.se_w2].off : nullptr,
                                              pg ? pg + fe->params[so.se_b2].off : nullptr, se_scratch, B, o.H * o.W, o.Cin,
-                                             so.R, s, fuse_ptr);
+                                             so.R, s, fuse_ptr, fe->d_packed + so.packed_off);
                 release(kt);
             } else if (need_dx) {
                 const float* acc = nullptr;

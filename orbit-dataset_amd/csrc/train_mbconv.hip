@@ -159,8 +159,12 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_bn_kernel(const float* __r
 // SE MLP backward for one frame per block: pooled p[C] -> v = W1 p + b1 -> h = silu(v) -> u = W2 h + b2 -> g = sigmoid(u)
 // given dgate: du = dgate g (1-g); dh = W2^T du; dv = dh silu'(v); dp = W1^T dv.  W1 [R][C], W2 [C][R].
 // Writes du[b][C], dv[b][R], h[b][R] (for the parameter gradients) and dp[b][C].
+// w2t (optional): W2 transposed to [R][C] - what the plan packs for the inference gate kernel. With it every pass over W2 is
+// contiguous along c (the [C][R] layout is read with a stride of R floats by both the u and the dh pass: 12 of the 16 lanes
+// of a request wasted at R = 48, and the kernel is a chain of L2 round trips through one CU).
 __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ pooled, const float* __restrict__ w1,
                                                      const float* __restrict__ b1, const float* __restrict__ w2,
+                                                     const float* __restrict__ w2t,
                                                      const float* __restrict__ b2, const float* __restrict__ dgate,
                                                      float* __restrict__ du_out, float* __restrict__ dv_out,
                                                      float* __restrict__ h_out, float* __restrict__ dp_out, int C,
@@ -191,7 +195,19 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ p
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float u = b2[c];
-        for (int r = 0; r < R; ++r) u = fmaf(w2[(size_t)c * R + r], h[r], u);
+        if (w2t != nullptr) {
+            int r = 0;
+            for (; r + 8 <= R; r += 8) {  // eight independent coalesced loads per step
+                float wv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) wv[k] = w2t[(size_t)(r + k) * C + c];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) u = fmaf(wv[k], h[r + k], u);
+            }
+            for (; r < R; ++r) u = fmaf(w2t[(size_t)r * C + c], h[r], u);
+        } else {
+            for (int r = 0; r < R; ++r) u = fmaf(w2[(size_t)c * R + r], h[r], u);
+        }
         const float g = __builtin_amdgcn_rcpf(1.0f + __expf(-u));
         const float d = dgate[(size_t)b * C + c] * g * (1.0f - g);
         du[c] = d;
@@ -201,7 +217,10 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ p
     for (int r = tid >> 4; r < R; r += 16) {
         const int l = tid & 15;
         float acc = 0.f;
-        for (int c = l; c < C; c += 16) acc = fmaf(du[c], w2[(size_t)c * R + r], acc);
+        if (w2t != nullptr)
+            for (int c = l; c < C; c += 16) acc = fmaf(du[c], w2t[(size_t)r * C + c], acc);
+        else
+            for (int c = l; c < C; c += 16) acc = fmaf(du[c], w2[(size_t)c * R + r], acc);
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
         if (l == 0) {
@@ -222,38 +241,45 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ p
 }
 
 // dW2[c][r] = sum_b du[b][c] h[b][r]; db2[c] = sum_b du[b][c]; dW1[r][c] = sum_b dv[b][r] p[b][c]; db1[r] = sum_b dv[b][r]
+// 16 outputs per block, 16 lanes per output: lane l sums frames l, l + 16, ... (13 frames at B = 200, all loads of a lane in
+// flight at once), the lanes are combined by a fixed shuffle tree - deterministic. (One thread per output walking all B
+// frames was a chain of B / 20 dependent L2 round trips: 43-49 us per launch whatever the layer size, 16 launches per step.)
 __global__ __launch_bounds__(256) void se_param_grad_kernel(const float* __restrict__ du, const float* __restrict__ dv,
                                                             const float* __restrict__ h,
                                                             const float* __restrict__ pooled, int B, int C, int R,
                                                             float* __restrict__ dw1, float* __restrict__ db1,
                                                             float* __restrict__ dw2, float* __restrict__ db2) {
     const int total = 2 * C * R + C + R;
-    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
-        float s = 0.f;
-        if (i < C * R) {  // dW2[c][r]
-            const int c = i / R, r = i - c * R;
-            // 20 frames' loads in flight per pass (rolled, the 200-long loop was one L2 round trip per frame; 8 per pass still
-            // left 25 dependent round trips: 74 us per launch)
-#pragma unroll 20
-            for (int b = 0; b < B; ++b) s = fmaf(du[(size_t)b * C + c], h[(size_t)b * R + r], s);
-            dw2[i] = s;
-        } else if (i < 2 * C * R) {  // dW1[r][c]
-            const int j = i - C * R, r = j / C, c = j - r * C;
-#pragma unroll 20
-            for (int b = 0; b < B; ++b) s = fmaf(dv[(size_t)b * R + r], pooled[(size_t)b * C + c], s);
-            dw1[j] = s;
-        } else if (i < 2 * C * R + C) {
-            const int c = i - 2 * C * R;
+    const int l = threadIdx.x & 15;
+    const int i = blockIdx.x * 16 + (threadIdx.x >> 4);
+    const float* pa = nullptr;  // s = sum_b pa[b * sa] * pb[b * sb]   (pb == nullptr: sum_b pa[b * sa])
+    const float* pb = nullptr;
+    int sa = 0, sb = 0;
+    float* out = nullptr;
+    if (i < C * R) {  // dW2[c][r]
+        const int c = i / R, r = i - c * R;
+        pa = du + c, sa = C, pb = h + r, sb = R, out = dw2 + i;
+    } else if (i < 2 * C * R) {  // dW1[r][c]
+        const int j = i - C * R, r = j / C, c = j - r * C;
+        pa = dv + r, sa = R, pb = pooled + c, sb = C, out = dw1 + j;
+    } else if (i < 2 * C * R + C) {
+        pa = du + (i - 2 * C * R), sa = C, out = db2 + (i - 2 * C * R);
+    } else if (i < total) {
+        pa = dv + (i - 2 * C * R - C), sa = R, out = db1 + (i - 2 * C * R - C);
+    }
+    float s = 0.f;
+    if (pa != nullptr) {
+        if (pb != nullptr) {
 #pragma unroll 8
-            for (int b = 0; b < B; ++b) s += du[(size_t)b * C + c];
-            db2[c] = s;
+            for (int b = l; b < B; b += 16) s = fmaf(pa[(size_t)b * sa], pb[(size_t)b * sb], s);
         } else {
-            const int r = i - 2 * C * R - C;
 #pragma unroll 8
-            for (int b = 0; b < B; ++b) s += dv[(size_t)b * R + r];
-            db1[r] = s;
+            for (int b = l; b < B; b += 16) s += pa[(size_t)b * sa];
         }
     }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1) s += __shfl_xor(s, off, 16);
+    if (l == 0 && out != nullptr) *out = s;
 }
 
 // ---- depthwise convolution ------------------------------------------------------------------------------------------
@@ -364,12 +390,19 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_s2_kernel(const float* __res
 // kernel (one output pixel per step, every tap a load behind its own bounds branch, 64-bit div / mod per pixel) was bound by
 // the vector L1 and by address arithmetic (287 us per launch on the 5x5 layers of efficientnet_b0 @224). All index math is
 // 32-bit; out-of-image taps read a clamped address and are zeroed by a select. Fixed summation order (deterministic).
-template <int K, int S, int NB>
+// XF: `x` is the RAW output of the convolution before the depthwise layer and the layer's input is act(x * in_scale[c] +
+// in_shift[c]) - that convolution's BatchNorm + activation, applied as the kernel loads (the arithmetic of dw_xf in
+// csrc/ops.hip, which the forward depthwise kernel used on the same tensor). The taped forward of a batch-statistics step then
+// never writes the activated 6x-expanded tensor: it existed only to be read here and by the forward depthwise kernel.
+template <int K, int S, int NB, bool XF = false>
 __global__ __launch_bounds__(256) void dwconv_wgrad_partial_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ dy,
                                                                    float* __restrict__ partial, int B, int H, int W,
                                                                    int C4, int pad_t, int pad_l, int Ho, int Wo,
-                                                                   int rows_per_block, int G, int R) {
+                                                                   int rows_per_block, int G, int R,
+                                                                   const float* __restrict__ in_scale = nullptr,
+                                                                   const float* __restrict__ in_shift = nullptr,
+                                                                   int in_act = 0) {
     constexpr int NW = (NB - 1) * S + K;
     __shared__ f32x4 red[256];
     const int tid = threadIdx.x;
@@ -385,6 +418,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_partial_kernel(const float* 
     if (active) {
         const f32x4* x4 = reinterpret_cast<const f32x4*>(x) + q;
         const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy) + q;
+        f32x4 isc = {1.f, 1.f, 1.f, 1.f}, ish = zero;
+        if (XF) isc = reinterpret_cast<const f32x4*>(in_scale)[q], ish = reinterpret_cast<const f32x4*>(in_shift)[q];
         for (int row = row0 + rl; row < row1; row += R) {
             const int b = row / Ho, ho = row - b * Ho;
             const f32x4* dyr = dy4 + (size_t)row * Wo * C4;
@@ -409,8 +444,18 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_partial_kernel(const float* 
                     for (int u = 0; u < NW; ++u) {
                         const int wi = wi0 + u;
                         const bool ok = (unsigned)wi < (unsigned)W;
-                        const f32x4 v = xr[(size_t)(ok ? wi : 0) * C4];
-                        win[u] = ok ? v : zero;
+                        f32x4 v = xr[(size_t)(ok ? wi : 0) * C4];
+                        if (XF) {
+                            v = v * isc + ish;
+                            if (in_act == ORBIT_ACT_SILU) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) v[k] = v[k] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[k]));
+                            } else if (in_act == ORBIT_ACT_RELU) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
+                            }
+                        }
+                        win[u] = ok ? v : zero;  // (the zero padding belongs to the ACTIVATED tensor)
                     }
 #pragma unroll
                     for (int kw = 0; kw < K; ++kw)
@@ -489,7 +534,7 @@ size_t se_bwd_scratch_floats(int B, int C, int R) { return (size_t)B * (3 * (siz
 int launch_se_gate_backward(const float* dxg, const float* x, const float* pooled, const float* gate, const float* w1,
                             const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1,
                             float* dw2, float* db2, float* scratch, int B, int HW, int C, int R, hipStream_t s,
-                            const SeBnFuse* bn) {
+                            const SeBnFuse* bn, const float* w2t) {
     ORBIT_REQUIRE(C % 4 == 0 && R > 0 && R <= 256, "se_gate_backward: bad sizes (C=%d R=%d)", C, R);
     float* du = scratch;
     float* dv = du + (size_t)B * C;
@@ -501,10 +546,10 @@ int launch_se_gate_backward(const float* dxg, const float* x, const float* poole
     gate_bwd_reduce_kernel<<<dim3(B, yg), 256, 0, s>>>(dxg, x, dgate, HW, C / 4, G, Rl);
     ORBIT_LAUNCH_CHECK();
     const size_t lds = (size_t)(2 * C + 3 * R) * sizeof(float);
-    se_bwd_kernel<<<B, 256, lds, s>>>(pooled, w1, b1, w2, b2, dgate, du, dv, h, dp, C, R);
+    se_bwd_kernel<<<B, 256, lds, s>>>(pooled, w1, b1, w2, w2t, b2, dgate, du, dv, h, dp, C, R);
     ORBIT_LAUNCH_CHECK();
     if (dw1) {
-        se_param_grad_kernel<<<cdiv(2 * C * R + C + R, 256), 256, 0, s>>>(du, dv, h, pooled, B, C, R, dw1, db1, dw2, db2);
+        se_param_grad_kernel<<<cdiv(2 * C * R + C + R, 16), 256, 0, s>>>(du, dv, h, pooled, B, C, R, dw1, db1, dw2, db2);
         ORBIT_LAUNCH_CHECK();
     }
     if (bn != nullptr) {
@@ -583,8 +628,10 @@ size_t dwconv_wgrad_scratch_floats(int B, int Ho, int Wo, int C, int K) {
 }
 
 int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int C, int K,
-                        int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s) {
+                        int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, const float* in_scale,
+                        const float* in_shift, int in_act) {
     ORBIT_REQUIRE(C % 4 == 0 && (K == 3 || K == 5), "dwconv_wgrad: C %% 4 != 0 or K not in {3,5}");
+    ORBIT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dwconv_wgrad: the input transform needs scale and shift");
     int G, R, yg;
     dw_layout(C, G, R, yg);
     ORBIT_REQUIRE(stride == 1 || stride == 2, "dwconv_wgrad: stride %d", stride);
@@ -598,8 +645,14 @@ int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scrat
     chunks = cdiv(total_rows, rows);
     dim3 grid(chunks, yg);
 #define ORBIT_DWW(KK, SS, NBB)                                                                                          \
-    dwconv_wgrad_partial_kernel<KK, SS, NBB><<<grid, 256, 0, s>>>(x, dy, scratch, B, H, W, C / 4, pad_t, pad_l, Ho, Wo, \
-                                                                  rows, G, R)
+    do {                                                                                                                \
+        if (in_scale)                                                                                                   \
+            dwconv_wgrad_partial_kernel<KK, SS, NBB, true><<<grid, 256, 0, s>>>(x, dy, scratch, B, H, W, C / 4, pad_t, pad_l, \
+                                                                                Ho, Wo, rows, G, R, in_scale, in_shift, in_act); \
+        else                                                                                                            \
+            dwconv_wgrad_partial_kernel<KK, SS, NBB><<<grid, 256, 0, s>>>(x, dy, scratch, B, H, W, C / 4, pad_t, pad_l, Ho, \
+                                                                          Wo, rows, G, R);                              \
+    } while (0)
     if (K == 3 && stride == 1) ORBIT_DWW(3, 1, 4);
     else if (K == 3) ORBIT_DWW(3, 2, 4);
     else if (stride == 1) ORBIT_DWW(5, 1, 4);
@@ -645,11 +698,14 @@ int orbit_op_se_gate_backward(const float* dxg, const float* x, const float* poo
     hipStream_t s = (hipStream_t)stream;
     float* tmp = nullptr;
     const size_t nscr = se_bwd_scratch_floats(B, C, R);
-    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), (nscr + (size_t)B * C) * sizeof(float), s));
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), (nscr + (size_t)B * C + (size_t)C * R) * sizeof(float), s));
     float* gate = tmp + nscr;
+    float* w2t = gate + (size_t)B * C;  // [R][C], as the network plans pack it
     int rc = launch_se_gate(pooled, w1, b1, w2, b2, gate, B, C, R, s);
+    if (rc == ORBIT_OK) rc = launch_transpose(w2, w2t, C, R, s);
     if (rc == ORBIT_OK)
-        rc = launch_se_gate_backward(dxg, x, pooled, gate, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, tmp, B, HW, C, R, s);
+        rc = launch_se_gate_backward(dxg, x, pooled, gate, w1, b1, w2, b2, dx, dw1, db1, dw2, db2, tmp, B, HW, C, R, s, nullptr,
+                                     w2t);
     (void)hipFreeAsync(tmp, s);
     return rc;
 }

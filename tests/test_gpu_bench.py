@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 # the contract is about the LINE: the long legs of a real run are cut short (no settling chunks, one CPU-oracle task on two
 # thread settings instead of the median of three on six)
-FAST = dict(ORBIT_BENCH_SETTLE="0", ORBIT_BENCH_CPU_TASKS="1", ORBIT_BENCH_CPU_THREADS="16,32")
+FAST = dict(ORBIT_BENCH_SETTLE="0", ORBIT_BENCH_CPU_TASKS="1", ORBIT_BENCH_CPU_THREADS="8,16")
 
 
 def _run(args, timeout=900):
@@ -90,7 +90,7 @@ def test_bench_config5_command_contract():
     64 tasks per optimizer step sharded over 8 ranks, one all-reduce of the flat gradient bucket per step (reference
     single-step-learner.py:162-166,231). Eight ranks share this box's one GPU through the gloo self-test backend; the line
     must say n_gpus 8 / tasks_per_step 64 and that the ranks shared a device (no scaling claim is made from it)."""
-    env = dict(os.environ, ORBIT_BENCH_BACKEND="gloo", ORBIT_BENCH_SETTLE="0")
+    env = dict(os.environ, ORBIT_BENCH_BACKEND="gloo", ORBIT_BENCH_SETTLE="0", OMP_NUM_THREADS="8", MKL_NUM_THREADS="8")
     env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--mode", "lite_train", "--way", "10",
                           "--tasks-per-rank", "8", "--steps", "1", "--warmup", "1", "--no-cpu-baseline"],
