@@ -565,7 +565,7 @@ def main():
     # starts): the per-task label-set resolution - what the reference's configure pays as torch.unique + .item() per task,
     # model/classifier_heads.py:96-100,246-248 - is inside the timed region of `value`. (Round 4 resolved the label sets of
     # the resident tasks before the clock and memoised them; that variant is now reported as `value_memoised_labels`.)
-    fresh_labels = True
+    fresh_labels = os.environ.get("ORBIT_BENCH_FRESH_LABELS", "1") != "0"  # (0: A/B runs of the memoised form only)
     lib = _lib.load()
 
     def stream_of_tasks(n):
@@ -640,7 +640,7 @@ def main():
         loop(2)
         m_elapsed, _, _ = loop(args.steps)
         value_memoised = NUM_QUERY * args.steps * per_step / m_elapsed
-        fresh_labels = True
+        fresh_labels = os.environ.get("ORBIT_BENCH_FRESH_LABELS", "1") != "0"
     if train and getattr(run_step.bucket, "p2p", None) is not None:
         run_step.bucket.p2p.raise_on_error()  # (the loop ended on a barrier + synchronize: every exchange has completed)
 

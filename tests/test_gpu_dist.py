@@ -163,11 +163,9 @@ def test_task_parallel_training_step_equals_single_process(device, recipe, tmp_p
         assert torch.equal(b[k], init_sd[k].to(b[k].dtype)), k
 
 
-# ---- BASELINE config 5's split: 10-way tasks, one optimizer step per window of tasks_per_batch tasks dealt over the ranks, on 2 / 8
-# ranks, against one rank AND the oracle. (Round 4 ran 20 tasks / windows of 16 on 2, 4 and 8 ranks: 117 s of CPU-oracle replay +
-# 95 s of launches; 10 tasks / windows of 8 keep one full window - one task per rank at world 8 - and a ragged one.) --------
+# ---- BASELINE config 5's split: 10-way tasks, tasks_per_batch 16, on 2 / 8 ranks, against one rank AND the oracle --------
 C5 = dict(way=10, frames_per_shot=2, num_query_videos=2, frames_per_video=5, frame_size=64, batch_size=8, num_lite=4,
-          num_train_tasks=10, tasks_per_batch=8, lr=0.002, weight_decay=0.1)
+          num_train_tasks=20, tasks_per_batch=16, lr=0.002, weight_decay=0.1)
 C5_ARGS = ["--mode", "train", "--with_lite", "--num_lite_samples", str(C5["num_lite"]), "--frame_size", str(C5["frame_size"]),
            "--way", str(C5["way"]), "--shots", "1", "--frames_per_shot", str(C5["frames_per_shot"]), "--num_query_videos",
            str(C5["num_query_videos"]), "--frames_per_video", str(C5["frames_per_video"]), "--batch_size", str(C5["batch_size"]),
@@ -178,7 +176,7 @@ C5_RECIPE = ["--feature_extractor", "efficientnet_b0", "--learn_extractor"]
 
 
 def _oracle_config5_training():
-    """The same 10 tasks / 2 optimizer steps through oracle/training.py (PyTorch-CPU autograd restatement of
+    """The same 20 tasks / 2 optimizer steps through oracle/training.py (PyTorch-CPU autograd restatement of
     single-step-learner.py:212-243, pinned by goldens G6 / G8 / G9): same initial weights, tasks, LITE permutations
     (np.random seeded per task as learner.py does), loss scaling, SGD. Returns the trained extractor's state_dict."""
     import numpy as np
@@ -228,8 +226,8 @@ def config5_single(tmp_path_factory):
 @pytest.mark.parametrize("world", [2, 8])
 def test_task_parallel_training_config5_split(device, world, config5_single, tmp_path):
     """BASELINE config 5's partitioning (reference single-step-learner.py:162-166,231: an optimizer step every tasks_per_batch
-    = 8 tasks, 10-way tasks) on 2 and 8 ranks: 10 tasks = one full window (8: one task per rank at world 8) and a ragged
-    one (2 tasks: at world 8 ranks 2-7 run NOTHING in it, 10 % 8 != 0) - gradients all-reduced per step, BatchNorm running
+    = 16 tasks, 10-way tasks) on 2 and 8 ranks: 20 tasks = one full window (16: two tasks per rank at world 8) and a ragged
+    one (4 tasks: at world 8 ranks 4-7 run NOTHING in it, 20 % 8 != 0) - gradients all-reduced per step, BatchNorm running
     statistics combined over ranks that ran 0, 1 or 2 forwards. efficientnet_b0 at a learning rate at which the trained
     model stays finite (round 3's lr 0.05 sent its test-mode features to inf), so the comparison reaches the MODEL: parameters
     N ranks vs one, test-mode logits N ranks vs one, and both against the same training replayed through the CPU oracle."""
@@ -252,7 +250,7 @@ def test_task_parallel_training_config5_split(device, world, config5_single, tmp
             o = oracle_fe[k[len("feature_extractor."):]].float()
             win_o = (a - init_sd[k].float()).abs().max().item()
             stat_vs_oracle = max(stat_vs_oracle, (a - o).abs().max().item() / max(win_o, 1e-6))
-            assert (a - o).abs().max().item() <= 1e-5 + 2e-2 * win_o, "%s: product vs oracle training" % k
+            assert (a - o).abs().max().item() <= 1e-5 + 5e-2 * win_o, "%s: product vs oracle training" % k
             # Combined as sequential updates would have been (dist.RunningStatSync), up to the ORDER in which the recency
             # weights fall on the tasks: one process weights the window's last task most, N ranks weight their last tasks
             # alike. With ~4 train-mode forwards per task and a 4-task last window that is a visible share of how far the
@@ -279,14 +277,11 @@ def test_task_parallel_training_config5_split(device, world, config5_single, tmp
     same_stats = {k: (single[k] if k.endswith(("running_mean", "running_var", "num_batches_tracked")) else v)
                   for k, v in multi.items()}
     lb = _test_logits(device, C5_RECIPE, same_stats)
-    # the oracle's parameters under the product's statistics (each statistic was compared with the oracle's directly above)
-    lo = _oracle_test_logits({k: (single["feature_extractor." + k].cpu() if k.endswith(("running_mean", "running_var",
-                                                                                         "num_batches_tracked")) else v)
-                              for k, v in oracle_fe.items()})
+    lo = _oracle_test_logits(oracle_fe)
     scale = lo.abs().max().item()
     assert torch.isfinite(la).all() and torch.isfinite(lb).all() and torch.isfinite(lb_raw).all() and torch.isfinite(lo).all()
     print("world %d: test-mode logit scale %.3g; 1 vs N ranks |dlogit| %.3g with equal statistics, %.3g with each run's own; "
-          "product vs oracle %.3g (equal statistics; worst running statistic %.2e of its movement off the oracle's)"
+          "product vs oracle %.3g (worst running statistic %.2e of its movement off the oracle's)"
           % (world, scale, (la - lb).abs().max().item(), (la - lb_raw).abs().max().item(), (la - lo).abs().max().item(),
              stat_vs_oracle))
     assert (la - lb).abs().max().item() <= 0.02 * scale, ((la - lb).abs().max().item(), scale)

@@ -193,8 +193,17 @@ def test_spd_inverse(device):
         out = torch.empty_like(t)
         _lib.check(lib.orbit_spd_inverse(_lib.dptr(t), _lib.dptr(out), n, batch, _lib.stream_handle()), "orbit_spd_inverse")
         torch.cuda.synchronize()
-        want = torch.linalg.inv(A)
+        # the fp64 reference inverse on ONE thread (with the suite's 16 intra-op threads the host LAPACK of this image returned
+        # a wrong batched inverse: diagonal entries below 1 / lambda_max) and, independently of any host inverse, the residual
+        threads = torch.get_num_threads()
+        torch.set_num_threads(1)
+        try:
+            want = torch.linalg.inv(A)
+        finally:
+            torch.set_num_threads(threads)
+        assert (want @ A - torch.eye(n, dtype=torch.float64)).abs().max().item() < 1e-9
         assert (out.cpu().double() - want).abs().max().item() < 1e-5 * want.abs().max().item()
+        assert (out.cpu().double() @ A - torch.eye(n, dtype=torch.float64)).abs().max().item() < 2e-5
 
 
 def test_mahalanobis_predict_backward(device):

@@ -256,8 +256,10 @@ def test_mean_pool_and_set_mean(lib, device):
 MBROWS_CASES = [  # Cin, mid, K, stride, H, W: the five high-resolution block shapes of efficientnet_b0, at the 224x224
     # map sizes (full strips, several bands) and at odd sizes (ragged strips / bands, pad columns inside a row tile)
     (16, 96, 3, 2, 112, 112), (24, 144, 3, 1, 56, 56), (24, 144, 5, 2, 56, 56), (40, 240, 5, 1, 28, 28),
-    (40, 240, 3, 2, 28, 28), (16, 96, 3, 2, 37, 21), (16, 80, 3, 2, 116, 58), (24, 144, 3, 1, 29, 58), (24, 144, 3, 1, 15, 9),
-    (24, 100, 5, 2, 42, 31), (40, 240, 5, 1, 15, 29), (40, 240, 5, 1, 5, 8), (40, 236, 3, 2, 29, 30), (40, 240, 3, 2, 6, 3)]
+    (40, 240, 3, 2, 28, 28), (16, 96, 3, 2, 37, 21), (16, 80, 3, 2, 116, 58), (24, 144, 3, 1, 29, 58),
+    (24, 100, 5, 2, 42, 31), (40, 240, 5, 1, 15, 29), (40, 240, 5, 1, 5, 8), (40, 236, 3, 2, 29, 30)]
+# (maps whose step window is shorter than one MFMA row tile - e.g. 15x9 at 3x3/1, 6x3 at 3x3/2 - are not served by the fused
+# kernel: orbit_op_mbconv_front_partials returns 0 for them and the network plans keep the conv + depthwise pair there)
 
 
 @pytest.mark.parametrize("Cin,mid,K,stride,H,W", MBROWS_CASES)
