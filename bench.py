@@ -85,6 +85,7 @@ class LiteTrainStep:
         from orbit_dataset_amd.learner import init_optimizer
         self.model, self.world, self.batch_size = model, world, batch_size
         self.tasks_per_rank, self.calls = int(tasks_per_rank), 0
+        self.window_loss, self.step_losses = None, []  # device scalars: this rank's summed loss per optimizer step
         from argparse import Namespace
         # torch's fused multi-tensor Adam (same update formula, one kernel per group instead of ~10 foreach launches over
         # every parameter tensor: the LITE step is host-bound, measured 44.8 -> 42.2 ms on efficientnet_b0, 10.2 -> 9.5 ms on
@@ -101,9 +102,12 @@ class LiteTrainStep:
             self.bucket = odist.GradientBucket(model.parameters(), p2p=p2p)
         import numpy as np
         np.random.seed(1991)
+        self._np = np
 
     def __call__(self, model, task):
         from orbit_dataset_amd.optim import cross_entropy
+        if "task_index" in task:  # LITE's permutation is seeded per TASK, so a run does not depend on how tasks are dealt to ranks
+            self._np.random.seed((1991 + 7919 * (task["task_index"] + 1)) % (2 ** 32))
         ctx, lab, tgt, tlab = task["context_clips"], task["context_labels"], task["target_clips"], task["target_labels"]
         model._clear_caches()
         out = []
@@ -116,9 +120,12 @@ class LiteTrainStep:
                 loss = loss + 0.001 * model.film_generator.regularization_term()
                 loss.backward()
                 out.append(logits.detach())
+                self.window_loss = loss.detach() if self.window_loss is None else self.window_loss + loss.detach()
                 model._reset()
         self.calls += 1
         if self.calls % self.tasks_per_rank == 0:
+            self.step_losses.append(self.window_loss)
+            self.window_loss = None
             if self.bucket is not None:
                 self.bucket.sync()
             self.optimizer.step()
@@ -558,8 +565,8 @@ def main():
     if (WAY * SHOTS * FRAMES_PER_SHOT) % way:
         raise SystemExit("--way must divide %d support frames" % (WAY * SHOTS * FRAMES_PER_SHOT))
     frames_per_class = WAY * SHOTS * FRAMES_PER_SHOT // way  # keep 200 support frames per task
-    tasks = [synthetic.make_task_on_device(rank + world * i, way, 1, frames_per_class, NUM_QUERY, size, 1, device,
-                                           template=template)
+    tasks = [dict(synthetic.make_task_on_device(rank + world * i, way, 1, frames_per_class, NUM_QUERY, size, 1, device,
+                                                template=template), task_index=rank + world * i)
              for i in range(max(1, args.distinct_tasks))]
     # Every step of every loop below runs on a task whose LABEL TENSOR the head has never seen (a clone made before the clock
     # starts): the per-task label-set resolution - what the reference's configure pays as torch.unique + .item() per task,
@@ -568,9 +575,18 @@ def main():
     fresh_labels = os.environ.get("ORBIT_BENCH_FRESH_LABELS", "1") != "0"  # (0: A/B runs of the memoised form only)
     lib = _lib.load()
 
+    host_labels = [t["context_labels"].cpu() for t in tasks] if train else None
+
     def stream_of_tasks(n):
         if not fresh_labels:
             return [tasks[i % len(tasks)] for i in range(n)]
+        if train:
+            # the training loop's tasks come from a DataLoader on the host (reference data/queues.py:44-53) and are moved to the
+            # device by unpack_task (data/utils.py:30-47): a new device tensor per task, its label set taken from the host copy
+            from orbit_dataset_amd.data.utils import unpack_task
+            return [dict(tasks[i % len(tasks)],
+                         context_labels=unpack_task({"context_labels": host_labels[i % len(tasks)], "target_labels": None,
+                                                     "context_clips": None, "target_clips": None}, device)[2]) for i in range(n)]
         return [dict(tasks[i % len(tasks)], context_labels=tasks[i % len(tasks)]["context_labels"].clone()) for i in range(n)]
     # long-lived objects (torch, the model, the resident tasks) leave the cyclic collector's working set: a full
     # collection otherwise walks ~1e6 objects every few steps (measured: 19.7 -> 12.3 ms per LITE step at 84x84)
@@ -631,7 +647,13 @@ def main():
     todo = stream_of_tasks(args.warmup * per_step)
     for i in range(args.warmup * per_step):
         run_step(model, todo[i])
+    if train:
+        run_step.step_losses = []
     elapsed, correct, issued = loop(args.steps)  # the timed region behind `value`
+    train_losses = None
+    if train:  # the loss of every optimizer step of the timed region, summed over the ranks (each task's loss already carries
+        #        1 / tasks_per_batch, single-step-learner.py:231): N ranks x T tasks must reproduce 1 rank x N T tasks
+        train_losses = torch.stack(run_step.step_losses[:args.steps]).double() if run_step.step_losses else torch.zeros(0)
     value_memoised = None
     if not train:  # round 4's form: label sets of the resident tasks resolved and memoised before the clock
         fresh_labels = False
@@ -691,6 +713,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
         dist.all_reduce(correct)  # frame-accuracy counts: the only exchange of the task-parallel form
+        if train_losses is not None and train_losses.numel():
+            train_losses = train_losses.to(device)
+            dist.all_reduce(train_losses)
         torch.cuda.synchronize()
 
     rccl_ranks = rccl_check(lib, rank, world, backend, dist, device)  # every rank: it is a collective
@@ -775,9 +800,12 @@ def main():
                        else "")},
         "frame_accuracy": float(correct[0].item() / max(correct[1].item(), 1)),
         "train_graph_calls_replayed_eager": list(model.feature_extractor.train_graph_stats()) if train else None,
+        "train_loss_per_step": [float(x) for x in train_losses.cpu()] if train_losses is not None else None,
         "median_task_ms": median_task_ms,
         "labels": "every timed task carries a label tensor new to the head: its label set is resolved inside the timed region "
-                  "(orbit_label_set on a side stream, class count waited for at the head kernel)",
+                  "(orbit_label_set on a side stream, class count waited for at the head kernel)" if not train else
+                  "every task's labels are uploaded from the host as a new tensor before the clock (unpack_task); their label set "
+                  "comes from the host copy",
         # this rank's rate with the label sets of the resident tasks resolved and memoised before the clock (round 4's `value`)
         "value_memoised_labels": value_memoised,
         "value_overlap_off": value_overlap_off,

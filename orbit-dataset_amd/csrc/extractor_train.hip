@@ -56,16 +56,17 @@ static bool plan_trainable(const orbit_extractor* fe) {
 static bool has_bn(const Op& o) { return o.kind == OP_CONV || o.kind == OP_DWCONV; }
 
 // A batch-statistics conv whose activated output is read by ONE consumer, the depthwise conv that follows (EfficientNet's
-// expansion convs and stem): that consumer applies the conv's BatchNorm + SiLU as it loads the RAW output (DwInXf in
-// csrc/ops.hip; the depthwise filter gradient does the same, csrc/train_mbconv.hip), so the activated 6x-expanded tensor is
-// never written - on forwards that run no backward (round 3) and, since round 5, on taped ones: its only other reader would
-// be a ReLU mask, so the activation must not be ReLU there. Forward and backward evaluate this on the same plan; the option
-// is read by both (do not flip train_dw_xf between a forward and its backward).
+// expansion convs and stem), on a forward that runs NO backward (LITE's cache passes under torch.no_grad()): that consumer
+// applies the conv's BatchNorm + SiLU as it loads the RAW output (DwInXf in csrc/ops.hip), so the activated 6x-expanded tensor
+// is never written. Round 5 measured the same on TAPED forwards, with the depthwise filter gradient rebuilding its input from
+// the raw tensor on load: the forward's activation passes fell from 1.74 to 0.52 ms per step, but the filter-gradient kernels -
+// which load every input K times, once per tap row - went from 1.76 to 3.98 ms (SiLU per load, 20 more registers): 33.6
+// against 32.75 ms per step on one box (profiles/r05_lite_ab_taped_xf.txt). Not kept.
 static bool conv_feeds_dw_raw(const orbit_extractor* fe, size_t i, int bn_train, bool no_backward) {
     const Op& o = fe->ops[i];
     if (o.kind != OP_CONV || !bn_train || !get_option("train_dw_xf") || o.pool2 || o.res >= 0 || o.Cout % 4 != 0) return false;
     if (i + 1 >= fe->ops.size() || fe->ops[i + 1].kind != OP_DWCONV || fe->ops[i + 1].in != o.out) return false;
-    if (!no_backward && o.act != ORBIT_ACT_SILU && o.act != ORBIT_ACT_NONE) return false;
+    if (!no_backward) return false;
     for (size_t j = i + 2; j < fe->ops.size(); ++j) {  // no later reader of the buffer before it is written again
         const Op& q = fe->ops[j];
         if (q.in == o.out || q.res == o.out) return false;
@@ -647,16 +648,8 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
             if (rc != ORBIT_OK) return rc;
             release(g), grad_slot[i] = -1;
             if (wg) {
-                if (src >= 0 && conv_feeds_dw_raw(fe, (size_t)src, bn_train, false)) {
-                    // the forward never wrote this layer's input: rebuild it from the producing conv's raw output on load
-                    const BNDesc& sbn = fe->bns[fe->ops[src].bn];
-                    rc = launch_dwconv_wgrad(tf(L.y[src]), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
-                                             wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s,
-                                             scale + sbn.fold_off, shift + sbn.fold_off, fe->ops[src].act);
-                } else {
-                    rc = launch_dwconv_wgrad(out_tensor(src), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
-                                             wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
-                }
+                rc = launch_dwconv_wgrad(out_tensor(src), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
+                                         wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
                 if (rc != ORBIT_OK) return rc;
             }
             if (need_dx) {

@@ -182,7 +182,17 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ p
     for (int r = tid >> 4; r < R; r += 16) {
         const int l = tid & 15;
         float acc = 0.f;
-        for (int c = l; c < C; c += 16) acc = fmaf(w1[(size_t)r * C + c], p[c], acc);
+        {   // eight loads in flight per lane (a rolled loop is one L2 round trip per iteration: C / 16 = 72 of them at C = 1152)
+            int c = l;
+            for (; c + 7 * 16 < C; c += 8 * 16) {
+                float wv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) wv[k] = w1[(size_t)r * C + c + 16 * k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc = fmaf(wv[k], p[c + 16 * k], acc);
+            }
+            for (; c < C; c += 16) acc = fmaf(w1[(size_t)r * C + c], p[c], acc);
+        }
         // reduce the 16 lanes
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
@@ -217,10 +227,19 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ p
     for (int r = tid >> 4; r < R; r += 16) {
         const int l = tid & 15;
         float acc = 0.f;
-        if (w2t != nullptr)
-            for (int c = l; c < C; c += 16) acc = fmaf(du[c], w2t[(size_t)r * C + c], acc);
-        else
+        if (w2t != nullptr) {
+            int c = l;
+            for (; c + 7 * 16 < C; c += 8 * 16) {
+                float wv[8];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) wv[k] = w2t[(size_t)r * C + c + 16 * k];
+#pragma unroll
+                for (int k = 0; k < 8; ++k) acc = fmaf(du[c + 16 * k], wv[k], acc);
+            }
+            for (; c < C; c += 16) acc = fmaf(du[c], w2t[(size_t)r * C + c], acc);
+        } else {
             for (int c = l; c < C; c += 16) acc = fmaf(du[c], w2[(size_t)c * R + r], acc);
+        }
 #pragma unroll
         for (int off = 8; off > 0; off >>= 1) acc += __shfl_xor(acc, off, 16);
         if (l == 0) {
@@ -235,7 +254,15 @@ __global__ __launch_bounds__(256) void se_bwd_kernel(const float* __restrict__ p
     __syncthreads();
     for (int c = tid; c < C; c += 256) {
         float d = 0.f;
-        for (int r = 0; r < R; ++r) d = fmaf(dv[r], w1[(size_t)r * C + c], d);
+        int r = 0;
+        for (; r + 8 <= R; r += 8) {
+            float wv[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) wv[k] = w1[(size_t)(r + k) * C + c];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) d = fmaf(dv[r + k], wv[k], d);
+        }
+        for (; r < R; ++r) d = fmaf(dv[r], w1[(size_t)r * C + c], d);
         dp_out[(size_t)b * C + c] = d;
     }
 }
@@ -390,19 +417,12 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_s2_kernel(const float* __res
 // kernel (one output pixel per step, every tap a load behind its own bounds branch, 64-bit div / mod per pixel) was bound by
 // the vector L1 and by address arithmetic (287 us per launch on the 5x5 layers of efficientnet_b0 @224). All index math is
 // 32-bit; out-of-image taps read a clamped address and are zeroed by a select. Fixed summation order (deterministic).
-// XF: `x` is the RAW output of the convolution before the depthwise layer and the layer's input is act(x * in_scale[c] +
-// in_shift[c]) - that convolution's BatchNorm + activation, applied as the kernel loads (the arithmetic of dw_xf in
-// csrc/ops.hip, which the forward depthwise kernel used on the same tensor). The taped forward of a batch-statistics step then
-// never writes the activated 6x-expanded tensor: it existed only to be read here and by the forward depthwise kernel.
-template <int K, int S, int NB, bool XF = false>
+template <int K, int S, int NB>
 __global__ __launch_bounds__(256) void dwconv_wgrad_partial_kernel(const float* __restrict__ x,
                                                                    const float* __restrict__ dy,
                                                                    float* __restrict__ partial, int B, int H, int W,
                                                                    int C4, int pad_t, int pad_l, int Ho, int Wo,
-                                                                   int rows_per_block, int G, int R,
-                                                                   const float* __restrict__ in_scale = nullptr,
-                                                                   const float* __restrict__ in_shift = nullptr,
-                                                                   int in_act = 0) {
+                                                                   int rows_per_block, int G, int R) {
     constexpr int NW = (NB - 1) * S + K;
     __shared__ f32x4 red[256];
     const int tid = threadIdx.x;
@@ -418,8 +438,6 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_partial_kernel(const float* 
     if (active) {
         const f32x4* x4 = reinterpret_cast<const f32x4*>(x) + q;
         const f32x4* dy4 = reinterpret_cast<const f32x4*>(dy) + q;
-        f32x4 isc = {1.f, 1.f, 1.f, 1.f}, ish = zero;
-        if (XF) isc = reinterpret_cast<const f32x4*>(in_scale)[q], ish = reinterpret_cast<const f32x4*>(in_shift)[q];
         for (int row = row0 + rl; row < row1; row += R) {
             const int b = row / Ho, ho = row - b * Ho;
             const f32x4* dyr = dy4 + (size_t)row * Wo * C4;
@@ -444,18 +462,8 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_partial_kernel(const float* 
                     for (int u = 0; u < NW; ++u) {
                         const int wi = wi0 + u;
                         const bool ok = (unsigned)wi < (unsigned)W;
-                        f32x4 v = xr[(size_t)(ok ? wi : 0) * C4];
-                        if (XF) {
-                            v = v * isc + ish;
-                            if (in_act == ORBIT_ACT_SILU) {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) v[k] = v[k] * __builtin_amdgcn_rcpf(1.0f + __expf(-v[k]));
-                            } else if (in_act == ORBIT_ACT_RELU) {
-#pragma unroll
-                                for (int k = 0; k < 4; ++k) v[k] = fmaxf(v[k], 0.f);
-                            }
-                        }
-                        win[u] = ok ? v : zero;  // (the zero padding belongs to the ACTIVATED tensor)
+                        const f32x4 v = xr[(size_t)(ok ? wi : 0) * C4];
+                        win[u] = ok ? v : zero;
                     }
 #pragma unroll
                     for (int kw = 0; kw < K; ++kw)
@@ -628,10 +636,8 @@ size_t dwconv_wgrad_scratch_floats(int B, int Ho, int Wo, int C, int K) {
 }
 
 int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int C, int K,
-                        int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, const float* in_scale,
-                        const float* in_shift, int in_act) {
+                        int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s) {
     ORBIT_REQUIRE(C % 4 == 0 && (K == 3 || K == 5), "dwconv_wgrad: C %% 4 != 0 or K not in {3,5}");
-    ORBIT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dwconv_wgrad: the input transform needs scale and shift");
     int G, R, yg;
     dw_layout(C, G, R, yg);
     ORBIT_REQUIRE(stride == 1 || stride == 2, "dwconv_wgrad: stride %d", stride);
@@ -645,14 +651,8 @@ int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scrat
     chunks = cdiv(total_rows, rows);
     dim3 grid(chunks, yg);
 #define ORBIT_DWW(KK, SS, NBB)                                                                                          \
-    do {                                                                                                                \
-        if (in_scale)                                                                                                   \
-            dwconv_wgrad_partial_kernel<KK, SS, NBB, true><<<grid, 256, 0, s>>>(x, dy, scratch, B, H, W, C / 4, pad_t, pad_l, \
-                                                                                Ho, Wo, rows, G, R, in_scale, in_shift, in_act); \
-        else                                                                                                            \
-            dwconv_wgrad_partial_kernel<KK, SS, NBB><<<grid, 256, 0, s>>>(x, dy, scratch, B, H, W, C / 4, pad_t, pad_l, Ho, \
-                                                                          Wo, rows, G, R);                              \
-    } while (0)
+    dwconv_wgrad_partial_kernel<KK, SS, NBB><<<grid, 256, 0, s>>>(x, dy, scratch, B, H, W, C / 4, pad_t, pad_l, Ho, Wo, \
+                                                                  rows, G, R)
     if (K == 3 && stride == 1) ORBIT_DWW(3, 1, 4);
     else if (K == 3) ORBIT_DWW(3, 2, 4);
     else if (stride == 1) ORBIT_DWW(5, 1, 4);

@@ -65,7 +65,14 @@ def unpack_task(task_dict, device, context_to_device=True, target_to_device=Fals
     context_labels = task_dict["context_labels"]
     target_labels = task_dict["target_labels"]
     if context_to_device and isinstance(context_labels, torch.Tensor):
+        host_labels = context_labels
         context_labels = context_labels.to(device)
+        if not host_labels.is_cuda and context_labels.is_cuda:
+            # the labels arrive on the host (the reference moves them here, data/utils.py:42-43): the task's label set - what
+            # the head's configure needs the COUNT of before it can shape anything - is taken from the host copy, so neither
+            # a torch.unique on the device nor its host sync happens later (model/classifier_heads.py memoises it per tensor)
+            from ..model.classifier_heads import PrototypicalClassifier
+            PrototypicalClassifier.register_label_set(context_labels, host_labels)
     if target_to_device and isinstance(target_labels, torch.Tensor):
         target_labels = target_labels.to(device)
     return (task_dict["context_clips"], task_dict.get("context_paths"), context_labels, task_dict["target_clips"],

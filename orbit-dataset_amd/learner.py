@@ -33,7 +33,7 @@ import torch
 
 from . import dist as odist
 from . import synthetic
-from .data.utils import attach_frame_history
+from .data.utils import attach_frame_history, unpack_task
 from .model.few_shot_recognisers import SingleStepFewShotRecogniser
 from .optim import apply_lr_scale, cross_entropy, init_optimizer  # noqa: F401  (re-exported: bench.py, tools)
 
@@ -198,7 +198,7 @@ class Learner:
 
     def train_task(self, task):
         a = self.args
-        self.model.personalise(task["context_clips"], task["context_labels"].to(self.device))
+        self.model.personalise(task["context_clips"], self._labels_to_device(task["context_labels"]))
         target_logits = self.model.predict(task["target_clips"])
         task_loss = cross_entropy(target_logits, task["target_labels"].to(self.device)) / a.tasks_per_batch
         task_loss = task_loss + 0.001 * self.model.film_generator.regularization_term()
@@ -208,7 +208,7 @@ class Learner:
 
     def train_task_with_lite(self, task):
         a = self.args
-        context_clips, context_labels = task["context_clips"], task["context_labels"].to(self.device)
+        context_clips, context_labels = task["context_clips"], self._labels_to_device(task["context_labels"])
         target_clips, target_labels = task["target_clips"], task["target_labels"]
         self.model._clear_caches()
         task_loss, target_logits = 0, []
@@ -315,6 +315,11 @@ class Learner:
                      self.world))
         return stats
 
+    def _labels_to_device(self, labels):
+        """the reference's unpack_task (data/utils.py:42-43) for the context labels; the label set rides along from the host copy"""
+        return unpack_task({"context_labels": labels, "target_labels": None, "context_clips": None, "target_clips": None},
+                           self.device)[2]
+
     def test_directory(self):
         """The reference's test loop (single-step-learner.py:298-375) over a JPEG directory: one task per user, personalise
         on the context clips, then per target VIDEO predict on its frame history, frame accuracy per video averaged per
@@ -403,7 +408,7 @@ class Learner:
         with torch.no_grad():
             for t in odist.tasks_for_rank(a.num_test_tasks, self.rank, self.world):
                 context_clips, context_labels, videos = self.make_task(t)
-                context_labels = context_labels.to(self.device)
+                context_labels = self._labels_to_device(context_labels)
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 self.model.personalise(context_clips, context_labels)

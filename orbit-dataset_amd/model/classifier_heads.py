@@ -175,6 +175,13 @@ class PrototypicalClassifier(nn.Module):
         return PendingLabelSet(context_labels, device)
 
     @classmethod
+    def register_label_set(cls, device_labels, host_labels):
+        """`device_labels` is an upload of `host_labels`: memoise its label set from the host copy (no device work, no sync)."""
+        ids = torch.unique(host_labels.to(torch.int64)).to(device_labels.device, non_blocking=True)
+        cls._memoise(device_labels, ids)
+        return ids
+
+    @classmethod
     def _memoise(cls, context_labels, ids):
         import weakref
         key = (context_labels.data_ptr(), context_labels._version, context_labels.numel(), str(context_labels.device))

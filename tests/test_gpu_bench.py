@@ -103,3 +103,35 @@ def test_bench_config5_command_contract():
     assert "10-way" in d["config"]["workload"] and "LITE" in d["config"]["workload"] and "gradient all-reduce" in d["config"]["workload"]
     assert d["scaling"] == "weak" and d["ms_per_step"] > 0 and d["value"] > 0
     assert 0.0 <= d["frame_accuracy"] <= 1.0
+
+
+def test_bench_training_form_two_ranks_reproduces_one_rank():
+    """`bench.py --gpus 2 --mode lite_train` launches its own two ranks (gloo: they share this box's GPU), all-reduces the flat
+    gradient bucket before every optimizer step and must reproduce the ONE-rank run that accumulates the same tasks (task i on
+    rank i % 2; reference tasks_per_batch semantics, single-step-learner.py:162-166,231): the summed loss of every timed
+    optimizer step agrees - the second step's only if the first step's all-reduced gradients moved the parameters alike. The
+    line also carries the per-rank report a SCALE record needs (bucket bytes, all-reduce time by carrier)."""
+    common = ["--mode", "lite_train", "--workload", "resnet18_84", "--steps", "3", "--warmup", "0", "--no-cpu-baseline",
+              "--distinct-tasks", "6"]  # (tasks 0 .. 5 in windows of two on either run)
+    env = dict(os.environ, ORBIT_BENCH_BACKEND="gloo", ORBIT_DIST_BACKEND="gloo", OMP_NUM_THREADS="8", **FAST)
+    env.pop("WORLD_SIZE", None), env.pop("RANK", None), env.pop("LOCAL_RANK", None)
+    outs = []
+    for extra in (["--gpus", "1", "--tasks-per-rank", "2"], ["--gpus", "2", "--tasks-per-rank", "1"]):
+        out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + common + extra, capture_output=True, text=True,
+                             timeout=900, cwd=ROOT, env=env)
+        assert out.returncode == 0, out.stderr[-3000:]
+        lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+        assert len(lines) == 1
+        outs.append(json.loads(lines[0]))
+    one, two = outs
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2 and two["ranks_share_gpus"] is True and two["rccl_ranks"] is None
+    assert one["config"]["tasks_per_step"] == two["config"]["tasks_per_step"] == 2
+    la, lb = one["train_loss_per_step"], two["train_loss_per_step"]
+    assert len(la) == len(lb) == 3 and all(x > 0 for x in la)
+    for a, b in zip(la, lb):
+        assert abs(a - b) <= 2e-3 * abs(a), (la, lb)
+    pr = two["per_rank"]
+    assert [r["rank"] for r in pr] == [0, 1]
+    for r in pr:
+        assert r["gradient_bucket_bytes"] > 40e6 and r["allreduce_us_backend"] > 0  # resnet18: 11.2 M parameters
+        assert r.get("allreduce_us_p2p", 0) > 0 or "allreduce_p2p_error" in r
