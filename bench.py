@@ -762,7 +762,7 @@ def main():
                         reverse=True):
         with open(os.path.join(ROOT, "profiles", tname)) as f:
             tj = json.load(f)
-        if tj.get("workload") != args.workload:
+        if tj.get("workload") != args.workload + (":lite_train" if train else ""):
             continue
         if tj.get("kernel_sources_sha16") == kernel_sources_sha16():
             traffic = tj.get("traffic_bytes_per_launch")

@@ -68,6 +68,13 @@ def build_parser():
     p.add_argument("--num_test_tasks", type=int, default=8)
     p.add_argument("--num_train_tasks", type=int, default=16)
     p.add_argument("--epochs", "-e", type=int, default=1)
+    p.add_argument("--num_val_tasks", type=int, default=0,
+                   help="validation tasks run after every epoch from --validation_on_epoch on (reference validate(), "
+                        "single-step-learner.py:245-296; 0 = no validation)")
+    p.add_argument("--validation_on_epoch", type=int, default=1, help="epoch to turn on validation (reference utils/args.py:117)")
+    p.add_argument("--save_best_model_path", default=None,
+                   help="where the model with the best validation frame accuracy so far is written (reference "
+                        "checkpoint_dir/best.pt, single-step-learner.py:290-293)")
     p.add_argument("--learning_rate", "-lr", type=float, default=5e-6)
     p.add_argument("--extractor_lr_scale", type=float, default=1.0)
     p.add_argument("--optimizer", default="adam", choices=["adam", "sgd"])
@@ -297,6 +304,10 @@ class Learner:
                             self.grad_bucket.zero_()  # one memset; gradients keep living inside the flat bucket
                         else:
                             self.optimizer.zero_grad()
+                if a.num_val_tasks > 0 and (epoch + 1) >= a.validation_on_epoch:
+                    self.validate(epoch + 1)
+                    torch.set_grad_enabled(True)
+                    self.model.set_test_mode(False)
         finally:
             torch.set_grad_enabled(prev)
         if self.grad_bucket is not None and self.grad_bucket.p2p is not None:
@@ -308,12 +319,48 @@ class Learner:
             torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()}, a.save_model_path)
         stats = {"loss": mean_ci(losses) if losses else (0.0, 0.0), "frame_acc": mean_ci(accs) if accs else (0.0, 0.0),
                  "ms_per_task": mean_ci(times) if times else (0.0, 0.0), "num_tasks": len(losses),
-                 "world_size": self.world}
+                 "world_size": self.world, "validation": getattr(self, "validation_history", None),
+                 "best_validation": getattr(self, "best_validation", None)}
         if self.rank == 0:
             print("train: loss %.5f | frame_acc %.2f %% | %.1f ms/task | %d tasks on this rank, %d GPU(s)"
                   % (stats["loss"][0], 100 * stats["frame_acc"][0], stats["ms_per_task"][0], stats["num_tasks"],
                      self.world))
         return stats
+
+    def validate(self, epoch=0):
+        """The reference's validate() (single-step-learner.py:245-296) on held-out synthetic tasks: test mode, no grad,
+        personalise on the context clips, predict every target video on its frame history, per-video frame accuracy; the
+        model whose mean per-video accuracy beats the best so far (ValidationEvaluator.is_better, utils/eval_metrics.py:351-357:
+        strictly greater, starting from 0) is written to --save_best_model_path. Tasks are dealt to the ranks and the
+        per-video accuracies gathered, so every rank takes the same decision."""
+        a = self.args
+        self.model.set_test_mode(True)
+        accs = []
+        with torch.no_grad():
+            for t in odist.tasks_for_rank(a.num_val_tasks, self.rank, self.world):
+                context_clips, context_labels, videos = self.make_task(20_000 + t)
+                self.model.personalise(context_clips, self._labels_to_device(context_labels))
+                for frames, labels in videos:
+                    logits = self.model.predict_video(frames)  # = predict(attach_frame_history(frames, clip_length))
+                    accs.append(frame_accuracy(logits.cpu(), labels))
+                self.model._reset()
+        if self.world > 1:
+            import torch.distributed as dist
+            gathered = [None] * self.world
+            dist.all_gather_object(gathered, accs)
+            accs = [x for g in gathered for x in g]
+        stat = mean_ci(accs)
+        best = getattr(self, "best_validation", (0.0, 0.0))
+        better = stat[0] is not None and stat[0] > best[0]
+        if better:
+            self.best_validation = stat
+            if a.save_best_model_path and self.rank == 0:
+                torch.save({k: v.detach().cpu() for k, v in self.model.state_dict().items()}, a.save_best_model_path)
+        self.validation_history = getattr(self, "validation_history", []) + [(epoch, stat[0], better)]
+        if self.rank == 0:
+            print("validation (epoch %d): per-video frame_acc %.2f (%.2f) %% over %d videos%s"
+                  % (epoch, 100 * _shown(stat)[0], 100 * stat[1], len(accs), " - best so far, model saved" if better else ""))
+        return stat
 
     def _labels_to_device(self, labels):
         """the reference's unpack_task (data/utils.py:42-43) for the context labels; the label set rides along from the host copy"""

@@ -257,6 +257,21 @@ def test_learner_test_mode_end_to_end(device, tmp_path):
         assert tr["num_tasks"] == 4 and np.isfinite(tr["loss"][0]) and tr["loss"][0] > 0
     tr = main(["--mode", "train", "--learn_extractor", "--with_lite", "--feature_extractor", "efficientnet_b0"] + common)
     assert tr["train"]["num_tasks"] == 4 and np.isfinite(tr["train"]["loss"][0])
+    # validate() after every epoch (reference single-step-learner.py:245-296): per-video frame accuracy on held-out tasks, the
+    # best model so far is saved - strictly-greater rule, so the history's `better` flags follow the running maximum
+    best = tmp_path / "best.pt"
+    tr = main(["--mode", "train", "--feature_extractor", "resnet18", "--learn_extractor", "--with_lite", "--epochs", "3",
+               "--num_val_tasks", "2", "--learning_rate", "1e-3", "--save_best_model_path", str(best)] + common)["train"]
+    hist = tr["validation"]
+    assert [h[0] for h in hist] == [1, 2, 3] and all(0.0 <= h[1] <= 1.0 for h in hist)
+    running = 0.0
+    for _, acc, better in hist:
+        assert better == (acc > running)
+        running = max(running, acc)
+    assert tr["best_validation"][0] == running and (best.exists() == (running > 0.0))
+    if best.exists():
+        sd = torch.load(str(best))
+        assert any(k.startswith("feature_extractor.") for k in sd)
 
 
 def test_sharded_forms_on_device_world1(device):

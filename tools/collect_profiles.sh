@@ -21,11 +21,13 @@ done
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_lite -- \
     python $R/bench.py --mode lite_train --steps 10 --warmup 5 --no-cpu-baseline > $O/${TAG}_bench_lite_train_profiled.json 2> $O/${TAG}_bench_lite.err
 cp $(ls $O/stats_lite/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_lite_train_efficientnet_b0_224.csv
-for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $C --output-format csv -d $O/pmc_$C -- \
-      python $R/bench.py --workload efficientnet_b0_224 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/${TAG}_pmc_$C.err
-  F=$(ls $O/pmc_$C/*/*counter_collection.csv | head -1)
-  python - "$F" "$C" > $O/${TAG}_pmc_${C}_summary.txt <<'PY'
+traffic() {  # traffic <name> <workload tag> <kernel substrings, |-separated> <bench.py args...>
+  local NAME=$1 WL=$2 KERN=$3; shift 3
+  for C in FETCH_SIZE WRITE_SIZE; do
+    timeout 900 rocprofv3 --pmc $C --output-format csv -d $O/pmc_${NAME}_$C -- \
+        python $R/bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/${TAG}_pmc_${NAME}_$C.err
+    F=$(ls $O/pmc_${NAME}_$C/*/*counter_collection.csv | head -1)
+    python - "$F" "$C" > $O/${TAG}_pmc_${NAME}_${C}_summary.txt <<'PY'
 import csv, sys, collections
 f, c = sys.argv[1], sys.argv[2]
 agg = collections.defaultdict(lambda: [0, 0.0])
@@ -39,34 +41,37 @@ print("# %s per kernel (sum over dispatches, and per launch); unit = KiB as repo
 for k, (n, v) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:25]:
     print("%-92s launches %6d  total %14.0f  per_launch %12.1f" % (k, n, v, v / n))
 PY
-done
-# HBM traffic of the dominant kernel family per launch, from the two PMC passes (rocprofv3 reports KiB; on gfx950
-# FETCH_SIZE counts wide 16-B/lane streaming reads at exactly half their bytes -> x2, see MI355X_MICROARCH.md §HBM)
-python - "$O" "$TAG" > $O/${TAG}_traffic.json <<'PY'
-import csv, glob, json, os, sys
-out, tag = sys.argv[1], sys.argv[2]
+  done
+  # HBM traffic of the kernel family per launch from the two PMC passes (rocprofv3 reports KiB; on gfx950 FETCH_SIZE counts
+  # wide 16-B/lane streaming reads at exactly half their bytes -> x2, see MI355X_MICROARCH.md section HBM)
+  python - "$O" "$NAME" "$WL" "$KERN" > $O/${TAG}_${NAME}.json <<'PY'
+import csv, glob, json, os, subprocess, sys
+out, name, wl, kern = sys.argv[1:5]
+kern = kern.split("|")
 tot = {}
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    f = glob.glob("%s/pmc_%s/*/*counter_collection.csv" % (out, c))[0]
+    f = glob.glob("%s/pmc_%s_%s/*/*counter_collection.csv" % (out, name, c))[0]
     n, v = 0, 0.0
     for r in csv.DictReader(open(f)):
-        if r.get("Counter_Name") == c and ("conv_igemm_kernel" in r["Kernel_Name"] or "pw_rgemm_kernel" in r["Kernel_Name"]):
+        if r.get("Counter_Name") == c and any(k in r["Kernel_Name"] for k in kern):
             n += 1
             v += float(r["Counter_Value"])
     tot[c] = (n, v)
 launches = tot["FETCH_SIZE"][0]
 fetch = 2.0 * tot["FETCH_SIZE"][1] * 1024 / max(launches, 1)
 write = tot["WRITE_SIZE"][1] * 1024 / max(tot["WRITE_SIZE"][0], 1)
-import subprocess
 sha = subprocess.run([sys.executable, "-c", "import sys; sys.path.insert(0, %r); import bench; print(bench.kernel_sources_sha16())" % os.environ.get("GRAFT_REPO_ROOT", ".")],
                      capture_output=True, text=True).stdout.strip().splitlines()[-1]
-print(json.dumps({"workload": "efficientnet_b0_224", "kernel": "orbit::conv_igemm_kernel (all instantiations) + orbit::pw_rgemm_kernel",
-                  "kernel_sources_sha16": sha,
+print(json.dumps({"workload": wl, "kernel": " + ".join("orbit::" + k for k in kern), "kernel_sources_sha16": sha,
                   "launches_profiled": launches, "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write,
                   "traffic_bytes_per_launch": fetch + write,
                   "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of bench.py; FETCH_SIZE x2 "
                             "(gfx950 wide-load correction), WRITE_SIZE as reported"}))
 PY
+}
+traffic traffic efficientnet_b0_224 "conv_igemm_kernel|pw_rgemm_kernel" --workload efficientnet_b0_224
+# the LITE training step's dense-conv family: forward + data-gradient (conv_igemm) and filter-gradient (conv_wgrad) kernels
+traffic lite_traffic efficientnet_b0_224:lite_train "conv_igemm_kernel|pw_rgemm_kernel|conv_wgrad_kernel" --mode lite_train --workload efficientnet_b0_224
 # ---- distance kernel (64-task batched launch): kernel-trace stats + FETCH_SIZE / WRITE_SIZE in their own passes ----------
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_head -- python $R/tools/head_roofline.py quick > $O/${TAG}_head_roofline.log 2>&1
@@ -97,11 +102,6 @@ PY
 cd $R
 bash tools/conv_pmc.sh $OUT/convpmc effnet_224 > /dev/null 2>&1; cp $O/convpmc/summary.txt $O/${TAG}_conv_sq_counters.txt 2>/dev/null
 bash tools/kernel_pmc.sh $OUT/rgemmpmc pw_rgemm python tools/rgemm_bench.py > /dev/null 2>&1; cp $O/rgemmpmc/summary.txt $O/${TAG}_rgemm_sq_counters.txt 2>/dev/null
-bash tools/kernel_pmc.sh $OUT/bf3pmc conv_bf3_kernel python tools/bf3_bench.py > /dev/null 2>&1; cp $O/bf3pmc/summary.txt $O/${TAG}_bf3_sq_counters.txt 2>/dev/null
-if [ -x tools/dispatch_probe.bin ]; then
-  { echo "# tools/dispatch_probe.bin <blocks> <dynamic LDS bytes>: how the dispatcher spreads co-resident 256-thread blocks over the CUs";
-    tools/dispatch_probe.bin 770 36864; tools/dispatch_probe.bin 1535 0; tools/dispatch_probe.bin 1535 20480; tools/dispatch_probe.bin 3080 36864; } > $O/${TAG}_dispatch_probe.txt 2>&1
-fi
 # raw rocprofv3 output stays on the box: only the summaries travel back (gpurun merges at most 64 MiB)
 rm -rf $O/stats_* $O/pmc_* $O/convpmc/pass* $O/rgemmpmc/pass* $O/bf3pmc/pass*
 ls -la $O | head -60

@@ -12,13 +12,6 @@ done
 for w in cnaps_versa_resnet18_224 simple_cnaps_resnet18_224; do python bench.py --workload $w --no-cpu-baseline > $O/full_$w.json 2> $O/full_$w.err; done
 python bench.py --workload efficientnet_b0_224 --way 10 --no-cpu-baseline > $O/full_efficientnet_b0_224_10way.json 2> $O/full_10way.err
 python bench.py --mode lite_train --workload efficientnet_b0_224 --way 10 --tasks-per-rank 8 --steps 10 --warmup 3 --no-cpu-baseline > $O/lite_config5_10way_8tasks.json 2> $O/lite_config5.err
-# round 4: the opt-in bf16x3 conv path (per layer, logits against the fp64 oracle, the MFMA rounding probe) and the vendor GEMM beside ours
-timeout 400 python tools/bf3_bench.py resnet > $O/bf3_bench.txt 2>&1
-timeout 800 python tools/bf3_logit_error.py 200 > $O/bf3_logit_error.txt 2>&1
-timeout 800 python tools/bf3_logit_error.py 200 trained >> $O/bf3_logit_error.txt 2>&1
-{ python tools/bf3_race_probe3.py; python tools/bf3_race_probe2.py; } > $O/bf3_repeatability.txt 2>&1
-tools/mfma_round_probe.bin > $O/mfma_round_probe.txt 2>&1
-timeout 400 python tools/blas_compare.py conv3x3 > $O/blas_compare.txt 2>&1
 python - "$O" <<'PY'
 import json, glob, os, sys
 for f in sorted(glob.glob(sys.argv[1] + '/*.json')):

@@ -1,9 +1,20 @@
-mkdir -p gpurun_out/r5c
-timeout 900 python -m pytest tests -m gpu -q --durations=25 -p no:cacheprovider > gpurun_out/r5c/pytest.log 2>&1; tail -3 gpurun_out/r5c/pytest.log
-for cfg in "ORBIT_TRAIN_DW_XF=1" "ORBIT_TRAIN_DW_XF=0" "ORBIT_TRAIN_DW_XF=1 ORBIT_BENCH_FRESH_LABELS=0" "ORBIT_TRAIN_DW_XF=1 ORBIT_TRAIN_GRAPH=0" "ORBIT_TRAIN_DW_XF=1" "ORBIT_TRAIN_DW_XF=0"; do
-  tag=$(echo "$cfg" | tr ' =' '__')
-  env $cfg timeout 300 python bench.py --mode lite_train --no-cpu-baseline --steps 30 --warmup 10 > gpurun_out/r5c/lite_$tag.$RANDOM.json 2> gpurun_out/r5c/lite_$tag.err
+# GPU box: LITE step A/B on one box (interleaved) + a per-launch trace of one step. bash tools/r5_lite_ab.sh <outdir> "ENV=V ..." ...
+O=${1:-gpurun_out/r5d}; shift; mkdir -p $O
+for rep in 1 2; do
+  for cfg in "$@"; do
+    tag=$(echo "$cfg" | tr ' =' '__')
+    env $cfg timeout 300 python bench.py --mode lite_train --no-cpu-baseline --steps 30 --warmup 10 > $O/lite_${tag}_$rep.json 2> $O/lite_${tag}_$rep.err
+  done
 done
-cd /tmp && export TMPDIR=/tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/lt -o trace -- python $GRAFT_REPO_ROOT/tools/lite_trace.py > /dev/null 2>&1
-cd $GRAFT_REPO_ROOT && python tools/lite_trace.py --parse $(find /tmp/lt -name "trace_kernel_trace.csv" | head -1) gpurun_out/r5c/lite_timeline.txt > gpurun_out/r5c/lite_summary.txt 2>&1
-tail -2 gpurun_out/r5c/lite_summary.txt
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/lt && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/lt -o trace -- python $R/tools/lite_trace.py > /dev/null 2>&1
+cd $R && python tools/lite_trace.py --parse $(find /tmp/lt -name "trace_kernel_trace.csv" | head -1) $O/lite_timeline.txt > $O/lite_summary.txt 2>&1
+python - $O <<'PY'
+import json, glob, os, sys
+for f in sorted(glob.glob(sys.argv[1] + '/lite_*.json')):
+    try:
+        d = json.loads(open(f).read().strip().splitlines()[-1])
+        print("%-60s ms %.2f host %.2f graph %s frac %.3f" % (os.path.basename(f), d['ms_per_step'], d['host_enqueue_ms_per_step'], d['train_graph_calls_replayed_eager'], d['roofline']['frac']))
+    except Exception as e:
+        print(f, 'ERR', e)
+PY
