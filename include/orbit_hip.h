@@ -397,6 +397,11 @@ int orbit_op_conv2d_dgrad(const float* dy, const float* w, const float* accumula
 /* dw (OIHW) of a convolution; x NHWC (or NCHW when x_nchw, Cin <= 4) */
 int orbit_op_conv2d_wgrad(const float* x, int x_nchw, const float* dy, float* dw, int B, int H, int W, int Cin, int Cout,
                           int KH, int KW, int stride, int pad_top, int pad_left, int Ho, int Wo, orbit_stream_t stream);
+/* The filter gradient of a squeeze-excite-gated pointwise projection, dW[co][ci] = sum_m dy[m][co] * x[m][ci] * gate[b(m)][ci]
+ * (timm InvertedResidual.conv_pwl behind the SE module; x NHWC [B][H][W][Cin], gate [B][Cin], dy [B][H][W][Cout]): the product
+ * x * gate is never materialised. Single-operator entry for the parity tests. */
+int orbit_op_conv2d_wgrad_gated(const float* x, const float* gate, const float* dy, float* dw, int B, int H, int W, int Cin,
+                                int Cout, orbit_stream_t stream);
 /* max-pool that records the argmax (position inside the window, first maximum in scan order) and its backward */
 int orbit_op_maxpool2d_train(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, int K, int stride,
                              int pad, int Ho, int Wo, orbit_stream_t stream);

@@ -90,6 +90,7 @@ _SIGNATURES = {
     "orbit_op_bn_backward": (c_int, [P, P, P, c_int, c_int, P, P, P, c_int, c_int, P, P, P, P, P]),
     "orbit_op_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 12 + [P]),
     "orbit_op_conv2d_wgrad": (c_int, [P, c_int, P, P] + [c_int] * 12 + [P]),
+    "orbit_op_conv2d_wgrad_gated": (c_int, [P, P, P, P] + [c_int] * 5 + [P]),
     "orbit_op_maxpool2d_train": (c_int, [P, P, P] + [c_int] * 9 + [P]),
     "orbit_op_maxpool2d_backward": (c_int, [P, P, P] + [c_int] * 9 + [P]),
     "orbit_op_avgpool_backward": (c_int, [P, P, c_int, c_int, c_int, P]),

@@ -14,6 +14,8 @@
 //   dgrad   is the forward implicit-GEMM kernel (conv_igemm.hip) run on dY with the filter rotated by 180 degrees and
 //           its in/out channels swapped; strided layers first spread dY over the input grid (zero insertion,
 //           train_ops.hip). conv_pack_dgrad_weights builds that filter directly in the packed layout.
+#include <algorithm>
+
 #include "common.h"
 
 namespace orbit {
@@ -198,6 +200,146 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
     }
 }
 
+// ---- thin pointwise layers: one of (Cin, Cout) <= 48 channels, millions of rows --------------------------------------------
+// EfficientNet's high-resolution expansions and projections (16 -> 96 at 112x112, 96 -> 24 / 24 <-> 144 at 56x56, 40 <-> 240 at
+// 28x28; timm InvertedResidual conv_pw / conv_pwl behind model/feature_extractors.py:39-43) have a filter gradient of a few
+// thousand numbers summed over 0.16 - 2.5 million rows. The 64x64-tile kernel above pads the thin side to 64 columns: for
+// 16 -> 96 only 19 % of its MFMA work and LDS traffic is real and the launch takes 455 us for 1.12 GB of operands (HBM time
+// ~250 us); 96 -> 24 at 56x56 takes 233 us for 300 MB. Here a WAVE owns a run of rows and keeps the whole [fat tiles of its
+// group] x [thin tiles] gradient block in accumulators (v_mfma_f32_16x16x4_f32: K = 4 rows per instruction, lane = (channel of
+// a 16-channel tile, row of the step) for both operands, so operands go global -> register -> MFMA with one dword per lane and
+// tile - no LDS stage, no padding beyond 16 channels). The fat side is cut into groups of 8 tiles (grid.y) when it has more.
+// The four waves of a block are added in wave order through LDS, blocks through the reduce kernel below: deterministic.
+struct WthinParams {
+    const float* fat;    // [M][Cf]
+    const float* thin;   // [M][Ct]
+    const float* gate;   // [B][Cin] on the x side or nullptr
+    float* partial;      // [blocks][Cout][Cin]
+    int M, Cf, Ct, Cout, Cin, rows_per_wave, ftiles, tpg;  // tpg: fat tiles per group (<= 8), groups balanced
+    FastDiv fd_hw;
+};
+
+// TF: fat tiles a wave holds (>= the group's tile count; a missing tile costs MFMAs on zeros but no loads). S = K-steps of
+// 4 rows per loop iteration, chosen so that ~24-32 operand dwords per lane are in flight: with 2 + 1 tiles (32 -> 16 at
+// 112x112) two steps per iteration left 6 loads in flight and the walk was a chain of 77 HBM round trips per wave.
+template <int TF, int TT, bool FAT_IS_CO, bool GATE>
+__global__ __launch_bounds__(256) void conv_wgrad_thin_kernel(const WthinParams p) {
+    constexpr int S = TF + TT <= 4 ? 8 : TF + TT <= 8 ? 4 : 2;
+    __shared__ f32x4 red[TF * TT * 64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int col = lane & 15, kq = lane >> 4;
+    const int t0 = blockIdx.y * p.tpg;               // first fat tile of this group
+    const int nv = min(p.tpg, p.ftiles - t0);        // its tiles (<= TF)
+    const int wg = blockIdx.x * 4 + wave;
+    const int m_begin = wg * p.rows_per_wave;
+    const int m_end = min(p.M, m_begin + p.rows_per_wave);
+    f32x4 acc[TF][TT];
+#pragma unroll
+    for (int t = 0; t < TF; ++t)
+#pragma unroll
+        for (int u = 0; u < TT; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // per-lane channel validity (fixed for the whole walk)
+    bool fok[TF], tok[TT];
+#pragma unroll
+    for (int t = 0; t < TF; ++t) fok[t] = t < nv && (t0 + t) * 16 + col < p.Cf;
+#pragma unroll
+    for (int u = 0; u < TT; ++u) tok[u] = u * 16 + col < p.Ct;
+    const float* fbase = p.fat + (size_t)(t0 * 16 + col);
+    const float* tbase = p.thin + col;
+    // squeeze-excite gate of the x side: a lane's channels are fixed, so its gate values only change with the FRAME of its
+    // row - kept in registers and reloaded when the frame changes (once per H*W rows)
+    float gfat[TF], gthin[TT];
+    int bcur = -1;
+#pragma unroll
+    for (int t = 0; t < TF; ++t) gfat[t] = 1.f;
+#pragma unroll
+    for (int u = 0; u < TT; ++u) gthin[u] = 1.f;
+    for (int m0 = m_begin; m0 < m_end; m0 += 4 * S) {
+        float fv[S][TF], tv[S][TT];
+#pragma unroll
+        for (int h = 0; h < S; ++h) {
+            const int row = m0 + 4 * h + kq;
+            const bool ok = row < m_end;
+            const size_t r = (size_t)(ok ? row : m_begin);
+            if (GATE) {
+                const int b = (int)fdiv((unsigned)r, p.fd_hw);
+                if (b != bcur) {
+                    bcur = b;
+                    const float* grow = p.gate + (size_t)b * p.Cin;
+                    if (FAT_IS_CO) {
+#pragma unroll
+                        for (int u = 0; u < TT; ++u) gthin[u] = tok[u] ? grow[u * 16 + col] : 0.f;
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < TF; ++t) gfat[t] = fok[t] ? grow[(t0 + t) * 16 + col] : 0.f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < TF; ++t) {
+                float v = fok[t] ? fbase[r * p.Cf + t * 16] : 0.f;
+                if (GATE && !FAT_IS_CO) v *= gfat[t];   // the fat side is x
+                fv[h][t] = ok ? v : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < TT; ++u) {
+                float v = tok[u] ? tbase[r * p.Ct + u * 16] : 0.f;
+                if (GATE && FAT_IS_CO) v *= gthin[u];   // the thin side is x
+                tv[h][u] = ok ? v : 0.f;
+            }
+        }
+#pragma unroll
+        for (int h = 0; h < S; ++h)
+#pragma unroll
+            for (int t = 0; t < TF; ++t)
+#pragma unroll
+                for (int u = 0; u < TT; ++u)
+                    acc[t][u] = FAT_IS_CO ? __builtin_amdgcn_mfma_f32_16x16x4f32(fv[h][t], tv[h][u], acc[t][u], 0, 0, 0)
+                                          : __builtin_amdgcn_mfma_f32_16x16x4f32(tv[h][u], fv[h][t], acc[t][u], 0, 0, 0);
+    }
+    // the block's four waves, added in wave order
+    for (int w = 0; w < 4; ++w) {
+        if (wave == w) {
+#pragma unroll
+            for (int t = 0; t < TF; ++t)
+#pragma unroll
+                for (int u = 0; u < TT; ++u) {
+                    f32x4* slot = &red[(t * TT + u) * 64 + lane];
+                    *slot = w == 0 ? acc[t][u] : *slot + acc[t][u];
+                }
+        }
+        __syncthreads();
+    }
+    // D[i = 4 * (lane / 16) + r][j = lane % 16]: i indexes the A operand's channels (co), j the B operand's (ci)
+    float* out = p.partial + (size_t)blockIdx.x * p.Cout * p.Cin;
+    for (int e = threadIdx.x; e < nv * TT * 64; e += 256) {
+        const int l = e & 63, tu = e >> 6, t = tu / TT, u = tu - t * TT;
+        const f32x4 v = red[e];
+        const int fat_c0 = (t0 + t) * 16, thin_c0 = u * 16;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int i = 4 * (l >> 4) + r, j = l & 15;
+            const int co = FAT_IS_CO ? fat_c0 + i : thin_c0 + i;
+            const int ci = FAT_IS_CO ? thin_c0 + j : fat_c0 + j;
+            if (co < p.Cout && ci < p.Cin) out[(size_t)co * p.Cin + ci] = v[r];
+        }
+    }
+}
+
+// the thin kernel serves: NHWC pointwise layers (1x1, stride 1, no padding) with >= 2^18 rows (the 112- and 56-pixel maps of a
+// 200-frame batch) whose thinner side has <= 2 tiles of 16 channels; blocks = row splits (<= 1024, >= 64 rows per wave).
+// (Measured, 200 frames: 16 -> 96 @112 455 -> 224 us; with 3 thin tiles - 40 <-> 240 @28 - the 24 MFMAs per 4-row step bound
+// the walk: 159-222 us against 70 us for the tiled kernel, which keeps those layers.)
+static bool wgrad_thin_geometry(int M, int Cin, int Cout, int KH, int KW, int stride, int pad_t, int pad_l, int x_nchw, int& blocks,
+                                int& rows_per_wave) {
+    if (x_nchw || KH != 1 || KW != 1 || stride != 1 || pad_t != 0 || pad_l != 0 || M < (1 << 18)) return false;
+    if (std::min(cdiv(Cin, 16), cdiv(Cout, 16)) > 2) return false;
+    blocks = std::min(1024, cdiv(M, 4 * 64));
+    rows_per_wave = cdiv(cdiv(M, blocks * 4), 32) * 32;  // whole loop iterations of every instantiation (4 * S rows, S <= 8)
+    blocks = cdiv(M, rows_per_wave * 4);
+    return true;
+}
+
 // number of m-splits for a layer: enough blocks to fill the chip, at least 8 K-steps per block
 static void wgrad_geometry(int M, int Cout, int NC, int& co_tiles, int& n_tiles, int& splits, int& steps_per_split) {
     co_tiles = cdiv(Cout, 64), n_tiles = cdiv(NC, 64);
@@ -215,6 +357,8 @@ size_t conv_wgrad_scratch_floats(int B, int Cin, int Cout, int KH, int KW, int H
     int ct, nt, sp, sps;
     const int NC = KH * KW * Cin;
     wgrad_geometry(B * Ho * Wo, Cout, NC, ct, nt, sp, sps);
+    int tb = 0, rpw = 0;  // (the thin form of a pointwise layer: the caller's stride / padding are not known here - size for it)
+    if (wgrad_thin_geometry(B * Ho * Wo, Cin, Cout, KH, KW, 1, 0, 0, 0, tb, rpw)) sp = std::max(sp, tb);
     return (size_t)sp * Cout * NC;
 }
 
@@ -231,6 +375,48 @@ int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oih
     p.pad_t = pad_t, p.pad_l = pad_l, p.Ho = Ho, p.Wo = Wo;
     p.M = B * Ho * Wo, p.NC = KH * KW * Cin;
     p.fd_howo = make_fastdiv((unsigned)(Ho * Wo)), p.fd_wo = make_fastdiv((unsigned)Wo);
+    int thin_blocks = 0, thin_rpw = 0;
+    if (wgrad_thin_geometry(p.M, Cin, Cout, KH, KW, stride, pad_t, pad_l, x_nchw, thin_blocks, thin_rpw)) {
+        const int tci = cdiv(Cin, 16), tco = cdiv(Cout, 16);
+        const bool fat_is_co = tco >= tci;
+        WthinParams q;
+        q.fat = fat_is_co ? dy : x, q.thin = fat_is_co ? x : dy, q.gate = gate, q.partial = scratch;
+        q.M = p.M, q.Cf = fat_is_co ? Cout : Cin, q.Ct = fat_is_co ? Cin : Cout, q.Cout = Cout, q.Cin = Cin;
+        q.rows_per_wave = thin_rpw, q.ftiles = fat_is_co ? tco : tci, q.fd_hw = p.fd_howo;
+        const int tt = fat_is_co ? tci : tco;
+        const int groups = cdiv(q.ftiles, 8);
+        q.tpg = cdiv(q.ftiles, groups);
+        const dim3 grid(thin_blocks, groups);
+        const int rec = prof_start("conv_wgrad_thin", 2.0 * p.M * Cout * Cin,
+                                   4.0 * ((double)p.M * Cin + (double)p.M * Cout + (double)Cout * Cin), s);
+#define ORBIT_WTHIN(TF_, TT_)                                                                                \
+    do {                                                                                                     \
+        if (fat_is_co) {                                                                                     \
+            if (gate) conv_wgrad_thin_kernel<TF_, TT_, true, true><<<grid, 256, 0, s>>>(q);                  \
+            else conv_wgrad_thin_kernel<TF_, TT_, true, false><<<grid, 256, 0, s>>>(q);                      \
+        } else {                                                                                             \
+            if (gate) conv_wgrad_thin_kernel<TF_, TT_, false, true><<<grid, 256, 0, s>>>(q);                 \
+            else conv_wgrad_thin_kernel<TF_, TT_, false, false><<<grid, 256, 0, s>>>(q);                     \
+        }                                                                                                    \
+    } while (0)
+#define ORBIT_WTHIN_TF(TT_)                                                                                  \
+    do {                                                                                                     \
+        if (q.tpg <= 2) ORBIT_WTHIN(2, TT_);                                                                 \
+        else if (q.tpg <= 4) ORBIT_WTHIN(4, TT_);                                                            \
+        else if (q.tpg <= 6) ORBIT_WTHIN(6, TT_);                                                            \
+        else ORBIT_WTHIN(8, TT_);                                                                            \
+    } while (0)
+        if (tt == 1) ORBIT_WTHIN_TF(1);
+        else ORBIT_WTHIN_TF(2);
+#undef ORBIT_WTHIN_TF
+#undef ORBIT_WTHIN
+        prof_stop(rec, s);
+        ORBIT_LAUNCH_CHECK();
+        const size_t total = (size_t)Cout * p.NC;
+        conv_wgrad_reduce_kernel<<<(int)((total + 15) / 16), 256, 0, s>>>(scratch, thin_blocks, Cout, p.NC, Cin, 1, 1, 0, dw_oihw);
+        ORBIT_LAUNCH_CHECK();
+        return ORBIT_OK;
+    }
     wgrad_geometry(p.M, Cout, p.NC, p.co_tiles, p.n_tiles, p.splits, p.steps_per_split);
     const int grid = p.co_tiles * p.n_tiles * p.splits;
     // algorithmic work: 2*M*Cout*K flops; bytes = input + output gradient once, filter gradient once
@@ -316,6 +502,19 @@ int orbit_op_conv2d_wgrad(const float* x, int x_nchw, const float* dy, float* dw
                                    conv_wgrad_scratch_floats(B, Cin, Cout, KH, KW, Ho, Wo) * sizeof(float), s));
     const int rc = launch_conv_wgrad(x, x_nchw, dy, dw, B, H, W, Cin, Cout, KH, KW, stride, pad_top, pad_left, Ho, Wo,
                                      scratch, s);
+    (void)hipFreeAsync(scratch, s);
+    return rc;
+}
+
+int orbit_op_conv2d_wgrad_gated(const float* x, const float* gate, const float* dy, float* dw, int B, int H, int W, int Cin,
+                                int Cout, orbit_stream_t stream) {
+    ORBIT_REQUIRE(x && gate && dy && dw, "op_conv2d_wgrad_gated: null pointer");
+    ORBIT_REQUIRE(B > 0 && H > 0 && W > 0, "op_conv2d_wgrad_gated: bad geometry");
+    hipStream_t s = (hipStream_t)stream;
+    float* scratch = nullptr;
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&scratch), conv_wgrad_scratch_floats(B, Cin, Cout, 1, 1, H, W) * sizeof(float),
+                                   s));
+    const int rc = launch_conv_wgrad(x, 0, dy, dw, B, H, W, Cin, Cout, 1, 1, 1, 0, 0, H, W, scratch, s, gate);
     (void)hipFreeAsync(scratch, s);
     return rc;
 }

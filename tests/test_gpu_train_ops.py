@@ -157,7 +157,18 @@ def test_conv_dgrad(device, case, accumulate):
     assert rel_err(nchw(dx.cpu()), ref) < 2e-5
 
 
-@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+# thin pointwise layers with >= 2^18 rows: the register form of csrc/conv_wgrad.hip (conv_wgrad_thin_kernel) - 1 / 2 thin tiles
+# of 16 channels, the fat side as dY or as x, one and two groups of fat tiles, ragged channel counts, ragged last rows
+WGRAD_THIN_CASES = [
+    (21, 16, 112, 112, 96, 1, 1, 0),   # efficientnet_b0 block 1.0 expansion: fat = dY (6 tiles), 1 thin tile; 263 424 rows
+    (84, 96, 56, 56, 24, 1, 1, 0),     # block 1.0 projection: fat = x, thin = 24 channels (2 tiles, the second half full)
+    (85, 24, 56, 56, 144, 1, 1, 0),    # block 1.1 expansion: 9 fat tiles = two groups of 5 + 4; a ragged last row split
+    (84, 136, 56, 56, 20, 1, 1, 0),    # fat = x with a ragged last tile, 20 thin channels
+    (21, 32, 112, 112, 16, 1, 1, 0),   # block 0 projection
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES + WGRAD_THIN_CASES, ids=lambda c: "x".join(map(str, c)))
 def test_conv_wgrad(device, case):
     lib = _lib.load()
     B, Cin, H, W, Cout, K, stride, pad = case
@@ -169,6 +180,31 @@ def test_conv_wgrad(device, case):
                                          stride, pad, pad, Ho, Wo, _st()), "conv2d_wgrad")
     torch.cuda.synchronize()
     assert rel_err(dw.cpu(), w.grad) < 2e-5
+
+
+@pytest.mark.parametrize("B,Cin,HW,Cout", [(84, 96, 56, 24), (85, 144, 56, 24), (21, 32, 112, 16), (84, 24, 56, 144),
+                                           (3, 672, 14, 112)])
+def test_conv_wgrad_gated_projection(device, B, Cin, HW, Cout):
+    """d/dW of conv1x1(x * gate) with the squeeze-excite gate multiplied in inside the kernel: the thin register form
+    (gate of the fat / of the thin side kept in registers per frame; >= 2^18 rows) and the tiled form (last case)."""
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(B + Cin + Cout)
+    x = torch.randn(B, Cin, HW, HW, generator=g)
+    gate = torch.rand(B, Cin, generator=g)
+    w = (torch.randn(Cout, Cin, 1, 1, generator=g) / Cin ** 0.5).requires_grad_(True)
+    y = F.conv2d(x * gate[:, :, None, None], w)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    t_x, t_g, t_dy = nhwc(x).to(device), gate.to(device), nhwc(dy).to(device)
+    dw = torch.full((Cout, Cin, 1, 1), float("nan"), device=device)
+    _lib.check(lib.orbit_op_conv2d_wgrad_gated(_lib.dptr(t_x), _lib.dptr(t_g), _lib.dptr(t_dy), _lib.dptr(dw), B, HW, HW, Cin,
+                                               Cout, _st()), "conv2d_wgrad_gated")
+    again = torch.empty_like(dw)
+    _lib.check(lib.orbit_op_conv2d_wgrad_gated(_lib.dptr(t_x), _lib.dptr(t_g), _lib.dptr(t_dy), _lib.dptr(again), B, HW, HW,
+                                               Cin, Cout, _st()), "conv2d_wgrad_gated")
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), w.grad) < 2e-5
+    assert torch.equal(dw, again)  # deterministic: waves and blocks are added in a fixed order
 
 
 @pytest.mark.parametrize("B,H,W,Cout,K,stride,pad", [(3, 32, 32, 64, 7, 2, 3), (2, 33, 29, 32, 3, 2, 1),
