@@ -412,6 +412,13 @@ int orbit_op_avgpool_backward(const float* dy, float* dx, int B, int HW, int C, 
 int orbit_op_dwconv2d_backward(const float* x, const float* w, const float* dy, float* dx, float* dw, int B, int H, int W,
                                int C, int K, int stride, int pad_top, int pad_left, int Ho, int Wo,
                                orbit_stream_t stream);
+/* The depthwise filter gradient with the layer's input rebuilt on load: x_raw is the RAW output of the preceding convolution and
+ * the layer's input is act(x_raw * in_scale[c] + in_shift[c]) (that convolution's batch-statistics BatchNorm + SiLU / ReLU;
+ * reference: autograd through timm InvertedResidual's bn1 + act1 + conv_dw, few_shot_recognisers.py:99-122). The taped forward
+ * of the LITE step never writes the activated tensor. dw [C][1][K][K]. Single-operator entry for the parity tests. */
+int orbit_op_dwconv2d_wgrad_xf(const float* x_raw, const float* in_scale, const float* in_shift, int in_act, const float* dy,
+                               float* dw, int B, int H, int W, int C, int K, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                               orbit_stream_t stream);
 /* backward of the squeeze-excite product xg = x * gate(mean_hw(x)) (timm SqueezeExcite: conv_reduce -> SiLU ->
  * conv_expand -> sigmoid): given dxg writes dx and (all or none) dW1 [R][C], db1 [R], dW2 [C][R], db2 [C].
  * x NHWC [B][HW][C]; pooled [B][C] = mean over HW of x. */

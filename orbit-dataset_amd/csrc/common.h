@@ -226,7 +226,11 @@ int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, 
                         int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, float* flip_scratch = nullptr);
 size_t dwconv_wgrad_scratch_floats(int B, int Ho, int Wo, int C, int K);
 int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int C, int K,
-                        int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s);
+                        int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, const float* in_scale = nullptr,
+                        const float* in_shift = nullptr, int in_act = 0);
+// (in_scale / in_shift: x is the RAW output of the producing conv; act(x * in_scale[c] + in_shift[c]) is applied as the patch is
+// staged in LDS - only where dwconv_wgrad_xf_supported says the LDS form fits the layer)
+bool dwconv_wgrad_xf_supported(int B, int H, int W, int C, int K, int stride, int Ho, int Wo);
 size_t conv_wgrad_scratch_floats(int B, int Cin, int Cout, int KH, int KW, int Ho, int Wo);
 int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
                       int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float* scratch, hipStream_t s,

@@ -56,17 +56,23 @@ static bool plan_trainable(const orbit_extractor* fe) {
 static bool has_bn(const Op& o) { return o.kind == OP_CONV || o.kind == OP_DWCONV; }
 
 // A batch-statistics conv whose activated output is read by ONE consumer, the depthwise conv that follows (EfficientNet's
-// expansion convs and stem), on a forward that runs NO backward (LITE's cache passes under torch.no_grad()): that consumer
-// applies the conv's BatchNorm + SiLU as it loads the RAW output (DwInXf in csrc/ops.hip), so the activated 6x-expanded tensor
-// is never written. Round 5 measured the same on TAPED forwards, with the depthwise filter gradient rebuilding its input from
-// the raw tensor on load: the forward's activation passes fell from 1.74 to 0.52 ms per step, but the filter-gradient kernels -
-// which load every input K times, once per tap row - went from 1.76 to 3.98 ms (SiLU per load, 20 more registers): 33.6
-// against 32.75 ms per step on one box (profiles/r05_lite_ab_taped_xf.txt). Not kept.
-static bool conv_feeds_dw_raw(const orbit_extractor* fe, size_t i, int bn_train, bool no_backward) {
+// expansion convs and stem): that consumer applies the conv's BatchNorm + SiLU as it loads the RAW output (DwInXf in
+// csrc/ops.hip), so the activated 6x-expanded tensor is never written - on forwards that run no backward (round 3) and, since
+// round 5, on TAPED ones: the only other reader of the activation is the depthwise filter gradient, whose LDS form applies the
+// same transform as it stages its input patch (dwconv_wgrad_lds_kernel, csrc/train_mbconv.hip; each element passes once). A
+// first attempt with the transform inside the global-load filter-gradient kernel - every input loaded K times, SiLU per load -
+// lost more there (1.76 -> 3.98 ms) than the forward gained (profiles/r05_lite_ab_taped_xf.txt). The activation must not be
+// ReLU on a taped forward (its BatchNorm backward reads the mask from the activated tensor). Forward and backward evaluate
+// this on the same plan and batch; the option is read by both (do not flip train_dw_xf between a forward and its backward).
+static bool conv_feeds_dw_raw(const orbit_extractor* fe, size_t i, int bn_train, bool no_backward, int B) {
     const Op& o = fe->ops[i];
     if (o.kind != OP_CONV || !bn_train || !get_option("train_dw_xf") || o.pool2 || o.res >= 0 || o.Cout % 4 != 0) return false;
     if (i + 1 >= fe->ops.size() || fe->ops[i + 1].kind != OP_DWCONV || fe->ops[i + 1].in != o.out) return false;
-    if (!no_backward) return false;
+    if (!no_backward) {
+        const Op& d = fe->ops[i + 1];
+        if (o.act != ORBIT_ACT_SILU && o.act != ORBIT_ACT_NONE) return false;
+        if (!dwconv_wgrad_xf_supported(B, d.H, d.W, d.Cin, d.KH, d.stride, d.Ho, d.Wo)) return false;
+    }
     for (size_t j = i + 2; j < fe->ops.size(); ++j) {  // no later reader of the buffer before it is written again
         const Op& q = fe->ops[j];
         if (q.in == o.out || q.res == o.out) return false;
@@ -407,7 +413,7 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
             }
             // the only consumer is the depthwise conv that follows: it applies this BatchNorm + activation as it loads the raw
             // output (conv_feeds_dw_raw above), so the activated 6x-expanded tensor is neither written nor read back
-            dw_in_raw = conv_feeds_dw_raw(fe, i, bn_train, no_backward);
+            dw_in_raw = conv_feeds_dw_raw(fe, i, bn_train, no_backward, B);
             if (dw_in_raw) {
                 cur[o.out] = d.y;
                 dw_in_bn = o.bn, dw_in_act = o.act;
@@ -648,8 +654,17 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
             if (rc != ORBIT_OK) return rc;
             release(g), grad_slot[i] = -1;
             if (wg) {
-                rc = launch_dwconv_wgrad(out_tensor(src), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
-                                         wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+                if (src >= 0 && conv_feeds_dw_raw(fe, (size_t)src, bn_train, false, B)) {
+                    // the forward never wrote this layer's input: the filter gradient rebuilds it from the producing conv's raw
+                    // output as it stages its patch
+                    const BNDesc& sbn = fe->bns[fe->ops[src].bn];
+                    rc = launch_dwconv_wgrad(tf(L.y[src]), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
+                                             wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s,
+                                             scale + sbn.fold_off, shift + sbn.fold_off, fe->ops[src].act);
+                } else {
+                    rc = launch_dwconv_wgrad(out_tensor(src), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
+                                             wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+                }
                 if (rc != ORBIT_OK) return rc;
             }
             if (need_dx) {

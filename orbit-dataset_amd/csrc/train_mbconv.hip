@@ -5,6 +5,7 @@
 //   backward and its parameter gradients.
 // NHWC fp32, float4 over channels; every reduction has a fixed order (deterministic, no atomics). All HBM-bound.
 #include <algorithm>
+#include <cstdlib>
 #include "common.h"
 
 namespace orbit {
@@ -486,6 +487,187 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_partial_kernel(const float* 
     }
 }
 
+// ---- depthwise filter gradient from an LDS-staged input patch (round 5) ------------------------------------------------------
+// The kernel above loads every input element K times (once per tap row, through the vector L1). Here a block stages the input
+// rows of one (frame, output-row chunk) tile for a slice of cs4 channel quads in LDS ONCE - the staging of dwconv_lds_kernel,
+// csrc/ops.hip - and the taps read LDS; a block walks `tpb` tiles with its K*K accumulators in registers and reduces once at the
+// end. Because an element is touched once on its way in, the preceding BatchNorm + SiLU can be applied THERE (XF: `x` is the RAW
+// output of the expansion conv, act(x * in_scale[c] + in_shift[c]) is staged; the zero padding stays zero): the taped forward
+// of a batch-statistics step then never writes the activated 6x-expanded tensor (conv_feeds_dw_raw, csrc/extractor_train.hip).
+// partial[group][tap][c]; thread = (channel quad lc of the slice, 4-column group g, row lane rl); fixed summation order.
+struct DwWgLdsParams {
+    const float* x;
+    const float* dy;
+    float* partial;
+    const float* in_scale;
+    const float* in_shift;
+    int in_act;
+    int H, W, C, pad_t, pad_l, Ho, Wo, cs4, rpc, G, IWA, chunks, tiles_total, tpb;
+};
+
+template <int K, int S, bool XF>
+__global__ __launch_bounds__(256) void dwconv_wgrad_lds_kernel(const DwWgLdsParams p) {
+    constexpr int NCOL = 3 * S + K, U = 8;
+    extern __shared__ __attribute__((aligned(16))) float smw[];
+    const int cs4 = p.cs4, CSP = cs4 * 4 + 4, IWA = p.IWA;
+    const int tid = threadIdx.x;
+    const int lc = tid % cs4, pp = tid / cs4, P = 256 / cs4;
+    const int c = (blockIdx.x * cs4 + lc) * 4;
+    const int G = p.G, RL = P / G;
+    const int g = pp % G, rl = pp / G;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[K * K];
+#pragma unroll
+    for (int t = 0; t < K * K; ++t) acc[t] = zero;
+    f32x4 xsc = {1.f, 1.f, 1.f, 1.f}, xsh = zero;
+    if (XF) xsc = *reinterpret_cast<const f32x4*>(p.in_scale + c), xsh = *reinterpret_cast<const f32x4*>(p.in_shift + c);
+    const int t_begin = blockIdx.y * p.tpb, t_end = min(p.tiles_total, t_begin + p.tpb);
+    for (int tile_i = t_begin; tile_i < t_end; ++tile_i) {
+        const int b = tile_i / p.chunks, chunk = tile_i - b * p.chunks;
+        const int ho0 = chunk * p.rpc;
+        const int TH = min(p.Ho, ho0 + p.rpc) - ho0;
+        const int IH = (TH - 1) * S + K;
+        __syncthreads();  // the previous tile's readers are done with the patch
+        {
+            const int hi0 = ho0 * S - p.pad_t;
+            const float* xb = p.x + (size_t)b * p.H * p.W * p.C + c;
+            const int n_items = IH * IWA;
+            const int dr = P / IWA, dc = P % IWA;
+            int r = pp / IWA, col = pp % IWA;
+            for (int i0 = pp; i0 < n_items; i0 += U * P) {
+                f32x4 v[U];
+                int dst[U];
+                unsigned loaded = 0;
+#pragma unroll
+                for (int u = 0; u < U; ++u) {
+                    const bool in = i0 + u * P < n_items;
+                    const int hi = hi0 + r, wi = col - p.pad_l;
+                    v[u] = zero;
+                    dst[u] = in ? (r * IWA + col) * CSP + lc * 4 : -1;
+                    if (in && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
+                        v[u] = *reinterpret_cast<const f32x4*>(xb + ((size_t)hi * p.W + wi) * p.C);
+                        loaded |= 1u << u;
+                    }
+                    r += dr, col += dc;
+                    if (col >= IWA) col -= IWA, ++r;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (dst[u] >= 0) {
+                        f32x4 w = v[u];
+                        if (XF && ((loaded >> u) & 1u)) {  // the arithmetic of dw_xf (csrc/ops.hip): what the forward kernel read
+                            w = w * xsc + xsh;
+                            if (p.in_act == ORBIT_ACT_SILU) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) w[k] = w[k] * __builtin_amdgcn_rcpf(1.0f + __expf(-w[k]));
+                            } else if (p.in_act == ORBIT_ACT_RELU) {
+#pragma unroll
+                                for (int k = 0; k < 4; ++k) w[k] = fmaxf(w[k], 0.f);
+                            }
+                        }
+                        *reinterpret_cast<f32x4*>(smw + dst[u]) = w;
+                    }
+            }
+        }
+        // the output gradients of this thread's first row are requested BEFORE the barrier (they do not depend on the patch), the
+        // next row's while the current one is consumed: a load per row iteration right before its use was a full HBM round trip
+        // per iteration at 2-3 waves per SIMD (28x28x240, 5x5: 182 us against 63 us for the forward kernel on the same patch)
+        const float* dyb = p.dy + ((size_t)b * p.Ho * p.Wo) * p.C + c;
+        f32x4 dn[4];
+        auto load_dy = [&](int ro) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int wo = g * 4 + j;
+                const bool ok = wo < p.Wo && ro < TH && rl < RL;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(dyb + ((size_t)(ho0 + (ok ? ro : 0)) * p.Wo + (ok ? wo : 0)) * p.C);
+                dn[j] = ok ? v : zero;
+            }
+        };
+        load_dy(rl);
+        __syncthreads();
+        if (rl < RL) {
+            for (int ro = rl; ro < TH; ro += RL) {
+                f32x4 d[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) d[j] = dn[j];
+                load_dy(ro + RL);
+                const float* t0 = smw + ((size_t)(ro * S) * IWA + g * 4 * S) * CSP + lc * 4;
+#pragma unroll
+                for (int kh = 0; kh < K; ++kh) {
+                    f32x4 col[NCOL];
+#pragma unroll
+                    for (int q = 0; q < NCOL; ++q) col[q] = *reinterpret_cast<const f32x4*>(t0 + (kh * IWA + q) * CSP);
+#pragma unroll
+                    for (int kw = 0; kw < K; ++kw)
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) acc[kh * K + kw] += d[j] * col[j * S + kw];
+                }
+            }
+        }
+    }
+    // reduce over the P pixel lanes of every channel quad through LDS, TB taps per round (TB * 256 float4 = 36 KiB for TB = 9):
+    // write [tap][lane][quad], then thread (tap, quad) sums its P lanes in lane order - two barriers per round instead of four
+    // per tap (at 7x7 a block walks two tiles: 100 barriers of epilogue cost more than its work)
+    constexpr int TB = 9;
+    f32x4* red = reinterpret_cast<f32x4*>(smw);
+#pragma unroll
+    for (int t0 = 0; t0 < K * K; t0 += TB) {
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < TB; ++t)
+            if (t0 + t < K * K) red[(t * P + pp) * cs4 + lc] = acc[t0 + t];
+        __syncthreads();
+        for (int o = tid; o < TB * cs4; o += 256) {
+            const int t = o / cs4, q = o - t * cs4;
+            if (t0 + t < K * K) {
+                f32x4 tot = red[(t * P) * cs4 + q];
+                for (int l = 1; l < P; ++l) tot += red[(t * P + l) * cs4 + q];
+                *reinterpret_cast<f32x4*>(p.partial + ((size_t)blockIdx.y * K * K + t0 + t) * p.C + (blockIdx.x * cs4 + q) * 4) = tot;
+            }
+        }
+    }
+}
+
+struct DwWgLdsGeom {
+    bool ok = false;
+    int cs4 = 0, rpc = 0, G = 0, IWA = 0, chunks = 0, tpb = 0, groups = 0;
+    size_t lds = 0;
+};
+// the (channel slice, row chunk) whose patch fits 60 KiB with the most work per staged patch; blocks walk `tpb` tiles so that
+// the launch has ~2048 blocks and at most 512 partial rows
+static DwWgLdsGeom dw_wgrad_lds_geom(int B, int H, int W, int C, int K, int S, int Ho, int Wo) {
+    DwWgLdsGeom g;
+    if (C % 4 != 0 || (K != 3 && K != 5) || (S != 1 && S != 2)) return g;
+    const int c4 = C / 4, G = cdiv(Wo, 4);
+    const int IWA = (4 * G - 1) * S + K;
+    long best = 0;
+    for (int cand : {16, 8, 4}) {
+        if (c4 % cand != 0 || G > 256 / cand) continue;
+        const int RL = (256 / cand) / G;
+        for (int rpc = std::min(Ho, 16); rpc >= 1; --rpc) {
+            const int IH = (rpc - 1) * S + K;
+            const size_t lds = std::max((size_t)IH * IWA * (cand * 4 + 4) * sizeof(float), (size_t)9 * 256 * 16);  // (epilogue buffer)
+            if (lds > 60 * 1024) continue;
+            // every row lane busy at least once, and prefer long contiguous runs per pixel
+            const long score = (long)std::min(rpc, 4 * RL) * cand * (rpc >= RL ? 2 : 1);
+            if (score > best) best = score, g.cs4 = cand, g.rpc = rpc, g.lds = lds;
+            break;  // the largest rpc that fits for this slice width
+        }
+    }
+    if (best == 0) return g;
+    g.ok = true, g.G = G, g.IWA = IWA;
+    g.chunks = cdiv(Ho, g.rpc);
+    const int tiles = B * g.chunks, ncg = c4 / g.cs4;
+    // (~4096 blocks / 2048 partial rows measured no faster: 260 against 237 us on the 112x112x32 layer)
+    int groups = std::max(1, std::min(std::min(512, tiles), 2048 / std::max(ncg, 1)));
+    g.tpb = cdiv(tiles, groups);
+    g.groups = cdiv(tiles, g.tpb);
+    return g;
+}
+bool dwconv_wgrad_xf_supported(int B, int H, int W, int C, int K, int stride, int Ho, int Wo) {
+    return dw_wgrad_lds_geom(B, H, W, C, K, stride, Ho, Wo).ok;
+}
+
 // dw[c][0][kh][kw] = sum over chunks of partial[chunk][tap][c]: 16 outputs per block, 16 lanes per output take every
 // 16th chunk, fixed-order LDS combine (a single thread walking ~1000 chunks is a 200 us latency chain)
 __global__ __launch_bounds__(256) void dwconv_wgrad_reduce_kernel(const float* __restrict__ partial, int chunks, int KK,
@@ -632,15 +814,45 @@ int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, 
 }
 
 size_t dwconv_wgrad_scratch_floats(int B, int Ho, int Wo, int C, int K) {
-    return (size_t)dwconv_wgrad_chunks(B, Ho, Wo, C) * K * K * C;
+    // (the LDS form writes at most 512 partial rows, whatever stride the caller's layer has)
+    return (size_t)std::max(dwconv_wgrad_chunks(B, Ho, Wo, C), 512) * K * K * C;
 }
 
 int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int C, int K,
-                        int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s) {
+                        int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, const float* in_scale,
+                        const float* in_shift, int in_act) {
     ORBIT_REQUIRE(C % 4 == 0 && (K == 3 || K == 5), "dwconv_wgrad: C %% 4 != 0 or K not in {3,5}");
+    ORBIT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dwconv_wgrad: the input transform needs scale and shift");
+    ORBIT_REQUIRE(stride == 1 || stride == 2, "dwconv_wgrad: stride %d", stride);
+    const DwWgLdsGeom lg = dw_wgrad_lds_geom(B, H, W, C, K, stride, Ho, Wo);
+    // Without the input transform the global-load form below stays the default: measured on the whole LITE step (one box,
+    // profiles/r05_lite_ab_taped_xf.txt) 31.40 ms against 31.55 ms with the LDS form everywhere - its gain is the transform
+    // (30.31 ms). ORBIT_DW_WGRAD_LDS=1 forces the LDS form (parity tests, A/B runs).
+    static const char* lds_env = getenv("ORBIT_DW_WGRAD_LDS");
+    ORBIT_REQUIRE(!in_scale || lg.ok, "dwconv_wgrad: the input transform needs the LDS form, which does not fit this layer");
+    if (lg.ok && (in_scale || (lds_env && atoi(lds_env) == 1))) {
+        DwWgLdsParams q;
+        q.x = x, q.dy = dy, q.partial = scratch, q.in_scale = in_scale, q.in_shift = in_shift, q.in_act = in_act;
+        q.H = H, q.W = W, q.C = C, q.pad_t = pad_t, q.pad_l = pad_l, q.Ho = Ho, q.Wo = Wo;
+        q.cs4 = lg.cs4, q.rpc = lg.rpc, q.G = lg.G, q.IWA = lg.IWA, q.chunks = lg.chunks, q.tiles_total = B * lg.chunks, q.tpb = lg.tpb;
+        const dim3 grid(C / 4 / lg.cs4, lg.groups);
+#define ORBIT_DWWL(KK, SS)                                                                          \
+    do {                                                                                            \
+        if (in_scale) dwconv_wgrad_lds_kernel<KK, SS, true><<<grid, 256, lg.lds, s>>>(q);           \
+        else dwconv_wgrad_lds_kernel<KK, SS, false><<<grid, 256, lg.lds, s>>>(q);                   \
+    } while (0)
+        if (K == 3 && stride == 1) ORBIT_DWWL(3, 1);
+        else if (K == 3) ORBIT_DWWL(3, 2);
+        else if (stride == 1) ORBIT_DWWL(5, 1);
+        else ORBIT_DWWL(5, 2);
+#undef ORBIT_DWWL
+        ORBIT_LAUNCH_CHECK();
+        dwconv_wgrad_reduce_kernel<<<cdiv(K * K * C, 16), 256, 0, s>>>(scratch, lg.groups, K * K, C, dw);
+        ORBIT_LAUNCH_CHECK();
+        return ORBIT_OK;
+    }
     int G, R, yg;
     dw_layout(C, G, R, yg);
-    ORBIT_REQUIRE(stride == 1 || stride == 2, "dwconv_wgrad: stride %d", stride);
     ORBIT_REQUIRE((long long)B * H * W * (C / 4) < (1ll << 31), "dwconv_wgrad: tensor too large for 32-bit pixel indices");
     // chunks of whole output rows; never more blocks than the scratch was sized for (dwconv_wgrad_chunks), and at least one
     // row per row lane
@@ -684,6 +896,20 @@ int orbit_op_dwconv2d_backward(const float* x, const float* w, const float* dy, 
         rc = launch_dwconv_dgrad(dy, tmp, dx, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, s, tmp + npack);
     if (rc == ORBIT_OK && dw)
         rc = launch_dwconv_wgrad(x, dy, dw, tmp + npack, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, s);
+    (void)hipFreeAsync(tmp, s);
+    return rc;
+}
+
+int orbit_op_dwconv2d_wgrad_xf(const float* x_raw, const float* in_scale, const float* in_shift, int in_act, const float* dy,
+                               float* dw, int B, int H, int W, int C, int K, int stride, int pad_top, int pad_left, int Ho, int Wo,
+                               orbit_stream_t stream) {
+    ORBIT_REQUIRE(x_raw && in_scale && in_shift && dy && dw, "op_dwconv2d_wgrad_xf: null pointer");
+    ORBIT_REQUIRE(dwconv_wgrad_xf_supported(B, H, W, C, K, stride, Ho, Wo), "op_dwconv2d_wgrad_xf: the LDS form does not fit this layer");
+    hipStream_t s = (hipStream_t)stream;
+    float* tmp = nullptr;
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), dwconv_wgrad_scratch_floats(B, Ho, Wo, C, K) * sizeof(float), s));
+    const int rc = launch_dwconv_wgrad(x_raw, dy, dw, tmp, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, s, in_scale, in_shift,
+                                       in_act);
     (void)hipFreeAsync(tmp, s);
     return rc;
 }

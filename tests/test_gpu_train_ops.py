@@ -336,6 +336,35 @@ def test_dwconv_backward(device, case):
     assert rel_err(dw.cpu(), w.grad) < 2e-5
 
 
+@pytest.mark.parametrize("case", DW_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("in_act", [2, 1])
+def test_dwconv_wgrad_with_input_transform(device, case, in_act):
+    """The LDS form of the depthwise filter gradient with the preceding BatchNorm + activation applied as the input patch is
+    staged (the taped LITE forward never writes the activated tensor): against autograd through act(x * scale + shift) ->
+    depthwise conv, incl. TF-SAME padding (the padding of the ACTIVATED tensor is zero), ragged chunks, every (K, stride)."""
+    lib = _lib.load()
+    B, C, H, W, K, stride, p0, p1 = case
+    if (C // 4) % 4 != 0:
+        pytest.skip("the LDS form stages slices of 4 / 8 / 16 channel quads (every depthwise layer of efficientnet_b0); a plan "
+                    "whose layer it does not fit keeps the separate activation pass")
+    g = torch.Generator().manual_seed(sum(case) + in_act)
+    x = torch.randn(B, C, H, W, generator=g) * 1.5
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3 + 0.2
+    w = (torch.randn(C, 1, K, K, generator=g) / K).requires_grad_(True)
+    a = x * sc[None, :, None, None] + sh[None, :, None, None]
+    a = F.silu(a) if in_act == 2 else F.relu(a)
+    y = F.conv2d(F.pad(a, [p0, p1, p0, p1]), w, None, stride, 0, 1, C)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    Ho, Wo = y.shape[2:]
+    t_x, t_dy, t_sc, t_sh = nhwc(x).to(device), nhwc(dy).to(device), sc.to(device), sh.to(device)
+    dw = torch.full((C, 1, K, K), float("nan"), device=device)
+    _lib.check(lib.orbit_op_dwconv2d_wgrad_xf(_lib.dptr(t_x), _lib.dptr(t_sc), _lib.dptr(t_sh), in_act, _lib.dptr(t_dy),
+                                              _lib.dptr(dw), B, H, W, C, K, stride, p0, p0, Ho, Wo, _st()), "dwconv2d_wgrad_xf")
+    torch.cuda.synchronize()
+    assert rel_err(dw.cpu(), w.grad) < 2e-5
+
+
 @pytest.mark.parametrize("B,HW,C,R", [(5, 49, 96, 4), (3, 16, 1152, 48), (2, 196, 144, 6), (7, 9, 32, 8)])
 def test_se_gate_backward(device, B, HW, C, R):
     lib = _lib.load()

@@ -12,7 +12,7 @@ cd /tmp && export TMPDIR=/tmp
 # kernels must run one at a time for their durations / counters to be attributable: the support/query stream overlap of
 # the timed leg is switched off here, exactly as bench.py does for its own roofline leg
 export ORBIT_BENCH_OVERLAP=0
-for W in efficientnet_b0_224 resnet18_84 resnet18_224; do
+for W in efficientnet_b0_224 resnet18_84 ${EXTRA_WORKLOADS:-}; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- \
       python $R/bench.py --workload $W --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_$W.json 2> $O/${TAG}_bench_$W.err
   cp $(ls $O/stats_$W/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_$W.csv
@@ -24,8 +24,9 @@ cp $(ls $O/stats_lite/*/*kernel_stats.csv | head -1) $O/${TAG}_kernel_stats_lite
 traffic() {  # traffic <name> <workload tag> <kernel substrings, |-separated> <bench.py args...>
   local NAME=$1 WL=$2 KERN=$3; shift 3
   for C in FETCH_SIZE WRITE_SIZE; do
-    timeout 900 rocprofv3 --pmc $C --output-format csv -d $O/pmc_${NAME}_$C -- \
-        python $R/bench.py "$@" --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/${TAG}_pmc_${NAME}_$C.err
+    # (counter collection serialises every dispatch: no settling chunks, eager launches, two steps - a LITE step is ~900 launches)
+    ORBIT_BENCH_SETTLE=0 ORBIT_TRAIN_GRAPH=0 ORBIT_GRAPH=0 timeout 600 rocprofv3 --pmc $C --output-format csv -d $O/pmc_${NAME}_$C -- \
+        python $R/bench.py "$@" --steps 2 --warmup 1 --no-cpu-baseline > /dev/null 2> $O/${TAG}_pmc_${NAME}_$C.err
     F=$(ls $O/pmc_${NAME}_$C/*/*counter_collection.csv | head -1)
     python - "$F" "$C" > $O/${TAG}_pmc_${NAME}_${C}_summary.txt <<'PY'
 import csv, sys, collections
@@ -98,10 +99,12 @@ print(json.dumps({"kernel": "orbit::proto_predict_stream_kernel<8, 2, 5, lean> (
                   "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes of tools/head_roofline.py quick; "
                             "FETCH_SIZE x2 (gfx950 wide-load correction), WRITE_SIZE as reported"}))
 PY
-# ---- SQ counters of the dense-conv kernels per layer shape, and of the pointwise register GEMM (own passes) ----------------
+# ---- SQ counters of the dense-conv kernels per layer shape, and of the pointwise register GEMM (own passes; FULL=1 only) -----
 cd $R
-bash tools/conv_pmc.sh $OUT/convpmc effnet_224 > /dev/null 2>&1; cp $O/convpmc/summary.txt $O/${TAG}_conv_sq_counters.txt 2>/dev/null
-bash tools/kernel_pmc.sh $OUT/rgemmpmc pw_rgemm python tools/rgemm_bench.py > /dev/null 2>&1; cp $O/rgemmpmc/summary.txt $O/${TAG}_rgemm_sq_counters.txt 2>/dev/null
+if [ "${FULL:-0}" = "1" ]; then
+  bash tools/conv_pmc.sh $OUT/convpmc effnet_224 > /dev/null 2>&1; cp $O/convpmc/summary.txt $O/${TAG}_conv_sq_counters.txt 2>/dev/null
+  bash tools/kernel_pmc.sh $OUT/rgemmpmc pw_rgemm python tools/rgemm_bench.py > /dev/null 2>&1; cp $O/rgemmpmc/summary.txt $O/${TAG}_rgemm_sq_counters.txt 2>/dev/null
+fi
 # raw rocprofv3 output stays on the box: only the summaries travel back (gpurun merges at most 64 MiB)
 rm -rf $O/stats_* $O/pmc_* $O/convpmc/pass* $O/rgemmpmc/pass* $O/bf3pmc/pass*
 ls -la $O | head -60
