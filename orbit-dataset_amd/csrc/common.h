@@ -120,12 +120,29 @@ bool conv_prof_enabled();
 int prof_start(const char* name, double flops, double bytes, hipStream_t s);
 void prof_stop(int idx, hipStream_t s);  // per-launch event profiling is on (graphs are bypassed while it is)
 
+// The depthwise DATA gradient fused with the first pass of the preceding BatchNorm's backward (the LITE step): the tensor a
+// depthwise dgrad produces is d(act(BatchNorm(y))) of the expansion conv before it; with this the kernel reads y at its output
+// pixels, writes g = dx * act'(y * scale + shift) instead of dx and emits the per-block channel sums of g and of g * xhat
+// (xhat = (y - mean) * invstd) to partial[block][2][C] - the layout bn_bwd_finalize reads - so that BatchNorm's backward needs
+// no reduction pass over (dx, y) of its own (launch_bn_backward_reduced finishes it).
+struct DwBnBwd {
+    const float* y = nullptr;  // raw output of the producing conv, laid out like the dgrad's output
+    const float* mean = nullptr;
+    const float* invstd = nullptr;
+    const float* scale = nullptr;
+    const float* shift = nullptr;
+    int act = 0;
+    float* partial = nullptr;
+    int* nblk = nullptr;  // out: partial rows written, 0 when the chosen kernel has no fused form (then dx was written plain)
+};
 // depthwise + fused SE pooling partials [B][chunks][C] (pool_partial may be nullptr); chunks = dwconv_se_chunks(Ho)
 int dwconv_se_chunks(int Ho);
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                      float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
                      int Wo, int act, hipStream_t s, int stats = 0, const float* in_scale = nullptr,
-                     const float* in_shift = nullptr, int in_act = 0);
+                     const float* in_shift = nullptr, int in_act = 0, const DwBnBwd* bnb = nullptr);
+// (bnb: the data-gradient use of these kernels - rotated taps, no scale / shift / activation, no pooling - with the
+// BatchNorm-backward epilogue above; *bnb->nblk tells whether the chosen kernel family had it)
 // in_scale / in_shift (with stats): x is the RAW output of the producing conv; act(x * in_scale[c] + in_shift[c]) is applied
 // as the kernel loads it, so the activated tensor of that layer is never written (no-backward passes of the LITE step)
 // stats != 0: pool_partial receives [B * dwconv_se_chunks(Ho)][2][C] column sums / sums of squares of the outputs instead
@@ -223,7 +240,9 @@ int launch_bn_backward_reduced(const float* g, const float* y, const float* mean
 // flip_scratch (K*K*C floats, optional): stride-1 layers then run as a FORWARD depthwise convolution of dy with the flipped
 // taps through the LDS-patch kernels of csrc/ops.hip instead of the per-pixel gather
 int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, int H, int W, int C, int K, int stride,
-                        int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, float* flip_scratch = nullptr);
+                        int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, float* flip_scratch = nullptr,
+                        const DwBnBwd* bnb = nullptr);
+int dwconv_dgrad_bn_blocks(int B, int H, int W, int C, int stride);  // upper bound of the partial rows a fused dgrad writes
 size_t dwconv_wgrad_scratch_floats(int B, int Ho, int Wo, int C, int K);
 int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int C, int K,
                         int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, const float* in_scale = nullptr,

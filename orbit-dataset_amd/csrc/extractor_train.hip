@@ -88,7 +88,13 @@ static size_t max_bn_partial_floats(const orbit_extractor* fe, int B) {
             const size_t M = (size_t)B * o.Ho * o.Wo;
             m = std::max(m, (size_t)bn_reduce_blocks((int)M, o.Cout) * 2 * o.Cout + 3 * (size_t)o.Cout);
             // statistics partials written by the producing kernel's epilogue (one per 32+ conv rows / per depthwise chunk)
-            if (o.kind == OP_CONV) m = std::max(m, bn_partial_floats((M + 31) / 32, o.Cout));
+            if (o.kind == OP_CONV) {
+                m = std::max(m, bn_partial_floats((M + 31) / 32, o.Cout));
+                // backward: reduction written by the data gradient of the depthwise convolution it feeds (+ coefficients)
+                for (int st : {1, 2})
+                    m = std::max(m, bn_partial_floats((size_t)dwconv_dgrad_bn_blocks(B, o.Ho, o.Wo, o.Cout, st), o.Cout) +
+                                        3 * (size_t)o.Cout);
+            }
             else m = std::max(m, bn_partial_floats((size_t)B * dwconv_se_chunks(o.Ho), o.Cout));
             // backward of a depthwise BatchNorm whose reduction rides on the squeeze-excite backward (+ 3*C coefficients)
             if (o.kind == OP_DWCONV)
@@ -570,7 +576,8 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
     bool used[BwdLayout::NSLOTS] = {false};
     std::vector<int> grad_slot(n, -1);  // gradient w.r.t. the OUTPUT tensor of op i
     // > 0: the slot of op i already holds g = d out * act'(.) and `partial` the [n][2][C] sums of its BatchNorm backward
-    // (written by the squeeze-excite backward of the block, launch_se_gate_backward with SeBnFuse)
+    // (written by the squeeze-excite backward of the block, launch_se_gate_backward with SeBnFuse, or - for the expansion
+    // convolution - by the data gradient of the depthwise convolution it feeds, DwBnBwd)
     std::vector<int> pre_reduced(n, 0);
     auto slot_ptr = [&](int k) { return reinterpret_cast<float*>(ws + W.slots + (size_t)k * W.slot_bytes); };
     auto alloc = [&]() {
@@ -672,8 +679,25 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                 SLOT_OR_FAIL(k);
                 grad_slot[src] = k;
                 // wgrad_scratch is free again here (the weight-gradient launches above are earlier on the stream)
+                // the producer is a convolution + BatchNorm + SiLU whose only reader is this layer: the data gradient goes
+                // through the activation in the same kernel and leaves the channel sums of that BatchNorm's backward, so the
+                // convolution's own backward starts at the finalize step (no reduction pass over dx and y)
+                const Op& po = fe->ops[src >= 0 ? src : 0];
+                int nblk = 0;
+                DwBnBwd bnb;
+                const DwBnBwd* bnb_ptr = nullptr;
+                if (src == i - 1 && po.kind == OP_CONV && bn_train && !po.pool2 && po.res < 0 && po.Cout % 4 == 0 &&
+                    fe->bns[po.bn].conv_bias < 0 && (po.act == ORBIT_ACT_SILU || po.act == ORBIT_ACT_NONE) &&
+                    get_option("train_dw_xf")) {
+                    const BNDesc& sbn = fe->bns[po.bn];
+                    bnb.y = tf(L.y[src]), bnb.mean = mean + sbn.fold_off, bnb.invstd = invstd + sbn.fold_off;
+                    bnb.scale = scale + sbn.fold_off, bnb.shift = shift + sbn.fold_off, bnb.act = po.act;
+                    bnb.partial = partial, bnb.nblk = &nblk;
+                    bnb_ptr = &bnb;
+                }
                 rc = launch_dwconv_dgrad(slot_ptr(kdy), fe->d_packed + o.packed_off, slot_ptr(k), B, o.H, o.W, o.Cin, o.KH,
-                                         o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s, wgrad_scratch);
+                                         o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s, wgrad_scratch, bnb_ptr);
+                if (bnb_ptr) pre_reduced[src] = nblk;  // 0: that kernel form has no such epilogue, the slot holds plain dx
             }
             release(kdy);
         } else {  // OP_CONV
@@ -717,11 +741,19 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                 kdy = alloc();
                 if (kdy < 0) return set_err(ORBIT_ERR_STATE, "extractor_backward: gradient slots exhausted");
             }
-            // partial holds [blocks][2][C] followed by the 3*C apply coefficients
-            float* coef = partial + (size_t)bn_reduce_blocks(M, o.Cout) * 2 * o.Cout;
-            rc = launch_bn_backward(slot_ptr(g), tf(L.a[i]), tf(L.y[i]), mean + bn.fold_off, invstd + bn.fold_off, gamma,
-                                    scale + bn.fold_off, shift + bn.fold_off, bn_train, o.act, M, o.Cout,
-                                    need_dy ? slot_ptr(kdy) : nullptr, dres, dres_acc, dgam, dbet, dbias, partial, coef, s);
+            if (pre_reduced[i] > 0) {
+                ORBIT_REQUIRE(!dres && !dbias && !o.pool2, "extractor_backward: pre-reduced BatchNorm with a residual or bias");
+                float* coef = partial + bn_partial_floats((size_t)pre_reduced[i], o.Cout);
+                rc = launch_bn_backward_reduced(slot_ptr(g), tf(L.y[i]), mean + bn.fold_off, invstd + bn.fold_off, gamma,
+                                                bn_train, M, o.Cout, need_dy ? slot_ptr(kdy) : nullptr, dgam, dbet, partial,
+                                                pre_reduced[i], coef, s);
+            } else {
+                // partial holds [blocks][2][C] followed by the 3*C apply coefficients
+                float* coef = partial + (size_t)bn_reduce_blocks(M, o.Cout) * 2 * o.Cout;
+                rc = launch_bn_backward(slot_ptr(g), tf(L.a[i]), tf(L.y[i]), mean + bn.fold_off, invstd + bn.fold_off, gamma,
+                                        scale + bn.fold_off, shift + bn.fold_off, bn_train, o.act, M, o.Cout,
+                                        need_dy ? slot_ptr(kdy) : nullptr, dres, dres_acc, dgam, dbet, dbias, partial, coef, s);
+            }
             if (rc != ORBIT_OK) return rc;
             if (!need_dy && dres) {
                 // reductions only, but the residual branch still needs g: rerun the apply pass is not available

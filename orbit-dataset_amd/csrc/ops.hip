@@ -30,6 +30,28 @@ struct DwInXf {
     const float* shift;
     int act;
 };
+// BatchNorm-backward epilogue of the data-gradient use (DwBnBwd, common.h): g = dx * act'(z), z = y * scale + shift; the fast
+// exp / rcp of the forward activation; returns g and adds g, g * xhat to the running sums
+struct DwBnbVec {
+    v4f sc, sh, mu, is;
+};
+__device__ __forceinline__ v4f dw_bnb(v4f dx, v4f yv, const DwBnbVec& b, int act, v4f& s0, v4f& s1) {
+    const v4f z = yv * b.sc + b.sh;
+    v4f g = dx;
+    if (act == ORBIT_ACT_SILU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z[k]));
+            g[k] *= sg * (1.0f + z[k] * (1.0f - sg));
+        }
+    } else if (act == ORBIT_ACT_RELU) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) g[k] = z[k] > 0.f ? g[k] : 0.f;
+    }
+    s0 += g;
+    s1 += g * ((yv - b.mu) * b.is);
+    return g;
+}
 __device__ __forceinline__ v4f dw_xf(v4f v, v4f isc, v4f ish, int act) {
     v = v * isc + ish;
     if (act == ORBIT_ACT_RELU) {
@@ -299,13 +321,14 @@ __global__ __launch_bounds__(256) void dwconv_pipe_kernel(const float* __restric
 // (K x NCOL quads) in registers: every output row loads only the S new input rows instead of all K, i.e. 3-5x fewer
 // L1/L2 requests (the plain kernel re-reads each input ~K*NCOL/NOUT times and is L2-bandwidth-bound on the 5x5 layers).
 // The ring slot of an input row is static: the row loop is unrolled over one ring period (K steps).
-template <int K, int S, int NOUT, bool STATS = false, bool XF = false>
+template <int K, int S, int NOUT, bool STATS = false, bool XF = false, bool BNB = false>
 __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          float* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          float* __restrict__ pool_partial, int H, int W, int C,
                                                          int pad_t, int pad_l, int Ho, int Wo, int act, int cb4,
-                                                         int rows_per_chunk, DwInXf xf = DwInXf{nullptr, nullptr, 0}) {
+                                                         int rows_per_chunk, DwInXf xf = DwInXf{nullptr, nullptr, 0},
+                                                         DwBnBwd bnb = DwBnBwd{}) {
     constexpr int NCOL = (NOUT - 1) * S + K;
     extern __shared__ __attribute__((aligned(16))) float smw[];
     v4f* wl = reinterpret_cast<v4f*>(smw);  // [K*K][cb4]
@@ -329,6 +352,13 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
     if (XF) isc = *reinterpret_cast<const v4f*>(xf.scale + c), ish = *reinterpret_cast<const v4f*>(xf.shift + c);
     const float* xb = x + (size_t)b * H * W * C + c;
     float* yb = y + (size_t)b * Ho * Wo * C + c;
+    DwBnbVec bv;
+    const float* byb = nullptr;
+    if (BNB) {
+        bv.sc = *reinterpret_cast<const v4f*>(bnb.scale + c), bv.sh = *reinterpret_cast<const v4f*>(bnb.shift + c);
+        bv.mu = *reinterpret_cast<const v4f*>(bnb.mean + c), bv.is = *reinterpret_cast<const v4f*>(bnb.invstd + c);
+        byb = bnb.y + (size_t)b * Ho * Wo * C + c;
+    }
     const int ho0 = chunk * rows_per_chunk;
     const int ho_end = min(Ho, ho0 + rows_per_chunk);
     const int WQ = (Wo + NOUT - 1) / NOUT;
@@ -366,6 +396,12 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
 #pragma unroll
                         for (int s2 = 0; s2 < S; ++s2)
                             load_row(hi_base + rel + ph * S + K - S + s2, win[(ph * S + K - S + s2) % K]);
+                        v4f yv[NOUT];  // BNB: the producer's raw outputs under this row's results, in flight with the row above
+                        if (BNB) {
+#pragma unroll
+                            for (int j = 0; j < NOUT; ++j)
+                                yv[j] = *reinterpret_cast<const v4f*>(byb + ((size_t)ho * Wo + min(wq * NOUT + j, Wo - 1)) * C);
+                        }
                         v4f acc[NOUT];
 #pragma unroll
                         for (int j = 0; j < NOUT; ++j) acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -382,12 +418,16 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
                         for (int j = 0; j < NOUT; ++j) {
                             const int wo = wq * NOUT + j;
                             if (wo < Wo) {
-                                v4f o = acc[j] * sc + sh;
-                                o[0] = act_fn(o[0], act), o[1] = act_fn(o[1], act), o[2] = act_fn(o[2], act),
-                                o[3] = act_fn(o[3], act);
-                                *reinterpret_cast<v4f*>(yb + ((size_t)ho * Wo + wo) * C) = o;
-                                psum += o;
-                                if (STATS) psq += o * o;
+                                if (BNB) {
+                                    *reinterpret_cast<v4f*>(yb + ((size_t)ho * Wo + wo) * C) = dw_bnb(acc[j], yv[j], bv, bnb.act, psum, psq);
+                                } else {
+                                    v4f o = acc[j] * sc + sh;
+                                    o[0] = act_fn(o[0], act), o[1] = act_fn(o[1], act), o[2] = act_fn(o[2], act),
+                                    o[3] = act_fn(o[3], act);
+                                    *reinterpret_cast<v4f*>(yb + ((size_t)ho * Wo + wo) * C) = o;
+                                    psum += o;
+                                    if (STATS) psq += o * o;
+                                }
                             }
                         }
                     }
@@ -423,14 +463,14 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
 // once - and the taps are ds_read_b128 (4x the L1's bytes per clock). Pixel stride is padded by one quad so that the
 // lanes of a read (same channel quad, neighbouring pixels) spread over the banks.
 // Thread = channel quad x (4-column output group, row lane); outputs, pooling partials and chunking as dwconv_se_kernel.
-template <int K, int S, int U, bool STATS = false, bool XF = false>
+template <int K, int S, int U, bool STATS = false, bool XF = false, bool BNB = false>
 __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          float* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
                                                          float* __restrict__ pool_partial, int H, int W, int C,
                                                          int pad_t, int pad_l, int Ho, int Wo, int act, int cs4,
                                                          int rows_per_chunk, int G, int IWA,
-                                                         DwInXf xf = DwInXf{nullptr, nullptr, 0}) {
+                                                         DwInXf xf = DwInXf{nullptr, nullptr, 0}, DwBnBwd bnb = DwBnBwd{}) {
     constexpr int NCOL = 3 * S + K;
     extern __shared__ __attribute__((aligned(16))) float sml[];
     const int CSP = cs4 * 4 + 4;                     // padded pixel stride (floats)
@@ -497,6 +537,13 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict
     const int RL = P / G;                            // row lanes
     const int g = p % G, rl = p / G;
     float* yb = y + (size_t)b * Ho * Wo * C + c;
+    DwBnbVec bv;
+    const float* byb = nullptr;
+    if (BNB) {
+        bv.sc = *reinterpret_cast<const v4f*>(bnb.scale + c), bv.sh = *reinterpret_cast<const v4f*>(bnb.shift + c);
+        bv.mu = *reinterpret_cast<const v4f*>(bnb.mean + c), bv.is = *reinterpret_cast<const v4f*>(bnb.invstd + c);
+        byb = bnb.y + (size_t)b * Ho * Wo * C + c;
+    }
     if (rl < RL) {
         for (int ro = rl; ro < TH; ro += RL) {
             v4f acc[4];
@@ -504,6 +551,13 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict
             for (int j = 0; j < 4; ++j) acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
             const float* t0 = tile + ((size_t)(ro * S) * IWA + g * 4 * S) * CSP + lc * 4;
             const v4f* wk = wl + lc;
+            const int ho = ho0 + ro;
+            v4f yv[4];  // BNB: the producer's raw outputs under these four results, in flight with the tap loop
+            if (BNB) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    yv[j] = *reinterpret_cast<const v4f*>(byb + ((size_t)ho * Wo + min(g * 4 + j, Wo - 1)) * C);
+            }
             // a real loop over the tap rows: fully unrolled, the compiler hoists all K*(NCOL + K) LDS reads (260 VGPRs,
             // one wave per SIMD); one tap row is NCOL + K reads in flight and 4*K quad FMAs
 #pragma unroll 1
@@ -520,16 +574,19 @@ __global__ __launch_bounds__(256) void dwconv_lds_kernel(const float* __restrict
                 t0 += IWA * CSP;
                 wk += K * cs4;
             }
-            const int ho = ho0 + ro;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int wo = g * 4 + j;
                 if (wo < Wo) {
-                    v4f o = acc[j] * sc + sh;
-                    o[0] = act_fn(o[0], act), o[1] = act_fn(o[1], act), o[2] = act_fn(o[2], act), o[3] = act_fn(o[3], act);
-                    *reinterpret_cast<v4f*>(yb + ((size_t)ho * Wo + wo) * C) = o;
-                    psum += o;
-                    if (STATS) psq += o * o;
+                    if (BNB) {
+                        *reinterpret_cast<v4f*>(yb + ((size_t)ho * Wo + wo) * C) = dw_bnb(acc[j], yv[j], bv, bnb.act, psum, psq);
+                    } else {
+                        v4f o = acc[j] * sc + sh;
+                        o[0] = act_fn(o[0], act), o[1] = act_fn(o[1], act), o[2] = act_fn(o[2], act), o[3] = act_fn(o[3], act);
+                        *reinterpret_cast<v4f*>(yb + ((size_t)ho * Wo + wo) * C) = o;
+                        psum += o;
+                        if (STATS) psq += o * o;
+                    }
                 }
             }
         }
@@ -794,8 +851,15 @@ int dwconv_se_chunks(int Ho) { return cdiv(Ho, dwconv_se_rows_per_chunk(Ho)); }
 
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                      float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
-                     int Wo, int act, hipStream_t s, int stats, const float* in_scale, const float* in_shift, int in_act) {
+                     int Wo, int act, hipStream_t s, int stats, const float* in_scale, const float* in_shift, int in_act, const DwBnBwd* bnb) {
     ORBIT_REQUIRE(x && w_khwc && y, "dwconv_se: null pointer");
+    if (bnb) {
+        ORBIT_REQUIRE(bnb->y && bnb->mean && bnb->invstd && bnb->scale && bnb->shift && bnb->partial && bnb->nblk,
+                      "dwconv_se: incomplete BatchNorm-backward epilogue");
+        ORBIT_REQUIRE(!stats && !in_scale && !scale && !shift && !pool_partial && stride == 1 && act == ORBIT_ACT_NONE,
+                      "dwconv_se: the BatchNorm-backward epilogue belongs to the plain stride-1 data-gradient use");
+        *bnb->nblk = 0;
+    }
     ORBIT_REQUIRE(!stats || pool_partial, "dwconv_se: statistics requested without a buffer");
     ORBIT_REQUIRE((in_scale == nullptr) == (in_shift == nullptr), "dwconv_se: the input transform needs scale and shift");
     ORBIT_REQUIRE(!in_scale || stats, "dwconv_se: the input transform is instantiated for the statistics form only");
@@ -835,7 +899,13 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
                 const bool deep = IHmax * IWA > 8 * (256 / cs4);
 #define ORBIT_DWL(KK, SS)                                                                                              \
     do {                                                                                                               \
-        if (use_xf)                                                                                                    \
+        if (bnb) {                                                                                                     \
+            if constexpr (SS == 1)                                                                                     \
+                dwconv_lds_kernel<KK, SS, 8, true, false, true><<<gl, 256, ldsb, s>>>(x, w_khwc, y, nullptr, nullptr, bnb->partial, H, \
+                                                                                      W, C, pad_t, pad_l, Ho, Wo, act, cs4, rpc, G,  \
+                                                                                      IWA, DwInXf{nullptr, nullptr, 0}, *bnb); \
+            *bnb->nblk = (int)(gl.y * gl.z);                                                                           \
+        } else if (use_xf)                                                                                             \
             dwconv_lds_kernel<KK, SS, 8, true, true><<<gl, 256, ldsb, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, W, \
                                                                            C, pad_t, pad_l, Ho, Wo, act, cs4, rpc, G,  \
                                                                            IWA, xf);                                   \
@@ -868,7 +938,14 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     if (win_opt == 2 || (win_opt == 1 && K == 3 && stride == 1 && Ho >= 14)) {
 #define ORBIT_DWW(KK, SS, NO)                                                                                          \
     do {                                                                                                               \
-        if (use_xf)                                                                                                    \
+        if (bnb) {                                                                                                     \
+            if constexpr (SS == 1)                                                                                     \
+                dwconv_win_kernel<KK, SS, NO, true, false, true><<<grid, 256, lds, s>>>(x, w_khwc, y, nullptr, nullptr,   \
+                                                                                        bnb->partial, H, W, C, pad_t, pad_l, Ho, Wo, \
+                                                                                        act, cb4, rpc, DwInXf{nullptr, nullptr, 0}, \
+                                                                                        *bnb);                         \
+            *bnb->nblk = (int)(grid.y * grid.z);                                                                       \
+        } else if (use_xf)                                                                                             \
             dwconv_win_kernel<KK, SS, NO, true, true><<<grid, 256, lds, s>>>(x, w_khwc, y, scale, shift, pool_partial, H, \
                                                                              W, C, pad_t, pad_l, Ho, Wo, act, cb4, rpc, \
                                                                              xf);                                      \

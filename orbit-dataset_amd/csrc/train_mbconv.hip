@@ -350,13 +350,16 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restri
 // filter loads behind per-tap branches for EVERY pixel: 561 / 409 us on the 112x112x96 / 56x56x144 layers of
 // efficientnet_b0 against ~240 / ~90 us of HBM time) and the filter taps from LDS. PT / PL = parity of pad_t / pad_l
 // (compile time, so that every register index is static).
-template <int K, int PT, int PL>
+// BNB: the BatchNorm-backward epilogue of DwBnBwd (common.h): g = dx * act'(y * scale + shift) is written instead of dx and every
+// block emits the channel sums of g and g * xhat over ITS 2x2 blocks (a fixed set: deterministic) to partial[blockIdx.x][2][C].
+template <int K, int PT, int PL, bool BNB = false>
 __global__ __launch_bounds__(256) void dwconv_dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                               float* __restrict__ dx, int B, int H, int W, int C4,
-                                                              int pad_t, int pad_l, int Ho, int Wo, int G, int R) {
+                                                              int pad_t, int pad_l, int Ho, int Wo, int G, int R,
+                                                              DwBnBwd bnb = DwBnBwd{}) {
     constexpr int NR = (K + 1) / 2;  // dy rows / columns one 2x2 block touches (2 for 3x3, 3 for 5x5)
     extern __shared__ __attribute__((aligned(16))) float smd[];
-    f32x4* wl = reinterpret_cast<f32x4*>(smd);  // [K*K][G]
+    f32x4* wl = reinterpret_cast<f32x4*>(smd);  // [K*K][G] (+ [2][256] for the BNB sums)
     const int tid = threadIdx.x;
     const int rl = tid / G, qi = tid - rl * G, q = blockIdx.y * G + qi;
     for (int i = tid; i < K * K * G; i += 256) {
@@ -364,11 +367,17 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_s2_kernel(const float* __res
         wl[i] = qq < C4 ? reinterpret_cast<const f32x4*>(w)[(size_t)tap * C4 + qq] : (f32x4){0.f, 0.f, 0.f, 0.f};
     }
     __syncthreads();
-    if (rl >= R || q >= C4) return;
+    const bool live = rl < R && q < C4;
+    if (!BNB && !live) return;
     const int H2 = (H + 1) >> 1, W2 = (W + 1) >> 1;
     const unsigned total = (unsigned)B * H2 * W2;  // 2x2 blocks (launcher: < 2^31)
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    for (unsigned i = blockIdx.x * R + rl; i < total; i += gridDim.x * R) {
+    f32x4 s0 = zero, s1 = zero, bsc = zero, bsh = zero, bmu = zero, bis = zero;
+    if (BNB && live) {
+        bsc = reinterpret_cast<const f32x4*>(bnb.scale)[q], bsh = reinterpret_cast<const f32x4*>(bnb.shift)[q];
+        bmu = reinterpret_cast<const f32x4*>(bnb.mean)[q], bis = reinterpret_cast<const f32x4*>(bnb.invstd)[q];
+    }
+    for (unsigned i = blockIdx.x * R + rl; live && i < total; i += gridDim.x * R) {
         const unsigned bw = i / (unsigned)W2, b = bw / (unsigned)H2;
         const int w0 = (int)(i - bw * W2) * 2, h0 = (int)(bw - b * H2) * 2;
         // dy patch: rows hb .. hb + NR - 1, hb = the smallest output row any tap of row h0 reaches
@@ -390,6 +399,15 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_s2_kernel(const float* __res
             }
         }
         f32x4* dxb = reinterpret_cast<f32x4*>(dx) + (size_t)b * H * W * C4 + q;
+        f32x4 yq[2][2];  // BNB: the producer's raw outputs under the 2x2 block, in flight with the dy patch
+        if (BNB) {
+            const f32x4* yb = reinterpret_cast<const f32x4*>(bnb.y) + (size_t)b * H * W * C4 + q;
+#pragma unroll
+            for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+                for (int dw = 0; dw < 2; ++dw)
+                    yq[dh][dw] = yb[(size_t)(min(h0 + dh, H - 1) * W + min(w0 + dw, W - 1)) * C4];
+        }
 #pragma unroll
         for (int dh = 0; dh < 2; ++dh) {
 #pragma unroll
@@ -405,8 +423,39 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_s2_kernel(const float* __res
                         acc += patch[r][c] * wl[(kh * K + kw) * G + qi];
                     }
                 }
-                if (h0 + dh < H && w0 + dw < W) dxb[(size_t)((h0 + dh) * W + (w0 + dw)) * C4] = acc;
+                if (h0 + dh < H && w0 + dw < W) {
+                    const size_t o = (size_t)((h0 + dh) * W + (w0 + dw)) * C4;
+                    if (BNB) {
+                        const f32x4 yv = yq[dh][dw];
+                        const f32x4 z = yv * bsc + bsh;
+                        if (bnb.act == ORBIT_ACT_SILU) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) {
+                                const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z[k]));
+                                acc[k] *= sg * (1.0f + z[k] * (1.0f - sg));
+                            }
+                        } else if (bnb.act == ORBIT_ACT_RELU) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) acc[k] = z[k] > 0.f ? acc[k] : 0.f;
+                        }
+                        s0 += acc;
+                        s1 += acc * ((yv - bmu) * bis);
+                    }
+                    dxb[o] = acc;
+                }
             }
+        }
+    }
+    if (BNB) {
+        f32x4* red = wl + K * K * G;  // [2][256]
+        red[tid] = s0, red[256 + tid] = s1;
+        __syncthreads();
+        if (rl == 0 && q < C4) {
+            f32x4 a = red[qi], c2 = red[256 + qi];
+            for (int j = 1; j < R; ++j) a += red[j * G + qi], c2 += red[256 + j * G + qi];
+            float* out = bnb.partial + (size_t)blockIdx.x * 2 * (C4 * 4) + q * 4;
+            *reinterpret_cast<f32x4*>(out) = a;
+            *reinterpret_cast<f32x4*>(out + C4 * 4) = c2;
         }
     }
 }
@@ -772,8 +821,21 @@ __global__ __launch_bounds__(256) void dwconv_flip_kernel(const float* __restric
     }
 }
 
+static int dgrad_s2_blocks(int B, int H, int W, int C) {
+    int G, R, yg;
+    dw_layout(C, G, R, yg);
+    const size_t blocks2 = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+    // (2048 row blocks when the BatchNorm sums ride along: each is a partial row of 2 * C floats; 16384 without)
+    return (int)std::min<size_t>((blocks2 + R - 1) / R, 16384);
+}
+int dwconv_dgrad_bn_blocks(int B, int H, int W, int C, int stride) {
+    if (stride == 1) return B * dwconv_se_chunks(H);
+    return std::min(dgrad_s2_blocks(B, H, W, C), 2048);
+}
+
 int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, int H, int W, int C, int K, int stride,
-                        int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, float* flip_scratch) {
+                        int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, float* flip_scratch, const DwBnBwd* bnb) {
+    if (bnb) *bnb->nblk = 0;
     if (stride == 1 && flip_scratch != nullptr) {
         // dx[h][w] = sum dy[h + pad_t - kh][w + pad_l - kw] w[kh][kw] = a forward depthwise conv of dy with the rotated
         // taps and padding K-1-pad: the LDS-patch forward kernels (35-60 us on these layers) replace the gather below
@@ -781,7 +843,7 @@ int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, 
         dwconv_flip_kernel<<<cdiv(K * K * C, 256), 256, 0, s>>>(w_khwc, flip_scratch, K * K, C);
         ORBIT_LAUNCH_CHECK();
         return launch_dwconv_se(dy, flip_scratch, dx, nullptr, nullptr, nullptr, B, Ho, Wo, C, K, 1, K - 1 - pad_t,
-                                K - 1 - pad_l, H, W, ORBIT_ACT_NONE, s);
+                                K - 1 - pad_l, H, W, ORBIT_ACT_NONE, s, 0, nullptr, nullptr, 0, bnb);
     }
 
     ORBIT_REQUIRE(C % 4 == 0 && (K == 3 || K == 5), "dwconv_dgrad: C %% 4 != 0 or K not in {3,5}");
@@ -789,12 +851,18 @@ int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, 
         // 2x2-block form: one dy patch + LDS taps per four outputs (see dwconv_dgrad_s2_kernel)
         int G, R, yg;
         dw_layout(C, G, R, yg);
-        const size_t blocks2 = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
-        int gx = (int)std::min<size_t>((blocks2 + R - 1) / R, 16384);
-        const size_t lds = (size_t)K * K * G * sizeof(f32x4);
+        int gx = dgrad_s2_blocks(B, H, W, C);
+        if (bnb) gx = std::min(gx, 2048), *bnb->nblk = gx;
+        const size_t lds = (size_t)(K * K * G + (bnb ? 512 : 0)) * sizeof(f32x4);
 #define ORBIT_DG2(KK, PT_, PL_)                                                                                       \
-    dwconv_dgrad_s2_kernel<KK, PT_, PL_><<<dim3(gx, yg), 256, lds, s>>>(dy, w_khwc, dx, B, H, W, C / 4, pad_t, pad_l, Ho, \
-                                                                        Wo, G, R)
+    do {                                                                                                              \
+        if (bnb)                                                                                                      \
+            dwconv_dgrad_s2_kernel<KK, PT_, PL_, true><<<dim3(gx, yg), 256, lds, s>>>(dy, w_khwc, dx, B, H, W, C / 4, pad_t,  \
+                                                                                      pad_l, Ho, Wo, G, R, *bnb);     \
+        else                                                                                                          \
+            dwconv_dgrad_s2_kernel<KK, PT_, PL_><<<dim3(gx, yg), 256, lds, s>>>(dy, w_khwc, dx, B, H, W, C / 4, pad_t, pad_l, \
+                                                                                Ho, Wo, G, R);                        \
+    } while (0)
         const int pt = pad_t & 1, pl = pad_l & 1;
         if (K == 3) {
             if (!pt && !pl) ORBIT_DG2(3, 0, 0); else if (!pt) ORBIT_DG2(3, 0, 1); else if (!pl) ORBIT_DG2(3, 1, 0); else ORBIT_DG2(3, 1, 1);
@@ -896,6 +964,26 @@ int orbit_op_dwconv2d_backward(const float* x, const float* w, const float* dy, 
         rc = launch_dwconv_dgrad(dy, tmp, dx, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, s, tmp + npack);
     if (rc == ORBIT_OK && dw)
         rc = launch_dwconv_wgrad(x, dy, dw, tmp + npack, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, s);
+    (void)hipFreeAsync(tmp, s);
+    return rc;
+}
+
+int orbit_op_dwconv2d_dgrad_bn(const float* dy, const float* w, const float* y_raw, const float* mean, const float* invstd,
+                               const float* scale, const float* shift, int act, float* g, float* sums, int B, int H, int W, int C,
+                               int K, int stride, int pad_top, int pad_left, int Ho, int Wo, orbit_stream_t stream) {
+    ORBIT_REQUIRE(dy && w && y_raw && mean && invstd && scale && shift && g && sums, "op_dwconv2d_dgrad_bn: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    float* tmp = nullptr;
+    const size_t npack = (size_t)(C * K * K + 3) / 4 * 4;
+    const size_t nscr = dwconv_wgrad_scratch_floats(B, Ho, Wo, C, K);
+    const size_t npart = bn_partial_floats((size_t)dwconv_dgrad_bn_blocks(B, H, W, C, stride), C);
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), (npack + nscr + npart) * sizeof(float), s));
+    int nblk = 0;
+    const DwBnBwd bnb{y_raw, mean, invstd, scale, shift, act, tmp + npack + nscr, &nblk};
+    int rc = dwconv_pack_weights(w, tmp, C, K, s);
+    if (rc == ORBIT_OK) rc = launch_dwconv_dgrad(dy, tmp, g, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, s, tmp + npack, &bnb);
+    if (rc == ORBIT_OK && nblk <= 0) rc = set_err(ORBIT_ERR_ARG, "op_dwconv2d_dgrad_bn: no kernel form with the epilogue for this layer");
+    if (rc == ORBIT_OK) rc = launch_sum_partials(bnb.partial, nblk, C, sums, s);
     (void)hipFreeAsync(tmp, s);
     return rc;
 }

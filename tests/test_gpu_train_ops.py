@@ -312,6 +312,7 @@ DW_CASES = [
     (2, 40, 11, 9, 3, 2, 1, 1),      # stride 2, odd map, padding parity 1 (the 2x2-block data-gradient kernel's 4th variant)
     (3, 672, 14, 14, 5, 2, 1, 2),    # efficientnet_b0 block 5.0's depthwise layer
     (1, 96, 112, 112, 3, 2, 0, 1),   # block 1.0's (the largest tensor of the network)
+    (2, 48, 30, 28, 3, 1, 1, 1),     # 3x3 stride 1 above 14 rows: the register-window kernel form
 ]
 
 
@@ -363,6 +364,45 @@ def test_dwconv_wgrad_with_input_transform(device, case, in_act):
                                               _lib.dptr(dw), B, H, W, C, K, stride, p0, p0, Ho, Wo, _st()), "dwconv2d_wgrad_xf")
     torch.cuda.synchronize()
     assert rel_err(dw.cpu(), w.grad) < 2e-5
+
+
+@pytest.mark.parametrize("case", DW_CASES, ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("act", [2, 0])
+def test_dwconv_dgrad_with_batchnorm_epilogue(device, case, act):
+    """The depthwise data gradient that goes on through the producer's SiLU and leaves the sums of that producer's BatchNorm
+    backward (sum g, sum g * xhat): against autograd through act(y * scale + shift) -> depthwise conv, every (K, stride),
+    TF-SAME padding, ragged chunks. A layer no kernel form with the epilogue fits reports ORBIT_ERR_ARG (the plan then
+    keeps the separate reduction pass)."""
+    lib = _lib.load()
+    B, C, H, W, K, stride, p0, p1 = case
+    g = torch.Generator().manual_seed(sum(case) + 7 * act)
+    yr = (torch.randn(B, C, H, W, generator=g) * 1.5).requires_grad_(True)
+    sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3 + 0.2
+    mean, invstd = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5
+    w = torch.randn(C, 1, K, K, generator=g) / K
+    z = yr * sc[None, :, None, None] + sh[None, :, None, None]
+    a = F.silu(z) if act == 2 else z
+    out = F.conv2d(F.pad(a, [p0, p1, p0, p1]), w, None, stride, 0, 1, C)
+    dy = torch.randn(out.shape, generator=g)
+    out.backward(dy)
+    gz = (yr.grad / sc[None, :, None, None]).double()  # d loss / d z
+    xhat = ((yr.detach() - mean[None, :, None, None]) * invstd[None, :, None, None]).double()
+    want_sums = torch.stack([gz.sum(dim=(0, 2, 3)), (gz * xhat).sum(dim=(0, 2, 3))])
+    Ho, Wo = out.shape[2:]
+    dev = lambda t: t.detach().float().to(device).contiguous()
+    t_dy, t_w, t_y = dev(nhwc(dy)), dev(w), dev(nhwc(yr.detach()))
+    t_m, t_i, t_sc, t_sh = dev(mean), dev(invstd), dev(sc), dev(sh)
+    gout = torch.full((B, H, W, C), float("nan"), device=device)
+    sums = torch.full((2, C), float("nan"), device=device)
+    rc = lib.orbit_op_dwconv2d_dgrad_bn(_lib.dptr(t_dy), _lib.dptr(t_w), _lib.dptr(t_y), _lib.dptr(t_m), _lib.dptr(t_i),
+                                        _lib.dptr(t_sc), _lib.dptr(t_sh), act, _lib.dptr(gout), _lib.dptr(sums), B, H, W, C, K,
+                                        stride, p0, p0, Ho, Wo, _st())
+    if rc == -1:
+        pytest.skip("no kernel form with the epilogue for this layer: " + _lib.last_error())
+    _lib.check(rc, "dwconv2d_dgrad_bn")
+    torch.cuda.synchronize()
+    assert rel_err(gout.cpu(), nhwc(gz.float())) < 2e-5
+    assert rel_err(sums.cpu().double(), want_sums) < 2e-5
 
 
 @pytest.mark.parametrize("B,HW,C,R", [(5, 49, 96, 4), (3, 16, 1152, 48), (2, 196, 144, 6), (7, 9, 32, 8)])
