@@ -415,11 +415,13 @@ int orbit_op_dwconv2d_backward(const float* x, const float* w, const float* dy, 
 /* The depthwise data gradient continued through the producer's activation, with the first pass of that producer's BatchNorm
  * backward in its epilogue: g = dx * act'(y_raw * scale[c] + shift[c]) [B][H][W][C] and sums [2][C] = sum over (b,h,w) of g and
  * of g * (y_raw - mean[c]) * invstd[c] (reference: autograd through timm InvertedResidual's conv_dw <- act1 <- bn1,
- * few_shot_recognisers.py:99-122). Fails with ORBIT_ERR_ARG where no kernel form carries the epilogue (the caller then runs
- * the plain data gradient + the BatchNorm backward's own reduction). Single-operator entry for the parity tests. */
+ * few_shot_recognisers.py:99-122). dw (optional, [C][1][K][K]): the layer's filter gradient from the same pass - its input is
+ * act(y_raw * scale + shift), rebuilt at the output pixels anyway (stride-2 layers). Fails with ORBIT_ERR_ARG where no kernel
+ * form carries the epilogue / the filter gradient (the caller then runs the separate passes). Single-operator entry for the
+ * parity tests. */
 int orbit_op_dwconv2d_dgrad_bn(const float* dy, const float* w, const float* y_raw, const float* mean, const float* invstd,
-                               const float* scale, const float* shift, int act, float* g, float* sums, int B, int H, int W, int C,
-                               int K, int stride, int pad_top, int pad_left, int Ho, int Wo, orbit_stream_t stream);
+                               const float* scale, const float* shift, int act, float* g, float* sums, float* dw, int B, int H,
+                               int W, int C, int K, int stride, int pad_top, int pad_left, int Ho, int Wo, orbit_stream_t stream);
 /* The depthwise filter gradient with the layer's input rebuilt on load: x_raw is the RAW output of the preceding convolution and
  * the layer's input is act(x_raw * in_scale[c] + in_shift[c]) (that convolution's batch-statistics BatchNorm + SiLU / ReLU;
  * reference: autograd through timm InvertedResidual's bn1 + act1 + conv_dw, few_shot_recognisers.py:99-122). The taped forward

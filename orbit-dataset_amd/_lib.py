@@ -95,7 +95,7 @@ _SIGNATURES = {
     "orbit_op_maxpool2d_backward": (c_int, [P, P, P] + [c_int] * 9 + [P]),
     "orbit_op_avgpool_backward": (c_int, [P, P, c_int, c_int, c_int, P]),
     "orbit_op_dwconv2d_backward": (c_int, [P, P, P, P, P] + [c_int] * 10 + [P]),
-    "orbit_op_dwconv2d_dgrad_bn": (c_int, [P] * 7 + [c_int, P, P] + [c_int] * 10 + [P]),
+    "orbit_op_dwconv2d_dgrad_bn": (c_int, [P] * 7 + [c_int, P, P, P] + [c_int] * 10 + [P]),
     "orbit_op_dwconv2d_wgrad_xf": (c_int, [P, P, P, c_int, P, P] + [c_int] * 10 + [P]),
     "orbit_op_se_gate_backward": (c_int, [P] * 12 + [c_int] * 4 + [P]),
     "orbit_frames_from_uint8": (c_int, [P, c_int, c_int, c_int, c_int, POINTER(c_float), POINTER(c_float), P, P]),

@@ -134,6 +134,12 @@ struct DwBnBwd {
     int act = 0;
     float* partial = nullptr;
     int* nblk = nullptr;  // out: partial rows written, 0 when the chosen kernel has no fused form (then dx was written plain)
+    // optional: the layer's FILTER gradient in the same pass. The layer's input is act(y * scale + shift) - the tensor the kernel
+    // rebuilds at its output pixels anyway - and every (output pixel, tap) pair meets the dy element the data gradient multiplies
+    // with that tap, so sum dy * input(tap) accumulates beside it: wgrad_partial[block][K*K][C] (dwconv_bwd_fused_scratch_floats),
+    // finished by launch_dwconv_wgrad_reduce. *wgrad_rows = rows written, 0 when the chosen kernel does not carry it.
+    float* wgrad_partial = nullptr;
+    int* wgrad_rows = nullptr;
 };
 // depthwise + fused SE pooling partials [B][chunks][C] (pool_partial may be nullptr); chunks = dwconv_se_chunks(Ho)
 int dwconv_se_chunks(int Ho);
@@ -243,6 +249,8 @@ int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, 
                         int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, float* flip_scratch = nullptr,
                         const DwBnBwd* bnb = nullptr);
 int dwconv_dgrad_bn_blocks(int B, int H, int W, int C, int stride);  // upper bound of the partial rows a fused dgrad writes
+size_t dwconv_bwd_fused_scratch_floats(int B, int H, int W, int C, int K, int stride);  // of DwBnBwd::wgrad_partial (0: no fused form)
+int launch_dwconv_wgrad_reduce(const float* partial, int rows, int K, int C, float* dw, hipStream_t s);
 size_t dwconv_wgrad_scratch_floats(int B, int Ho, int Wo, int C, int K);
 int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int C, int K,
                         int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, const float* in_scale = nullptr,

@@ -186,6 +186,7 @@ static BwdLayout bwd_layout(const orbit_extractor* fe, int B) {
             slot = std::max(slot, (size_t)B * o.H * o.W * o.Cin);
             slot = std::max(slot, (size_t)B * o.Ho * o.Wo * o.Cout);
             wg = std::max(wg, dwconv_wgrad_scratch_floats(B, o.Ho, o.Wo, o.Cin, o.KH));
+            wg = std::max(wg, dwconv_bwd_fused_scratch_floats(B, o.H, o.W, o.Cin, o.KH, o.stride));
         } else if (o.kind == OP_SE) {
             se = std::max(se, se_bwd_scratch_floats(B, o.Cin, o.R));
         } else if (o.kind == OP_CONV) {
@@ -660,18 +661,29 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
             }
             if (rc != ORBIT_OK) return rc;
             release(g), grad_slot[i] = -1;
-            if (wg) {
-                if (src >= 0 && conv_feeds_dw_raw(fe, (size_t)src, bn_train, false, B)) {
+            // the producer is a convolution + BatchNorm + SiLU whose only reader is this layer (see the data gradient below)
+            const Op& po = fe->ops[src >= 0 ? src : 0];
+            const bool through_act = need_dx && src == i - 1 && po.kind == OP_CONV && bn_train && !po.pool2 && po.res < 0 &&
+                                     po.Cout % 4 == 0 && fe->bns[po.bn].conv_bias < 0 &&
+                                     (po.act == ORBIT_ACT_SILU || po.act == ORBIT_ACT_NONE) && get_option("train_dw_xf");
+            const bool raw_fed = src >= 0 && conv_feeds_dw_raw(fe, (size_t)src, bn_train, false, B);
+            // ... and on the stride-2 layers the filter gradient rides on that data-gradient kernel (DwBnBwd::wgrad_partial)
+            const bool wg_fused = wg && through_act && raw_fed &&
+                                  dwconv_bwd_fused_scratch_floats(B, o.H, o.W, o.Cin, o.KH, o.stride) > 0;
+            auto filter_gradient = [&]() {
+                if (raw_fed) {
                     // the forward never wrote this layer's input: the filter gradient rebuilds it from the producing conv's raw
                     // output as it stages its patch
                     const BNDesc& sbn = fe->bns[fe->ops[src].bn];
-                    rc = launch_dwconv_wgrad(tf(L.y[src]), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
-                                             wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s,
-                                             scale + sbn.fold_off, shift + sbn.fold_off, fe->ops[src].act);
-                } else {
-                    rc = launch_dwconv_wgrad(out_tensor(src), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
-                                             wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+                    return launch_dwconv_wgrad(tf(L.y[src]), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
+                                               wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s,
+                                               scale + sbn.fold_off, shift + sbn.fold_off, fe->ops[src].act);
                 }
+                return launch_dwconv_wgrad(out_tensor(src), slot_ptr(kdy), param_grads + fe->params[o.weight].off,
+                                           wgrad_scratch, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
+            };
+            if (wg && !wg_fused) {
+                rc = filter_gradient();
                 if (rc != ORBIT_OK) return rc;
             }
             if (need_dx) {
@@ -679,17 +691,15 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                 SLOT_OR_FAIL(k);
                 grad_slot[src] = k;
                 // wgrad_scratch is free again here (the weight-gradient launches above are earlier on the stream)
-                // the producer is a convolution + BatchNorm + SiLU whose only reader is this layer: the data gradient goes
-                // through the activation in the same kernel and leaves the channel sums of that BatchNorm's backward, so the
-                // convolution's own backward starts at the finalize step (no reduction pass over dx and y)
-                const Op& po = fe->ops[src >= 0 ? src : 0];
-                int nblk = 0;
+                // through_act: the data gradient goes through the producer's activation in the same kernel and leaves the channel
+                // sums of that BatchNorm's backward, so the convolution's own backward starts at the finalize step (no reduction
+                // pass over dx and y)
+                int nblk = 0, wrows = 0;
                 DwBnBwd bnb;
                 const DwBnBwd* bnb_ptr = nullptr;
-                if (src == i - 1 && po.kind == OP_CONV && bn_train && !po.pool2 && po.res < 0 && po.Cout % 4 == 0 &&
-                    fe->bns[po.bn].conv_bias < 0 && (po.act == ORBIT_ACT_SILU || po.act == ORBIT_ACT_NONE) &&
-                    get_option("train_dw_xf")) {
+                if (through_act) {
                     const BNDesc& sbn = fe->bns[po.bn];
+                    if (wg_fused) bnb.wgrad_partial = wgrad_scratch, bnb.wgrad_rows = &wrows;
                     bnb.y = tf(L.y[src]), bnb.mean = mean + sbn.fold_off, bnb.invstd = invstd + sbn.fold_off;
                     bnb.scale = scale + sbn.fold_off, bnb.shift = shift + sbn.fold_off, bnb.act = po.act;
                     bnb.partial = partial, bnb.nblk = &nblk;
@@ -697,7 +707,11 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                 }
                 rc = launch_dwconv_dgrad(slot_ptr(kdy), fe->d_packed + o.packed_off, slot_ptr(k), B, o.H, o.W, o.Cin, o.KH,
                                          o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s, wgrad_scratch, bnb_ptr);
+                if (rc != ORBIT_OK) return rc;
                 if (bnb_ptr) pre_reduced[src] = nblk;  // 0: that kernel form has no such epilogue, the slot holds plain dx
+                if (wg_fused)
+                    rc = wrows > 0 ? launch_dwconv_wgrad_reduce(wgrad_scratch, wrows, o.KH, o.Cin, param_grads + fe->params[o.weight].off, s)
+                                   : filter_gradient();
             }
             release(kdy);
         } else {  // OP_CONV

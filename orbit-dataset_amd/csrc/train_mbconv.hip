@@ -352,7 +352,11 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const float* __restri
 // (compile time, so that every register index is static).
 // BNB: the BatchNorm-backward epilogue of DwBnBwd (common.h): g = dx * act'(y * scale + shift) is written instead of dx and every
 // block emits the channel sums of g and g * xhat over ITS 2x2 blocks (a fixed set: deterministic) to partial[blockIdx.x][2][C].
-template <int K, int PT, int PL, bool BNB = false>
+// WG (with BNB): the filter gradient of the layer rides along (DwBnBwd::wgrad_partial): the layer's input at the 2x2 block is
+// act(y * scale + shift), already formed for the activation derivative, and tap (kh, kw) of output pixel (dh, dw) multiplies
+// exactly the dy patch element the data gradient pairs it with - K*K more quad FMAs per 2x2 block, K*K accumulators per thread,
+// one [K*K][C] partial row per block (the separate filter-gradient pass read y and dy again: 0.74 ms of the LITE step).
+template <int K, int PT, int PL, bool BNB = false, bool WG = false>
 __global__ __launch_bounds__(256) void dwconv_dgrad_s2_kernel(const float* __restrict__ dy, const float* __restrict__ w,
                                                               float* __restrict__ dx, int B, int H, int W, int C4,
                                                               int pad_t, int pad_l, int Ho, int Wo, int G, int R,
@@ -373,6 +377,9 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_s2_kernel(const float* __res
     const unsigned total = (unsigned)B * H2 * W2;  // 2x2 blocks (launcher: < 2^31)
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 s0 = zero, s1 = zero, bsc = zero, bsh = zero, bmu = zero, bis = zero;
+    f32x4 wacc[WG ? K * K : 1];
+#pragma unroll
+    for (int t = 0; t < (WG ? K * K : 1); ++t) wacc[t] = zero;
     if (BNB && live) {
         bsc = reinterpret_cast<const f32x4*>(bnb.scale)[q], bsh = reinterpret_cast<const f32x4*>(bnb.shift)[q];
         bmu = reinterpret_cast<const f32x4*>(bnb.mean)[q], bis = reinterpret_cast<const f32x4*>(bnb.invstd)[q];
@@ -412,6 +419,25 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_s2_kernel(const float* __res
         for (int dh = 0; dh < 2; ++dh) {
 #pragma unroll
             for (int dw = 0; dw < 2; ++dw) {
+                const bool inside = h0 + dh < H && w0 + dw < W;
+                // the activation's derivative and (WG) the layer's input at this pixel, before the taps
+                f32x4 dact = {1.f, 1.f, 1.f, 1.f}, ain = zero;
+                if (BNB) {
+                    const f32x4 z = yq[dh][dw] * bsc + bsh;
+                    ain = z;
+                    if (bnb.act == ORBIT_ACT_SILU) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z[k]));
+                            dact[k] = sg * (1.0f + z[k] * (1.0f - sg));
+                            ain[k] = z[k] * sg;
+                        }
+                    } else if (bnb.act == ORBIT_ACT_RELU) {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) dact[k] = z[k] > 0.f ? 1.f : 0.f, ain[k] = z[k] > 0.f ? z[k] : 0.f;
+                    }
+                    if (!inside) ain = zero;
+                }
                 f32x4 acc = zero;
 #pragma unroll
                 for (int kh = (dh + PT) & 1; kh < K; kh += 2) {
@@ -421,25 +447,15 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_s2_kernel(const float* __res
                     for (int kw = (dw + PL) & 1; kw < K; kw += 2) {
                         const int c = (dw + ((K - 1) - (((K - 1) ^ PL) & 1)) - kw) / 2;
                         acc += patch[r][c] * wl[(kh * K + kw) * G + qi];
+                        if (WG) wacc[kh * K + kw] += patch[r][c] * ain;
                     }
                 }
-                if (h0 + dh < H && w0 + dw < W) {
+                if (inside) {
                     const size_t o = (size_t)((h0 + dh) * W + (w0 + dw)) * C4;
                     if (BNB) {
-                        const f32x4 yv = yq[dh][dw];
-                        const f32x4 z = yv * bsc + bsh;
-                        if (bnb.act == ORBIT_ACT_SILU) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) {
-                                const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z[k]));
-                                acc[k] *= sg * (1.0f + z[k] * (1.0f - sg));
-                            }
-                        } else if (bnb.act == ORBIT_ACT_RELU) {
-#pragma unroll
-                            for (int k = 0; k < 4; ++k) acc[k] = z[k] > 0.f ? acc[k] : 0.f;
-                        }
+                        acc *= dact;
                         s0 += acc;
-                        s1 += acc * ((yv - bmu) * bis);
+                        s1 += acc * ((yq[dh][dw] - bmu) * bis);
                     }
                     dxb[o] = acc;
                 }
@@ -456,6 +472,28 @@ __global__ __launch_bounds__(256) void dwconv_dgrad_s2_kernel(const float* __res
             float* out = bnb.partial + (size_t)blockIdx.x * 2 * (C4 * 4) + q * 4;
             *reinterpret_cast<f32x4*>(out) = a;
             *reinterpret_cast<f32x4*>(out + C4 * 4) = c2;
+        }
+    }
+    if (WG) {
+        // filter-gradient partial row of this block: taps in rounds of 8 through the [8][256] buffer, row lanes added in order
+        f32x4* red = wl + K * K * G;
+        constexpr int TB = 8;
+#pragma unroll
+        for (int t0 = 0; t0 < K * K; t0 += TB) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < TB; ++u)
+                if (t0 + u < K * K) red[u * 256 + tid] = wacc[t0 + u];
+            __syncthreads();
+            for (int i = tid; i < TB * G; i += 256) {
+                const int u = i / G, qq = i - u * G;
+                if (t0 + u < K * K && blockIdx.y * G + qq < C4) {
+                    f32x4 a = red[u * 256 + qq];
+                    for (int j = 1; j < R; ++j) a += red[u * 256 + j * G + qq];
+                    *reinterpret_cast<f32x4*>(bnb.wgrad_partial + ((size_t)blockIdx.x * K * K + t0 + u) * (C4 * 4) +
+                                              (blockIdx.y * G + qq) * 4) = a;
+                }
+            }
         }
     }
 }
@@ -832,10 +870,33 @@ int dwconv_dgrad_bn_blocks(int B, int H, int W, int C, int stride) {
     if (stride == 1) return B * dwconv_se_chunks(H);
     return std::min(dgrad_s2_blocks(B, H, W, C), 2048);
 }
+// row blocks of the stride-2 kernel when the filter gradient rides along: a block's [K*K + 2][C] partial rows stay a few
+// percent of what it streams (about 9 quads per row lane and 2x2 block), at most 2048 rows
+static int dgrad_s2_fused_blocks(int B, int H, int W, int C, int K) {
+    int G, R, yg;
+    dw_layout(C, G, R, yg);
+    const size_t blocks2 = (size_t)B * ((H + 1) / 2) * ((W + 1) / 2);
+    const size_t per_block = (size_t)R * (size_t)cdiv(K * K + 2, R);  // 2x2 blocks per row block: >= ~2 x the epilogue's quads / 9
+    return (int)std::max<size_t>(1, std::min<size_t>(2048, blocks2 / std::max<size_t>(per_block * 2, 1)));
+}
+size_t dwconv_bwd_fused_scratch_floats(int B, int H, int W, int C, int K, int stride) {
+    if (stride != 2 || C % 4 != 0 || (K != 3 && K != 5)) return 0;
+    return (size_t)dgrad_s2_fused_blocks(B, H, W, C, K) * K * K * C;
+}
+int launch_dwconv_wgrad_reduce(const float* partial, int rows, int K, int C, float* dw, hipStream_t s) {
+    ORBIT_REQUIRE(partial && dw && rows > 0, "dwconv_wgrad_reduce: bad arguments");
+    dwconv_wgrad_reduce_kernel<<<cdiv(K * K * C, 16), 256, 0, s>>>(partial, rows, K * K, C, dw);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
 
 int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, int H, int W, int C, int K, int stride,
                         int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, float* flip_scratch, const DwBnBwd* bnb) {
-    if (bnb) *bnb->nblk = 0;
+    if (bnb) {
+        *bnb->nblk = 0;
+        ORBIT_REQUIRE((bnb->wgrad_partial == nullptr) == (bnb->wgrad_rows == nullptr), "dwconv_dgrad: wgrad_partial without wgrad_rows");
+        if (bnb->wgrad_rows) *bnb->wgrad_rows = 0;
+    }
     if (stride == 1 && flip_scratch != nullptr) {
         // dx[h][w] = sum dy[h + pad_t - kh][w + pad_l - kw] w[kh][kw] = a forward depthwise conv of dy with the rotated
         // taps and padding K-1-pad: the LDS-patch forward kernels (35-60 us on these layers) replace the gather below
@@ -852,11 +913,17 @@ int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, 
         int G, R, yg;
         dw_layout(C, G, R, yg);
         int gx = dgrad_s2_blocks(B, H, W, C);
-        if (bnb) gx = std::min(gx, 2048), *bnb->nblk = gx;
-        const size_t lds = (size_t)(K * K * G + (bnb ? 512 : 0)) * sizeof(f32x4);
+        const bool fuse_wg = bnb && bnb->wgrad_partial;
+        if (bnb) gx = std::min(gx, 2048);
+        if (fuse_wg) gx = std::min(gx, dgrad_s2_fused_blocks(B, H, W, C, K)), *bnb->wgrad_rows = gx;
+        if (bnb) *bnb->nblk = gx;
+        const size_t lds = (size_t)(K * K * G + (fuse_wg ? 8 * 256 : bnb ? 512 : 0)) * sizeof(f32x4);
 #define ORBIT_DG2(KK, PT_, PL_)                                                                                       \
     do {                                                                                                              \
-        if (bnb)                                                                                                      \
+        if (fuse_wg)                                                                                                  \
+            dwconv_dgrad_s2_kernel<KK, PT_, PL_, true, true><<<dim3(gx, yg), 256, lds, s>>>(dy, w_khwc, dx, B, H, W, C / 4,   \
+                                                                                            pad_t, pad_l, Ho, Wo, G, R, *bnb); \
+        else if (bnb)                                                                                                 \
             dwconv_dgrad_s2_kernel<KK, PT_, PL_, true><<<dim3(gx, yg), 256, lds, s>>>(dy, w_khwc, dx, B, H, W, C / 4, pad_t,  \
                                                                                       pad_l, Ho, Wo, G, R, *bnb);     \
         else                                                                                                          \
@@ -969,21 +1036,26 @@ int orbit_op_dwconv2d_backward(const float* x, const float* w, const float* dy, 
 }
 
 int orbit_op_dwconv2d_dgrad_bn(const float* dy, const float* w, const float* y_raw, const float* mean, const float* invstd,
-                               const float* scale, const float* shift, int act, float* g, float* sums, int B, int H, int W, int C,
-                               int K, int stride, int pad_top, int pad_left, int Ho, int Wo, orbit_stream_t stream) {
+                               const float* scale, const float* shift, int act, float* g, float* sums, float* dw, int B, int H,
+                               int W, int C, int K, int stride, int pad_top, int pad_left, int Ho, int Wo, orbit_stream_t stream) {
     ORBIT_REQUIRE(dy && w && y_raw && mean && invstd && scale && shift && g && sums, "op_dwconv2d_dgrad_bn: null pointer");
     hipStream_t s = (hipStream_t)stream;
     float* tmp = nullptr;
     const size_t npack = (size_t)(C * K * K + 3) / 4 * 4;
-    const size_t nscr = dwconv_wgrad_scratch_floats(B, Ho, Wo, C, K);
+    const size_t nfused = dw ? dwconv_bwd_fused_scratch_floats(B, H, W, C, K, stride) : 0;
+    if (dw && nfused == 0) return set_err(ORBIT_ERR_ARG, "op_dwconv2d_dgrad_bn: no kernel form carries the filter gradient for this layer");
+    const size_t nscr = std::max(dwconv_wgrad_scratch_floats(B, Ho, Wo, C, K), nfused);
     const size_t npart = bn_partial_floats((size_t)dwconv_dgrad_bn_blocks(B, H, W, C, stride), C);
     ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), (npack + nscr + npart) * sizeof(float), s));
-    int nblk = 0;
-    const DwBnBwd bnb{y_raw, mean, invstd, scale, shift, act, tmp + npack + nscr, &nblk};
+    int nblk = 0, wrows = 0;
+    DwBnBwd bnb{y_raw, mean, invstd, scale, shift, act, tmp + npack + nscr, &nblk};
+    if (dw) bnb.wgrad_partial = tmp + npack, bnb.wgrad_rows = &wrows;
     int rc = dwconv_pack_weights(w, tmp, C, K, s);
     if (rc == ORBIT_OK) rc = launch_dwconv_dgrad(dy, tmp, g, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, s, tmp + npack, &bnb);
     if (rc == ORBIT_OK && nblk <= 0) rc = set_err(ORBIT_ERR_ARG, "op_dwconv2d_dgrad_bn: no kernel form with the epilogue for this layer");
+    if (rc == ORBIT_OK && dw && wrows <= 0) rc = set_err(ORBIT_ERR_ARG, "op_dwconv2d_dgrad_bn: no kernel form carries the filter gradient for this layer");
     if (rc == ORBIT_OK) rc = launch_sum_partials(bnb.partial, nblk, C, sums, s);
+    if (rc == ORBIT_OK && dw) rc = launch_dwconv_wgrad_reduce(bnb.wgrad_partial, wrows, K, C, dw, s);
     (void)hipFreeAsync(tmp, s);
     return rc;
 }

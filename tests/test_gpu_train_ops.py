@@ -379,7 +379,7 @@ def test_dwconv_dgrad_with_batchnorm_epilogue(device, case, act):
     yr = (torch.randn(B, C, H, W, generator=g) * 1.5).requires_grad_(True)
     sc, sh = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3 + 0.2
     mean, invstd = torch.randn(C, generator=g) * 0.2, torch.rand(C, generator=g) + 0.5
-    w = torch.randn(C, 1, K, K, generator=g) / K
+    w = (torch.randn(C, 1, K, K, generator=g) / K).requires_grad_(True)
     z = yr * sc[None, :, None, None] + sh[None, :, None, None]
     a = F.silu(z) if act == 2 else z
     out = F.conv2d(F.pad(a, [p0, p1, p0, p1]), w, None, stride, 0, 1, C)
@@ -394,15 +394,18 @@ def test_dwconv_dgrad_with_batchnorm_epilogue(device, case, act):
     t_m, t_i, t_sc, t_sh = dev(mean), dev(invstd), dev(sc), dev(sh)
     gout = torch.full((B, H, W, C), float("nan"), device=device)
     sums = torch.full((2, C), float("nan"), device=device)
+    dw = torch.full((C, 1, K, K), float("nan"), device=device) if stride == 2 else None  # (the stride-2 form carries it)
     rc = lib.orbit_op_dwconv2d_dgrad_bn(_lib.dptr(t_dy), _lib.dptr(t_w), _lib.dptr(t_y), _lib.dptr(t_m), _lib.dptr(t_i),
-                                        _lib.dptr(t_sc), _lib.dptr(t_sh), act, _lib.dptr(gout), _lib.dptr(sums), B, H, W, C, K,
-                                        stride, p0, p0, Ho, Wo, _st())
+                                        _lib.dptr(t_sc), _lib.dptr(t_sh), act, _lib.dptr(gout), _lib.dptr(sums),
+                                        _lib.dptr(dw) if dw is not None else None, B, H, W, C, K, stride, p0, p0, Ho, Wo, _st())
     if rc == -1:
         pytest.skip("no kernel form with the epilogue for this layer: " + _lib.last_error())
     _lib.check(rc, "dwconv2d_dgrad_bn")
     torch.cuda.synchronize()
     assert rel_err(gout.cpu(), nhwc(gz.float())) < 2e-5
     assert rel_err(sums.cpu().double(), want_sums) < 2e-5
+    if dw is not None:
+        assert rel_err(dw.cpu(), w.grad) < 2e-5
 
 
 @pytest.mark.parametrize("B,HW,C,R", [(5, 49, 96, 4), (3, 16, 1152, 48), (2, 196, 144, 6), (7, 9, 32, 8)])
