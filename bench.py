@@ -700,12 +700,13 @@ def main():
         model.overlap_query = timed_mode
     # roofline leg: the SAME K steps again with one HIP-event pair recorded per conv_igemm launch on its stream
     # (kept out of the timed region above: recording ~80 events per task costs host time and serialises the queue)
-    overlap = getattr(model, "overlap_query", False)
+    overlap, lite_overlap = getattr(model, "overlap_query", False), getattr(model, "lite_overlap", False)
     model.overlap_query = False  # per-launch durations are only meaningful when the kernels run one at a time
+    model.lite_overlap = False   # (LITE: the H-subset pass otherwise runs beside the cache pass on a second stream)
     lib.orbit_prof_enable(1)
     elapsed_prof, _, _ = loop(args.steps)
     lib.orbit_prof_enable(0)
-    model.overlap_query = overlap
+    model.overlap_query, model.lite_overlap = overlap, lite_overlap
     per_rank = None
     if dist is not None:
         per_rank = per_rank_report(rank, world, dist, device, elapsed, issued, args.steps, run_step if train else None)
@@ -800,6 +801,8 @@ def main():
                        else "")},
         "frame_accuracy": float(correct[0].item() / max(correct[1].item(), 1)),
         "train_graph_calls_replayed_eager": list(model.feature_extractor.train_graph_stats()) if train else None,
+        # LITE: the H-clip subset pass of each task runs on a second stream beside the cache pass (ORBIT_LITE_OVERLAP=0: serial)
+        "lite_subset_beside_cache_pass": bool(getattr(model, "lite_overlap", False)) if train else None,
         "train_loss_per_step": [float(x) for x in train_losses.cpu()] if train_losses is not None else None,
         "median_task_ms": median_task_ms,
         "labels": "every timed task carries a label tensor new to the head: its label set is resolved inside the timed region "

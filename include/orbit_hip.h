@@ -328,9 +328,19 @@ int orbit_extractor_train_forward(orbit_extractor_t* fe, const float* frames, in
  * materialised (the depthwise convs apply the preceding BatchNorm + activation while loading the raw conv output). Features
  * are bit-identical to the flag-less call; orbit_extractor_backward on such a tape is undefined. */
 #define ORBIT_TRAIN_NO_BACKWARD 1
+/* ORBIT_TRAIN_DEFER_RUNNING_STATS (bn_train != 0): the running-statistics update is NOT applied; the batch mean / unbiased
+ * variance of every BatchNorm stay on the tape and orbit_extractor_apply_deferred_bn_stats applies
+ * running = (1 - momentum) * running + momentum * stat afterwards (same arithmetic, so the result equals the in-place update
+ * made at that point of the sequence). Such a forward touches no mutable state of the plan: it may run on ANOTHER stream
+ * while a forward of the same plan that does update the statistics is in flight - LITE re-encodes its H-clip subset (16
+ * frames: launch-bound kernels) beside the cache pass over the whole context set (few_shot_recognisers.py:388-437), and the
+ * reference's update order (cache pass, then subset) is kept by applying the subset's update after both. */
+#define ORBIT_TRAIN_DEFER_RUNNING_STATS 2
 int orbit_extractor_train_forward_ex(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
                                      const float* film_beta, int bn_train, float momentum, float* feats, void* tape,
                                      size_t tape_bytes, int flags, orbit_stream_t stream);
+int orbit_extractor_apply_deferred_bn_stats(orbit_extractor_t* fe, const void* tape, size_t tape_bytes, int B, float momentum,
+                                            orbit_stream_t stream);
 /* Reverse pass for the tape of one train_forward (same frames / B / film / bn_train).
  *   dfeats [B][D]: gradient w.r.t. the features.
  *   param_grads: NULL (frozen extractor) or orbit_extractor_grad_floats() floats; the gradient of parameter i is

@@ -78,6 +78,7 @@ _SIGNATURES = {
     "orbit_extractor_export_bn_stats": (c_int, [P, P, P]),
     "orbit_extractor_train_forward": (c_int, [P, P, c_int, P, P, c_int, c_float, P, P, c_size_t, P]),
     "orbit_extractor_train_forward_ex": (c_int, [P, P, c_int, P, P, c_int, c_float, P, P, c_size_t, c_int, P]),
+    "orbit_extractor_apply_deferred_bn_stats": (c_int, [P, P, c_size_t, c_int, c_float, P]),
     "orbit_extractor_backward": (c_int, [P, P, c_int, P, P, c_int, P, P, c_size_t, P, c_int, P, P, P, c_size_t, P]),
     "orbit_filmgen_grad_floats": (c_size_t, [P]),
     "orbit_filmgen_param_offset": (c_size_t, [P, c_int, c_char_p]),
@@ -204,9 +205,33 @@ def require_gpu():
     _gpu_ok = True
 
 
+_stream_override = None
+
+
+class use_stream:
+    """Within the block the native entry points are handed `stream` (a torch.cuda.Stream) instead of torch's current stream,
+    while torch itself - its allocator included - stays on the current one: the caller orders the two streams with events
+    (LITE's subset pass beside the cache pass, few_shot_recognisers._get_features_with_split_batch)."""
+
+    def __init__(self, stream):
+        self.handle = c_void_p(stream.cuda_stream)
+
+    def __enter__(self):
+        global _stream_override
+        self.prev, _stream_override = _stream_override, self.handle
+        return self
+
+    def __exit__(self, *exc):
+        global _stream_override
+        _stream_override = self.prev
+        return False
+
+
 def stream_handle():
-    """hipStream_t of torch's CURRENT stream on the current device, as an opaque pointer. Uses the raw accessor:
-    torch.cuda.current_stream() re-checks device availability on every call (~80 us each)."""
+    """hipStream_t of torch's CURRENT stream on the current device, as an opaque pointer (or the stream a `use_stream` block
+    names). Uses the raw accessor: torch.cuda.current_stream() re-checks device availability on every call (~80 us each)."""
+    if _stream_override is not None:
+        return _stream_override
     import torch
     try:
         return c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))

@@ -35,11 +35,25 @@ __global__ __launch_bounds__(256) void bn_export_kernel(const BNDev* __restrict_
     }
 }
 
+// running = (1 - momentum) * running + momentum * stat for every BatchNorm: the update an ORBIT_TRAIN_DEFER_RUNNING_STATS forward
+// left undone (stat[0][fold_off + c] = batch mean (+ conv bias), stat[1][.] = unbiased batch variance; the expression is the one
+// bn_stats_finalize_kernel evaluates)
+__global__ __launch_bounds__(256) void bn_apply_deferred_kernel(const BNDev* __restrict__ descs, float* __restrict__ pool,
+                                                                const float* __restrict__ stat, size_t fold_floats,
+                                                                float momentum) {
+    const BNDev d = descs[blockIdx.x];
+    for (int c = blockIdx.y * 256 + threadIdx.x; c < d.C; c += gridDim.y * 256) {
+        pool[d.mean + c] = (1.f - momentum) * pool[d.mean + c] + momentum * stat[d.fold_off + c];
+        pool[d.var + c] = (1.f - momentum) * pool[d.var + c] + momentum * stat[fold_floats + d.fold_off + c];
+    }
+}
+
 struct TapeLayout {
     // byte offsets per op ((size_t)-1: none). conv / depthwise: y raw output, a activation, p/idx fused pool, xg gated
     // input. squeeze-excite: p = pooled means [B][C], a = gate [B][C]. max-pool: p output, idx argmax.
     std::vector<size_t> y, a, p, idx, xg;
     size_t mean = 0, invstd = 0, scale = 0, shift = 0, partial = 0, pool = 0, total = 0;
+    size_t rstat = 0;  // [2][fold_floats]: batch mean / unbiased variance of an ORBIT_TRAIN_DEFER_RUNNING_STATS forward
 };
 
 static const size_t NONE = (size_t)-1;
@@ -153,6 +167,7 @@ static TapeLayout tape_layout(const orbit_extractor* fe, int B) {
     L.scale = take(fe->fold_floats * 4), L.shift = take(fe->fold_floats * 4);
     L.partial = take(max_bn_partial_floats(fe, B) * 4);
     L.pool = take(max_se_pool_floats(fe, B) * 4);
+    L.rstat = take(2 * fe->fold_floats * 4);
     L.total = off;
     return L;
 }
@@ -278,7 +293,7 @@ static int ensure_dgrad_filters(orbit_extractor* fe, orbit_train_state** out, hi
 
 static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
                              const float* film_beta, int bn_train, float momentum, float* feats, void* tape,
-                             hipStream_t s, bool no_backward = false);
+                             hipStream_t s, bool no_backward = false, bool defer_stats = false);
 static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const float* frames, int B, const float* film_gamma,
                         const float* film_beta, int bn_train, const float* dfeats, const void* tape, float* param_grads,
                         int filter_grads, float* dfilm_gamma, float* dfilm_beta, void* workspace, hipStream_t s);
@@ -323,8 +338,10 @@ int orbit_extractor_train_forward_ex(orbit_extractor_t* fe, const float* frames,
                                      const float* film_beta, int bn_train, float momentum, float* feats, void* tape,
                                      size_t tape_bytes, int flags, orbit_stream_t stream) {
     ORBIT_REQUIRE(fe && frames && feats && tape, "extractor_train_forward: null pointer");
-    ORBIT_REQUIRE((flags & ~ORBIT_TRAIN_NO_BACKWARD) == 0, "extractor_train_forward: unknown flags %d", flags);
+    ORBIT_REQUIRE((flags & ~(ORBIT_TRAIN_NO_BACKWARD | ORBIT_TRAIN_DEFER_RUNNING_STATS)) == 0,
+                  "extractor_train_forward: unknown flags %d", flags);
     const bool no_backward = (flags & ORBIT_TRAIN_NO_BACKWARD) != 0;
+    const bool defer_stats = (flags & ORBIT_TRAIN_DEFER_RUNNING_STATS) != 0;
     ORBIT_REQUIRE(B > 0, "extractor_train_forward: empty batch");
     if (!fe->finalized) return set_err(ORBIT_ERR_STATE, "extractor_train_forward: call orbit_extractor_finalize first");
     if (!plan_trainable(fe))
@@ -337,22 +354,49 @@ int orbit_extractor_train_forward_ex(orbit_extractor_t* fe, const float* frames,
     orbit_extractor::TrainGraphKey key;
     memset(&key, 0, sizeof(key));
     key.p[0] = frames, key.p[1] = film_gamma, key.p[2] = film_beta, key.p[3] = feats, key.p[4] = tape;
-    key.v[0] = no_backward ? 3 : 1 /* forward */, key.v[1] = B, key.v[2] = bn_train;
+    key.v[0] = (no_backward ? 3 : 1) /* forward */ + (defer_stats ? 16 : 0), key.v[1] = B, key.v[2] = bn_train;
     memcpy(&key.v[3], &momentum, sizeof(float));
     return fe->run_train_graphed(key, (hipStream_t)stream, [&](hipStream_t s) {
-        return train_forward_run(fe, frames, B, film_gamma, film_beta, bn_train, momentum, feats, tape, s, no_backward);
+        return train_forward_run(fe, frames, B, film_gamma, film_beta, bn_train, momentum, feats, tape, s, no_backward,
+                                 defer_stats);
     });
+}
+
+int orbit_extractor_apply_deferred_bn_stats(orbit_extractor_t* fe, const void* tape, size_t tape_bytes, int B, float momentum,
+                                            orbit_stream_t stream) {
+    ORBIT_REQUIRE(fe && tape && B > 0, "extractor_apply_deferred_bn_stats: null pointer or empty batch");
+    if (!fe->finalized) return set_err(ORBIT_ERR_STATE, "extractor_apply_deferred_bn_stats: plan is not finalized");
+    const TapeLayout L = tape_layout(fe, B);
+    ORBIT_REQUIRE(tape_bytes >= L.total, "extractor_apply_deferred_bn_stats: tape too small (%zu < %zu bytes)", tape_bytes, L.total);
+    bn_apply_deferred_kernel<<<dim3((unsigned)fe->bns.size(), 2), 256, 0, (hipStream_t)stream>>>(
+        fe->d_bn, fe->d_pool, reinterpret_cast<const float*>(static_cast<const char*>(tape) + L.rstat), fe->fold_floats, momentum);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
 }
 
 }  // extern "C"
 
 static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, const float* film_gamma,
                              const float* film_beta, int bn_train, float momentum, float* feats, void* tape,
-                             hipStream_t s, bool no_backward) {
+                             hipStream_t s, bool no_backward, bool defer_stats) {
     const TapeLayout L = tape_layout(fe, B);
     char* tp = static_cast<char*>(tape);
     auto fl = [&](size_t off) { return reinterpret_cast<float*>(tp + off); };
     float *mean = fl(L.mean), *invstd = fl(L.invstd), *scale = fl(L.scale), *shift = fl(L.shift);
+    // deferred running statistics: the finalize kernels run their update with momentum 1 on a zeroed slot of the tape
+    // (0 * 0 + 1 * stat = stat exactly) instead of on the plan's running statistics; orbit_extractor_apply_deferred_bn_stats
+    // applies the real update later - so this forward may overlap, on another stream, with a forward that updates them
+    defer_stats = defer_stats && bn_train;
+    if (defer_stats) {
+        ORBIT_HIP_CHECK(hipMemsetAsync(fl(L.rstat), 0, 2 * fe->fold_floats * sizeof(float), s));
+        momentum = 1.0f;
+    }
+    auto run_mean = [&](const BNDesc& bn) {
+        return defer_stats ? fl(L.rstat) + bn.fold_off : fe->d_pool + fe->params[bn.mean].off;
+    };
+    auto run_var = [&](const BNDesc& bn) {
+        return defer_stats ? fl(L.rstat) + fe->fold_floats + bn.fold_off : fe->d_pool + fe->params[bn.var].off;
+    };
     const bool film = film_gamma && fe->film_size > 0;
     if (!bn_train) {
         dim3 grid((unsigned)fe->bns.size(), 2);
@@ -409,13 +453,11 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
                 if (stat_blocks > 0)
                     rc = launch_bn_stats_from_partials(fl(L.partial), stat_blocks, M, o.Cout, bn.eps, momentum, gam, bet, cb,
                                                        mean + bn.fold_off, invstd + bn.fold_off, scale + bn.fold_off,
-                                                       shift + bn.fold_off, fe->d_pool + fe->params[bn.mean].off,
-                                                       fe->d_pool + fe->params[bn.var].off, s);
+                                                       shift + bn.fold_off, run_mean(bn), run_var(bn), s);
                 else  // (fused pooling / split-K launches do not emit them: the statistics pass of its own)
                     rc = launch_bn_stats(d.y, M, o.Cout, bn.eps, momentum, gam, bet, cb, mean + bn.fold_off,
                                          invstd + bn.fold_off, scale + bn.fold_off, shift + bn.fold_off,
-                                         fe->d_pool + fe->params[bn.mean].off, fe->d_pool + fe->params[bn.var].off,
-                                         fl(L.partial), s);
+                                         run_mean(bn), run_var(bn), fl(L.partial), s);
                 if (rc != ORBIT_OK) return rc;
             }
             // the only consumer is the depthwise conv that follows: it applies this BatchNorm + activation as it loads the raw
@@ -454,8 +496,7 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
                                                    fm ? film_gamma + bn.film_off : fe->d_pool + fe->params[bn.gamma].off,
                                                    fm ? film_beta + bn.film_off : fe->d_pool + fe->params[bn.beta].off,
                                                    nullptr, mean + bn.fold_off, invstd + bn.fold_off, scale + bn.fold_off,
-                                                   shift + bn.fold_off, fe->d_pool + fe->params[bn.mean].off,
-                                                   fe->d_pool + fe->params[bn.var].off, s);
+                                                   shift + bn.fold_off, run_mean(bn), run_var(bn), s);
                 if (rc != ORBIT_OK) return rc;
             }
             // the activation pass also produces the squeeze-excite pooling partials when an SE op consumes this tensor

@@ -36,10 +36,14 @@ class ExtractorFunction(torch.autograd.Function):
         dev = frames.device
         tape = _empty_bytes(lib.orbit_extractor_tape_bytes(plan.handle, B), dev)
         feats = torch.empty(B, net.output_size, device=dev, dtype=torch.float32)
-        _lib.check(lib.orbit_extractor_train_forward(
+        # (flag 2 = ORBIT_TRAIN_DEFER_RUNNING_STATS: the network applies the running-statistics update later, see
+        # HipNetwork.deferred_stats)
+        _lib.check(lib.orbit_extractor_train_forward_ex(
             plan.handle, _lib.dptr(frames, torch.float32), B, _lib.dptr(gamma), _lib.dptr(beta), int(bn_train),
-            float(momentum), _lib.dptr(feats), ctypes.c_void_p(tape.data_ptr()), tape.numel(), _lib.stream_handle()),
-            "orbit_extractor_train_forward")
+            float(momentum), _lib.dptr(feats), ctypes.c_void_p(tape.data_ptr()), tape.numel(),
+            2 if net._defer_stats is not None else 0, _lib.stream_handle()), "orbit_extractor_train_forward")
+        if net._defer_stats is not None:
+            net._defer_stats.append((plan, tape, B))
         ctx.net, ctx.plan, ctx.tape, ctx.bn_train, ctx.param_index = net, plan, tape, int(bn_train), param_index
         ctx.save_for_backward(frames, gamma, beta)
         ctx.film_needs = (gamma is not None and gamma.requires_grad) or (beta is not None and beta.requires_grad)

@@ -81,6 +81,7 @@ class HipNetwork(nn.Module):
         super().__init__()
         self.native_name = native_name
         self._plans = {}
+        self._defer_stats = None  # list of (plan, tape, B) inside a deferred_stats block
         lib = _lib.load()
         # a throw-away plan at a nominal size enumerates the state_dict keys and FiLM slots
         probe = _Plan(native_name, 64, 64)
@@ -148,6 +149,10 @@ class HipNetwork(nn.Module):
                 raise _lib.OrbitHipError("native plan enumerates different parameters than the module tree")
             self._plans[(H, W, trainable)] = plan
         return plan
+
+    def prepare(self, H, W, trainable=True):
+        """Build (if needed) and bring up to date the plan a forward at this frame size will use, on the current stream."""
+        self.sync(self._plan(H, W, trainable))
 
     def _stamp(self):
         # swapped-in FiLM tensors (functional_call) are plain tensors, not Parameters: they do not count as a
@@ -313,13 +318,44 @@ class HipNetwork(nn.Module):
             feats = out if out is not None else torch.empty(B, self.output_size, device=x.device, dtype=torch.float32)
             tape = torch.empty(lib.orbit_extractor_tape_bytes(plan.handle, B), dtype=torch.uint8, device=x.device)
             # no autograd node will ever read this tape (a cache pass under torch.no_grad()): ORBIT_TRAIN_NO_BACKWARD = 1
+            # (+ 2 = ORBIT_TRAIN_DEFER_RUNNING_STATS inside a deferred_stats block)
             _lib.check(lib.orbit_extractor_train_forward_ex(
                 plan.handle, _lib.dptr(x, torch.float32), B, _lib.dptr(gamma), _lib.dptr(beta), int(bn_train),
                 float(self.bn_momentum), _lib.dptr(feats, torch.float32), ctypes.c_void_p(tape.data_ptr()), tape.numel(),
-                1, _lib.stream_handle()), "orbit_extractor_train_forward_ex")
-        if bn_train:
+                1 | (2 if self._defer_stats is not None else 0), _lib.stream_handle()), "orbit_extractor_train_forward_ex")
+            if self._defer_stats is not None:
+                self._defer_stats.append((plan, tape, B))
+        if bn_train and self._defer_stats is None:
             self._pull_running_stats(plan)
         return feats
+
+    class deferred_stats:
+        """Train-mode forwards issued inside the block leave the running statistics of the plan untouched (their batch
+        statistics stay on the tape): such a forward may run on another stream (`_lib.use_stream`) beside a forward that
+        does update them. `apply()` - after the streams have been joined - performs the updates in the order the forwards
+        were issued and copies the result into the module's buffers, exactly as the forward itself would have."""
+
+        def __init__(self, net):
+            self.net, self.pending = net, []
+
+        def __enter__(self):
+            if self.net._defer_stats is not None:
+                raise RuntimeError("deferred_stats blocks do not nest")
+            self.net._defer_stats = self.pending
+            return self
+
+        def __exit__(self, *exc):
+            self.net._defer_stats = None
+            return False
+
+        def apply(self):
+            lib = _lib.load()
+            for plan, tape, B in self.pending:
+                _lib.check(lib.orbit_extractor_apply_deferred_bn_stats(
+                    plan.handle, ctypes.c_void_p(tape.data_ptr()), tape.numel(), B, float(self.net.bn_momentum),
+                    _lib.stream_handle()), "orbit_extractor_apply_deferred_bn_stats")
+                self.net._pull_running_stats(plan)
+            self.pending = []
 
     # ---- forward ------------------------------------------------------------------------------------
     def forward(self, x, film=None, out=None, check_sync=True):

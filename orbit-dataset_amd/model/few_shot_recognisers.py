@@ -15,6 +15,8 @@ Meta-training: with autograd enabled the same calls reco
 `loss.backward()` runs the native backward kernels (model/autograd.py) — train-mode BatchNorm, conv dgrad/wgrad,
 depthwise / squeeze-excite / SiLU backward, FiLM-generator and set-encoder gradients — for both extractors.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -274,6 +276,9 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         # then produced on the second stream: `logits_ready` (an event) must be waited for - or the device synchronised -
         # before another stream reads them.
         self.overlap_query = False
+        # LITE: the H-subset pass of a task's first query batch runs beside the cache pass (_get_features_with_split_batch)
+        self.lite_overlap = os.environ.get("ORBIT_LITE_OVERLAP", "1") != "0"
+        self._lite_stream = None
         self._film_ready = None
         self._configured = None
         self.logits_ready = None
@@ -401,11 +406,37 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
 
     def _get_features_with_split_batch(self, context_clips, film_dict, grad_idxs, no_grad_idxs):
         self._set_batch_norm_state()
-        if self.features_cache is None:
+        grad_dev, no_grad_dev = self._split_indices(grad_idxs, no_grad_idxs)
+        fe = self.feature_extractor
+        if (self.features_cache is None and self.lite_overlap and fe.training and not film_dict and len(grad_idxs) > 0
+                and hasattr(fe, "deferred_stats")):
+            # First query batch of a task: the cache pass over the WHOLE context set (no autograd) and the re-encoding of the
+            # H-clip subset are independent, and the subset's kernels (16 frames) are launch-bound: it runs on a second stream
+            # beside the cache pass (1.6 ms of a 29 ms step when serial). Both passes are train-mode BatchNorm forwards of one
+            # plan; the reference updates the running statistics with the cache pass first (:404-408) - the subset's update
+            # is deferred and applied after the join, so the statistics end up as in the serial order. The subset is issued
+            # FIRST on the host: its tape must not be an allocator block the cache pass frees while its kernels still run.
+            h_clips = self._upload(self._take(context_clips, grad_idxs, grad_dev))
+            if h_clips.dim() == 5:
+                h_clips = h_clips.flatten(end_dim=1)
+            h_clips = h_clips.contiguous().float()
+            fe.prepare(h_clips.shape[-2], h_clips.shape[-1])  # parameter upload (if stale) on THIS stream, before the fork
+            side = self._lite_side_stream()
+            fork, done = torch.cuda.Event(), torch.cuda.Event()
+            fork.record()
+            side.wait_event(fork)
+            with fe.deferred_stats(fe) as deferred, _lib.use_stream(side):
+                features_with_grads = fe(h_clips, film=None)
+            done.record(side)
             with torch.no_grad():
                 self.features_cache = self._get_features_in_batches(context_clips, film_dict)
-        grad_dev, no_grad_dev = self._split_indices(grad_idxs, no_grad_idxs)
-        features_with_grads = self._get_features(self._take(context_clips, grad_idxs, grad_dev), film_dict)
+            torch.cuda.current_stream().wait_event(done)
+            deferred.apply()
+        else:
+            if self.features_cache is None:
+                with torch.no_grad():
+                    self.features_cache = self._get_features_in_batches(context_clips, film_dict)
+            features_with_grads = self._get_features(self._take(context_clips, grad_idxs, grad_dev), film_dict)
         if context_clips.dim() == 5 and context_clips.shape[1] > 1:
             # the cache holds frame features [N*T, D]; the reference indexes it with clip indices (:434),
             # which is only meaningful for T == 1 — keep clip granularity here
@@ -415,6 +446,11 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         else:
             features_without_grads = self.features_cache.index_select(0, no_grad_dev)
         return torch.cat((features_with_grads, features_without_grads))
+
+    def _lite_side_stream(self):
+        if self._lite_stream is None:
+            self._lite_stream = torch.cuda.Stream(device=self.device)
+        return self._lite_stream
 
     def _split_indices(self, grad_idxs, no_grad_idxs):
         """Device copies of the LITE index arrays: the slices personalise_with_lite prepared, or (when the helpers are

@@ -171,6 +171,32 @@ def test_G8_lite_unfrozen_extractor(device, tag, adapt):
     assert has == bool(g[tag + "_bn1_weight_has_grad"])
 
 
+def test_lite_subset_pass_beside_cache_pass_changes_nothing(device):
+    """The first query batch of a LITE task re-encodes the H-clip subset on a second stream beside the cache pass, with the
+    subset's running-statistics update deferred (ORBIT_TRAIN_DEFER_RUNNING_STATS + orbit_extractor_apply_deferred_bn_stats):
+    logits and every gradient are bit-identical to the serial order, the running statistics agree to the last bit or two
+    (the deferred update evaluates the same expression in another kernel)."""
+    g = gold("G8_lite_learn_extractor")
+    outs = []
+    for overlap in (True, False):
+        m = native(False, int(g["batch_size"]), int(g["num_lite_samples"]), True)
+        m.lite_overlap = overlap
+        lite_steps(m, g, 800, prefix="a_")
+        torch.cuda.synchronize()
+        outs.append(({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None},
+                     {k: v.detach().clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}))
+    (g1, s1), (g0, s0) = outs
+    assert sorted(g1) == sorted(g0) and len(g1) > 20
+    for n in g1:
+        assert torch.equal(g1[n], g0[n]), n
+    assert sorted(s1) == sorted(s0) and len(s1) > 20
+    for k in s1:
+        if "num_batches" in k:
+            assert torch.equal(s1[k], s0[k]), k
+        else:
+            assert rel(s1[k].float().cpu(), s0[k].float().cpu()) < 1e-6, k
+
+
 @pytest.mark.parametrize("tag,adapt", [("a", False), ("b", True)])
 def test_G9_lite_efficientnet(device, tag, adapt):
     """The README's main recipe on the efficientnet_b0 plan: gradients recorded from the reference's loss.backward().

@@ -11,7 +11,7 @@ mkdir -p "$R/$OUT"; O="$R/$OUT"
 cd /tmp && export TMPDIR=/tmp
 # kernels must run one at a time for their durations / counters to be attributable: the support/query stream overlap of
 # the timed leg is switched off here, exactly as bench.py does for its own roofline leg
-export ORBIT_BENCH_OVERLAP=0
+export ORBIT_BENCH_OVERLAP=0 ORBIT_LITE_OVERLAP=0  # (LITE: the H-subset pass serial, not beside the cache pass)
 for W in efficientnet_b0_224 resnet18_84 ${EXTRA_WORKLOADS:-}; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- \
       python $R/bench.py --workload $W --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_$W.json 2> $O/${TAG}_bench_$W.err

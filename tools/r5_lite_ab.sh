@@ -7,7 +7,8 @@ for rep in 1 2; do
   done
 done
 R=${GRAFT_REPO_ROOT:-$(pwd)}
-cd /tmp && export TMPDIR=/tmp && rm -rf /tmp/lt && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/lt -o trace -- python $R/tools/lite_trace.py > /dev/null 2>&1
+# (the traced step runs the H-subset pass serially: per-kernel durations are only attributable one kernel at a time)
+cd /tmp && export TMPDIR=/tmp ORBIT_LITE_OVERLAP=0 && rm -rf /tmp/lt && timeout 600 rocprofv3 --kernel-trace --output-format csv -d /tmp/lt -o trace -- python $R/tools/lite_trace.py > /dev/null 2>&1
 cd $R && python tools/lite_trace.py --parse $(find /tmp/lt -name "trace_kernel_trace.csv" | head -1) $O/lite_timeline.txt > $O/lite_summary.txt 2>&1
 python - $O <<'PY'
 import json, glob, os, sys
