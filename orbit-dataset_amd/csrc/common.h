@@ -249,7 +249,11 @@ int launch_dwconv_dgrad(const float* dy, const float* w_khwc, float* dx, int B, 
                         int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, float* flip_scratch = nullptr,
                         const DwBnBwd* bnb = nullptr);
 int dwconv_dgrad_bn_blocks(int B, int H, int W, int C, int stride);  // upper bound of the partial rows a fused dgrad writes
-size_t dwconv_bwd_fused_scratch_floats(int B, int H, int W, int C, int K, int stride);  // of DwBnBwd::wgrad_partial (0: no fused form)
+// scratch of a data gradient that carries the filter gradient (0: no fused form for the layer): the flipped taps of the stride-1
+// form in the first dwconv_bwd_fused_partial_offset floats, DwBnBwd::wgrad_partial behind them
+size_t dwconv_bwd_fused_scratch_floats(int B, int H, int W, int C, int K, int stride);
+size_t dwconv_bwd_fused_partial_offset(int C, int K);
+bool dwconv_se_window_form(int K, int stride, int Ho);
 int launch_dwconv_wgrad_reduce(const float* partial, int rows, int K, int C, float* dw, hipStream_t s);
 size_t dwconv_wgrad_scratch_floats(int B, int Ho, int Wo, int C, int K);
 int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scratch, int B, int H, int W, int C, int K,

@@ -708,7 +708,8 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                                      po.Cout % 4 == 0 && fe->bns[po.bn].conv_bias < 0 &&
                                      (po.act == ORBIT_ACT_SILU || po.act == ORBIT_ACT_NONE) && get_option("train_dw_xf");
             const bool raw_fed = src >= 0 && conv_feeds_dw_raw(fe, (size_t)src, bn_train, false, B);
-            // ... and on the stride-2 layers the filter gradient rides on that data-gradient kernel (DwBnBwd::wgrad_partial)
+            // ... and on the stride-2 layers and the large 3x3 maps the filter gradient rides on that data-gradient kernel
+            // (DwBnBwd::wgrad_partial)
             const bool wg_fused = wg && through_act && raw_fed &&
                                   dwconv_bwd_fused_scratch_floats(B, o.H, o.W, o.Cin, o.KH, o.stride) > 0;
             auto filter_gradient = [&]() {
@@ -740,7 +741,8 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                 const DwBnBwd* bnb_ptr = nullptr;
                 if (through_act) {
                     const BNDesc& sbn = fe->bns[po.bn];
-                    if (wg_fused) bnb.wgrad_partial = wgrad_scratch, bnb.wgrad_rows = &wrows;
+                    if (wg_fused)
+                        bnb.wgrad_partial = wgrad_scratch + dwconv_bwd_fused_partial_offset(o.Cin, o.KH), bnb.wgrad_rows = &wrows;
                     bnb.y = tf(L.y[src]), bnb.mean = mean + sbn.fold_off, bnb.invstd = invstd + sbn.fold_off;
                     bnb.scale = scale + sbn.fold_off, bnb.shift = shift + sbn.fold_off, bnb.act = po.act;
                     bnb.partial = partial, bnb.nblk = &nblk;
@@ -751,7 +753,8 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                 if (rc != ORBIT_OK) return rc;
                 if (bnb_ptr) pre_reduced[src] = nblk;  // 0: that kernel form has no such epilogue, the slot holds plain dx
                 if (wg_fused)
-                    rc = wrows > 0 ? launch_dwconv_wgrad_reduce(wgrad_scratch, wrows, o.KH, o.Cin, param_grads + fe->params[o.weight].off, s)
+                    rc = wrows > 0 ? launch_dwconv_wgrad_reduce(bnb.wgrad_partial, wrows, o.KH, o.Cin,
+                                                                param_grads + fe->params[o.weight].off, s)
                                    : filter_gradient();
             }
             release(kdy);

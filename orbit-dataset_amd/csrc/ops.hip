@@ -321,7 +321,11 @@ __global__ __launch_bounds__(256) void dwconv_pipe_kernel(const float* __restric
 // (K x NCOL quads) in registers: every output row loads only the S new input rows instead of all K, i.e. 3-5x fewer
 // L1/L2 requests (the plain kernel re-reads each input ~K*NCOL/NOUT times and is L2-bandwidth-bound on the 5x5 layers).
 // The ring slot of an input row is static: the row loop is unrolled over one ring period (K steps).
-template <int K, int S, int NOUT, bool STATS = false, bool XF = false, bool BNB = false>
+// WG (with BNB, the data-gradient use): the layer's filter gradient rides along (DwBnBwd::wgrad_partial) - the window holds
+// dy, the layer's input at the output pixel is act(y * scale + shift), and window element (kh, j + kw) times that input is the
+// (K-1-kh, K-1-kw) tap's term (the data gradient runs with flipped taps): K*K accumulators per thread, one [K*K][C] partial row
+// per block.
+template <int K, int S, int NOUT, bool STATS = false, bool XF = false, bool BNB = false, bool WG = false>
 __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                          float* __restrict__ y, const float* __restrict__ scale,
                                                          const float* __restrict__ shift,
@@ -359,6 +363,9 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
         bv.mu = *reinterpret_cast<const v4f*>(bnb.mean + c), bv.is = *reinterpret_cast<const v4f*>(bnb.invstd + c);
         byb = bnb.y + (size_t)b * Ho * Wo * C + c;
     }
+    v4f wacc[WG ? K * K : 1];
+#pragma unroll
+    for (int t = 0; t < (WG ? K * K : 1); ++t) wacc[t] = (v4f){0.f, 0.f, 0.f, 0.f};
     const int ho0 = chunk * rows_per_chunk;
     const int ho_end = min(Ho, ho0 + rows_per_chunk);
     const int WQ = (Wo + NOUT - 1) / NOUT;
@@ -402,6 +409,14 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
                             for (int j = 0; j < NOUT; ++j)
                                 yv[j] = *reinterpret_cast<const v4f*>(byb + ((size_t)ho * Wo + min(wq * NOUT + j, Wo - 1)) * C);
                         }
+                        v4f ain[WG ? NOUT : 1];  // WG: the layer's input at the NOUT pixels (0 beyond the row's end)
+                        if (WG) {
+#pragma unroll
+                            for (int j = 0; j < NOUT; ++j) {
+                                ain[j] = dw_xf(yv[j], bv.sc, bv.sh, bnb.act);
+                                if (wq * NOUT + j >= Wo) ain[j] = (v4f){0.f, 0.f, 0.f, 0.f};
+                            }
+                        }
                         v4f acc[NOUT];
 #pragma unroll
                         for (int j = 0; j < NOUT; ++j) acc[j] = (v4f){0.f, 0.f, 0.f, 0.f};
@@ -411,7 +426,10 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
                             for (int kw = 0; kw < K; ++kw) {
                                 const v4f f = wl[(kh * K + kw) * cb4 + lc];
 #pragma unroll
-                                for (int j = 0; j < NOUT; ++j) acc[j] += win[(ph * S + kh) % K][j * S + kw] * f;
+                                for (int j = 0; j < NOUT; ++j) {
+                                    acc[j] += win[(ph * S + kh) % K][j * S + kw] * f;
+                                    if (WG) wacc[kh * K + kw] += win[(ph * S + kh) % K][j * S + kw] * ain[j];
+                                }
                             }
                         }
 #pragma unroll
@@ -452,6 +470,29 @@ __global__ __launch_bounds__(256) void dwconv_win_kernel(const float* __restrict
             v4f t = red[tid];
             for (int l = 1; l < WL; ++l) t += red[l * cb4 + tid];
             *reinterpret_cast<v4f*>(pool_partial + (prow + 1) * C + (c4_0 + tid) * 4) = t;
+        }
+    }
+    if (WG) {
+        // this block's filter-gradient partial row: taps in rounds of 8 through an [8][256] buffer, column lanes added in order;
+        // accumulator t belongs to tap K*K - 1 - t (flipped taps)
+        v4f* wred = wl + K * K * cb4;
+        constexpr int TB = 8;
+        const size_t wrow = (size_t)b * gridDim.y + chunk;
+#pragma unroll
+        for (int t0 = 0; t0 < K * K; t0 += TB) {
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < TB; ++u)
+                if (t0 + u < K * K) wred[u * 256 + tid] = active ? wacc[t0 + u] : (v4f){0.f, 0.f, 0.f, 0.f};
+            __syncthreads();
+            for (int i = tid; i < TB * cb4; i += 256) {
+                const int u = i / cb4, cc = i - u * cb4;
+                if (t0 + u < K * K) {
+                    v4f t = wred[u * 256 + cc];
+                    for (int l = 1; l < WL; ++l) t += wred[u * 256 + l * cb4 + cc];
+                    *reinterpret_cast<v4f*>(bnb.wgrad_partial + (wrow * K * K + (K * K - 1 - (t0 + u))) * C + (c4_0 + cc) * 4) = t;
+                }
+            }
         }
     }
 }
@@ -849,6 +890,14 @@ int dwconv_se_rows_per_chunk(int Ho) {
 }
 int dwconv_se_chunks(int Ho) { return cdiv(Ho, dwconv_se_rows_per_chunk(Ho)); }
 
+// whether launch_dwconv_se runs a (K, stride) layer with Ho output rows through the register-window kernel (the form that can
+// carry the filter gradient, DwBnBwd::wgrad_partial); conservative: false where the LDS form is tried first
+bool dwconv_se_window_form(int K, int stride, int Ho) {
+    const int lds_opt = get_option("dw_lds"), win_opt = get_option("dw_window");
+    if (lds_opt == 2 || (lds_opt == 1 && stride == 1 && (K == 5 || Ho <= 14))) return false;
+    return win_opt == 2 || (win_opt == 1 && K == 3 && stride == 1 && Ho >= 14);
+}
+
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                      float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
                      int Wo, int act, hipStream_t s, int stats, const float* in_scale, const float* in_shift, int in_act, const DwBnBwd* bnb) {
@@ -936,9 +985,16 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     // VGPRs, 1 wave/SIMD) and on stride 2. dw_window: 1 = auto (default), 0 = never, 2 = always.
     const int win_opt = get_option("dw_window");
     if (win_opt == 2 || (win_opt == 1 && K == 3 && stride == 1 && Ho >= 14)) {
+        const size_t lds_wg = (size_t)(K * K * cb4 + 8 * 256) * sizeof(float4);
 #define ORBIT_DWW(KK, SS, NO)                                                                                          \
     do {                                                                                                               \
-        if (bnb) {                                                                                                     \
+        if (bnb && bnb->wgrad_partial) {                                                                               \
+            if constexpr (SS == 1)                                                                                     \
+                dwconv_win_kernel<KK, SS, NO, true, false, true, true><<<grid, 256, lds_wg, s>>>(                      \
+                    x, w_khwc, y, nullptr, nullptr, bnb->partial, H, W, C, pad_t, pad_l, Ho, Wo, act, cb4, rpc,           \
+                    DwInXf{nullptr, nullptr, 0}, *bnb);                                                                \
+            *bnb->nblk = *bnb->wgrad_rows = (int)(grid.y * grid.z);                                                    \
+        } else if (bnb) {                                                                                              \
             if constexpr (SS == 1)                                                                                     \
                 dwconv_win_kernel<KK, SS, NO, true, false, true><<<grid, 256, lds, s>>>(x, w_khwc, y, nullptr, nullptr,   \
                                                                                         bnb->partial, H, W, C, pad_t, pad_l, Ho, Wo, \

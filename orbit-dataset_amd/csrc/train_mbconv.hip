@@ -879,9 +879,13 @@ static int dgrad_s2_fused_blocks(int B, int H, int W, int C, int K) {
     const size_t per_block = (size_t)R * (size_t)cdiv(K * K + 2, R);  // 2x2 blocks per row block: >= ~2 x the epilogue's quads / 9
     return (int)std::max<size_t>(1, std::min<size_t>(2048, blocks2 / std::max<size_t>(per_block * 2, 1)));
 }
+size_t dwconv_bwd_fused_partial_offset(int C, int K) { return (size_t)(C * K * K + 3) / 4 * 4; }
 size_t dwconv_bwd_fused_scratch_floats(int B, int H, int W, int C, int K, int stride) {
-    if (stride != 2 || C % 4 != 0 || (K != 3 && K != 5)) return 0;
-    return (size_t)dgrad_s2_fused_blocks(B, H, W, C, K) * K * K * C;
+    if (C % 4 != 0 || (K != 3 && K != 5)) return 0;
+    if (stride == 2) return dwconv_bwd_fused_partial_offset(C, K) + (size_t)dgrad_s2_fused_blocks(B, H, W, C, K) * K * K * C;
+    // stride 1: the register-window kernel (the data gradient is a forward depthwise pass over dy with H output rows)
+    if (stride != 1 || !dwconv_se_window_form(K, 1, H)) return 0;
+    return dwconv_bwd_fused_partial_offset(C, K) + (size_t)B * dwconv_se_chunks(H) * K * K * C;
 }
 int launch_dwconv_wgrad_reduce(const float* partial, int rows, int K, int C, float* dw, hipStream_t s) {
     ORBIT_REQUIRE(partial && dw && rows > 0, "dwconv_wgrad_reduce: bad arguments");
@@ -1049,7 +1053,7 @@ int orbit_op_dwconv2d_dgrad_bn(const float* dy, const float* w, const float* y_r
     ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), (npack + nscr + npart) * sizeof(float), s));
     int nblk = 0, wrows = 0;
     DwBnBwd bnb{y_raw, mean, invstd, scale, shift, act, tmp + npack + nscr, &nblk};
-    if (dw) bnb.wgrad_partial = tmp + npack, bnb.wgrad_rows = &wrows;
+    if (dw) bnb.wgrad_partial = tmp + npack + dwconv_bwd_fused_partial_offset(C, K), bnb.wgrad_rows = &wrows;
     int rc = dwconv_pack_weights(w, tmp, C, K, s);
     if (rc == ORBIT_OK) rc = launch_dwconv_dgrad(dy, tmp, g, B, H, W, C, K, stride, pad_top, pad_left, Ho, Wo, s, tmp + npack, &bnb);
     if (rc == ORBIT_OK && nblk <= 0) rc = set_err(ORBIT_ERR_ARG, "op_dwconv2d_dgrad_bn: no kernel form with the epilogue for this layer");
