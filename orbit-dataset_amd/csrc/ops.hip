@@ -923,7 +923,10 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     const int lds_opt = get_option("dw_lds");
     // measured (tools/dw_bench.py, 200 frames): 5x5 stride 1 -39..-41 % time (28x240, 14x480, 14x672), -15 % at 7x1152;
     // 3x3 stride 1 on <= 14 rows -10..-20 %; stride 2 and the large 3x3 maps are faster through the streaming kernels
-    if (lds_opt == 2 || (lds_opt == 1 && stride == 1 && (K == 5 || Ho <= 14))) {
+    // train form (statistics epilogue, the input transform applied per load) at 200 frames, tools/dw_train_bench.py: the small
+    // stride-2 map (14 -> 7 rows, 5x5) 158 -> 84 us through the LDS patch (the transform once per element instead of once per tap)
+    const bool train_form = stats != 0;
+    if (lds_opt == 2 || (lds_opt == 1 && ((stride == 1 && (K == 5 || Ho <= 14)) || (train_form && stride == 2 && Ho < 14)))) {
         const int c4 = C / 4;
         const int G = cdiv(Wo, 4);
         // channel quads per block: the widest slice (longest contiguous run per pixel) whose (256 / cs4) / G row lanes
@@ -1023,7 +1026,8 @@ int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float*
     // software-pipelined streaming kernel (dw_pipe: 1 = auto, 0 = never, 2 = always): measured +5..9 % on the large
     // stride-2 layers (112x96 3x3, 56x144 5x5), slower on the small maps (two tap rows of registers -> 2 waves per SIMD)
     const int pipe_opt = get_option("dw_pipe");
-    if (pipe_opt == 2 || (pipe_opt == 1 && stride == 2 && Ho >= 28)) {
+    // (train form: also the 28 -> 14 row layer, 102 -> 60 us)
+    if (pipe_opt == 2 || (pipe_opt == 1 && stride == 2 && Ho >= (train_form ? 14 : 28))) {
 #define ORBIT_DWP(KK, SS)                                                                                              \
     do {                                                                                                               \
         if (use_xf)                                                                                                    \
