@@ -71,8 +71,8 @@ print(json.dumps({"workload": wl, "kernel": " + ".join("orbit::" + k for k in ke
 PY
 }
 traffic traffic efficientnet_b0_224 "conv_igemm_kernel|pw_rgemm_kernel" --workload efficientnet_b0_224
-# the LITE training step's dense-conv family: forward + data-gradient (conv_igemm) and filter-gradient (conv_wgrad) kernels
-traffic lite_traffic efficientnet_b0_224:lite_train "conv_igemm_kernel|pw_rgemm_kernel|conv_wgrad_kernel" --mode lite_train --workload efficientnet_b0_224
+# the LITE training step's dense-conv family: forward + data-gradient (conv_igemm) and filter-gradient (conv_wgrad, conv_wgrad_thin) kernels
+traffic lite_traffic efficientnet_b0_224:lite_train "conv_igemm_kernel|pw_rgemm_kernel|conv_wgrad_kernel|conv_wgrad_thin_kernel" --mode lite_train --workload efficientnet_b0_224
 # ---- distance kernel (64-task batched launch): kernel-trace stats + FETCH_SIZE / WRITE_SIZE in their own passes ----------
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_head -- python $R/tools/head_roofline.py quick > $O/${TAG}_head_roofline.log 2>&1
