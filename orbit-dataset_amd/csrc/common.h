@@ -237,6 +237,13 @@ int launch_se_gate_backward(const float* dxg, const float* x, const float* poole
                             const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1,
                             float* dw2, float* db2, float* scratch, int B, int HW, int C, int R, hipStream_t s,
                             const SeBnFuse* bn = nullptr, const float* w2t = nullptr);
+// With bn, dx may be nullptr: g is then NOT written (one pass over the expanded tensor less); the BatchNorm's apply pass
+// rebuilds it from dxg, the gate and the pooled-branch gradient the MLP backward left in `scratch` (se_bwd_dpooled):
+const float* se_bwd_dpooled(const float* scratch, int B, int C, int R);
+int launch_bn_backward_reduced_gated(const float* dxg, const float* gate, const float* dpooled, int HW, const float* y,
+                                     const float* mean, const float* invstd, const float* scale, const float* shift, int act,
+                                     const float* gamma, int train, int M, int C, float* dy, float* dgamma, float* dbeta,
+                                     float* partial, int nblk, float* coef, hipStream_t s);
 // (w2t, optional: W2 transposed to [R][C] - the plan's packed copy; the MLP backward then reads W2 contiguously)
 // BatchNorm backward whose reduction pass already ran (g = dout * act'(.) in `g`, [nblk][2][C] sums of g and g * xhat in
 // `partial`): finalize + apply only. coef: 3*C floats

@@ -621,6 +621,13 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
     // (written by the squeeze-excite backward of the block, launch_se_gate_backward with SeBnFuse, or - for the expansion
     // convolution - by the data gradient of the depthwise convolution it feeds, DwBnBwd)
     std::vector<int> pre_reduced(n, 0);
+    // ... and when the squeeze-excite backward left only the SUMS: the slot of op i holds d(x * gate) and g is rebuilt in the
+    // BatchNorm's apply pass from it, the gate and the pooled-branch gradient (launch_bn_backward_reduced_gated)
+    struct GatedG {
+        const float *gate = nullptr, *dpooled = nullptr;
+        int HW = 0;
+    };
+    std::vector<GatedG> gated(n);
     auto slot_ptr = [&](int k) { return reinterpret_cast<float*>(ws + W.slots + (size_t)k * W.slot_bytes); };
     auto alloc = [&]() {
         for (int k = 0; k < BwdLayout::NSLOTS; ++k)
@@ -689,7 +696,14 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                 kdy = alloc();
                 if (kdy < 0) return set_err(ORBIT_ERR_STATE, "extractor_backward: gradient slots exhausted");
             }
-            if (pre_reduced[i] > 0) {
+            if (pre_reduced[i] > 0 && gated[i].gate) {
+                float* coef = partial + bn_partial_floats((size_t)pre_reduced[i], o.Cout);
+                rc = launch_bn_backward_reduced_gated(slot_ptr(g), gated[i].gate, gated[i].dpooled, gated[i].HW, tf(L.y[i]),
+                                                      mean + bn.fold_off, invstd + bn.fold_off, scale + bn.fold_off,
+                                                      shift + bn.fold_off, o.act, gamma, bn_train, M, o.Cout,
+                                                      need_dy ? slot_ptr(kdy) : nullptr, dgam, dbet, partial, pre_reduced[i],
+                                                      coef, s);
+            } else if (pre_reduced[i] > 0) {
                 float* coef = partial + bn_partial_floats((size_t)pre_reduced[i], o.Cout);
                 rc = launch_bn_backward_reduced(slot_ptr(g), tf(L.y[i]), mean + bn.fold_off, invstd + bn.fold_off, gamma,
                                                 bn_train, M, o.Cout, need_dy ? slot_ptr(kdy) : nullptr, dgam, dbet, partial,
@@ -835,13 +849,21 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                 rc = launch_conv_dgrad(slot_ptr(kdy), st->d_dgrad + st->dgrad_off[i], nullptr, slot_ptr(kt), up, B, o.H, o.W,
                                        o.Cin, o.Cout, o.KH, o.KW, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
                 if (rc != ORBIT_OK) return rc;
-                SLOT_OR_FAIL(k);
-                grad_slot[src] = k;
                 float* pg = wg ? param_grads : nullptr;
                 // x = SiLU(BatchNorm(depthwise output)): the first (reduction) pass of that BatchNorm's backward is folded
-                // into the last pass of the squeeze-excite backward
+                // into the last pass of the squeeze-excite backward, which then leaves only the sums - g itself is rebuilt by
+                // that BatchNorm's apply pass from d(x * gate) (slot kt stays the depthwise op's gradient slot)
                 SeBnFuse fuse;
                 const SeBnFuse* fuse_ptr = nullptr;
+                static const char* write_g_env = getenv("ORBIT_SE_BWD_WRITE_G");  // tuning experiments only
+                const bool sums_only = fe->ops[src].kind == OP_DWCONV && !(write_g_env && atoi(write_g_env) != 0) &&
+                                       (unsigned long long)B * o.H * o.W * (o.Cin / 4) < (1ull << 32);
+                int k = kt;
+                if (!sums_only) {
+                    k = alloc();
+                    if (k < 0) return set_err(ORBIT_ERR_STATE, "extractor_backward: gradient slots exhausted");
+                }
+                grad_slot[src] = k;
                 if (fe->ops[src].kind == OP_DWCONV) {
                     const BNDesc& sbn = fe->bns[fe->ops[src].bn];
                     fuse.y = tf(L.y[src]), fuse.mean = mean + sbn.fold_off, fuse.invstd = invstd + sbn.fold_off;
@@ -849,16 +871,19 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
                     fuse.partial = partial;
                     fuse_ptr = &fuse;
                     pre_reduced[src] = B * se_pool_chunks(B, o.H * o.W, o.Cin);
+                    if (sums_only)
+                        gated[src].gate = tf(L.a[se]), gated[src].dpooled = se_bwd_dpooled(se_scratch, B, o.Cin, so.R),
+                        gated[src].HW = o.H * o.W;
                 }
                 rc = launch_se_gate_backward(slot_ptr(kt), out_tensor(src), tf(L.p[se]), tf(L.a[se]),
                                              fe->d_pool + fe->params[so.se_w1].off, fe->d_pool + fe->params[so.se_b1].off,
                                              fe->d_pool + fe->params[so.se_w2].off, fe->d_pool + fe->params[so.se_b2].off,
-                                             slot_ptr(k), pg ? pg + fe->params[so.se_w1].off : nullptr,
+                                             sums_only ? nullptr : slot_ptr(k), pg ? pg + fe->params[so.se_w1].off : nullptr,
                                              pg ? pg + fe->params[so.se_b1].off : nullptr,
                                              pg ? pg + fe->params[so.se_w2].off : nullptr,
                                              pg ? pg + fe->params[so.se_b2].off : nullptr, se_scratch, B, o.H * o.W, o.Cin,
                                              so.R, s, fuse_ptr, fe->d_packed + so.packed_off);
-                release(kt);
+                if (!sums_only) release(kt);
             } else if (need_dx) {
                 const float* acc = nullptr;
                 if (grad_slot[src] < 0) {

@@ -142,7 +142,7 @@ __global__ __launch_bounds__(256) void gate_bwd_apply_bn_kernel(const float* __r
 #pragma unroll
                 for (int k = 0; k < 4; ++k) g[k] = z[k] > 0.f ? g[k] : 0.f;
             }
-            *reinterpret_cast<f32x4*>(gout + o) = g;
+            if (gout) *reinterpret_cast<f32x4*>(gout + o) = g;  // (nullptr: sums only, launch_bn_backward_reduced_gated rebuilds g)
             s += g;
             sx += g * ((yv - mu) * is);
         }
@@ -808,11 +808,16 @@ int launch_gate_mul(const float* x, const float* gate, float* xg, int B, int HW,
 // scratch: du [B*C] | dv [B*R] | h [B*R] | dgate [B*C] | dpooled [B*C]
 size_t se_bwd_scratch_floats(int B, int C, int R) { return (size_t)B * (3 * (size_t)C + 2 * (size_t)R) + 16; }
 
+const float* se_bwd_dpooled(const float* scratch, int B, int C, int R) {
+    return scratch + (size_t)B * C + 2 * (size_t)B * R + (size_t)B * C;  // (the layout launch_se_gate_backward lays down)
+}
+
 int launch_se_gate_backward(const float* dxg, const float* x, const float* pooled, const float* gate, const float* w1,
                             const float* b1, const float* w2, const float* b2, float* dx, float* dw1, float* db1,
                             float* dw2, float* db2, float* scratch, int B, int HW, int C, int R, hipStream_t s,
                             const SeBnFuse* bn, const float* w2t) {
     ORBIT_REQUIRE(C % 4 == 0 && R > 0 && R <= 256, "se_gate_backward: bad sizes (C=%d R=%d)", C, R);
+    ORBIT_REQUIRE(dx || bn, "se_gate_backward: dx may only be omitted with the BatchNorm fusion");
     float* du = scratch;
     float* dv = du + (size_t)B * C;
     float* h = dv + (size_t)B * R;

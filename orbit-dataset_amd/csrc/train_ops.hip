@@ -552,6 +552,80 @@ int launch_bn_backward_reduced(const float* g, const float* y, const float* mean
     return ORBIT_OK;
 }
 
+// dy = k1 * (g - k2 - xhat * k3) with g = (dxg * gate[b] + dpooled[b] / HW) * act'(y * scale + shift) rebuilt on the fly - the
+// expression gate_bwd_apply_bn_kernel (csrc/train_mbconv.hip) summed, so the sums in coef belong to exactly this g
+__global__ __launch_bounds__(256) void gate_bn_bwd_apply_kernel(const float* __restrict__ dxg, const float* __restrict__ gate,
+                                                                const float* __restrict__ dpooled,
+                                                                const float* __restrict__ y, const float* __restrict__ mean,
+                                                                const float* __restrict__ invstd,
+                                                                const float* __restrict__ scale,
+                                                                const float* __restrict__ shift,
+                                                                const float* __restrict__ coef, int act, int HW, int C4,
+                                                                size_t total4, float* __restrict__ dy) {
+    const int C = C4 * 4;
+    const float inv = 1.0f / (float)HW;
+    const unsigned per_frame = (unsigned)HW * (unsigned)C4;  // grid = (blocks per frame, frames); total4 = per_frame here
+    const unsigned b = blockIdx.y;
+    const unsigned stride = gridDim.x * 256u, stride_mod = stride % (unsigned)C4;  // see scale_shift_act_kernel
+    unsigned q = (blockIdx.x * 256u + threadIdx.x) % (unsigned)C4;
+    const size_t base = (size_t)b * per_frame;
+    for (unsigned j = blockIdx.x * 256u + threadIdx.x; j < per_frame;
+         j += stride, q = q + stride_mod >= (unsigned)C4 ? q + stride_mod - C4 : q + stride_mod) {
+        const size_t i = base + j;
+        f32x4 g = reinterpret_cast<const f32x4*>(dxg)[i] * reinterpret_cast<const f32x4*>(gate)[(size_t)b * C4 + q] +
+                  reinterpret_cast<const f32x4*>(dpooled)[(size_t)b * C4 + q] * inv;
+        const f32x4 yv = reinterpret_cast<const f32x4*>(y)[i];
+        if (act == ORBIT_ACT_SILU) {
+            const f32x4 z = yv * reinterpret_cast<const f32x4*>(scale)[q] + reinterpret_cast<const f32x4*>(shift)[q];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float sg = __builtin_amdgcn_rcpf(1.0f + __expf(-z[k]));
+                g[k] *= sg * (1.0f + z[k] * (1.0f - sg));
+            }
+        } else if (act == ORBIT_ACT_RELU) {
+            const f32x4 z = yv * reinterpret_cast<const f32x4*>(scale)[q] + reinterpret_cast<const f32x4*>(shift)[q];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) g[k] = z[k] > 0.f ? g[k] : 0.f;
+        }
+        const f32x4 xh = (yv - reinterpret_cast<const f32x4*>(mean)[q]) * reinterpret_cast<const f32x4*>(invstd)[q];
+        const f32x4 k1 = reinterpret_cast<const f32x4*>(coef)[q];
+        const f32x4 k2 = reinterpret_cast<const f32x4*>(coef + C)[q];
+        const f32x4 k3 = reinterpret_cast<const f32x4*>(coef + 2 * C)[q];
+        reinterpret_cast<f32x4*>(dy)[i] = k1 * (g - k2 - xh * k3);
+    }
+}
+
+int launch_bn_backward_reduced_gated(const float* dxg, const float* gate, const float* dpooled, int HW, const float* y,
+                                     const float* mean, const float* invstd, const float* scale, const float* shift, int act,
+                                     const float* gamma, int train, int M, int C, float* dy, float* dgamma, float* dbeta,
+                                     float* partial, int nblk, float* coef, hipStream_t s) {
+    ORBIT_REQUIRE(C % 4 == 0 && M > 0 && HW > 0 && M % HW == 0 && nblk > 0 && dxg && gate && dpooled && y && partial && coef,
+                  "bn_backward_reduced_gated: bad arguments");
+    ORBIT_REQUIRE(act != ORBIT_ACT_SILU || (scale && shift), "bn_backward_reduced_gated: SiLU needs the folded scale/shift");
+    const float* src = partial;
+    if (nblk > BN_COMPACT_ABOVE) {
+        const int GS = cdiv(nblk, BN_COMPACT_TO), nout = cdiv(nblk, GS), cols4 = 2 * C / 4;
+        float* out = partial + (size_t)nblk * 2 * C;
+        const size_t items = (size_t)nout * cols4;
+        bn_partial_compact_kernel<<<(unsigned)((items + 255) / 256), 256, 0, s>>>(partial, nblk, cols4, GS, nout, out);
+        ORBIT_LAUNCH_CHECK();
+        src = out, nblk = nout;
+    }
+    bn_bwd_finalize_kernel<<<cdiv(C, BN_FIN_CH), 256, 0, s>>>(src, nblk, M, C, train, gamma, invstd, dgamma, dbeta, nullptr, coef);
+    ORBIT_LAUNCH_CHECK();
+    if (dy) {
+        const size_t total4 = (size_t)M * (C / 4);
+        ORBIT_REQUIRE((unsigned long long)total4 < (1ull << 32), "tensor too large for the 32-bit index arithmetic of this kernel");
+        const unsigned per_frame4 = (unsigned)HW * (unsigned)(C / 4);
+        const int B = M / HW;
+        const int gx = std::max(1, std::min(cdiv((int)per_frame4, 256), cdiv(16384, B)));
+        gate_bn_bwd_apply_kernel<<<dim3(gx, B), 256, 0, s>>>(dxg, gate, dpooled, y, mean, invstd, scale, shift, coef, act, HW,
+                                                             C / 4, total4, dy);
+        ORBIT_LAUNCH_CHECK();
+    }
+    return ORBIT_OK;
+}
+
 int launch_maxpool_idx(const float* x, float* y, uint8_t* idx, int B, int H, int W, int C, int K, int stride, int pad,
                        int Ho, int Wo, hipStream_t s) {
     ORBIT_REQUIRE(C % 4 == 0 && K * K <= 255, "maxpool: C %% 4 != 0 or window too large");
