@@ -16,6 +16,7 @@ CNAPs), the other two single-step recipes of the reference README, are built on 
 'linear' is the head of the multi-step finetuner (MultiStepFewShotRecogniser).
 """
 import ctypes
+import time
 
 import torch
 import torch.nn as nn
@@ -34,6 +35,8 @@ class PendingLabelSet:
     CAP = 32  # class slots the head kernels are launched over until the count is known (ORBIT users own <= ~20 objects)
     _slots = None  # pinned ring of counts, shared by the process
     _next = 0
+    wait_seconds = 0.0  # host time spent blocked in resolve() since the process started (the kernel itself takes microseconds:
+    #                     a long wait means the host ran ahead of the stream the labels were produced on)
 
     def __init__(self, labels, device):
         cls = PendingLabelSet
@@ -69,7 +72,9 @@ class PendingLabelSet:
         """host-side: the exact class ids [C] (or None when the task has more than CAP classes: the caller then takes the
         exact path). Blocks only until the side stream's kernel + 4-byte copy are done."""
         if self._resolved is None:
+            t0 = time.perf_counter()
             self.done.synchronize()
+            PendingLabelSet.wait_seconds += time.perf_counter() - t0  # (bench.py reports it beside the host's enqueue time)
             c = int(PendingLabelSet._slots[self.slot])
             self._resolved = (self.ids[:c] if c <= self.CAP else None,)
         return self._resolved[0]
