@@ -70,6 +70,9 @@ def build_model(workload, device, batch_size=256, train=False):
     # ORBIT_BENCH_OVERLAP=2: pipelined form (head on the query stream, no join: consecutive tasks overlap out of phase)
     mode = os.environ.get("ORBIT_BENCH_OVERLAP", "1")
     model.overlap_query = False if (train or mode == "0") else (2 if mode == "2" else True)
+    # LITE: the query batch's taped pass starts beside the cache pass as well (same readiness requirement as overlap_query:
+    # the clips are resident); ORBIT_LITE_OVERLAP=0 / ORBIT_LITE_QUERY_OVERLAP=0 restore the serial order
+    model.lite_query_overlap = bool(train and model.lite_overlap and os.environ.get("ORBIT_LITE_QUERY_OVERLAP", "1") != "0")
     return model
 
 
@@ -705,12 +708,13 @@ def main():
     # roofline leg: the SAME K steps again with one HIP-event pair recorded per conv_igemm launch on its stream
     # (kept out of the timed region above: recording ~80 events per task costs host time and serialises the queue)
     overlap, lite_overlap = getattr(model, "overlap_query", False), getattr(model, "lite_overlap", False)
+    lite_query_overlap = getattr(model, "lite_query_overlap", False)
     model.overlap_query = False  # per-launch durations are only meaningful when the kernels run one at a time
-    model.lite_overlap = False   # (LITE: the H-subset pass otherwise runs beside the cache pass on a second stream)
+    model.lite_overlap = model.lite_query_overlap = False  # (LITE: the H-subset and query passes otherwise run beside the cache pass)
     lib.orbit_prof_enable(1)
     elapsed_prof, _, _ = loop(args.steps)
     lib.orbit_prof_enable(0)
-    model.overlap_query, model.lite_overlap = overlap, lite_overlap
+    model.overlap_query, model.lite_overlap, model.lite_query_overlap = overlap, lite_overlap, lite_query_overlap
     per_rank = None
     if dist is not None:
         per_rank = per_rank_report(rank, world, dist, device, elapsed, issued, args.steps, run_step if train else None)
@@ -807,6 +811,7 @@ def main():
         "train_graph_calls_replayed_eager": list(model.feature_extractor.train_graph_stats()) if train else None,
         # LITE: the H-clip subset pass of each task runs on a second stream beside the cache pass (ORBIT_LITE_OVERLAP=0: serial)
         "lite_subset_beside_cache_pass": bool(getattr(model, "lite_overlap", False)) if train else None,
+        "lite_query_pass_beside_cache_pass": bool(getattr(model, "lite_query_overlap", False)) if train else None,
         "train_loss_per_step": [float(x) for x in train_losses.cpu()] if train_losses is not None else None,
         "median_task_ms": median_task_ms,
         "labels": "every timed task carries a label tensor new to the head: its label set is resolved inside the timed region "

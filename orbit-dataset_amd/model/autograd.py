@@ -34,8 +34,17 @@ class ExtractorFunction(torch.autograd.Function):
         lib = _lib.load()
         B = frames.shape[0]
         dev = frames.device
-        tape = _empty_bytes(lib.orbit_extractor_tape_bytes(plan.handle, B), dev)
-        feats = torch.empty(B, net.output_size, device=dev, dtype=torch.float32)
+        key = net._persist_key
+        if key is not None and net.persistent_available(key):
+            # (HipNetwork.persistent_buffers: a forward on a side stream records into buffers the network owns)
+            tape = net._persistent_tensor(key, "tape", lib.orbit_extractor_tape_bytes(plan.handle, B), torch.uint8, dev)
+            feats = net._persistent_tensor(key, "feats", B * net.output_size, torch.float32, dev).view(B, net.output_size)
+            net._persist_busy[key] = True
+        else:
+            key = None
+            tape = _empty_bytes(lib.orbit_extractor_tape_bytes(plan.handle, B), dev)
+            feats = torch.empty(B, net.output_size, device=dev, dtype=torch.float32)
+        ctx.persist_key = key
         # (flag 2 = ORBIT_TRAIN_DEFER_RUNNING_STATS: the network applies the running-statistics update later, see
         # HipNetwork.deferred_stats)
         _lib.check(lib.orbit_extractor_train_forward_ex(
@@ -83,6 +92,8 @@ class ExtractorFunction(torch.autograd.Function):
             _lib.stream_handle()),
             "orbit_extractor_backward")
         ctx.tape = None
+        if ctx.persist_key is not None:
+            net.persistent_release(ctx.persist_key)
         if need_film:
             out[3], out[4] = dgamma, dbeta
         if need_params:

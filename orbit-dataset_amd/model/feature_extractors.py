@@ -82,6 +82,10 @@ class HipNetwork(nn.Module):
         self.native_name = native_name
         self._plans = {}
         self._defer_stats = None  # list of (plan, tape, B) inside a deferred_stats block
+        # persistent tape / feature buffers of taped forwards issued on a side stream (persistent_buffers below)
+        self._persist_key = None
+        self._persist = {}       # (key, kind) -> tensor
+        self._persist_busy = {}  # key -> True while a tape recorded into the buffers awaits its backward
         lib = _lib.load()
         # a throw-away plan at a nominal size enumerates the state_dict keys and FiLM slots
         probe = _Plan(native_name, 64, 64)
@@ -149,6 +153,44 @@ class HipNetwork(nn.Module):
                 raise _lib.OrbitHipError("native plan enumerates different parameters than the module tree")
             self._plans[(H, W, trainable)] = plan
         return plan
+
+    def in_sync(self, H, W, trainable=True):
+        """True when the plan a forward at this frame size would use exists and holds the current parameters."""
+        plan = self._plans.get((H, W, trainable))
+        return plan is not None and plan.stamp == self._stamp()
+
+    class persistent_buffers:
+        """A taped forward issued inside the block records into buffers the network keeps under `key` (tape and features)
+        instead of fresh allocations: a forward that runs on a side stream NOT ordered behind the caller's stream must not
+        be handed an allocator block whose previous user is still in flight there, and fixed addresses let the training
+        entry points replay their graphs. One tape per key at a time: `release(key)` (or the tape's backward) frees it;
+        while it is busy `available(key)` is False and the caller takes its ordinary path."""
+
+        def __init__(self, net, key):
+            self.net, self.key = net, key
+
+        def __enter__(self):
+            self.net._persist_key = self.key
+            return self
+
+        def __exit__(self, *exc):
+            self.net._persist_key = None
+            return False
+
+    def persistent_available(self, key):
+        return not self._persist_busy.get(key, False)
+
+    def persistent_release(self, key=None):
+        if key is None:
+            self._persist_busy.clear()
+        else:
+            self._persist_busy[key] = False
+
+    def _persistent_tensor(self, key, kind, numel, dtype, device):
+        t = self._persist.get((key, kind))
+        if t is None or t.numel() < numel or t.dtype != dtype or t.device != device:
+            t = self._persist[(key, kind)] = torch.empty(max(int(numel), 256), dtype=dtype, device=device)
+        return t[:numel] if t.numel() != numel else t
 
     def prepare(self, H, W, trainable=True):
         """Build (if needed) and bring up to date the plan a forward at this frame size will use, on the current stream."""

@@ -171,16 +171,19 @@ def test_G8_lite_unfrozen_extractor(device, tag, adapt):
     assert has == bool(g[tag + "_bn1_weight_has_grad"])
 
 
-def test_lite_subset_pass_beside_cache_pass_changes_nothing(device):
+@pytest.mark.parametrize("query_too", [False, True], ids=["subset", "subset+query"])
+def test_lite_subset_pass_beside_cache_pass_changes_nothing(device, query_too):
     """The first query batch of a LITE task re-encodes the H-clip subset on a second stream beside the cache pass, with the
-    subset's running-statistics update deferred (ORBIT_TRAIN_DEFER_RUNNING_STATS + orbit_extractor_apply_deferred_bn_stats):
-    logits and every gradient are bit-identical to the serial order, the running statistics agree to the last bit or two
-    (the deferred update evaluates the same expression in another kernel)."""
+    subset's running-statistics update deferred (ORBIT_TRAIN_DEFER_RUNNING_STATS + orbit_extractor_apply_deferred_bn_stats);
+    with `lite_query_overlap` the query batch's taped pass starts from the same fork point on a third stream, recording into
+    buffers the network keeps. Logits and every gradient are bit-identical to the serial order, the running statistics agree
+    to the last bit or two (the deferred update evaluates the same expression in another kernel)."""
     g = gold("G8_lite_learn_extractor")
     outs = []
     for overlap in (True, False):
         m = native(False, int(g["batch_size"]), int(g["num_lite_samples"]), True)
         m.lite_overlap = overlap
+        m.lite_query_overlap = overlap and query_too
         lite_steps(m, g, 800, prefix="a_")
         torch.cuda.synchronize()
         outs.append(({n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None},
