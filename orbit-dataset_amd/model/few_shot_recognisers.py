@@ -279,9 +279,10 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         # LITE: the H-subset pass of a task's first query batch runs beside the cache pass (_get_features_with_split_batch)
         self.lite_overlap = os.environ.get("ORBIT_LITE_OVERLAP", "1") != "0"
         self._lite_stream = None
-        # ... and (opt-in, like overlap_query: the query clips must be READY - resident, not produced by pending work on the
-        # caller's stream - when predict_a_batch() is called) the query batch's taped pass runs on a third stream from the
-        # same fork point, beside the cache pass still in flight: two 200-frame passes overlap in their small late layers
+        # ... and the query batch's taped pass runs on a third stream from the same fork point, beside the cache pass still in
+        # flight (clips on the host: always, their upload is issued on that stream; clips on the device: opt-in like
+        # overlap_query, they must be READY - not produced by pending work on the caller's stream - when predict_a_batch()
+        # is called): two 200-frame passes overlap in their small late layers
         # as the support / query passes of the test path do. Its running-statistics update is deferred as well (order kept:
         # cache pass, subset, query batch).
         self.lite_query_overlap = False
@@ -542,22 +543,32 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         self._set_batch_norm_state()
         fe, fork = self.feature_extractor, self._lite_fork
         self._lite_fork = None
-        if (fork is not None and self.lite_query_overlap and fe.training and not self.film_dict and torch.is_grad_enabled()
-                and target_clips.is_cuda and target_clips.dtype == torch.float32 and target_clips.is_contiguous()
-                and len(target_clips) > 0 and fe.persistent_available("lite_query")):
-            clips = target_clips.flatten(end_dim=1) if target_clips.dim() == 5 else target_clips
-            if fe.in_sync(clips.shape[-2], clips.shape[-1]) and fe.wants_grad(None):
-                if self._lite_query_stream is None:
-                    self._lite_query_stream = torch.cuda.Stream(device=self.device)
-                side = self._lite_query_stream
-                side.wait_event(fork)  # after the previous step's backward + this step's parameter upload, NOT after the cache pass
-                with fe.deferred_stats(fe) as deferred, fe.persistent_buffers(fe, "lite_query"), _lib.use_stream(side):
-                    target_features = fe(clips, film=None)
-                done = torch.cuda.Event()
-                done.record(side)
-                torch.cuda.current_stream().wait_event(done)
-                deferred.apply()
-                return self.classifier.predict(self._pool_features(target_features))
+        # (clips that live on the HOST are always safe - their upload is issued on the query stream; device-resident clips
+        # need the opt-in: they must not be the product of work still pending on the caller's stream)
+        resident = (target_clips.is_cuda and self.lite_query_overlap and target_clips.dtype == torch.float32
+                    and target_clips.is_contiguous())
+        if (fork is not None and self.lite_overlap and (resident or not target_clips.is_cuda) and fe.training
+                and not self.film_dict and torch.is_grad_enabled() and len(target_clips) > 0
+                and fe.persistent_available("lite_query") and fe.wants_grad(None)
+                and fe.in_sync(target_clips.shape[-2], target_clips.shape[-1])):
+            if self._lite_query_stream is None:
+                self._lite_query_stream = torch.cuda.Stream(device=self.device)
+            side = self._lite_query_stream
+            side.wait_event(fork)  # after the previous step's backward + this step's parameter upload, NOT after the cache pass
+            clips = target_clips
+            if not resident:
+                with torch.cuda.stream(side), _lib.use_stream(side):
+                    clips = self._upload(target_clips).contiguous().float()
+                clips.record_stream(torch.cuda.current_stream())  # (the tape's backward reads the frames on the caller's stream)
+            if clips.dim() == 5:
+                clips = clips.flatten(end_dim=1)
+            with fe.deferred_stats(fe) as deferred, fe.persistent_buffers(fe, "lite_query"), _lib.use_stream(side):
+                target_features = fe(clips, film=None)
+            done = torch.cuda.Event()
+            done.record(side)
+            torch.cuda.current_stream().wait_event(done)
+            deferred.apply()
+            return self.classifier.predict(self._pool_features(target_features))
         target_features = self._get_features(target_clips, self.film_dict)
         target_features = self._pool_features(target_features)
         return self.classifier.predict(target_features)
