@@ -240,6 +240,20 @@ int launch_se_gate_backward(const float* dxg, const float* x, const float* poole
 // With bn, dx may be nullptr: g is then NOT written (one pass over the expanded tensor less); the BatchNorm's apply pass
 // rebuilds it from dxg, the gate and the pooled-branch gradient the MLP backward left in `scratch` (se_bwd_dpooled):
 const float* se_bwd_dpooled(const float* scratch, int B, int C, int R);
+// The parameter gradients of several squeeze-excite blocks in one launch: call launch_se_gate_backward with dw1 = nullptr
+// and a scratch of the block's own, keep se_bwd_param_job(scratch, ...) and run the batch when all blocks are through.
+constexpr int SE_PARAM_JOBS = 16;
+struct SeParamJob {
+    const float *du, *dv, *h, *pooled;
+    float *dw1, *db1, *dw2, *db2;
+    int B, C, R;
+};
+struct SeParamJobs {
+    SeParamJob j[SE_PARAM_JOBS];
+};
+SeParamJob se_bwd_param_job(const float* scratch, const float* pooled, int B, int C, int R, float* dw1, float* db1, float* dw2,
+                            float* db2);
+int launch_se_param_grad_batched(const SeParamJobs& jobs, int n, hipStream_t s);
 int launch_bn_backward_reduced_gated(const float* dxg, const float* gate, const float* dpooled, int HW, const float* y,
                                      const float* mean, const float* invstd, const float* scale, const float* shift, int act,
                                      const float* gamma, int train, int M, int C, float* dy, float* dgamma, float* dbeta,
@@ -270,9 +284,23 @@ int launch_dwconv_wgrad(const float* x, const float* dy, float* dw, float* scrat
 // staged in LDS - only where dwconv_wgrad_xf_supported says the LDS form fits the layer)
 bool dwconv_wgrad_xf_supported(int B, int H, int W, int C, int K, int stride, int Ho, int Wo);
 size_t conv_wgrad_scratch_floats(int B, int Cin, int Cout, int KH, int KW, int Ho, int Wo);
+// The split reduction of several filter gradients in ONE launch: launch_conv_wgrad with `defer` fills a job instead of
+// running its reduce (the layer's partial tiles must then stay in `scratch` until launch_conv_wgrad_reduce_batched has run).
+constexpr int WGRAD_REDUCE_JOBS = 48;
+struct WgradReduceJob {
+    const float* partial;
+    float* dw;
+    int splits, Cout, NC, Cin, KH, KW, mode;
+};
+struct WgradReduceJobs {
+    WgradReduceJob j[WGRAD_REDUCE_JOBS];
+    unsigned first_block[WGRAD_REDUCE_JOBS + 1];  // filled by the launcher: blocks [first_block[k], first_block[k + 1]) serve layer k
+    int n;
+};
+int launch_conv_wgrad_reduce_batched(WgradReduceJobs& jobs, int n, hipStream_t s);
 int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
                       int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float* scratch, hipStream_t s,
-                      const float* gate = nullptr);  // gate [B][Cin]: the filter gradient w.r.t. x * gate without materialising it
+                      const float* gate = nullptr, WgradReduceJob* defer = nullptr);  // gate [B][Cin]: the filter gradient w.r.t. x * gate without materialising it
 size_t conv_dgrad_packed_floats(int Cin, int Cout, int KH, int KW);
 int conv_pack_dgrad_weights(const float* w_oihw, float* w_packed, int Cin, int Cout, int KH, int KW, hipStream_t s);
 int launch_conv_dgrad(const float* dy, const float* w_dgrad_packed, const float* accumulate, float* dx, float* up, int B,

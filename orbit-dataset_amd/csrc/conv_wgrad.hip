@@ -200,6 +200,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_reduce_kernel(const float* __r
     }
 }
 
+// the same for up to WGRAD_REDUCE_JOBS layers in one launch (blockIdx.y = layer): a network's reverse pass keeps every layer's
+// partial tiles and reduces them all at its end - 33 launches of ~10 us, each a latency chain on the step's critical path,
+// become one
+__global__ __launch_bounds__(256) void conv_wgrad_reduce_batched_kernel(WgradReduceJobs jobs) {
+    __shared__ float sh[16][16];
+    int k = 0;
+    while (k + 1 < jobs.n && blockIdx.x >= jobs.first_block[k + 1]) ++k;  // (<= 48 layers: a uniform scalar walk)
+    const WgradReduceJob& j = jobs.j[k];
+    const size_t total = (size_t)j.Cout * j.NC;
+    const int ol = threadIdx.x & 15, ln = threadIdx.x >> 4;
+    const size_t i = (size_t)(blockIdx.x - jobs.first_block[k]) * 16 + ol;
+    float s = 0.f;
+    if (i < total) {
+#pragma unroll 4
+        for (int sp = ln; sp < j.splits; sp += 16) s += j.partial[(size_t)sp * total + i];
+    }
+    sh[ln][ol] = s;
+    __syncthreads();
+    if (ln != 0 || i >= total) return;
+    for (int q = 1; q < 16; ++q) s += sh[q][ol];
+    if (j.mode == 1) {
+        j.dw[i] = s;
+    } else {
+        const int co = (int)(i / j.NC), n = (int)(i % j.NC);
+        const int tap = n / j.Cin, ci = n - tap * j.Cin;
+        j.dw[((size_t)co * j.Cin + ci) * j.KH * j.KW + tap] = s;
+    }
+}
+
 // ---- thin pointwise layers: one of (Cin, Cout) <= 48 channels, millions of rows --------------------------------------------
 // EfficientNet's high-resolution expansions and projections (16 -> 96 at 112x112, 96 -> 24 / 24 <-> 144 at 56x56, 40 <-> 240 at
 // 28x28; timm InvertedResidual conv_pw / conv_pwl behind model/feature_extractors.py:39-43) have a filter gradient of a few
@@ -362,9 +391,23 @@ size_t conv_wgrad_scratch_floats(int B, int Cin, int Cout, int KH, int KW, int H
     return (size_t)sp * Cout * NC;
 }
 
+int launch_conv_wgrad_reduce_batched(WgradReduceJobs& jobs, int n, hipStream_t s) {
+    ORBIT_REQUIRE(n >= 0 && n <= WGRAD_REDUCE_JOBS, "conv_wgrad_reduce_batched: %d jobs", n);
+    if (n == 0) return ORBIT_OK;
+    unsigned blocks = 0;
+    for (int k = 0; k < n; ++k) {
+        jobs.first_block[k] = blocks;
+        blocks += (unsigned)(((size_t)jobs.j[k].Cout * jobs.j[k].NC + 15) / 16);
+    }
+    jobs.first_block[n] = blocks, jobs.n = n;
+    conv_wgrad_reduce_batched_kernel<<<blocks, 256, 0, s>>>(jobs);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
 int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oihw, int B, int H, int W, int Cin, int Cout,
                       int KH, int KW, int stride, int pad_t, int pad_l, int Ho, int Wo, float* scratch, hipStream_t s,
-                      const float* gate) {
+                      const float* gate, WgradReduceJob* defer) {
     ORBIT_REQUIRE(x && dy && dw_oihw && scratch, "conv_wgrad: null pointer");
     ORBIT_REQUIRE(!gate || !x_nchw, "conv_wgrad: the squeeze-excite gate needs the NHWC path");
     ORBIT_REQUIRE(Cout % 4 == 0, "conv_wgrad: Cout %% 4 != 0");
@@ -412,6 +455,10 @@ int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oih
 #undef ORBIT_WTHIN
         prof_stop(rec, s);
         ORBIT_LAUNCH_CHECK();
+        if (defer) {
+            *defer = WgradReduceJob{scratch, dw_oihw, thin_blocks, Cout, p.NC, Cin, 1, 1, 0};
+            return ORBIT_OK;
+        }
         const size_t total = (size_t)Cout * p.NC;
         conv_wgrad_reduce_kernel<<<(int)((total + 15) / 16), 256, 0, s>>>(scratch, thin_blocks, Cout, p.NC, Cin, 1, 1, 0, dw_oihw);
         ORBIT_LAUNCH_CHECK();
@@ -426,6 +473,10 @@ int launch_conv_wgrad(const float* x, int x_nchw, const float* dy, float* dw_oih
     else conv_wgrad_kernel<0><<<grid, 256, 0, s>>>(p);
     prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();
+    if (defer) {
+        *defer = WgradReduceJob{scratch, dw_oihw, p.splits, Cout, p.NC, Cin, KH, KW, x_nchw ? 1 : 0};
+        return ORBIT_OK;
+    }
     const size_t total = (size_t)Cout * p.NC;
     const int rblocks = (int)((total + 15) / 16);
     conv_wgrad_reduce_kernel<<<rblocks, 256, 0, s>>>(scratch, p.splits, Cout, p.NC, Cin, KH, KW, x_nchw ? 1 : 0, dw_oihw);

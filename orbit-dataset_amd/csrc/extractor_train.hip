@@ -192,10 +192,11 @@ static Producers producers(const orbit_extractor* fe) {
 struct BwdLayout {
     static const int NSLOTS = 8;
     size_t slot_bytes = 0, slots = 0, up = 0, wgrad = 0, partial = 0, se = 0, total = 0;
+    size_t cwgrad = 0;  // the dense filter gradients' partial tiles, one region per layer (their reduce runs batched at the end)
 };
 static BwdLayout bwd_layout(const orbit_extractor* fe, int B) {
     BwdLayout L;
-    size_t slot = 4, up = 4, wg = 4, se = 4;
+    size_t slot = 4, up = 4, wg = 4, se = 4, cwg = 4;
     for (const Op& o : fe->ops) {
         if (o.kind == OP_DWCONV) {
             slot = std::max(slot, (size_t)B * o.H * o.W * o.Cin);
@@ -203,12 +204,12 @@ static BwdLayout bwd_layout(const orbit_extractor* fe, int B) {
             wg = std::max(wg, dwconv_wgrad_scratch_floats(B, o.Ho, o.Wo, o.Cin, o.KH));
             wg = std::max(wg, dwconv_bwd_fused_scratch_floats(B, o.H, o.W, o.Cin, o.KH, o.stride));
         } else if (o.kind == OP_SE) {
-            se = std::max(se, se_bwd_scratch_floats(B, o.Cin, o.R));
+            se += align_up(se_bwd_scratch_floats(B, o.Cin, o.R), 64);  // one scratch per block (their parameter gradients run batched)
         } else if (o.kind == OP_CONV) {
             slot = std::max(slot, (size_t)B * o.Ho * o.Wo * o.Cout);
             if (!o.x_nchw) slot = std::max(slot, (size_t)B * o.H * o.W * o.Cin);
             if (o.stride > 1 && !o.x_nchw) up = std::max(up, (size_t)B * o.H * o.W * o.Cout);
-            wg = std::max(wg, conv_wgrad_scratch_floats(B, o.Cin, o.Cout, o.KH, o.KW, o.Ho, o.Wo));
+            cwg += align_up(conv_wgrad_scratch_floats(B, o.Cin, o.Cout, o.KH, o.KW, o.Ho, o.Wo), 64);
         } else if (o.kind == OP_MAXPOOL || o.kind == OP_AVGPOOL) {
             slot = std::max(slot, (size_t)B * o.H * o.W * o.Cin);
         }
@@ -218,6 +219,7 @@ static BwdLayout bwd_layout(const orbit_extractor* fe, int B) {
     L.slots = off, off += L.slot_bytes * BwdLayout::NSLOTS;
     L.up = off, off += align_up(up * 4, 256);
     L.wgrad = off, off += align_up(wg * 4, 256);
+    L.cwgrad = off, off += align_up(cwg * 4, 256);
     L.partial = off, off += align_up(max_bn_partial_floats(fe, B) * 4, 256);
     L.se = off, off += align_up(se * 4, 256);
     L.total = off;
@@ -602,7 +604,14 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
     float* up = reinterpret_cast<float*>(ws + W.up);
     float* wgrad_scratch = reinterpret_cast<float*>(ws + W.wgrad);
     float* partial = reinterpret_cast<float*>(ws + W.partial);
-    float* se_scratch = reinterpret_cast<float*>(ws + W.se);
+    float* cwgrad_base = reinterpret_cast<float*>(ws + W.cwgrad);
+    size_t cwgrad_used = 0;
+    WgradReduceJobs wg_jobs;
+    int n_wg_jobs = 0;
+    float* se_scratch_base = reinterpret_cast<float*>(ws + W.se);
+    size_t se_scratch_used = 0;
+    SeParamJobs se_jobs;
+    int n_se_jobs = 0;
     const float *mean = tf(L.mean), *invstd = tf(L.invstd), *scale = tf(L.scale), *shift = tf(L.shift);
 
     const Producers P = producers(fe);
@@ -834,22 +843,38 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
             }
             release(g), grad_slot[i] = -1;
             if (wg) {
-                // a gated projection: d/dW of conv(x * gate) - the gate is multiplied into x inside the kernel
+                // a gated projection: d/dW of conv(x * gate) - the gate is multiplied into x inside the kernel. The layer's
+                // partial tiles stay in a region of their own: the split reductions of all layers run as ONE launch at the end
+                float* cw = cwgrad_base + cwgrad_used;
+                cwgrad_used += align_up(conv_wgrad_scratch_floats(B, o.Cin, o.Cout, o.KH, o.KW, o.Ho, o.Wo), 64);
+                WgradReduceJob* defer = n_wg_jobs < WGRAD_REDUCE_JOBS ? &wg_jobs.j[n_wg_jobs] : nullptr;
                 rc = launch_conv_wgrad(out_tensor(src), o.x_nchw, slot_ptr(kdy), param_grads + fe->params[o.weight].off, B,
-                                       o.H, o.W, o.Cin, o.Cout, o.KH, o.KW, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo,
-                                       wgrad_scratch, s, o.use_gate ? tf(L.a[P.gate[i]]) : nullptr);
+                                       o.H, o.W, o.Cin, o.Cout, o.KH, o.KW, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, cw, s,
+                                       o.use_gate ? tf(L.a[P.gate[i]]) : nullptr, defer);
                 if (rc != ORBIT_OK) return rc;
+                if (defer) ++n_wg_jobs;
             }
             if (need_dx && o.use_gate) {
                 // d(x * gate): data gradient of the product, then squeeze-excite backward (gate MLP + average pool)
                 const int se = P.gate[i];
                 ORBIT_REQUIRE(se >= 0 && grad_slot[src] < 0, "extractor_backward: malformed squeeze-excite block");
                 const Op& so = fe->ops[se];
+                float* se_scratch = se_scratch_base + se_scratch_used;  // this block's own (see se_jobs)
+                se_scratch_used += align_up(se_bwd_scratch_floats(B, o.Cin, so.R), 64);
                 SLOT_OR_FAIL(kt);
                 rc = launch_conv_dgrad(slot_ptr(kdy), st->d_dgrad + st->dgrad_off[i], nullptr, slot_ptr(kt), up, B, o.H, o.W,
                                        o.Cin, o.Cout, o.KH, o.KW, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s);
                 if (rc != ORBIT_OK) return rc;
                 float* pg = wg ? param_grads : nullptr;
+                // the four parameter gradients of the block's MLP: summed over the frames for ALL blocks in one launch at the
+                // end of the reverse pass (nothing in it reads them)
+                const bool batch_params = pg != nullptr && n_se_jobs < SE_PARAM_JOBS && so.R <= 48;
+                if (batch_params) {
+                    se_jobs.j[n_se_jobs++] = se_bwd_param_job(se_scratch, tf(L.p[se]), B, o.Cin, so.R, pg + fe->params[so.se_w1].off,
+                                                              pg + fe->params[so.se_b1].off, pg + fe->params[so.se_w2].off,
+                                                              pg + fe->params[so.se_b2].off);
+                    pg = nullptr;
+                }
                 // x = SiLU(BatchNorm(depthwise output)): the first (reduction) pass of that BatchNorm's backward is folded
                 // into the last pass of the squeeze-excite backward, which then leaves only the sums - g itself is rebuilt by
                 // that BatchNorm's apply pass from d(x * gate) (slot kt stays the depthwise op's gradient slot)
@@ -900,7 +925,8 @@ static int backward_run(orbit_extractor_t* fe, orbit_train_state* st, const floa
         if (rc != ORBIT_OK) return rc;
     }
 #undef SLOT_OR_FAIL
-    return ORBIT_OK;
+    if (int rc = launch_conv_wgrad_reduce_batched(wg_jobs, n_wg_jobs, s)) return rc;
+    return launch_se_param_grad_batched(se_jobs, n_se_jobs, s);
 }
 
 extern "C" {

@@ -310,6 +310,62 @@ __global__ __launch_bounds__(256) void se_param_grad_kernel(const float* __restr
     if (l == 0 && out != nullptr) *out = s;
 }
 
+// The four parameter gradients of up to SE_PARAM_JOBS squeeze-excite blocks in ONE launch (blockIdx.y = block): the reverse
+// pass of a network collects its blocks' (du, dv, h, pooled) - each in its own scratch - and sums the frames once at the end.
+// They are two skinny GEMMs over the frames, dW2 = du^T h [C][R] and dW1 = dv^T pooled [R][C]: a block owns 64 channels,
+// stages 50 frames of (du, pooled) columns and of (h, dv) rows in LDS and every thread keeps a [<= 12] strip of both products
+// (channel = lane, r = strip) in registers - each du / pooled element is read from L2 once instead of R times (the one-output-
+// per-16-lanes form read 1.4 GB through the L2 per step: 16 launches, 446 us). Frames are added in order: deterministic.
+constexpr int SEP_CT = 64, SEP_BT = 50, SEP_RG = 12;  // channels per block, frames per stage, r per thread (R <= 48)
+__global__ __launch_bounds__(256) void se_param_grad_batched_kernel(SeParamJobs jobs) {
+    const SeParamJob& j = jobs.j[blockIdx.y];
+    const int B = j.B, C = j.C, R = j.R;
+    const int c0 = blockIdx.x * SEP_CT;
+    if (c0 >= C) return;
+    __shared__ float du_s[SEP_BT][SEP_CT], p_s[SEP_BT][SEP_CT], h_s[SEP_BT][48], dv_s[SEP_BT][48];
+    const int tid = threadIdx.x, cl = tid & (SEP_CT - 1), g = tid / SEP_CT;  // g = 0..3: r = g, g + 4, ...
+    const int c = c0 + cl;
+    float a2[SEP_RG], a1[SEP_RG], sdu = 0.f, sdv = 0.f;
+#pragma unroll
+    for (int k = 0; k < SEP_RG; ++k) a2[k] = a1[k] = 0.f;
+    for (int b0 = 0; b0 < B; b0 += SEP_BT) {
+        const int nb = min(SEP_BT, B - b0);
+        __syncthreads();
+        for (int i = tid; i < nb * SEP_CT; i += 256) {
+            const int b = i / SEP_CT, cc = i - b * SEP_CT;
+            const bool ok = c0 + cc < C;
+            du_s[b][cc] = ok ? j.du[(size_t)(b0 + b) * C + c0 + cc] : 0.f;
+            p_s[b][cc] = ok ? j.pooled[(size_t)(b0 + b) * C + c0 + cc] : 0.f;
+        }
+        for (int i = tid; i < nb * R; i += 256) {
+            const int b = i / R, r = i - b * R;
+            h_s[b][r] = j.h[(size_t)(b0 + b) * R + r];
+            dv_s[b][r] = j.dv[(size_t)(b0 + b) * R + r];
+        }
+        __syncthreads();
+        for (int b = 0; b < nb; ++b) {
+            const float a = du_s[b][cl], p = p_s[b][cl];
+            if (g == 0) sdu += a;
+#pragma unroll
+            for (int k = 0; k < SEP_RG; ++k) {
+                const int r = g + 4 * k;
+                if (r < R) a2[k] = fmaf(a, h_s[b][r], a2[k]), a1[k] = fmaf(dv_s[b][r], p, a1[k]);
+            }
+        }
+        if (blockIdx.x == 0 && tid < R)
+            for (int b = 0; b < nb; ++b) sdv += dv_s[b][tid];
+    }
+    if (c < C) {
+#pragma unroll
+        for (int k = 0; k < SEP_RG; ++k) {
+            const int r = g + 4 * k;
+            if (r < R) j.dw2[(size_t)c * R + r] = a2[k], j.dw1[(size_t)r * C + c] = a1[k];
+        }
+        if (g == 0) j.db2[c] = sdu;
+    }
+    if (blockIdx.x == 0 && tid < R) j.db1[tid] = sdv;
+}
+
 // ---- depthwise convolution ------------------------------------------------------------------------------------------
 // dx[b][h][w][c] = sum_{kh,kw} dy[b][(h+pt-kh)/s][(w+pl-kw)/s][c] * w[kh][kw][c]   (terms with non-integral / out-of-range
 // source positions vanish); w_khwc is the packed forward filter [K][K][C]
@@ -807,6 +863,26 @@ int launch_gate_mul(const float* x, const float* gate, float* xg, int B, int HW,
 
 // scratch: du [B*C] | dv [B*R] | h [B*R] | dgate [B*C] | dpooled [B*C]
 size_t se_bwd_scratch_floats(int B, int C, int R) { return (size_t)B * (3 * (size_t)C + 2 * (size_t)R) + 16; }
+
+SeParamJob se_bwd_param_job(const float* scratch, const float* pooled, int B, int C, int R, float* dw1, float* db1, float* dw2,
+                            float* db2) {
+    SeParamJob j;
+    j.du = scratch, j.dv = scratch + (size_t)B * C, j.h = j.dv + (size_t)B * R, j.pooled = pooled;
+    j.B = B, j.C = C, j.R = R, j.dw1 = dw1, j.db1 = db1, j.dw2 = dw2, j.db2 = db2;
+    return j;
+}
+int launch_se_param_grad_batched(const SeParamJobs& jobs, int n, hipStream_t s) {
+    ORBIT_REQUIRE(n >= 0 && n <= SE_PARAM_JOBS, "se_param_grad_batched: %d jobs", n);
+    if (n == 0) return ORBIT_OK;
+    int gx = 1;
+    for (int k = 0; k < n; ++k) {
+        ORBIT_REQUIRE(jobs.j[k].R <= 48, "se_param_grad_batched: R = %d > 48", jobs.j[k].R);
+        gx = std::max(gx, cdiv(jobs.j[k].C, SEP_CT));
+    }
+    se_param_grad_batched_kernel<<<dim3(gx, n), 256, 0, s>>>(jobs);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
 
 const float* se_bwd_dpooled(const float* scratch, int B, int C, int R) {
     return scratch + (size_t)B * C + 2 * (size_t)B * R + (size_t)B * C;  // (the layout launch_se_gate_backward lays down)
