@@ -385,14 +385,12 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
     char* tp = static_cast<char*>(tape);
     auto fl = [&](size_t off) { return reinterpret_cast<float*>(tp + off); };
     float *mean = fl(L.mean), *invstd = fl(L.invstd), *scale = fl(L.scale), *shift = fl(L.shift);
-    // deferred running statistics: the finalize kernels run their update with momentum 1 on a zeroed slot of the tape
-    // (0 * 0 + 1 * stat = stat exactly) instead of on the plan's running statistics; orbit_extractor_apply_deferred_bn_stats
-    // applies the real update later - so this forward may overlap, on another stream, with a forward that updates them
+    // deferred running statistics: the finalize kernels run their update with momentum 1 (the statistics replace the slot's
+    // content, which is never read) on a slot of the tape instead of on the plan's running statistics;
+    // orbit_extractor_apply_deferred_bn_stats applies the real update later - so this forward may overlap, on another stream,
+    // with a forward that updates them
     defer_stats = defer_stats && bn_train;
-    if (defer_stats) {
-        ORBIT_HIP_CHECK(hipMemsetAsync(fl(L.rstat), 0, 2 * fe->fold_floats * sizeof(float), s));
-        momentum = 1.0f;
-    }
+    if (defer_stats) momentum = 1.0f;
     auto run_mean = [&](const BNDesc& bn) {
         return defer_stats ? fl(L.rstat) + bn.fold_off : fe->d_pool + fe->params[bn.mean].off;
     };

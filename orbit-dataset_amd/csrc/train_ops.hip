@@ -121,8 +121,15 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
         // y holds the convolution WITHOUT its bias; the module's input to BatchNorm includes it
         const float cb = conv_bias ? conv_bias[c] : 0.f;
         const double unbiased = M > 1 ? var * (double)M / (double)(M - 1) : var;
-        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * ((float)mean + cb);
-        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        if (momentum >= 1.f) {
+            // momentum 1 (also the deferred form of the training forwards: the slot on the tape is uninitialised memory and
+            // 0 * NaN would poison it): the statistics replace the old value, which is never read
+            running_mean[c] = (float)mean + cb;
+            running_var[c] = (float)unbiased;
+        } else {
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * ((float)mean + cb);
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
     }
 }
 
