@@ -181,3 +181,42 @@ def test_unique_label_cache_is_weak_and_thread_safe():
     threads = [threading.Thread(target=work, args=(i,)) for i in range(4)]
     [t.start() for t in threads], [t.join() for t in threads]
     assert not errors
+
+
+def test_stream_override_and_deferred_blocks_restore_state():
+    """Host-side plumbing of the LITE stream overlap: `_lib.use_stream` hands the native entry points another stream only
+    inside its block (nested blocks restore the outer one), and the extractor's `deferred_stats` / `persistent_buffers`
+    blocks set and clear their markers, refuse to nest, and track one busy tape per key."""
+    from orbit_dataset_amd import _lib
+    from orbit_dataset_amd.model.feature_extractors import create_feature_extractor
+
+    class FakeStream:
+        def __init__(self, h):
+            self.cuda_stream = h
+
+    assert _lib._stream_override is None
+    with _lib.use_stream(FakeStream(0x1234)):
+        assert _lib.stream_handle().value == 0x1234
+        with _lib.use_stream(FakeStream(0x5678)):
+            assert _lib.stream_handle().value == 0x5678
+        assert _lib.stream_handle().value == 0x1234
+    assert _lib._stream_override is None
+
+    fe, _ = create_feature_extractor("resnet18", False, False, True)
+    assert fe._defer_stats is None and fe._persist_key is None
+    with fe.deferred_stats(fe) as d:
+        assert fe._defer_stats is d.pending == []
+        with pytest.raises(RuntimeError):
+            with fe.deferred_stats(fe):
+                pass
+        fe._defer_stats = d.pending  # (the failed nesting attempt's __exit__ cleared the marker)
+    assert fe._defer_stats is None
+    with fe.persistent_buffers(fe, "k"):
+        assert fe._persist_key == "k" and fe.persistent_available("k")
+        fe._persist_busy["k"] = True
+        assert not fe.persistent_available("k")
+    assert fe._persist_key is None
+    fe.persistent_release("k")
+    assert fe.persistent_available("k")
+    t = fe._persistent_tensor("k", "tape", 1000, torch.uint8, torch.device("cpu"))
+    assert t.numel() == 1000 and fe._persistent_tensor("k", "tape", 600, torch.uint8, torch.device("cpu")).data_ptr() == t.data_ptr()
