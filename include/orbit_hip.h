@@ -459,6 +459,14 @@ int orbit_prof_collect(double* total_ms, double* total_flops, long* launches);
 int orbit_prof_num_variants(void);
 /* one row per kernel instantiation: launches, summed duration, summed algorithmic flops and algorithmic HBM bytes */
 int orbit_prof_variant(int i, char* name48, long* launches, double* ms, double* flops, double* bytes);
+/* The roofs a launch's floor is priced on (defaults: 6.3e12 B/s achievable HBM, 157.3e12 FLOP/s fp32 MFMA, 5.93e12 SiLU
+ * evaluations/s = 11.06 ns of a SIMD per 64 of them x 1024 SIMDs; set before orbit_prof_collect) and, per row, the sum over
+ * its launches of max(bytes / HBM rate, FLOP / matrix rate), the same with the SiLU evaluations' VALU time added to the
+ * matrix time (a gfx950 SIMD issues either an MFMA or VALU instructions, never both), and the SiLU count. Round 6: every
+ * launch of the inference path - depthwise, squeeze-excite gate, pooling, head kernels included - records a row (bench.py
+ * roofline.families). */
+int orbit_prof_set_roofs(double hbm_bytes_per_s, double matrix_flop_per_s, double silu_evals_per_s);
+int orbit_prof_variant_floor(int i, double* floor_ms, double* floor_simd_ms, double* silu_evals);
 
 /* ---- RCCL over xGMI (one process per GPU) ------------------------------------------------------- */
 /* The reference has no collectives; this is the exchange step of the support-sharded variant: the

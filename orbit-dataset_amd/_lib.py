@@ -105,6 +105,8 @@ _SIGNATURES = {
     "orbit_prof_num_variants": (c_int, []),
     "orbit_prof_variant": (c_int, [c_int, ctypes.c_char_p, POINTER(ctypes.c_long), POINTER(c_double),
                                    POINTER(c_double), POINTER(c_double)]),
+    "orbit_prof_set_roofs": (c_int, [c_double, c_double, c_double]),
+    "orbit_prof_variant_floor": (c_int, [c_int, POINTER(c_double), POINTER(c_double), POINTER(c_double)]),
     "orbit_runtime_init": (c_int, []),
     "orbit_comm_unique_id": (c_int, [P]),
     "orbit_comm_init": (c_int, [c_int, c_int, P]),
@@ -205,33 +207,39 @@ def require_gpu():
     _gpu_ok = True
 
 
-_stream_override = None
+import threading
+
+_tls = threading.local()  # the stream override is PER THREAD, as torch's current stream is: the staging thread of
+#                           data/pipeline.TaskPrefetcher launches orbit_frames_from_uint8 on its copy stream while the main thread
+#                           may sit inside a LITE `use_stream(side)` block - a process-global override sent that conversion kernel
+#                           to the LITE side stream, unordered against the copy it reads
 
 
 class use_stream:
-    """Within the block the native entry points are handed `stream` (a torch.cuda.Stream) instead of torch's current stream,
-    while torch itself - its allocator included - stays on the current one: the caller orders the two streams with events
-    (LITE's subset pass beside the cache pass, few_shot_recognisers._get_features_with_split_batch)."""
+    """Within the block the native entry points called FROM THIS THREAD are handed `stream` (a torch.cuda.Stream) instead of
+    torch's current stream, while torch itself - its allocator included - stays on the current one: the caller orders the two
+    streams with events (LITE's subset pass beside the cache pass, few_shot_recognisers._get_features_with_split_batch)."""
 
     def __init__(self, stream):
         self.handle = c_void_p(stream.cuda_stream)
 
     def __enter__(self):
-        global _stream_override
-        self.prev, _stream_override = _stream_override, self.handle
+        self.prev = getattr(_tls, "stream", None)
+        _tls.stream = self.handle
         return self
 
     def __exit__(self, *exc):
-        global _stream_override
-        _stream_override = self.prev
+        _tls.stream = self.prev
         return False
 
 
 def stream_handle():
     """hipStream_t of torch's CURRENT stream on the current device, as an opaque pointer (or the stream a `use_stream` block
-    names). Uses the raw accessor: torch.cuda.current_stream() re-checks device availability on every call (~80 us each)."""
-    if _stream_override is not None:
-        return _stream_override
+    of this thread names). Uses the raw accessor: torch.cuda.current_stream() re-checks device availability on every call
+    (~80 us each)."""
+    override = getattr(_tls, "stream", None)
+    if override is not None:
+        return override
     import torch
     try:
         return c_void_p(torch._C._cuda_getCurrentRawStream(torch._C._cuda_getDevice()))

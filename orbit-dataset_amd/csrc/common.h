@@ -117,7 +117,7 @@ bool pw_rgemm_preferred(const ConvDesc& d);  // where it measured faster than th
 int launch_pw_rgemm(const ConvDesc& d, hipStream_t s);
 bool conv_prof_enabled();
 // per-launch HIP-event records of orbit_prof_* (no-ops returning -1 while profiling is off)
-int prof_start(const char* name, double flops, double bytes, hipStream_t s);
+int prof_start(const char* name, double flops, double bytes, hipStream_t s, double silu = 0.0);  // silu: SiLU evaluations of the launch
 void prof_stop(int idx, hipStream_t s);  // per-launch event profiling is on (graphs are bypassed while it is)
 
 // The depthwise DATA gradient fused with the first pass of the preceding BatchNorm's backward (the LITE step): the tensor a

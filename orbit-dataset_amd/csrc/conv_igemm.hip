@@ -625,13 +625,20 @@ int conv_pack_weights(const float* w_oihw, float* w_packed, int Cin, int Cout, i
 struct ProfRec {
     hipEvent_t start, stop;
     int variant;
-    double flops, bytes;
+    double flops, bytes, silu;
 };
 struct ProfVariant {
     char name[48];
     long launches;
     double ms, flops, bytes;
+    double floor_ms;  // sum over the launches of max(bytes / HBM rate, FLOP / matrix rate): the launch-by-launch roofline floor
+    double silu;      // SiLU evaluations (two transcendentals each: the VALU work the matrix roof does not see)
+    double floor_simd_ms;  // ... of max(bytes / HBM rate, FLOP / matrix rate + SiLU / SiLU rate): on gfx950 a SIMD issues EITHER
+                           // an MFMA OR VALU instructions (profiles/r03_coexec_probe.txt), so matrix and SiLU time add up
 };
+// orbit_prof_set_roofs. SiLU: 11.06 ns of one SIMD per 64 evaluations at 8 waves per SIMD (v_exp_f32 + v_rcp_f32 + 3 packed
+// multiply-adds, profiles/r03_valu_probe.txt) x 1024 SIMDs
+static double g_roof_bytes_per_s = 6.3e12, g_roof_flop_per_s = 157.3e12, g_roof_silu_per_s = 64.0 * 1024.0 / 11.06e-9;
 static bool g_prof_on = false;
 bool conv_prof_enabled() { return g_prof_on; }
 static std::vector<ProfRec> g_prof_recs;
@@ -659,11 +666,11 @@ static int prof_variant(const char* name) {
 }
 
 // shared with the other MFMA kernels (conv_wgrad.hip): returns a record index or -1 when profiling is off
-int prof_start(const char* name, double flops, double bytes, hipStream_t s) {
+int prof_start(const char* name, double flops, double bytes, hipStream_t s, double silu) {
     if (!g_prof_on) return -1;
     ProfRec r;
     r.start = prof_event(), r.stop = prof_event(), r.variant = prof_variant(name);
-    r.flops = flops, r.bytes = bytes;
+    r.flops = flops, r.bytes = bytes, r.silu = silu;
     (void)hipEventRecord(r.start, s);
     g_prof_recs.push_back(r);
     return (int)g_prof_recs.size() - 1;
@@ -699,6 +706,7 @@ static int launch_cfg2(ConvParams& p, hipStream_t s) {
         // algorithmic HBM bytes: input once, output once (pooled if fused), residual once, weights once
         r.bytes = 4.0 * ((double)p.B * p.H * p.W * p.Cin + (POOL2 ? pix / 4 : pix) * p.Cout * (p.residual ? 2.0 : 1.0) +
                          (double)p.Cout * p.KH * p.KW * p.Cin);
+        r.silu = p.act == ORBIT_ACT_SILU && p.ksplit <= 1 ? pix * p.Cout : 0.0;
         (void)hipEventRecord(r.start, s);
         kern<<<grid, 256, lds, s>>>(p);
         (void)hipEventRecord(r.stop, s);
@@ -881,7 +889,11 @@ int orbit_prof_collect(double* total_ms, double* total_flops, long* launches) {
         float t = 0.f;
         ORBIT_HIP_CHECK(hipEventElapsedTime(&t, r.start, r.stop));
         ProfVariant& v = g_prof_variants[r.variant];
-        v.launches += 1, v.ms += t, v.flops += r.flops, v.bytes += r.bytes;
+        v.launches += 1, v.ms += t, v.flops += r.flops, v.bytes += r.bytes, v.silu += r.silu;
+        const double fb = r.bytes / g_roof_bytes_per_s, ff = r.flops / g_roof_flop_per_s;
+        v.floor_ms += 1e3 * (fb > ff ? fb : ff);
+        const double fs = ff + r.silu / g_roof_silu_per_s;
+        v.floor_simd_ms += 1e3 * (fb > fs ? fb : fs);
         ms += t, fl += r.flops;
         g_prof_pool.push_back(r.start), g_prof_pool.push_back(r.stop);
     }
@@ -893,6 +905,20 @@ int orbit_prof_collect(double* total_ms, double* total_flops, long* launches) {
 }
 
 int orbit_prof_num_variants(void) { return (int)g_prof_variants.size(); }
+
+int orbit_prof_set_roofs(double hbm_bytes_per_s, double matrix_flop_per_s, double silu_evals_per_s) {
+    ORBIT_REQUIRE(hbm_bytes_per_s > 0 && matrix_flop_per_s > 0 && silu_evals_per_s > 0, "prof_set_roofs: rates must be positive");
+    g_roof_bytes_per_s = hbm_bytes_per_s, g_roof_flop_per_s = matrix_flop_per_s, g_roof_silu_per_s = silu_evals_per_s;
+    return ORBIT_OK;
+}
+
+int orbit_prof_variant_floor(int i, double* floor_ms, double* floor_simd_ms, double* silu_evals) {
+    ORBIT_REQUIRE(i >= 0 && i < (int)g_prof_variants.size(), "prof_variant_floor: index out of range");
+    if (floor_ms) *floor_ms = g_prof_variants[i].floor_ms;
+    if (floor_simd_ms) *floor_simd_ms = g_prof_variants[i].floor_simd_ms;
+    if (silu_evals) *silu_evals = g_prof_variants[i].silu;
+    return ORBIT_OK;
+}
 
 int orbit_prof_variant(int i, char* name48, long* launches, double* ms, double* flops, double* bytes) {
     ORBIT_REQUIRE(i >= 0 && i < (int)g_prof_variants.size(), "prof_variant: index out of range");

@@ -582,7 +582,9 @@ static int run_plan(orbit_extractor_t* fe, const float* frames, int B, const flo
     if (film_gamma && fe->film_size > 0) {
         float* fs = reinterpret_cast<float*>(ws + L.fold);
         dim3 grid((unsigned)fe->bns.size(), 2);
+        const int rec = prof_start("bn_fold_film", 0.0, 4.0 * 6.0 * fe->fold_floats, s);
         bn_fold_all_kernel<<<grid, 256, 0, s>>>(fe->d_bn, fe->d_pool, film_gamma, film_beta, fs, fs + fe->fold_floats);
+        prof_stop(rec, s);
         ORBIT_LAUNCH_CHECK();
         scale = fs, shift = fs + fe->fold_floats;
     }

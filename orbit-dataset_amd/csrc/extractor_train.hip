@@ -373,6 +373,10 @@ int orbit_extractor_apply_deferred_bn_stats(orbit_extractor_t* fe, const void* t
     bn_apply_deferred_kernel<<<dim3((unsigned)fe->bns.size(), 2), 256, 0, (hipStream_t)stream>>>(
         fe->d_bn, fe->d_pool, reinterpret_cast<const float*>(static_cast<const char*>(tape) + L.rstat), fe->fold_floats, momentum);
     ORBIT_LAUNCH_CHECK();
+    // the static fold follows the running statistics this call just changed (the deferred forward skipped its own re-fold)
+    bn_fold_all_kernel<<<dim3((unsigned)fe->bns.size(), 2), 256, 0, (hipStream_t)stream>>>(
+        fe->d_bn, fe->d_pool, nullptr, nullptr, fe->d_fold, fe->d_fold + fe->fold_floats);
+    ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
 
@@ -538,8 +542,11 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
         }
         if (rc != ORBIT_OK) return rc;
     }
-    if (bn_train) {
-        // the forward plans fold the running statistics at finalize time: refresh the static fold and drop graphs
+    if (bn_train && !defer_stats) {
+        // the forward plans fold the running statistics at finalize time: refresh the static fold and drop graphs. (A forward
+        // with deferred running statistics did not change them and may run beside a forward that does: it must neither read
+        // d_pool's statistics nor write the plan-owned d_fold here - orbit_extractor_apply_deferred_bn_stats re-folds after
+        // the join)
         dim3 grid((unsigned)fe->bns.size(), 2);
         bn_fold_all_kernel<<<grid, 256, 0, s>>>(fe->d_bn, fe->d_pool, nullptr, nullptr, fe->d_fold,
                                                 fe->d_fold + fe->fold_floats);

@@ -599,8 +599,12 @@ int orbit_proto_configure(const float* feats, const int64_t* labels, const int64
     ORBIT_REQUIRE(n_tasks > 0 && N > 0 && T > 0 && D > 0 && C > 0, "proto_configure: bad sizes");
     ORBIT_REQUIRE(C <= 65535 && n_tasks <= 65535, "proto_configure: C/n_tasks too large");
     dim3 grid(cdiv(D, 256), C, n_tasks);
+    // (per-launch event record for bench.py's roofline.families: SURVEY section 8(d): 4 (N D + C D + C) + 8 N bytes per task)
+    const int rec = prof_start("head_configure", 2.0 * n_tasks * N * T * D,
+                               (double)n_tasks * (4.0 * ((double)N * T * D + (double)C * D + C) + 8.0 * N), (hipStream_t)stream);
     proto_configure_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(feats, labels, class_ids, N, T, D, C,
                                                                   sums, counts);
+    prof_stop(rec, (hipStream_t)stream);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
@@ -608,7 +612,9 @@ int orbit_proto_configure(const float* feats, const int64_t* labels, const int64
 int orbit_label_set(const int64_t* labels, int N, int64_t* class_ids, int cap, int32_t* count, orbit_stream_t stream) {
     ORBIT_REQUIRE(labels && class_ids && count, "label_set: null pointer");
     ORBIT_REQUIRE(N >= 0 && cap > 0, "label_set: bad sizes");
+    const int rec = prof_start("head_label_set", 0.0, 8.0 * N + 8.0 * cap + 4.0, (hipStream_t)stream);
     label_set_kernel<<<1, 64, 0, (hipStream_t)stream>>>(labels, N, class_ids, cap, count);
+    prof_stop(rec, (hipStream_t)stream);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
@@ -619,14 +625,32 @@ int orbit_proto_finalize(const float* sums, const float* counts, int n_tasks, in
     ORBIT_REQUIRE(cosine || b, "proto_finalize: euclidean head needs a bias buffer");
     ORBIT_REQUIRE(n_tasks > 0 && D > 0 && C > 0, "proto_finalize: bad sizes");
     dim3 grid(C, n_tasks);
+    const int rec = prof_start("head_finalize", 3.0 * n_tasks * C * D, (double)n_tasks * 4.0 * (2.0 * C * D + 2.0 * C),
+                               (hipStream_t)stream);
     proto_finalize_kernel<<<grid, 256, 0, (hipStream_t)stream>>>(sums, counts, C, D, cosine, W, b);
+    prof_stop(rec, (hipStream_t)stream);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
 
+static int proto_predict_impl(const float* Q, const float* W, const float* b, int n_tasks, int M, int T, int D, int C,
+                              float logit_scale, int cosine, float* logits, int32_t* argmax, orbit_stream_t stream);
+
 int orbit_proto_predict(const float* Q, const float* W, const float* b, int n_tasks, int M, int T, int D,
                         int C, float logit_scale, int cosine, float* logits, int32_t* argmax,
                         orbit_stream_t stream) {
+    // (per-launch event record for bench.py's roofline.families: SURVEY section 8(d): 4 (M T D + C D + C + M C) bytes per task)
+    const int rec = prof_start("head_predict", 2.0 * n_tasks * M * D * C,
+                               (double)n_tasks * 4.0 * ((double)M * T * D + (double)C * D + C + (double)M * C), (hipStream_t)stream);
+    const int rc = proto_predict_impl(Q, W, b, n_tasks, M, T, D, C, logit_scale, cosine, logits, argmax, stream);
+    prof_stop(rec, (hipStream_t)stream);
+    return rc;
+}
+
+}  // extern "C"
+
+static int proto_predict_impl(const float* Q, const float* W, const float* b, int n_tasks, int M, int T, int D, int C,
+                              float logit_scale, int cosine, float* logits, int32_t* argmax, orbit_stream_t stream) {
     ORBIT_REQUIRE(Q && W && logits, "proto_predict: null pointer");
     ORBIT_REQUIRE(cosine || b, "proto_predict: weight and/or bias not set - is the model personalised?");
     ORBIT_REQUIRE(n_tasks > 0 && M > 0 && T > 0 && D > 0 && C > 0, "proto_predict: bad sizes");
@@ -681,6 +705,8 @@ int orbit_proto_predict(const float* Q, const float* W, const float* b, int n_ta
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
+
+extern "C" {
 
 int orbit_mean_pool(const float* x, int N, int T, int D, float* out, orbit_stream_t stream) {
     ORBIT_REQUIRE(x && out && N > 0 && T > 0 && D > 0, "mean_pool: bad arguments");

@@ -463,7 +463,7 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
     const size_t lds = (size_t)3 * n_new * ROWS_ES * sizeof(float) + (K == 3 ? 0 : (size_t)K * K * 8 * 16);
     const double pix = (double)B * H * W;
     const int rec = prof_start("mbconv_rows", 2.0 * pix * Cin * mid + 2.0 * B * Ho * Wo * mid * K * K,
-                               4.0 * (pix * Cin + (double)B * Ho * Wo * mid), s);
+                               4.0 * (pix * Cin + (double)B * Ho * Wo * mid), s, pix * mid + (double)B * Ho * Wo * mid);
 #define ORBIT_MBR3(KK, SS, TO_, NOUT_, NG_, SPR_, EX_, BF_)                                                       \
     do {                                                                                                \
         auto kern = mbconv_rows3_kernel<KK, SS, TO_, NOUT_, NG_, SPR_, EX_, BF_>;                                \
@@ -810,7 +810,7 @@ int launch_stem_rows(const float* frames, const float* w1_packed, const float* s
     const size_t lds = ((size_t)3 * 2 * g.SWi * ROWS_ES + 2 * 3 * 5 * STEM_PW + 14 * 64) * sizeof(float);
     const double pix = (double)B * H * W;
     const int rec = prof_start("stem_rows", 2.0 * pix * 32 * 27 + 2.0 * pix * 32 * 9,
-                               4.0 * ((double)B * 3 * FH * FW + pix * 32), s);
+                               4.0 * ((double)B * 3 * FH * FW + pix * 32), s, 2.0 * pix * 32);
     // branch-free stores: strips tile the width exactly and every band is a whole number of 2-row steps
     if (g.strips * g.SWo == W && H % 2 == 0 && g.band_rows % 2 == 0) stem_rows_kernel<true><<<grid, 256, lds, s>>>(p, w1_packed, sc1, sh1);
     else stem_rows_kernel<false><<<grid, 256, lds, s>>>(p, w1_packed, sc1, sh1);

@@ -898,9 +898,33 @@ bool dwconv_se_window_form(int K, int stride, int Ho) {
     return win_opt == 2 || (win_opt == 1 && K == 3 && stride == 1 && Ho >= 14);
 }
 
+static int launch_dwconv_se_impl(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
+                                 float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
+                                 int Wo, int act, hipStream_t s, int stats, const float* in_scale, const float* in_shift, int in_act,
+                                 const DwBnBwd* bnb);
+
+// (per-launch event record for bench.py's roofline.families: algorithmic bytes = input + output + taps, FLOP = 2 K^2 per output)
 int launch_dwconv_se(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
                      float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
                      int Wo, int act, hipStream_t s, int stats, const float* in_scale, const float* in_shift, int in_act, const DwBnBwd* bnb) {
+    int rec = -1;
+    if (conv_prof_enabled()) {
+        char name[48];
+        snprintf(name, sizeof(name), "dwconv<%dx%d/%d>%s", K, K, stride, bnb ? ",dgrad" : stats ? ",train" : "");
+        const double out = (double)B * Ho * Wo * C;
+        rec = prof_start(name, 2.0 * out * K * K, 4.0 * ((double)B * H * W * C + out * (bnb ? 2.0 : 1.0) + (double)K * K * C), s,
+                         act == ORBIT_ACT_SILU ? out : 0.0);
+    }
+    const int rc = launch_dwconv_se_impl(x, w_khwc, y, scale, shift, pool_partial, B, H, W, C, K, stride, pad_t, pad_l, Ho, Wo, act,
+                                         s, stats, in_scale, in_shift, in_act, bnb);
+    prof_stop(rec, s);
+    return rc;
+}
+
+static int launch_dwconv_se_impl(const float* x, const float* w_khwc, float* y, const float* scale, const float* shift,
+                                 float* pool_partial, int B, int H, int W, int C, int K, int stride, int pad_t, int pad_l, int Ho,
+                                 int Wo, int act, hipStream_t s, int stats, const float* in_scale, const float* in_shift, int in_act,
+                                 const DwBnBwd* bnb) {
     ORBIT_REQUIRE(x && w_khwc && y, "dwconv_se: null pointer");
     if (bnb) {
         ORBIT_REQUIRE(bnb->y && bnb->mean && bnb->invstd && bnb->scale && bnb->shift && bnb->partial && bnb->nblk,
@@ -1077,10 +1101,12 @@ int launch_se_gate2(const float* partial, int chunks, int HW, const float* w1, c
     // weights); 1024 threads take all 48 hidden units of the 1152-channel blocks in one round and every channel quad in one
     // pass (19-20 us -> measured below), 256 stay best for the narrow early blocks
     const size_t lds = (size_t)(((C + R + 3) & ~3) + 4 * 1024) * sizeof(float);
+    const int rec = prof_start("se_gate", 4.0 * B * C * R, 4.0 * ((double)B * chunks * C + 2.0 * C * R + C + R + (double)B * C), s);
     if (C >= 1024)  // measured per 200 frames: C = 1152: 19-20 -> 14.2-14.8 us; C = 672: 11.0-11.3 -> 11.3-13.1 (worse)
         se_gate2_kernel<1024><<<B, 1024, lds, s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2, gate, C, R, pooled_out);
     else
         se_gate2_kernel<256><<<B, 256, lds, s>>>(partial, chunks, 1.0f / (float)HW, w1, b1, w2t, b2, gate, C, R, pooled_out);
+    prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
@@ -1103,7 +1129,9 @@ int launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int K, 
     ORBIT_REQUIRE(C % 4 == 0, "maxpool: C %% 4 != 0 (C=%d)", C);
     const size_t total = (size_t)B * Ho * Wo * (C / 4);
     ORBIT_REQUIRE(total < (1ull << 32), "maxpool: tensor too large for 32-bit index arithmetic");
+    const int rec = prof_start("maxpool", 0.0, 4.0 * ((double)B * H * W * C + (double)B * Ho * Wo * C), s);
     maxpool_kernel<<<grid_for(total), 256, 0, s>>>(x, y, B, H, W, C, K, stride, pad, Ho, Wo);
+    prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
@@ -1111,7 +1139,9 @@ int launch_maxpool(const float* x, float* y, int B, int H, int W, int C, int K, 
 int launch_avgpool(const float* x, float* y, int B, int HW, int C, hipStream_t s) {
     ORBIT_REQUIRE(x && y && B > 0 && HW > 0 && C > 0, "avgpool: bad arguments");
     dim3 grid(cdiv(C, 64), B);
+    const int rec = prof_start("avgpool", (double)B * HW * C, 4.0 * ((double)B * HW * C + (double)B * C), s);
     avgpool_kernel<<<grid, 256, 0, s>>>(x, y, HW, C);
+    prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }

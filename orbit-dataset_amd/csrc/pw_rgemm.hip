@@ -328,7 +328,8 @@ int launch_pw_rgemm(const ConvDesc& d, hipStream_t s) {
     snprintf(name, sizeof(name), "conv_pw_rgemm<%d,k%d%s>", T, wk, d.gate ? ",gate" : "");
     const double pix = (double)p.M;
     const int rec = prof_start(name, 2.0 * pix * d.Cout * d.Cin * d.prof_flop_scale,
-                               4.0 * (pix * d.Cin + pix * d.Cout * (d.residual ? 2.0 : 1.0) + (double)d.Cout * d.Cin), s);
+                               4.0 * (pix * d.Cin + pix * d.Cout * (d.residual ? 2.0 : 1.0) + (double)d.Cout * d.Cin), s,
+                               d.act == ORBIT_ACT_SILU ? pix * d.Cout : 0.0);
     const int rc = d.gate ? pwr_dispatch<true>(T, p, grid, lds, s) : pwr_dispatch<false>(T, p, grid, lds, s);
     prof_stop(rec, s);
     return rc;

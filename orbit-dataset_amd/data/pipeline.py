@@ -357,6 +357,12 @@ class TaskPrefetcher:
                 raise self.error
             raise StopIteration
         torch.cuda.current_stream(self.device).wait_event(slot.ready)
+        # the clips were produced on the copy stream, complete at `slot.ready`: a recogniser in its default mode may start its
+        # query pass from that event instead of behind the support pass (data.utils.mark_ready)
+        from .utils import mark_ready
+        for key, val in slot.task.items():
+            if isinstance(val, torch.Tensor) and key.endswith("clips"):
+                mark_ready(val, slot.ready)
         self.current = slot
         return slot.task
 

@@ -45,6 +45,27 @@ def frames_from_uint8(frames, device, frame_norm_method="imagenet", channels_las
     return out
 
 
+def mark_ready(tensor, event=None):
+    """Declare a device tensor READY as of now: every operation that produces its content has been queued on the current
+    stream (or is covered by `event`, e.g. the copy-stream event of the upload that filled it). A recogniser in its default
+    mode (`overlap_query = "auto"`) then starts the query pass of predict() on its second stream from THAT point instead of
+    behind the support pass personalise() queued on the caller's stream: it no longer has to assume that the clips might be
+    the product of work still pending there. `data/pipeline.TaskPrefetcher` marks the clips it yields; host-resident clips
+    need no mark (their upload is issued on the second stream). The mark lives on the tensor OBJECT: views and slices of it
+    are unmarked (and take the serial order) unless marked themselves. Returns the tensor."""
+    if isinstance(tensor, torch.Tensor) and tensor.is_cuda:
+        if event is None:
+            event = torch.cuda.Event()
+            event.record(torch.cuda.current_stream(tensor.device))
+        tensor._orbit_ready = event
+    return tensor
+
+
+def ready_event(tensor):
+    """The readiness event `mark_ready` attached to this tensor object, or None."""
+    return getattr(tensor, "_orbit_ready", None)
+
+
 def get_batch_indices(index, last_element, batch_size):
     start = index * batch_size
     return start, min(start + batch_size, last_element)

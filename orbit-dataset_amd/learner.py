@@ -188,11 +188,24 @@ class Learner:
         return task["context_clips"], task["context_labels"], videos
 
     def run(self):
+        """train / test / train_test as the reference's run() (single-step-learner.py:136-193): after training, train_test
+        tests the FINAL model and then the best-validation checkpoint (`test(self.checkpoint_path_validation)`, :186-188), so
+        the model `best_validation` selected is the one a second test block reports (`test_best_validation`)."""
         stats = {}
         if "train" in self.args.mode:
             stats["train"] = self.train()
         if "test" in self.args.mode:
             stats["test"] = self.test()
+            best_path = getattr(self.args, "save_best_model_path", None)
+            if "train" in self.args.mode and getattr(self, "best_validation", None) is not None and best_path:
+                if self.world > 1:  # rank 0 wrote the file (validate()): every rank loads it after the write is complete
+                    import torch.distributed as dist
+                    dist.barrier()
+                self.model.load_state_dict(torch.load(best_path, map_location="cpu"))
+                self.model._send_to_device()
+                if self.rank == 0:
+                    print("testing the best-validation checkpoint %s" % best_path)
+                stats["test_best_validation"] = self.test()
         return stats
 
     # ---- meta-training (reference single-step-learner.py:128-243) ----------------------------------------------------
@@ -449,8 +462,8 @@ class Learner:
         if getattr(a, "data_root", None):
             return self.test_directory()
         self.model.set_test_mode(True)
-        # synthetic tasks live on the host and are uploaded per mini-batch, so the query pass may run on its own stream
-        self.model.overlap_query = True
+        # (synthetic tasks live on the host and are uploaded per mini-batch: in its default mode, overlap_query = "auto", the
+        # recogniser runs the query pass of predict() on its own stream for such clips)
         task_acc, personalise_ms, inference_ms = [], [], []
         with torch.no_grad():
             for t in odist.tasks_for_rank(a.num_test_tasks, self.rank, self.world):

@@ -33,18 +33,45 @@ class PendingLabelSet:
     on a GPU drains the launch queue once per task."""
 
     CAP = 32  # class slots the head kernels are launched over until the count is known (ORBIT users own <= ~20 objects)
-    _slots = None  # pinned ring of counts, shared by the process
-    _next = 0
+    # Pinned host ints the counts travel to: every PendingLabelSet OWNS one slot from a free list until it is resolved or
+    # dropped (ADVICE r5: a shared ring of 64 was overwritten when more than 64 label sets were pending, and resolve() then cut
+    # weight / class_ids to another task's class count). A released slot may be handed out while the previous owner's 4-byte
+    # copy is still queued: every copy of a device goes through that device's one label stream, so the new owner's copy lands
+    # after it, and the new owner only reads the slot after its own `done` event.
+    _chunks = {}  # device key -> list of pinned int32[64] tensors
+    _free = {}    # device key -> free (chunk, index) pairs
+    _lock = __import__("threading").Lock()
     wait_seconds = 0.0  # host time spent blocked in resolve() since the process started (the kernel itself takes microseconds:
     #                     a long wait means the host ran ahead of the stream the labels were produced on)
 
+    @classmethod
+    def _take_slot(cls, key):
+        with cls._lock:
+            free = cls._free.setdefault(key, [])
+            if not free:
+                chunk = torch.zeros(64, dtype=torch.int32).pin_memory()
+                cls._chunks.setdefault(key, []).append(chunk)
+                free.extend((chunk, i) for i in range(63, -1, -1))
+            return free.pop()
+
+    def _release_slot(self):
+        slot, self.slot = self.slot, None
+        if slot is not None:
+            with PendingLabelSet._lock:
+                PendingLabelSet._free.setdefault(self._key, []).append(slot)
+
+    def __del__(self):
+        try:
+            self._release_slot()
+        except Exception:  # (interpreter shutdown)
+            pass
+
     def __init__(self, labels, device):
         cls = PendingLabelSet
-        if cls._slots is None:
-            cls._slots = torch.zeros(64, dtype=torch.int32).pin_memory()
+        self.slot = None
+        self._key = str(device)
         self.labels = labels
-        self.slot = cls._next % 64
-        cls._next += 1
+        self.slot = cls._take_slot(self._key)
         lab = labels.to(torch.int64).contiguous()
         self.ids = torch.empty(self.CAP, dtype=torch.int64, device=device)
         self.count_dev = torch.empty(1, dtype=torch.int32, device=device)
@@ -56,8 +83,9 @@ class PendingLabelSet:
         _lib.check(_lib.load().orbit_label_set(_lib.dptr(lab, torch.int64), lab.numel(), _lib.dptr(self.ids, torch.int64),
                                                self.CAP, _lib.dptr(self.count_dev, torch.int32),
                                                ctypes.c_void_p(side.cuda_stream)), "orbit_label_set")
+        chunk, idx = self.slot
         with torch.cuda.stream(side):
-            cls._slots[self.slot:self.slot + 1].copy_(self.count_dev, non_blocking=True)
+            chunk[idx:idx + 1].copy_(self.count_dev, non_blocking=True)
         self.done = torch.cuda.Event()
         self.done.record(side)
         for t in (lab, self.ids, self.count_dev):
@@ -75,7 +103,9 @@ class PendingLabelSet:
             t0 = time.perf_counter()
             self.done.synchronize()
             PendingLabelSet.wait_seconds += time.perf_counter() - t0  # (bench.py reports it beside the host's enqueue time)
-            c = int(PendingLabelSet._slots[self.slot])
+            chunk, idx = self.slot
+            c = int(chunk[idx])
+            self._release_slot()
             self._resolved = (self.ids[:c] if c <= self.CAP else None,)
         return self._resolved[0]
 

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from ..data.utils import get_batch_indices
+from ..data.utils import get_batch_indices, ready_event
 from .classifier_heads import create_classifier
 from .feature_adapters import FilmParameterGenerator, NullGenerator
 from .feature_extractors import create_feature_extractor
@@ -265,17 +265,21 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         self.features_cache = None
         # overlap_query: in test mode predict() runs the query clips through the extractor on a second HIP stream, so it
         # overlaps with the support pass personalise() queued on the caller's stream (the two passes are independent
-        # given the FiLM parameters; small late layers do not fill the chip on their own: -18 % per efficientnet task,
-        # tools/overlap_probe.py). Opt-in because the query clips must then be READY when predict() is called: clips that
-        # an earlier, still pending operation on the caller's stream produces after personalise() would be read too early
-        # (host-resident clips are always safe: their upload is issued on the second stream).
-        # overlap_query = 2 ("pipelined") additionally runs the HEAD on the second stream and does NOT join it back: the
+        # given the FiLM parameters; small late layers do not fill the chip on their own: -13 % per efficientnet task).
+        # The query clips must then be READY when the second stream starts on them - clips that an earlier, still pending
+        # operation on the caller's stream produces after personalise() would be read too early. Modes:
+        #   "auto" (default, round 6): overlap exactly when that is known to hold - host-resident clips (their upload is issued
+        #          on the second stream) and device tensors carrying a readiness event (`data.utils.mark_ready`: recorded by
+        #          whoever produced the clips - `TaskPrefetcher` does it for the tasks it yields - the second stream waits for
+        #          it); any other device tensor takes the serial order on the caller's stream;
+        #   True   the caller vouches for every query tensor (round 2-5's opt-in);   False  never;
+        #   2      ("pipelined") additionally runs the HEAD on the second stream and does NOT join it back: the
         # caller's stream is free to start the next task's personalise() while this task's query pass is still running, so
         # consecutive tasks overlap out of phase (one stream in its HBM-bound early layers while the other is in its small
         # late layers) instead of both passes of a task marching through the same layers together. The returned logits are
         # then produced on the second stream: `logits_ready` (an event) must be waited for - or the device synchronised -
         # before another stream reads them.
-        self.overlap_query = False
+        self.overlap_query = "auto"
         # LITE: the H-subset pass of a task's first query batch runs beside the cache pass (_get_features_with_split_batch)
         self.lite_overlap = os.environ.get("ORBIT_LITE_OVERLAP", "1") != "0"
         self._lite_stream = None
@@ -314,6 +318,15 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
     def _clear_caches(self):
         self.reps_cache = None
         self.features_cache = None
+        # Once per task (single-step-learner.py:220): a `lite_query` tape whose graph was never backpropagated - an exception,
+        # or a forward run with autograd on only to read the logits - would otherwise keep the persistent buffers busy for the
+        # rest of the run and silently disable the query-pass overlap; a fork event of an abandoned task must not start the next
+        # task's query pass either. The features predict_a_batch() returned on that path are views of the persistent
+        # buffer: they are valid until the next task's predict_a_batch().
+        self._lite_fork = None
+        release = getattr(self.feature_extractor, "persistent_release", None)
+        if release is not None:
+            release("lite_query")
 
     # ---- personalise ---------------------------------------------------------------------------------
     def personalise(self, context_clips, context_labels, ops_counter=None):
@@ -325,7 +338,7 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
         class_ids = self._label_set(context_labels)
         task_embedding = self._get_task_embedding_in_batches(context_clips, ops_counter)
         self.film_dict = self._generate_film_params(task_embedding, ops_counter)
-        if self.overlap_query:
+        if self.overlap_query and not torch.is_grad_enabled() and not self.feature_extractor.training:
             # everything the query pass needs from this stream: the FiLM vectors AND the extractor's parameters inside
             # the native plan. The upload / repack / BatchNorm fold is queued HERE, explicitly, before the event — the
             # first forward below would otherwise queue it after the event, and a query pass on the side stream (whose
@@ -478,7 +491,11 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
     # ---- predict ----------------------------------------------------------------------------------------
     def predict(self, target_clips):
         self._set_batch_norm_state()
-        if self.overlap_query and not torch.is_grad_enabled() and not self.feature_extractor.training:
+        ready = ready_event(target_clips) if target_clips.is_cuda else None
+        mode = self.overlap_query
+        if mode == "auto":  # overlap exactly when the clips are known to be ready: on the host, or marked (data.utils.mark_ready)
+            mode = (not target_clips.is_cuda) or ready is not None
+        if mode and not torch.is_grad_enabled() and not self.feature_extractor.training:
             side = self.__dict__.get("_query_stream")
             if side is None:
                 side = self.__dict__["_query_stream"] = torch.cuda.Stream(device=self.device)
@@ -487,7 +504,9 @@ class SingleStepFewShotRecogniser(FewShotRecogniser):
                 side.wait_event(self._film_ready)  # FiLM vectors + uploaded parameters: all the query pass needs
             else:  # personalised through another route (sharded / LITE): order after everything queued so far
                 side.wait_stream(main)
-            if self.overlap_query == 2 and self._configured is not None:
+            if ready is not None:
+                side.wait_event(ready)  # whatever produced the clips (an upload on a copy stream, a decode kernel ...)
+            if mode == 2 and self._configured is not None:
                 # pipelined: extractor, pooling AND head on the second stream; no join (see __init__)
                 with torch.cuda.stream(side):
                     target_features = self._get_features_in_batches(target_clips, self.film_dict)

@@ -222,3 +222,41 @@ def test_mahalanobis_predict_backward(device):
     qr = q.double().requires_grad_(True)
     blocks.mahalanobis_predict(qr, head.means.cpu().double(), head.precisions.cpu().double(), 2.0).backward(dl.double())
     assert (qd.grad.cpu().double() - qr.grad).abs().max().item() < 2e-5 * qr.grad.abs().max().item()
+
+
+def test_many_pending_label_sets_keep_their_own_count(device):
+    """ADVICE r5: label sets resolved on the side stream carried their class count through a shared ring of 64 pinned slots;
+    with more than 64 of them pending, an earlier one read a later one's count. Each PendingLabelSet now owns a slot from a
+    free list: 150 pending sets with class counts 1..9 all resolve to their own ids, dropped (never resolved) sets give their
+    slot back, and a head configured on a pending set still exposes the exact weight / class_ids."""
+    from orbit_dataset_amd.model.classifier_heads import PendingLabelSet
+    dev = torch.device(device)
+    g = torch.Generator().manual_seed(3)
+    labels = []
+    for i in range(150):
+        c = 1 + i % 9
+        vals = torch.randperm(40, generator=g)[:c].sort().values
+        labels.append((vals, vals[torch.randint(0, c, (30,), generator=g)].scatter_(0, torch.arange(c), vals)))
+    pend = [PendingLabelSet(lab.to(dev), dev) for _, lab in labels]
+    slots = {(id(p.slot[0]), p.slot[1]) for p in pend}
+    assert len(slots) == 150  # distinct slots while all are pending
+    for (vals, _), p in zip(reversed(labels), reversed(pend)):  # resolve in the opposite order they were issued
+        assert p.resolve().cpu().tolist() == vals.tolist()
+        assert p.slot is None  # given back
+    free_before = len(PendingLabelSet._free[str(dev)])
+    dropped = [PendingLabelSet(lab.to(dev), dev) for _, lab in labels[:10]]
+    assert len(PendingLabelSet._free[str(dev)]) == free_before - 10
+    del dropped
+    import gc
+    gc.collect()
+    assert len(PendingLabelSet._free[str(dev)]) == free_before
+    # a head configured on a pending set, with 70 other sets issued before it is read
+    feats, lab, q, _ = _task(60, 20, 64, 6, seed=11, label_values=(1, 4, 5, 8, 13, 21))
+    head = PrototypicalClassifier(1.0, "euclidean")
+    lab_dev = lab.to(dev)
+    head.configure(feats.to(dev), lab_dev, class_ids=PrototypicalClassifier.label_set(lab_dev, dev))
+    later = [PendingLabelSet(l.to(dev), dev) for _, l in labels[:70]]
+    assert head.class_ids.cpu().tolist() == [1, 4, 5, 8, 13, 21] and head.weight.shape == (6, 64)
+    ids, W, b = blocks.proto_configure(feats, lab, "euclidean")
+    assert (head.weight.cpu() - W).abs().max().item() < 1e-5
+    del later

@@ -162,6 +162,46 @@ def test_overlap_query_stream_is_bit_identical(device, fe_name, adapt, size):
     model.overlap_query = False
 
 
+def test_default_overlap_mode_is_safe_and_bit_identical(device):
+    """Round 6: the recogniser's DEFAULT is overlap_query = "auto" - the query pass of predict() runs on the second stream
+    exactly when the clips are known to be ready: host-resident clips, or device tensors marked with data.utils.mark_ready
+    (TaskPrefetcher marks what it yields). An unmarked device tensor - possibly the product of work still pending on the
+    caller's stream - takes the serial order. Logits are bit-identical in all three cases, also when the query clips are
+    PRODUCED on the caller's stream after personalise() was queued (the case the opt-in forms must not be used for)."""
+    from orbit_dataset_amd.data.utils import mark_ready, ready_event
+    model, _ = build_pair("resnet18", False, "proto", 1, 16)
+    assert model.overlap_query == "auto"
+    t = synthetic.make_task(31, way=4, shots=2, frames_per_shot=6, num_query=40, frame_size=84)
+    ctx, lab, tgt = t["context_clips"].cuda(), t["context_labels"].cuda(), t["target_clips"].cuda()
+    torch.cuda.synchronize()
+
+    def run(q):
+        with torch.no_grad():
+            model.personalise(ctx, lab)
+            out = model.predict(q() if callable(q) else q).clone()
+        model._reset()
+        return out
+    model.overlap_query = False
+    base = run(tgt)
+    model.overlap_query = "auto"
+    used = lambda: model.__dict__.get("_query_stream") is not None
+    assert not used()
+    # unmarked device clips produced on the caller's stream AFTER personalise() was queued: serial order, correct values
+    late = lambda: (tgt * 2.0) * 0.5  # (exact in fp32: the same values, but a tensor that does not exist before this point)
+    assert torch.equal(run(late), base) and not used()
+    # marked clips: second stream, from the readiness event
+    marked = mark_ready(tgt.clone())
+    assert ready_event(marked) is not None and ready_event(marked[:10]) is None  # the mark lives on the tensor object
+    assert torch.equal(run(marked), base) and used()
+    # a mark recorded right after the producing kernel, consumed while that kernel's stream is still busy
+    def produced_then_marked():
+        return mark_ready((tgt * 2.0) * 0.5)
+    assert torch.equal(run(produced_then_marked), base)
+    # host-resident clips: their upload is issued on the second stream
+    assert torch.equal(run(t["target_clips"]), base)
+    torch.cuda.synchronize()
+
+
 def test_predict_video_equals_predict_on_frame_history(device):
     """predict_video: each frame through the extractor once, windows pooled on the features — bit-identical to the
     reference's attach_frame_history -> predict on the T-times larger clip tensor."""
@@ -272,6 +312,16 @@ def test_learner_test_mode_end_to_end(device, tmp_path):
     if best.exists():
         sd = torch.load(str(best))
         assert any(k.startswith("feature_extractor.") for k in sd)
+    # train_test tests the final model AND the best-validation checkpoint (reference run(), single-step-learner.py:186-188)
+    best2 = tmp_path / "best2.pt"
+    both = main(["--mode", "train_test", "--feature_extractor", "resnet18", "--learn_extractor", "--with_lite", "--epochs", "2",
+                 "--num_val_tasks", "2", "--num_test_tasks", "2", "--learning_rate", "1e-3",
+                 "--save_best_model_path", str(best2)] + common)
+    assert "test" in both and both["test"]["num_tasks"] == 2
+    if both["train"]["best_validation"] is not None and best2.exists():
+        assert both["test_best_validation"]["num_tasks"] == 2 and 0.0 <= both["test_best_validation"]["frame_acc"][0] <= 1.0
+    else:
+        assert "test_best_validation" not in both
 
 
 def test_sharded_forms_on_device_world1(device):

@@ -194,13 +194,28 @@ def test_stream_override_and_deferred_blocks_restore_state():
         def __init__(self, h):
             self.cuda_stream = h
 
-    assert _lib._stream_override is None
+    assert getattr(_lib._tls, "stream", None) is None
     with _lib.use_stream(FakeStream(0x1234)):
         assert _lib.stream_handle().value == 0x1234
         with _lib.use_stream(FakeStream(0x5678)):
             assert _lib.stream_handle().value == 0x5678
         assert _lib.stream_handle().value == 0x1234
-    assert _lib._stream_override is None
+        # the override is per THREAD (as torch's current stream is): the prefetcher's staging thread asks for ITS stream while
+        # the main thread sits inside a LITE use_stream block (a process-global override sent the staging thread's
+        # uint8 conversion kernel to the LITE side stream, unordered against the upload it reads)
+        import threading
+        seen = {}
+
+        def other_thread():
+            seen["inside"] = getattr(_lib._tls, "stream", None)
+            with _lib.use_stream(FakeStream(0x9abc)):
+                seen["own"] = _lib.stream_handle().value
+            seen["after"] = getattr(_lib._tls, "stream", None)
+        th = threading.Thread(target=other_thread)
+        th.start(), th.join()
+        assert seen == {"inside": None, "own": 0x9abc, "after": None}
+        assert _lib.stream_handle().value == 0x1234  # ... and the other thread's block did not touch this thread's override
+    assert getattr(_lib._tls, "stream", None) is None
 
     fe, _ = create_feature_extractor("resnet18", False, False, True)
     assert fe._defer_stats is None and fe._persist_key is None
