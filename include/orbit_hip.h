@@ -66,7 +66,7 @@ int orbit_runtime_init(void);
 const char* orbit_last_error(void);
 /* number of visible HIP devices (<=0: no usable GPU); does not create a context on failure */
 int orbit_device_count(void);
-/* Runtime options (14). Every option has an environment default ORBIT_<NAME in upper case>; the defaults are the measured-best
+/* Runtime options (15). Every option has an environment default ORBIT_<NAME in upper case>; the defaults are the measured-best
  * path. They exist so that the parity tests can reach every kernel a default path uses and so that A/B comparisons run
  * inside one process on one box. Setting an option bumps an epoch that invalidates captured launch sequences.
  *  network runtime:
@@ -81,6 +81,12 @@ int orbit_device_count(void);
  *                   kernel + depthwise kernel. Read when a plan is created
  *   "train_dw_xf"   1 (default) = ORBIT_TRAIN_NO_BACKWARD forwards skip the activation pass between an expand / stem conv and
  *                   its depthwise conv (applied on load instead); 0 = always the separate pass
+ *   "train_fused_fronts"  1 (default) = on ORBIT_TRAIN_NO_BACKWARD batch-statistics forwards (the LITE cache pass) the expansion
+ *                   conv + depthwise conv of EfficientNet's 112x112 / 56x56 MBConv blocks run as a statistics sweep of the
+ *                   expansion conv (nothing stored) + the row-streaming fused front of the inference plans in its RAW form
+ *                   (raw depthwise outputs + their column sums): the 6x-expanded tensor never reaches HBM; 2 = every shape the
+ *                   fused front serves; 0 = never (conv + depthwise pair). Same first-BatchNorm statistics bit for bit; the
+ *                   second BatchNorm's statistics are summed in another order
  *  dense convolutions (csrc/conv_igemm.hip, pw_rgemm.hip, conv_bf3.hip):
  *   "conv_tile"     0 = heuristic (default); 3 = 64x64, 4 = 128x32, 6 = 32x32 with K split over the four waves (the three
  *                   tilings the heuristic chooses from)

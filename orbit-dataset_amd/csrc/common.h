@@ -83,6 +83,11 @@ struct ConvDesc {
     // launch_bn_stats' own pass.
     float* stats = nullptr;
     int* stats_blocks = nullptr;
+    // statistics sweep (round 6, the no-grad cache pass of the LITE step on the row-streaming fronts): y == nullptr with
+    // `stats` set - the conv runs for its BatchNorm statistics alone and stores nothing (the 6x-expanded tensor of an MBConv
+    // block never reaches HBM: the fused front re-expands it in LDS with the scale / shift these statistics give). Same
+    // kernel, same tiles, same summation order as the storing form: the statistics are bit-identical to the unfused pass's.
+    bool stats_only = false;
     // dual write (training tape under running-statistics BatchNorm, where scale / shift are known before the conv runs):
     // the raw conv output goes to y_raw and y receives act(raw * scale + shift + residual) - the activation pass over the
     // tensor (read y, write a) disappears. Not with fused pooling, split-K or the narrow-pointwise kernel.
@@ -168,7 +173,11 @@ bool mbconv_rows_supported(int H, int W, int Cin, int mid, int K, int stride);
 int mbconv_rows_tiles(int H, int W, int Cin, int mid, int K, int stride);
 int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
                        const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
-                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, int plan_tiles = 0);
+                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, int plan_tiles = 0,
+                       bool raw_stats = false);
+// raw_stats (train-mode BatchNorm, no-grad passes): y receives the RAW depthwise outputs (no second BatchNorm / activation;
+// sc2 / sh2 are ignored) and `pool` the [B * mbconv_rows_tiles][2][mid] column sums / sums of squares of those outputs - the
+// partial layout launch_bn_stats_from_partials reads
 // (plan_tiles > 0: the tile count the caller sized `pool` and its consumer for; the launch fails if it would write another)
 // row-streaming stem + first depthwise (csrc/mbconv_rows.hip): w1_packed = stem_pack_weights' [32][32]; pool [B][stem_rows_tiles][32]
 bool stem_rows_supported(int H, int W, int mid, int K, int stride);

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                         o[0] = apply_act(o[0], p.act), o[1] = apply_act(o[1], p.act);
                         o[2] = apply_act(o[2], p.act), o[3] = apply_act(o[3], p.act);
                     }
-                    *reinterpret_cast<f32x4*>(yout + (size_t)(mo0 + r) * p.Cout + n) = o;
+                    if (yout) *reinterpret_cast<f32x4*>(yout + (size_t)(mo0 + r) * p.Cout + n) = o;  // (null: statistics sweep)
                 }
             }
         } else if (n < p.Cout) {
@@ -521,7 +521,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvParams p) {
                     v[0] = apply_act(v[0], p.act), v[1] = apply_act(v[1], p.act);
                     v[2] = apply_act(v[2], p.act), v[3] = apply_act(v[3], p.act);
                 }
-                *reinterpret_cast<f32x4*>(yout + (size_t)m * p.Cout + n) = v;
+                if (yout) *reinterpret_cast<f32x4*>(yout + (size_t)m * p.Cout + n) = v;
             }
         }
         // train-mode BatchNorm statistics of this tile's rows (rows beyond M never entered the sums): the RPO row lanes of a
@@ -698,13 +698,14 @@ static int launch_cfg2(ConvParams& p, hipStream_t s) {
         char name[48];
         snprintf(name, sizeof(name), "conv_igemm<%d,%d,%d,%s%s%s%s%s>", BM, BN, BK, MODE ? "nchw" : "nhwc",
                  POOL2 ? ",pool2" : "", GATE ? ",gate" : "", PW ? ",pw" : "",
-                 p.ksplit > 1 ? ",splitk" : WGK == 2 ? ",k2" : WGK == 4 ? ",k4" : "");
+                 p.ksplit > 1 ? ",splitk" : WGK == 2 ? ",k2" : WGK == 4 ? ",k4" : (!p.y ? ",stats" : ""));
         ProfRec r;
         r.start = prof_event(), r.stop = prof_event(), r.variant = prof_variant(name);
         const double pix = POOL2 ? (double)p.B * p.HoP * p.WoP * 4 : (double)p.B * p.Ho * p.Wo;
         r.flops = 2.0 * pix * p.Cout * p.KH * p.KW * p.Cin * p.prof_flop_scale;  // algorithmic (unpadded) FLOPs
         // algorithmic HBM bytes: input once, output once (pooled if fused), residual once, weights once
-        r.bytes = 4.0 * ((double)p.B * p.H * p.W * p.Cin + (POOL2 ? pix / 4 : pix) * p.Cout * (p.residual ? 2.0 : 1.0) +
+        r.bytes = 4.0 * ((double)p.B * p.H * p.W * p.Cin +
+                         (POOL2 ? pix / 4 : pix) * p.Cout * ((p.residual ? 1.0 : 0.0) + (p.y || p.ksplit > 1 ? 1.0 : 0.0)) +
                          (double)p.Cout * p.KH * p.KW * p.Cin);
         r.silu = p.act == ORBIT_ACT_SILU && p.ksplit <= 1 ? pix * p.Cout : 0.0;
         (void)hipEventRecord(r.start, s);
@@ -789,7 +790,9 @@ size_t conv_splitk_floats(const ConvDesc& d) {
 }
 
 int launch_conv(const ConvDesc& d, hipStream_t s) {
-    ORBIT_REQUIRE(d.x && d.w_packed && d.y, "conv: null pointer");
+    ORBIT_REQUIRE(d.x && d.w_packed && (d.y || d.stats_only), "conv: null pointer");
+    ORBIT_REQUIRE(!d.stats_only || (d.y == nullptr && d.stats && d.stats_blocks && !d.pool2 && !d.splitk_ws && !d.y_raw),
+                  "conv: the statistics sweep stores nothing and needs the whole-tile statistics epilogue");
     ORBIT_REQUIRE(d.B > 0 && d.H > 0 && d.W > 0 && d.Cin > 0 && d.Cout > 0 && d.Ho > 0 && d.Wo > 0,
                   "conv: bad sizes");
     ORBIT_REQUIRE(d.x_nchw ? d.Cin <= 4 : (d.Cin % 4 == 0),
@@ -800,8 +803,8 @@ int launch_conv(const ConvDesc& d, hipStream_t s) {
     if (d.stats_blocks) *d.stats_blocks = 0;
     // opt-in: three-way bf16 split of both operands on the bf16 matrix cores (a function of the layer only, like every routing
     // rule here: a frame's bits do not depend on its batch)
-    const int rg = get_option("conv_rgemm");
-    if ((get_option("conv_bf3") & 1) && conv_bf3_supported(d) &&
+    const int rg = d.stats_only ? 0 : get_option("conv_rgemm");
+    if (!d.stats_only && (get_option("conv_bf3") & 1) && conv_bf3_supported(d) &&
         !(rg == 1 && pw_rgemm_supported(d) && pw_rgemm_preferred(d)))  // (1152 -> 320 @7x7: 770 tiles on 768 slots - the register GEMM's 1 535 blocks win)
         return launch_conv_bf3(d, s);
     if (rg == 2 && pw_rgemm_supported(d)) return launch_pw_rgemm(d, s);

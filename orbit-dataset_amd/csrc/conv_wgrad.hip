@@ -374,7 +374,11 @@ static void wgrad_geometry(int M, int Cout, int NC, int& co_tiles, int& n_tiles,
     co_tiles = cdiv(Cout, 64), n_tiles = cdiv(NC, 64);
     const int tiles = co_tiles * n_tiles;
     const int total_steps = cdiv(M, WG_BKM);
-    splits = cdiv(2048, tiles);
+    static const int target = [] {  // (ORBIT_WGRAD_BLOCKS: tuning experiments only)
+        const char* e = getenv("ORBIT_WGRAD_BLOCKS");
+        return e && atoi(e) > 0 ? atoi(e) : 2048;
+    }();
+    splits = cdiv(target, tiles);
     const int max_splits = total_steps >= 8 ? total_steps / 8 : 1;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;

@@ -95,6 +95,32 @@ static bool conv_feeds_dw_raw(const orbit_extractor* fe, size_t i, int bn_train,
     return true;
 }
 
+// Round 6: on a NO-BACKWARD batch-statistics forward (the cache pass of the LITE step: 200 frames under torch.no_grad() while the
+// extractor is being learned, reference few_shot_recognisers.py:404-408) an MBConv block's expansion conv + depthwise conv run
+// as the row-streaming fused front of the inference plans in two sweeps: (1) the expansion conv as a STATISTICS SWEEP
+// (ConvDesc::stats_only: same kernel, same tiles, nothing stored) gives the first BatchNorm's batch statistics, (2) the fused
+// front (csrc/mbconv_rows.hip, RAW form) re-expands in its LDS ring with that scale / shift, stores the RAW depthwise outputs
+// and their column sums - the second BatchNorm then proceeds as on the unfused path. The 6x-expanded tensor (963 MB per 200
+// frames for block 1.0) is neither written nor read. Taped forwards keep the unfused pair: their backward reads that tensor.
+// `train_fused_fronts`: 1 (default) = where measured faster (the 112x112 / 56x56 blocks), 0 = never, 2 = every supported shape.
+static bool fused_front_sweeps(const orbit_extractor* fe, size_t i, int bn_train, bool no_backward) {
+    const Op& o = fe->ops[i];
+    const int opt = get_option("train_fused_fronts");
+    if (!opt || o.kind != OP_CONV || !bn_train || !no_backward || o.x_nchw || o.pool2 || o.res >= 0 || o.use_gate) return false;
+    if (o.KH != 1 || o.KW != 1 || o.stride != 1 || o.act != ORBIT_ACT_SILU) return false;
+    if (i + 1 >= fe->ops.size() || fe->ops[i + 1].kind != OP_DWCONV || fe->ops[i + 1].in != o.out) return false;
+    const Op& d = fe->ops[i + 1];
+    if (d.act != ORBIT_ACT_SILU || d.Cin != o.Cout || !mbconv_rows_supported(o.H, o.W, o.Cin, o.Cout, d.KH, d.stride)) return false;
+    if (fe->bns[o.bn].conv_bias >= 0) return false;
+    if (opt == 1 && o.H < 56) return false;  // (the 28x28 blocks: statistics sweep + front measured no faster than the pair)
+    for (size_t j = i + 2; j < fe->ops.size(); ++j) {  // no later reader of the expanded tensor before its buffer is rewritten
+        const Op& q = fe->ops[j];
+        if (q.in == o.out || q.res == o.out) return false;
+        if (q.out == o.out) break;
+    }
+    return true;
+}
+
 static size_t max_bn_partial_floats(const orbit_extractor* fe, int B) {
     size_t m = 4;
     for (const Op& o : fe->ops)
@@ -109,7 +135,11 @@ static size_t max_bn_partial_floats(const orbit_extractor* fe, int B) {
                     m = std::max(m, bn_partial_floats((size_t)dwconv_dgrad_bn_blocks(B, o.Ho, o.Wo, o.Cout, st), o.Cout) +
                                         3 * (size_t)o.Cout);
             }
-            else m = std::max(m, bn_partial_floats((size_t)B * dwconv_se_chunks(o.Ho), o.Cout));
+            else {
+                m = std::max(m, bn_partial_floats((size_t)B * dwconv_se_chunks(o.Ho), o.Cout));
+                // (the two-sweep fused front writes one row per frame and strip-band tile instead)
+                m = std::max(m, bn_partial_floats((size_t)B * 16, o.Cout));
+            }
             // backward of a depthwise BatchNorm whose reduction rides on the squeeze-excite backward (+ 3*C coefficients)
             if (o.kind == OP_DWCONV)
                 m = std::max(m, bn_partial_floats((size_t)B * se_pool_chunks(B, o.Ho * o.Wo, o.Cout), o.Cout) + 3 * (size_t)o.Cout);
@@ -416,12 +446,14 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
     bool dw_pooled = false;  // the last depthwise op's activation pass left pooling partials in L.pool
     bool dw_in_raw = false;  // the tensor the next depthwise op reads is a RAW conv output (see ORBIT_TRAIN_NO_BACKWARD)
     int dw_in_bn = -1, dw_in_act = ORBIT_ACT_NONE;
+    int front_conv = -1;  // the expansion conv whose statistics sweep just ran: the next depthwise op is the fused front
     for (size_t i = 0; i < fe->ops.size(); ++i) {
         const Op& o = fe->ops[i];
         int rc = ORBIT_OK;
         if (o.kind == OP_CONV) {
             const BNDesc& bn = fe->bns[o.bn];
             const float* xin = cur[o.in];
+            const bool sweep = fused_front_sweeps(fe, i, bn_train, no_backward);
             ConvDesc d;
             d.x = xin, d.w_packed = fe->d_packed + o.packed_off, d.y = fl(L.y[i]);
             d.scale = d.shift = d.residual = d.gate = nullptr;
@@ -442,12 +474,15 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
                 d.residual = o.res >= 0 ? cur[o.res] : nullptr;
                 d.act = o.act;
             }
+            if (sweep) d.y = nullptr, d.stats_only = true;  // statistics only: the fused front below re-expands in LDS
             rc = launch_conv(d, s);
             if (rc != ORBIT_OK) return rc;
             if (dual) {
                 cur[o.out] = fl(L.a[i]);
                 continue;
             }
+            if (sweep && stat_blocks <= 0)
+                return set_err(ORBIT_ERR_STATE, "extractor_train_forward: the statistics sweep of op %zu emitted no partials", i);
             const int M = B * o.Ho * o.Wo;
             if (bn_train) {
                 const bool fm = film && bn.film_off >= 0;
@@ -463,6 +498,11 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
                                          invstd + bn.fold_off, scale + bn.fold_off, shift + bn.fold_off,
                                          run_mean(bn), run_var(bn), fl(L.partial), s);
                 if (rc != ORBIT_OK) return rc;
+            }
+            if (sweep) {
+                front_conv = (int)i;
+                cur[o.out] = nullptr;
+                continue;
             }
             // the only consumer is the depthwise conv that follows: it applies this BatchNorm + activation as it loads the raw
             // output (conv_feeds_dw_raw above), so the activated 6x-expanded tensor is neither written nor read back
@@ -488,15 +528,30 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
             // train-mode BatchNorm: the depthwise kernel itself emits the column sums / sums of squares of its raw outputs
             const float* in_sc = dw_in_raw ? scale + fe->bns[dw_in_bn].fold_off : nullptr;
             const float* in_sh = dw_in_raw ? shift + fe->bns[dw_in_bn].fold_off : nullptr;
-            rc = launch_dwconv_se(cur[o.in], fe->d_packed + o.packed_off, y, nullptr, nullptr,
-                                  bn_train ? fl(L.partial) : nullptr, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l,
-                                  o.Ho, o.Wo, ORBIT_ACT_NONE, s, bn_train ? 1 : 0, in_sc, in_sh, dw_in_act);
+            int stat_rows = B * dwconv_se_chunks(o.Ho);
+            if (front_conv >= 0) {
+                // sweep 2 of the fused front: expand (first BatchNorm's batch statistics from the sweep above) + depthwise in
+                // one row-streaming kernel, RAW depthwise outputs + their column sums out
+                const Op& c = fe->ops[front_conv];
+                const BNDesc& bn1 = fe->bns[c.bn];
+                const int tiles = mbconv_rows_tiles(c.H, c.W, c.Cin, c.Cout, o.KH, o.stride);
+                if (tiles <= 0 || tiles > 16) return set_err(ORBIT_ERR_STATE, "extractor_train_forward: fused front tiling");
+                rc = launch_mbconv_rows(cur[c.in], fe->d_pool + fe->params[c.weight].off, scale + bn1.fold_off,
+                                        shift + bn1.fold_off, fe->d_packed + o.packed_off, nullptr, nullptr, y, fl(L.partial), B,
+                                        c.H, c.W, c.Cin, c.Cout, o.KH, o.stride, o.pad_t, o.pad_l, o.Ho, o.Wo, s, 0, true);
+                stat_rows = B * tiles;
+                front_conv = -1;
+            } else {
+                rc = launch_dwconv_se(cur[o.in], fe->d_packed + o.packed_off, y, nullptr, nullptr,
+                                      bn_train ? fl(L.partial) : nullptr, B, o.H, o.W, o.Cin, o.KH, o.stride, o.pad_t, o.pad_l,
+                                      o.Ho, o.Wo, ORBIT_ACT_NONE, s, bn_train ? 1 : 0, in_sc, in_sh, dw_in_act);
+            }
             dw_in_raw = false;
             if (rc != ORBIT_OK) return rc;
             const int M = B * o.Ho * o.Wo;
             if (bn_train) {
                 const bool fm = film && bn.film_off >= 0;
-                rc = launch_bn_stats_from_partials(fl(L.partial), B * dwconv_se_chunks(o.Ho), M, o.Cout, bn.eps, momentum,
+                rc = launch_bn_stats_from_partials(fl(L.partial), stat_rows, M, o.Cout, bn.eps, momentum,
                                                    fm ? film_gamma + bn.film_off : fe->d_pool + fe->params[bn.gamma].off,
                                                    fm ? film_beta + bn.film_off : fe->d_pool + fe->params[bn.beta].off,
                                                    nullptr, mean + bn.fold_off, invstd + bn.fold_off, scale + bn.fold_off,

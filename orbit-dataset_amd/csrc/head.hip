@@ -37,6 +37,7 @@ static Option g_options[] = {
     {"mbconv_rows", "ORBIT_MBCONV_ROWS", 1, false},  // row-streaming fused MBConv fronts at plan creation (0 = conv + depthwise pair)
     {"stem_rows", "ORBIT_STEM_ROWS", 1, false},      // the same for stem + first depthwise
     {"train_dw_xf", "ORBIT_TRAIN_DW_XF", 1, false},  // no-backward training forwards: BatchNorm + SiLU applied on the depthwise load
+    {"train_fused_fronts", "ORBIT_TRAIN_FUSED_FRONTS", 1, false},  // ... and MBConv fronts as statistics sweep + row-streaming kernel
     // dense convolutions
     {"conv_tile", "ORBIT_CONV_TILE", 0, false},      // 0 heuristic; 3 = 64x64, 4 = 128x32, 6 = 32x32 with K split over the waves
     {"conv_bk", "ORBIT_CONV_BK", 0, false},          // 0 = widest K-tile that divides Cin; 8 / 16 / 32 caps it
@@ -102,21 +103,54 @@ __global__ __launch_bounds__(256) void proto_configure_kernel(
     const float* f = feats + (size_t)task * N * T * D;
     const int64_t* lab = labels + (size_t)task * N;
     const float invT = 1.0f / (float)T;
+    // Round 6: the class's clips are first COMPACTED into an index list in LDS (ascending, chunks of 1024 labels: one coalesced
+    // label load per thread and a block scan), then summed from the list. The first form tested `lab[i] != cid` inside the
+    // row loop: N dependent label loads, each a wave-uniform L2 round trip, made a 200-clip configure a 25 us latency chain on
+    // the critical path between the support pass and the head (per-launch events, bench.py roofline.families); with the list
+    // the row loads of a class are independent of each other. Same rows, same ascending order: bit-identical sums.
+    __shared__ int idx[1024];
+    __shared__ int wave_cnt[4];
+    __shared__ int chunk_n;
     float acc = 0.f;
     int cnt = 0;
-    for (int i = 0; i < N; ++i) {
-        if (lab[i] != cid) continue;  // wave-uniform branch
-        ++cnt;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int base = 0; base < N; base += 1024) {
+        int mine[4], nm = 0;  // thread t owns labels base + 4 t .. + 3 (ascending inside the thread, threads ascending)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = base + 4 * (int)threadIdx.x + j;
+            if (i < N && lab[i] == cid) mine[nm++] = i;
+        }
+        // exclusive scan of nm over the block: wave prefix by lane walk through DPP-free shuffles, then the 4 wave totals
+        int pre = nm;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int o = __shfl_up(pre, off);
+            if (lane >= off) pre += o;
+        }
+        if (lane == 63) wave_cnt[wave] = pre;
+        __syncthreads();
+        int woff = 0;
+        for (int w = 0; w < wave; ++w) woff += wave_cnt[w];
+        const int start = woff + pre - nm;
+        for (int j = 0; j < nm; ++j) idx[start + j] = mine[j];
+        if (threadIdx.x == 255) chunk_n = woff + pre;
+        __syncthreads();
+        const int n = chunk_n;
+        cnt += n;
         if (d < D) {
-            const float* row = f + (size_t)i * T * D + d;
-            if (T == 1) {
-                acc += row[0];
-            } else {
-                float s = 0.f;
-                for (int t = 0; t < T; ++t) s += row[(size_t)t * D];
-                acc += s * invT;
+            for (int k = 0; k < n; ++k) {
+                const float* row = f + (size_t)idx[k] * T * D + d;
+                if (T == 1) {
+                    acc += row[0];
+                } else {
+                    float s = 0.f;
+                    for (int t = 0; t < T; ++t) s += row[(size_t)t * D];
+                    acc += s * invT;
+                }
             }
         }
+        __syncthreads();  // idx / wave_cnt are rewritten by the next chunk
     }
     if (d < D) sums[((size_t)task * C + c) * D + d] = acc;
     if (blockIdx.x == 0 && threadIdx.x == 0) counts[(size_t)task * C + c] = (float)cnt;

@@ -82,7 +82,12 @@ constexpr int ROWS_ES = 36;  // ring pixel stride (floats): 32 channels + 4
 // (six products per fp32 product; a k-step of 16 = two of this kernel's 8-deep k-groups, the odd last group paired with zeros):
 // 6 / 12 / 18 MFMAs of 32 cycles for Cin = 16 / 24 / 40 instead of 8 / 12 / 20 of 64 cycles; the window's x quads are split as
 // they arrive (~22 VALU instructions per quad), the chunk's filter quads once per block. Not bit-identical to the unfused pair.
-template <int K, int S, int TO, int NOUT, int NG, int SPR, bool EXACT, bool BF3>
+// RAW (round 6, train-mode BatchNorm on no-grad passes of the LITE step): the depthwise outputs are stored RAW - the second
+// BatchNorm needs their batch statistics before it can be applied - and p.pool receives, per (frame, tile), the column sums and
+// sums of squares of those raw outputs ([B * tiles][2][mid], the partial layout bn_stats_finalize reads) instead of the
+// squeeze-excite pooling partials; sc1 / sh1 are the FIRST BatchNorm's batch-statistics scale / shift, which the caller gets
+// from a statistics sweep of the expansion conv (ConvDesc::stats_only) - the expanded tensor itself exists only in the ring.
+template <int K, int S, int TO, int NOUT, int NG, int SPR, bool EXACT, bool BF3, bool RAW = false>
 __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const MbRowsParams p) {
     constexpr int NEW = TO * S;
     constexpr int NCOL = (NOUT - 1) * S + K;
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const
     const bool q_ok = EXACT || q_real;
     static_assert(TO % (32 / SPR) == 0, "a pass covers whole rows of the step");
     v4f s2 = {0.f, 0.f, 0.f, 0.f}, h2 = {0.f, 0.f, 0.f, 0.f};
-    if (q_ok) s2 = *reinterpret_cast<const v4f*>(p.sc2 + cq), h2 = *reinterpret_cast<const v4f*>(p.sh2 + cq);
+    if (!RAW && q_ok) s2 = *reinterpret_cast<const v4f*>(p.sc2 + cq), h2 = *reinterpret_cast<const v4f*>(p.sh2 + cq);
     // 3x3: the thread's nine tap quads stay in registers; 5x5: 25 quads do not fit, the chunk's taps sit in LDS behind the ring
     v4f* Ds = reinterpret_cast<v4f*>(ring + 3 * n_new * ES);  // 5x5 only: [K*K][8]
     v4f tapr[K == 3 ? K * K : 1];
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const
     const int orow = p.Wo * p.mid;
     const int band_len = y1 - y0;
     const int winfl = n_new * ES;  // floats per window
-    v4f psum = {0.f, 0.f, 0.f, 0.f};
+    v4f psum = {0.f, 0.f, 0.f, 0.f}, psq = {0.f, 0.f, 0.f, 0.f};
 
     auto depthwise = [&](int i, int slotA) {  // slotA = i % 3
         const int baseA = slotA * winfl;
@@ -354,7 +359,17 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const
             float* yrow = ystep + j * orow;
 #pragma unroll
             for (int n = 0; n < NOUT; ++n) {
-                if constexpr (EXACT) {
+                if constexpr (RAW) {
+                    const v4f o = {alo[n].x, alo[n].y, ahi[n].x, ahi[n].y};
+                    const bool mine = EXACT ? own : (rowok && ((okn >> n) & 1u));
+                    if (EXACT || mine) *reinterpret_cast<v4f*>(yrow + (o_col + n * p.mid)) = o;
+                    {
+#pragma clang fp contract(off)  // (one rounding per product and per sum, whatever the instantiation)
+                        const v4f z = {0.f, 0.f, 0.f, 0.f};
+                        psum = psum + (mine ? o : z);
+                        psq = psq + (mine ? o * o : z);
+                    }
+                } else if constexpr (EXACT) {
                     const v2f olo = silu2(fma2(alo[n], (v2f){s2[0], s2[1]}, (v2f){h2[0], h2[1]}));
                     const v2f ohi = silu2(fma2(ahi[n], (v2f){s2[2], s2[3]}, (v2f){h2[2], h2[3]}));
                     const v4f o = {olo.x, olo.y, ohi.x, ohi.y};
@@ -392,11 +407,20 @@ __global__ __launch_bounds__(256, K == 3 ? 3 : 2) void mbconv_rows3_kernel(const
     if (p.pool) {
         v4f* red = reinterpret_cast<v4f*>(ring);
         red[u * 8 + lc] = psum;
+        if constexpr (RAW) red[256 + u * 8 + lc] = psq;  // (the ring holds >= 3 * 33 * 36 floats: room for 512 quads)
         __syncthreads();
         if (tid < 8 && c0 + tid * 4 < p.mid) {
             v4f t4 = red[tid];
             for (int sl = 1; sl < 32; ++sl) t4 += red[sl * 8 + tid];
-            *reinterpret_cast<v4f*>(p.pool + ((size_t)b * tiles + tile) * p.mid + c0 + tid * 4) = t4;
+            if constexpr (RAW) {
+                v4f q4 = red[256 + tid];
+                for (int sl = 1; sl < 32; ++sl) q4 += red[256 + sl * 8 + tid];
+                float* row = p.pool + ((size_t)b * tiles + tile) * 2 * p.mid + c0 + tid * 4;
+                *reinterpret_cast<v4f*>(row) = t4;
+                *reinterpret_cast<v4f*>(row + p.mid) = q4;
+            } else {
+                *reinterpret_cast<v4f*>(p.pool + ((size_t)b * tiles + tile) * p.mid + c0 + tid * 4) = t4;
+            }
         }
     }
 }
@@ -444,8 +468,8 @@ int mbconv_rows_tiles(int H, int W, int Cin, int mid, int K, int stride) {
 
 int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const float* sh1, const float* wdw,
                        const float* sc2, const float* sh2, float* y, float* pool, int B, int H, int W, int Cin, int mid,
-                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, int plan_tiles) {
-    ORBIT_REQUIRE(x && w1 && sc1 && sh1 && wdw && sc2 && sh2 && y, "mbconv_rows: null pointer");
+                       int K, int stride, int pad_t, int pad_l, int Ho, int Wo, hipStream_t s, int plan_tiles, bool raw_stats) {
+    ORBIT_REQUIRE(x && w1 && sc1 && sh1 && wdw && y && (raw_stats ? pool != nullptr : (sc2 && sh2)), "mbconv_rows: null pointer");
     RowsGeom g;
     ORBIT_REQUIRE(Ho == cdiv(H, stride) && Wo == cdiv(W, stride) && rows_geom(H, W, Cin, mid, K, stride, Ho, Wo, g),
                   "mbconv_rows: unsupported shape (H=%d W=%d Cin=%d mid=%d K=%d s=%d)", H, W, Cin, mid, K, stride);
@@ -462,10 +486,23 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
     const int n_new = g.TO * stride * g.SWi;
     const size_t lds = (size_t)3 * n_new * ROWS_ES * sizeof(float) + (K == 3 ? 0 : (size_t)K * K * 8 * 16);
     const double pix = (double)B * H * W;
-    const int rec = prof_start("mbconv_rows", 2.0 * pix * Cin * mid + 2.0 * B * Ho * Wo * mid * K * K,
-                               4.0 * (pix * Cin + (double)B * Ho * Wo * mid), s, pix * mid + (double)B * Ho * Wo * mid);
+    const int rec = prof_start(raw_stats ? "mbconv_rows,raw" : "mbconv_rows", 2.0 * pix * Cin * mid + 2.0 * B * Ho * Wo * mid * K * K,
+                               4.0 * (pix * Cin + (double)B * Ho * Wo * mid), s, pix * mid + (raw_stats ? 0.0 : (double)B * Ho * Wo * mid));
 #define ORBIT_MBR3(KK, SS, TO_, NOUT_, NG_, SPR_, EX_, BF_)                                                       \
     do {                                                                                                \
+        if (raw_stats) {                                                                                \
+            if constexpr (!BF_) {                                                                       \
+                auto kern = mbconv_rows3_kernel<KK, SS, TO_, NOUT_, NG_, SPR_, EX_, false, true>;           \
+                static bool attr_set = false;                                                           \
+                if (!attr_set) {                                                                        \
+                    ORBIT_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(kern),            \
+                                                        hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); \
+                    attr_set = true;                                                                    \
+                }                                                                                       \
+                kern<<<grid, 256, lds, s>>>(p);                                                         \
+            }                                                                                           \
+            break;                                                                                      \
+        }                                                                                               \
         auto kern = mbconv_rows3_kernel<KK, SS, TO_, NOUT_, NG_, SPR_, EX_, BF_>;                                \
         static bool attr_set = false;                                                                   \
         if (!attr_set) {                                                                                \
@@ -480,7 +517,7 @@ int launch_mbconv_rows(const float* x, const float* w1, const float* sc1, const 
     // chunk is full or exactly half full (a missing quad duplicates the quad 16 channels below)
     const bool exact = g.strips * g.SWo == Wo && Ho % g.TO == 0 && g.band_rows % g.TO == 0 && (mid % 32 == 0 || mid % 32 == 16) &&
                        g.SWo % g.NOUT == 0;
-    const bool bf3 = (get_option("conv_bf3") & 2) != 0;  // (opt-in bit 2; the exact-tiling instantiations only)
+    const bool bf3 = !raw_stats && (get_option("conv_bf3") & 2) != 0;  // (opt-in bit 2; the exact-tiling instantiations only)
 #define ORBIT_MBR3X(KK, SS, TO_, NOUT_, NG_, SPR_)                    \
     do {                                                              \
         if (exact && bf3) ORBIT_MBR3(KK, SS, TO_, NOUT_, NG_, SPR_, true, true);   \

@@ -53,6 +53,26 @@ def test_bench_line_contract():
     assert d["rccl_ranks"] == 1 and d["ranks_share_gpus"] is False
     v = d["variants_of_the_metric"]
     assert v["h2d_inclusive_uint8_query_frames_per_s"] > 0 and v["h2d_inclusive_uint8_unpipelined_query_frames_per_s"] > 0
+    # round 6: the timed mode IS the library's default mode (overlap_query = "auto" + clips marked ready): one number
+    assert d["overlap_mode"].startswith("library default") and d["value_default_mode"] == d["value"]
+    # ... every kernel family of the task against its own floor
+    fams = {f["family"]: f for f in r["families"]}
+    assert {"dense_conv", "fused_front", "stem", "depthwise", "se_gate", "head"} <= set(fams)
+    for f in fams.values():
+        assert f["us_per_task"] > 0 and f["launches_per_task"] > 0
+    assert fams["dense_conv"]["x_floor"] > 1.0 and fams["fused_front"]["floor_simd_us_per_task"] > fams["fused_front"]["floor_us_per_task"]
+    assert 0.0 < r["task_floor_ms"] < r["task_floor_simd_ms"] < r["task_kernel_ms_serial"]
+    assert abs(r["whole_task_frac_of_floor"] - r["task_floor_ms"] / d["ms_per_step"]) < 1e-9
+    # ... the LITE meta-training step in the same line (item 2), `value` untouched by it
+    lt = d["lite_train"]
+    assert "error" not in lt and lt["ms_per_step"] > 0 and lt["steps"] >= 10 and len(lt["train_loss_per_step"]) == lt["steps"]
+    assert all(x > 0 for x in lt["train_loss_per_step"]) and 0.0 < lt["roofline"]["frac"] < 1.0
+    assert lt["train_graph_calls_replayed_eager"][0] > 0
+    # ... and one full-size HIP-vs-oracle task for every BASELINE config with a GPU (item 5)
+    gates = d["full_size_parity"]
+    assert len(gates) == 3 and {g["workload"] for g in gates} == {"efficientnet_b0_224", "cnaps_resnet18_224"}
+    assert sorted(g["way"] for g in gates) == [5, 5, 10]
+    assert all(g["max_abs_dlogit_vs_oracle"] <= 1e-3 and g["argmax_identical"] is True for g in gates)
 
 
 def test_bench_launches_its_own_ranks():
@@ -70,6 +90,11 @@ def test_bench_launches_its_own_ranks():
     assert d["n_gpus"] == 2 and d["config"]["tasks_per_step"] == 2 and d["ranks_share_gpus"] is True
     assert d["rccl_ranks"] is None  # RCCL refuses two ranks on one device: only checked one rank per GPU
     assert [r["rank"] for r in d["per_rank"]] == [0, 1] and all(r["ms_per_step"] > 0 for r in d["per_rank"])
+    # round 6: the line says which carrier the data path uses and whether the P2P inbox path (HIP IPC) works on this node
+    mg = d["multi_gpu"]
+    assert mg["data_path_collective"].startswith("none") and [c["rank"] for c in mg["comm_selfcheck"]] == [0, 1]
+    for c in mg["comm_selfcheck"]:
+        assert c["p2p_ipc_open"].startswith("ok") and c["p2p_allreduce_ok"] is True and c["p2p_error_word"] == 0, c
     import torch
     if torch.cuda.device_count() < 2:
         env.pop("ORBIT_BENCH_BACKEND")

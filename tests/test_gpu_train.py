@@ -550,22 +550,74 @@ def test_no_backward_forward_is_bit_identical_to_the_taped_forward(device, B, si
     with torch.enable_grad():
         taped = fe(x).detach().clone()
     sd_taped = {k: v.clone() for k, v in fe.state_dict().items()}
-    fe.load_state_dict(sd0)
-    with torch.no_grad():
-        plain = fe(x).clone()
-    sd_plain = fe.state_dict()
-    assert torch.isfinite(taped).all() and torch.equal(plain, taped)
-    moved = 0
-    for k in sd_taped:
-        assert torch.equal(sd_plain[k], sd_taped[k]), k
-        moved += int(k.endswith("running_mean") and not torch.equal(sd_taped[k], sd0[k]))
-    assert moved >= 40  # the forwards really ran on batch statistics and updated them
     from orbit_dataset_amd import _lib
     lib = _lib.load()
-    lib.orbit_set_option(b"train_dw_xf", 0)
+    fronts = lib.orbit_get_option(b"train_fused_fronts")
+    lib.orbit_set_option(b"train_fused_fronts", 0)  # (the two-sweep fused fronts have a test of their own below)
     try:
         fe.load_state_dict(sd0)
         with torch.no_grad():
-            assert torch.equal(fe(x), taped)
+            plain = fe(x).clone()
+        sd_plain = fe.state_dict()
+        assert torch.isfinite(taped).all() and torch.equal(plain, taped)
+        moved = 0
+        for k in sd_taped:
+            assert torch.equal(sd_plain[k], sd_taped[k]), k
+            moved += int(k.endswith("running_mean") and not torch.equal(sd_taped[k], sd0[k]))
+        assert moved >= 40  # the forwards really ran on batch statistics and updated them
+        lib.orbit_set_option(b"train_dw_xf", 0)
+        try:
+            fe.load_state_dict(sd0)
+            with torch.no_grad():
+                assert torch.equal(fe(x), taped)
+        finally:
+            lib.orbit_set_option(b"train_dw_xf", 1)
     finally:
-        lib.orbit_set_option(b"train_dw_xf", 1)
+        lib.orbit_set_option(b"train_fused_fronts", fronts)
+
+
+@pytest.mark.parametrize("B,size", [(5, 224), (4, 160), (3, 97)])
+def test_no_backward_forward_on_two_sweep_fused_fronts(device, B, size):
+    """Round 6 (option train_fused_fronts): on a no-grad batch-statistics forward the expansion conv + depthwise conv of an
+    MBConv block run as a STATISTICS SWEEP of the expansion conv (nothing stored) + the row-streaming fused front in its RAW form.
+    Against the unfused pair: the first BatchNorm of every fused block sees the SAME statistics bit for bit (same conv kernel,
+    same tiles - checked on its running statistics), everything downstream agrees to summation order of the second BatchNorm's
+    statistics (features and running statistics to 1e-5 relative). 224: the exact-tiling instantiations; 160 / 97: the guarded
+    ones. Option 2 = every shape the fused front serves (the default, 1, takes the 112x112 / 56x56 blocks)."""
+    from orbit_dataset_amd import _lib
+    from orbit_dataset_amd.model.feature_extractors import create_feature_extractor
+    lib = _lib.load()
+    fe, _ = create_feature_extractor("efficientnet_b0", True, False, True)
+    synthetic.init_parameters_(fe)
+    fe = fe.cuda().train()
+    sd0 = {k: v.clone() for k, v in fe.state_dict().items()}
+    x = torch.randn(B, 3, size, size, device=device, generator=torch.Generator(device=device).manual_seed(6))
+    prev = lib.orbit_get_option(b"train_fused_fronts")
+    outs = {}
+    try:
+        for opt in (0, 1, 2):
+            lib.orbit_set_option(b"train_fused_fronts", opt)
+            fe.load_state_dict(sd0)
+            with torch.no_grad():
+                feats = fe(x).clone()
+            outs[opt] = (feats, {k: v.clone() for k, v in fe.state_dict().items()})
+    finally:
+        lib.orbit_set_option(b"train_fused_fronts", prev)
+    base, sd_base = outs[0]
+    assert torch.isfinite(base).all()
+    for opt in (1, 2):
+        got, sd = outs[opt]
+        assert (got - base).abs().max().item() <= 1e-5 * max(1.0, base.abs().max().item()), opt
+        for k, v in sd.items():
+            if not k.endswith(("running_mean", "running_var")):
+                continue
+            w = sd_base[k]
+            assert (v - w).abs().max().item() <= 1e-5 * max(1.0, w.abs().max().item()), (opt, k)
+        # block 1.0 is the first fused front: its bn1 = the expansion conv's BatchNorm, fed by the statistics sweep, sees the
+        # same input as on the unfused path (later blocks' inputs already differ in their last bits)
+        assert torch.equal(sd["blocks.1.0.bn1.running_mean"], sd_base["blocks.1.0.bn1.running_mean"])
+        assert torch.equal(sd["blocks.1.0.bn1.running_var"], sd_base["blocks.1.0.bn1.running_var"])
+    # option 2 really changed something downstream of the first fused block (the second BatchNorm's statistics are summed in
+    # another order), i.e. the fused path ran
+    assert not torch.equal(outs[2][1]["blocks.1.0.bn2.running_var"], sd_base["blocks.1.0.bn2.running_var"]) or \
+        not torch.equal(outs[2][0], base)
