@@ -88,6 +88,7 @@ _SIGNATURES = {
     "orbit_cross_entropy_forward": (c_int, [P, P, c_int, c_int, c_int, P, P, P, P]),
     "orbit_cross_entropy_backward": (c_int, [P, P, P, c_int, c_int, c_int, P, P]),
     "orbit_op_bn_train_forward": (c_int, [P, c_int, c_int, P, P, c_float, c_float, P, P, P, c_int, P, P, P, P]),
+    "orbit_op_bn_stats_from_gram": (c_int, [P, c_int, c_int, P, c_int, c_float, P, P, P]),
     "orbit_op_bn_backward": (c_int, [P, P, P, c_int, c_int, P, P, P, c_int, c_int, P, P, P, P, P]),
     "orbit_op_conv2d_dgrad": (c_int, [P, P, P, P] + [c_int] * 12 + [P]),
     "orbit_op_conv2d_wgrad": (c_int, [P, c_int, P, P] + [c_int] * 12 + [P]),

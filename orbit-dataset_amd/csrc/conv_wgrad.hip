@@ -376,7 +376,9 @@ static void wgrad_geometry(int M, int Cout, int NC, int& co_tiles, int& n_tiles,
     const int total_steps = cdiv(M, WG_BKM);
     static const int target = [] {  // (ORBIT_WGRAD_BLOCKS: tuning experiments only)
         const char* e = getenv("ORBIT_WGRAD_BLOCKS");
-        return e && atoi(e) > 0 ? atoi(e) : 2048;
+        // 1536 (round 6; 2048 before): a quarter less partial-tile traffic (the split reductions move ~1 GB per LITE step),
+        // same-box A/B 24.54 / 24.53 -> 24.41 / 24.23 ms per step (profiles/r06_lite_ab_fused_fronts.txt)
+        return e && atoi(e) > 0 ? atoi(e) : 1536;
     }();
     splits = cdiv(target, tiles);
     const int max_splits = total_steps >= 8 ? total_steps / 8 : 1;

@@ -102,7 +102,9 @@ static bool conv_feeds_dw_raw(const orbit_extractor* fe, size_t i, int bn_train,
 // front (csrc/mbconv_rows.hip, RAW form) re-expands in its LDS ring with that scale / shift, stores the RAW depthwise outputs
 // and their column sums - the second BatchNorm then proceeds as on the unfused path. The 6x-expanded tensor (963 MB per 200
 // frames for block 1.0) is neither written nor read. Taped forwards keep the unfused pair: their backward reads that tensor.
-// `train_fused_fronts`: 1 (default) = where measured faster (the 112x112 / 56x56 blocks), 0 = never, 2 = every supported shape.
+// `train_fused_fronts`: 1 (default) = where measured faster (the 112x112 / 56x56 blocks), 0 = never, 2 = every supported shape,
+// 3 = as 2 with the statistics sweep of the conv instead of the Gram-matrix statistics (parity tests: bit-identical first
+// BatchNorm).
 static bool fused_front_sweeps(const orbit_extractor* fe, size_t i, int bn_train, bool no_backward) {
     const Op& o = fe->ops[i];
     const int opt = get_option("train_fused_fronts");
@@ -137,8 +139,10 @@ static size_t max_bn_partial_floats(const orbit_extractor* fe, int B) {
             }
             else {
                 m = std::max(m, bn_partial_floats((size_t)B * dwconv_se_chunks(o.Ho), o.Cout));
-                // (the two-sweep fused front writes one row per frame and strip-band tile instead)
+                // (the two-sweep fused front writes one row per frame and strip-band tile instead; its first sweep's Gram
+                // partials of the block input live here too)
                 m = std::max(m, bn_partial_floats((size_t)B * 16, o.Cout));
+                m = std::max(m, bn_gram_scratch_floats(B * o.H * o.W, 40));
             }
             // backward of a depthwise BatchNorm whose reduction rides on the squeeze-excite backward (+ 3*C coefficients)
             if (o.kind == OP_DWCONV)
@@ -473,6 +477,20 @@ static int train_forward_run(orbit_extractor_t* fe, const float* frames, int B, 
                 d.scale = scale + bn.fold_off, d.shift = shift + bn.fold_off;
                 d.residual = o.res >= 0 ? cur[o.res] : nullptr;
                 d.act = o.act;
+            }
+            if (sweep && bn_train && bn_gram_supported(o.Cin) && get_option("train_fused_fronts") != 3) {
+                // sweep 1 without the conv: the first BatchNorm's batch statistics from the Gram matrix of the block's input
+                // (csrc/train_ops.hip launch_bn_stats_from_gram; option value 3 keeps the statistics sweep of the conv itself)
+                const bool fm = film && bn.film_off >= 0;
+                rc = launch_bn_stats_from_gram(xin, B * o.H * o.W, o.Cin, fe->d_pool + fe->params[o.weight].off, o.Cout, bn.eps,
+                                               momentum, fm ? film_gamma + bn.film_off : fe->d_pool + fe->params[bn.gamma].off,
+                                               fm ? film_beta + bn.film_off : fe->d_pool + fe->params[bn.beta].off,
+                                               mean + bn.fold_off, invstd + bn.fold_off, scale + bn.fold_off, shift + bn.fold_off,
+                                               run_mean(bn), run_var(bn), fl(L.partial), s);
+                if (rc != ORBIT_OK) return rc;
+                front_conv = (int)i;
+                cur[o.out] = nullptr;
+                continue;
             }
             if (sweep) d.y = nullptr, d.stats_only = true;  // statistics only: the fused front below re-expands in LDS
             rc = launch_conv(d, s);

@@ -121,7 +121,7 @@ __global__ __launch_bounds__(256) void proto_configure_kernel(
             const int i = base + 4 * (int)threadIdx.x + j;
             if (i < N && lab[i] == cid) mine[nm++] = i;
         }
-        // exclusive scan of nm over the block: wave prefix by lane walk through DPP-free shuffles, then the 4 wave totals
+        // exclusive scan of nm over the block: prefix inside the wave by shuffles, then the 4 wave totals
         int pre = nm;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {

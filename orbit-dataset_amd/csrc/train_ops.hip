@@ -90,23 +90,14 @@ __device__ __forceinline__ bool reduce_partials(const float* __restrict__ partia
     return true;
 }
 
-// mean / biased variance -> invstd, folded scale/shift, running statistics (momentum update with the unbiased
-// variance, torch.nn.BatchNorm2d semantics). gamma/beta point at the layer's own or the per-task FiLM vectors.
-__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblk, int M,
-                                                                int C, float eps, float momentum,
-                                                                const float* __restrict__ gamma,
-                                                                const float* __restrict__ beta,
-                                                                const float* __restrict__ conv_bias,
-                                                                float* __restrict__ mean_out,
-                                                                float* __restrict__ invstd_out,
-                                                                float* __restrict__ scale, float* __restrict__ shift,
-                                                                float* __restrict__ running_mean,
-                                                                float* __restrict__ running_var) {
-    double s, ss;
-    int c;
-    if (!reduce_partials(partial, nblk, C, s, ss, c)) return;
-    const double mean = s / M;
-    double var = ss / M - mean * mean;
+// one channel's batch mean / biased variance -> invstd, folded scale / shift, running statistics (shared by the finalize
+// kernels: from [nblk][2][C] partial sums, and from the Gram matrix of a pointwise conv's input)
+__device__ __forceinline__ void bn_finalize_channel(int c, double mean, double var, int M, float eps, float momentum,
+                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                    const float* __restrict__ conv_bias, float* __restrict__ mean_out,
+                                                    float* __restrict__ invstd_out, float* __restrict__ scale,
+                                                    float* __restrict__ shift, float* __restrict__ running_mean,
+                                                    float* __restrict__ running_var) {
     if (var < 0.0) var = 0.0;
     const float invstd = (float)(1.0 / sqrt(var + (double)eps));
     mean_out[c] = (float)mean;
@@ -131,6 +122,134 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
             running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
         }
     }
+}
+
+// mean / biased variance -> invstd, folded scale/shift, running statistics (momentum update with the unbiased
+// variance, torch.nn.BatchNorm2d semantics). gamma/beta point at the layer's own or the per-task FiLM vectors.
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ partial, int nblk, int M,
+                                                                int C, float eps, float momentum,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
+                                                                const float* __restrict__ conv_bias,
+                                                                float* __restrict__ mean_out,
+                                                                float* __restrict__ invstd_out,
+                                                                float* __restrict__ scale, float* __restrict__ shift,
+                                                                float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var) {
+    double s, ss;
+    int c;
+    if (!reduce_partials(partial, nblk, C, s, ss, c)) return;
+    const double mean = s / M;
+    bn_finalize_channel(c, mean, ss / M - mean * mean, M, eps, momentum, gamma, beta, conv_bias, mean_out, invstd_out, scale,
+                        shift, running_mean, running_var);
+}
+
+// ---- BatchNorm statistics of a POINTWISE conv's output from the second moments of its input (round 6) -----------------
+// y = W x (1x1 conv, no bias) is linear, so over the P pixels of a batch  mean(y_c) = w_c . mean(x)  and
+// E[y_c^2] = w_c^T E[x x^T] w_c: the batch statistics of the first BatchNorm of an MBConv block (6x expanded: 96 .. 240
+// channels) follow from the Cin x Cin Gram matrix of the block's input (16 .. 40 channels) - a pass over a tensor six times
+// smaller than the one the statistics describe, and no matrix-core work. It replaces the statistics sweep of the expansion
+// conv in front of the two-sweep fused front (csrc/extractor_train.hip fused_front_sweeps: 229 -> ~35 us for 16 -> 96 at
+// 112x112). Sums: fp32 per thread over <= ~64 pixels, fp32 over a block's 256 threads in a fixed order, double over the
+// blocks and through the quadratic form; the variance is E[y^2] - mean^2 in double, as in bn_stats_finalize_kernel.
+// partial[blk][CIN * CIN + CIN]: G row-major, then the column sums. Grid (nblk, CIN / RS): a block owns RS rows of G.
+template <int CIN, int RS>
+__global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ x, int P, int pixels_per_block,
+                                                           float* __restrict__ partial) {
+    constexpr int Q = CIN / 4;
+    __shared__ float red[4][RS * CIN + RS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r0 = blockIdx.y * RS;
+    const int p0 = blockIdx.x * pixels_per_block, p1 = min(P, p0 + pixels_per_block);
+    float acc[RS][CIN], rs[RS];
+#pragma unroll
+    for (int i = 0; i < RS; ++i) {
+        rs[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < CIN; ++j) acc[i][j] = 0.f;
+    }
+#pragma unroll 2
+    for (int p = p0 + tid; p < p1; p += 256) {
+        f32x4 v[Q];
+#pragma unroll
+        for (int q = 0; q < Q; ++q) v[q] = *reinterpret_cast<const f32x4*>(x + (size_t)p * CIN + 4 * q);
+        // the block's own RS row values come through loads of their own (same cache lines as v: L1 hits) - indexing the
+        // register array v with the block-uniform r0 would send it through scratch memory
+        float xr[RS];
+#pragma unroll
+        for (int i = 0; i < RS; ++i) xr[i] = x[(size_t)p * CIN + r0 + i];
+#pragma unroll
+        for (int i = 0; i < RS; ++i) {
+            const float xi = xr[i];
+            rs[i] += xi;
+#pragma unroll
+            for (int j = 0; j < CIN; ++j) acc[i][j] += xi * v[j >> 2][j & 3];
+        }
+    }
+    // block sum in a fixed order: a butterfly over the wave's lanes, then the four waves in wave order
+    auto wave_total = [&](float t) {
+#pragma unroll
+        for (int off = 32; off; off >>= 1) t += __shfl_xor(t, off);
+        return t;
+    };
+#pragma unroll
+    for (int i = 0; i < RS; ++i) {
+#pragma unroll
+        for (int j = 0; j < CIN; ++j) {
+            const float t = wave_total(acc[i][j]);
+            if (lane == 0) red[wave][i * CIN + j] = t;
+        }
+        const float t = wave_total(rs[i]);
+        if (lane == 0) red[wave][RS * CIN + i] = t;
+    }
+    __syncthreads();
+    float* out = partial + (size_t)blockIdx.x * (CIN * CIN + CIN);
+    for (int e = tid; e < RS * CIN + RS; e += 256) {
+        const float t = (red[0][e] + red[1][e]) + (red[2][e] + red[3][e]);
+        if (e < RS * CIN) out[(r0 + e / CIN) * CIN + e % CIN] = t;
+        else out[CIN * CIN + r0 + (e - RS * CIN)] = t;
+    }
+}
+
+// one block per 64 output channels: the partials are summed in double (every block re-sums them: <= 1640 entries x nblk
+// L2-resident floats), then thread c evaluates its channel's mean and quadratic form and finishes like bn_stats_finalize_kernel
+template <int CIN>
+__global__ __launch_bounds__(256) void gram_bn_finalize_kernel(const float* __restrict__ partial, int nblk, int P,
+                                                               const float* __restrict__ w /* [C][CIN] */, int C, float eps,
+                                                               float momentum, const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, float* __restrict__ mean_out,
+                                                               float* __restrict__ invstd_out, float* __restrict__ scale,
+                                                               float* __restrict__ shift, float* __restrict__ running_mean,
+                                                               float* __restrict__ running_var) {
+    constexpr int NE = CIN * CIN + CIN;
+    __shared__ double G[NE];
+    for (int e = threadIdx.x; e < NE; e += 256) {
+        double a = 0.0;
+#pragma unroll 8
+        for (int b = 0; b < nblk; ++b) a += (double)partial[(size_t)b * NE + e];
+        G[e] = a;
+    }
+    __syncthreads();
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (threadIdx.x >= 64 || c >= C) return;
+    float wc[CIN];
+#pragma unroll
+    for (int q = 0; q < CIN / 4; ++q) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(w + (size_t)c * CIN + 4 * q);
+        wc[4 * q] = t[0], wc[4 * q + 1] = t[1], wc[4 * q + 2] = t[2], wc[4 * q + 3] = t[3];
+    }
+    double m = 0.0, q2 = 0.0;
+#pragma unroll
+    for (int i = 0; i < CIN; ++i) {
+        m += (double)wc[i] * G[CIN * CIN + i];
+        double row = 0.0;
+#pragma unroll
+        for (int j = 0; j < CIN; ++j) row += G[i * CIN + j] * (double)wc[j];
+        q2 += (double)wc[i] * row;
+    }
+    const double mean = m / P;
+    bn_finalize_channel(c, mean, q2 / P - mean * mean, P, eps, momentum, gamma, beta, nullptr, mean_out, invstd_out, scale,
+                        shift, running_mean, running_var);
 }
 
 // a = act(y * scale + shift + residual)
@@ -451,6 +570,36 @@ int launch_bn_stats_from_partials(float* partial, int nblk, int M, int C, float 
     }
     bn_stats_finalize_kernel<<<cdiv(C, BN_FIN_CH), 256, 0, s>>>(src, nblk, M, C, eps, momentum, gamma, beta, conv_bias, mean, invstd,
                                                           scale, shift, running_mean, running_var);
+    ORBIT_LAUNCH_CHECK();
+    return ORBIT_OK;
+}
+
+// batch statistics of y = W x (pointwise conv, W = [C][Cin] as torch stores it) from the Gram matrix of x [P][Cin]
+bool bn_gram_supported(int Cin) { return Cin == 16 || Cin == 24 || Cin == 40; }
+static int gram_blocks(int P) {
+    const int b = cdiv(P, 256 * 32);
+    return b > 1024 ? 1024 : (b ? b : 1);
+}
+size_t bn_gram_scratch_floats(int P, int Cin) { return (size_t)gram_blocks(P) * ((size_t)Cin * Cin + Cin); }
+int launch_bn_stats_from_gram(const float* x, int P, int Cin, const float* w, int C, float eps, float momentum,
+                              const float* gamma, const float* beta, float* mean, float* invstd, float* scale, float* shift,
+                              float* running_mean, float* running_var, float* scratch, hipStream_t s) {
+    ORBIT_REQUIRE(x && w && mean && invstd && scratch && P > 0 && C > 0, "bn_stats_from_gram: bad arguments");
+    ORBIT_REQUIRE(bn_gram_supported(Cin), "bn_stats_from_gram: Cin = %d not instantiated", Cin);
+    const int nblk = gram_blocks(P);
+    const int ppb = cdiv(cdiv(P, nblk), 256) * 256;
+    const int rec = prof_start("bn_gram", 2.0 * P * Cin * Cin, 4.0 * P * Cin, s);
+#define ORBIT_GRAM(CI, RS_)                                                                                                  \
+    do {                                                                                                                     \
+        gram_partial_kernel<CI, RS_><<<dim3(cdiv(P, ppb), CI / RS_), 256, 0, s>>>(x, P, ppb, scratch);                       \
+        gram_bn_finalize_kernel<CI><<<cdiv(C, 64), 256, 0, s>>>(scratch, cdiv(P, ppb), P, w, C, eps, momentum, gamma, beta,  \
+                                                                mean, invstd, scale, shift, running_mean, running_var);      \
+    } while (0)
+    if (Cin == 16) ORBIT_GRAM(16, 8);
+    else if (Cin == 24) ORBIT_GRAM(24, 6);
+    else ORBIT_GRAM(40, 4);
+#undef ORBIT_GRAM
+    prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();
     return ORBIT_OK;
 }
@@ -802,6 +951,18 @@ int orbit_op_bn_train_forward(const float* y, int M, int C, const float* gamma, 
     int rc = launch_bn_stats(y, M, C, eps, momentum, gamma, beta, nullptr, save_mean, save_invstd, scale, scale + C,
                              running_mean, running_var, tmp, s);
     if (rc == ORBIT_OK) rc = launch_scale_shift_act(y, scale, scale + C, residual, act, (size_t)M, C, out, s);
+    (void)hipFreeAsync(tmp, s);
+    return rc;
+}
+
+int orbit_op_bn_stats_from_gram(const float* x, int P, int Cin, const float* w, int C, float eps, float* save_mean,
+                                float* save_invstd, orbit_stream_t stream) {
+    ORBIT_REQUIRE(x && w && save_mean && save_invstd, "op_bn_stats_from_gram: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    float* tmp = nullptr;
+    ORBIT_HIP_CHECK(hipMallocAsync(reinterpret_cast<void**>(&tmp), bn_gram_scratch_floats(P, Cin) * sizeof(float), s));
+    const int rc = launch_bn_stats_from_gram(x, P, Cin, w, C, eps, 0.f, nullptr, nullptr, save_mean, save_invstd, nullptr, nullptr,
+                                             nullptr, nullptr, tmp, s);
     (void)hipFreeAsync(tmp, s);
     return rc;
 }

@@ -583,7 +583,8 @@ def test_no_backward_forward_on_two_sweep_fused_fronts(device, B, size):
     Against the unfused pair: the first BatchNorm of every fused block sees the SAME statistics bit for bit (same conv kernel,
     same tiles - checked on its running statistics), everything downstream agrees to summation order of the second BatchNorm's
     statistics (features and running statistics to 1e-5 relative). 224: the exact-tiling instantiations; 160 / 97: the guarded
-    ones. Option 2 = every shape the fused front serves (the default, 1, takes the 112x112 / 56x56 blocks)."""
+    ones. Option 2 = every shape the fused front serves (the default, 1, takes the 112x112 / 56x56 blocks); 3 = as 2 with the conv's
+    own statistics sweep instead of the Gram-matrix statistics."""
     from orbit_dataset_amd import _lib
     from orbit_dataset_amd.model.feature_extractors import create_feature_extractor
     lib = _lib.load()
@@ -595,7 +596,7 @@ def test_no_backward_forward_on_two_sweep_fused_fronts(device, B, size):
     prev = lib.orbit_get_option(b"train_fused_fronts")
     outs = {}
     try:
-        for opt in (0, 1, 2):
+        for opt in (0, 1, 2, 3):
             lib.orbit_set_option(b"train_fused_fronts", opt)
             fe.load_state_dict(sd0)
             with torch.no_grad():
@@ -605,7 +606,7 @@ def test_no_backward_forward_on_two_sweep_fused_fronts(device, B, size):
         lib.orbit_set_option(b"train_fused_fronts", prev)
     base, sd_base = outs[0]
     assert torch.isfinite(base).all()
-    for opt in (1, 2):
+    for opt in (1, 2, 3):
         got, sd = outs[opt]
         assert (got - base).abs().max().item() <= 1e-5 * max(1.0, base.abs().max().item()), opt
         for k, v in sd.items():
@@ -613,11 +614,40 @@ def test_no_backward_forward_on_two_sweep_fused_fronts(device, B, size):
                 continue
             w = sd_base[k]
             assert (v - w).abs().max().item() <= 1e-5 * max(1.0, w.abs().max().item()), (opt, k)
-        # block 1.0 is the first fused front: its bn1 = the expansion conv's BatchNorm, fed by the statistics sweep, sees the
-        # same input as on the unfused path (later blocks' inputs already differ in their last bits)
-        assert torch.equal(sd["blocks.1.0.bn1.running_mean"], sd_base["blocks.1.0.bn1.running_mean"])
-        assert torch.equal(sd["blocks.1.0.bn1.running_var"], sd_base["blocks.1.0.bn1.running_var"])
+        # block 1.0 is the first fused front: its bn1 = the expansion conv's BatchNorm sees the same input as on the unfused path
+        # (later blocks' inputs already differ in their last bits). Option 3 takes its statistics from a statistics sweep of the
+        # conv itself - the same kernel, tiles and summation order as the storing conv: bit-identical; options 1 / 2 from the
+        # Gram matrix of the block input (mean = w . mean(x), E[y^2] = w^T E[x x^T] w in double): equal to rounding
+        for stat in ("running_mean", "running_var"):
+            a, b_ = sd["blocks.1.0.bn1." + stat], sd_base["blocks.1.0.bn1." + stat]
+            if opt == 3:
+                assert torch.equal(a, b_), stat
+            else:
+                assert (a - b_).abs().max().item() <= 2e-6 * max(1.0, b_.abs().max().item()), (opt, stat)
     # option 2 really changed something downstream of the first fused block (the second BatchNorm's statistics are summed in
     # another order), i.e. the fused path ran
     assert not torch.equal(outs[2][1]["blocks.1.0.bn2.running_var"], sd_base["blocks.1.0.bn2.running_var"]) or \
         not torch.equal(outs[2][0], base)
+
+
+@pytest.mark.parametrize("Cin,C,P", [(16, 96, 50_000), (24, 144, 31_337), (40, 240, 9_999), (16, 96, 257)])
+def test_bn_statistics_of_a_pointwise_conv_from_the_gram_matrix_of_its_input(device, Cin, C, P):
+    """launch_bn_stats_from_gram (round 6): batch mean and 1 / sqrt(biased variance + eps) of y = W x WITHOUT forming y - mean(y_c) =
+    w_c . mean(x), E[y_c^2] = w_c^T E[x x^T] w_c - against the same statistics of the materialised y in float64. x has a mean far
+    from zero in some channels (the variance is a difference of two large numbers there)."""
+    import ctypes
+    from orbit_dataset_amd import _lib
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(Cin + P)
+    x = torch.randn(P, Cin, generator=g) * (0.5 + torch.rand(Cin, generator=g)) + torch.randn(Cin, generator=g) * 1.5
+    w = torch.randn(C, Cin, generator=g) / Cin ** 0.5
+    y = x.double() @ w.double().t()
+    want_mean, want_var = y.mean(0), y.var(0, unbiased=False)
+    eps = 1e-3
+    xd, wd = x.to(device), w.to(device)
+    mean, invstd = torch.empty(C, device=device), torch.empty(C, device=device)
+    _lib.check(lib.orbit_op_bn_stats_from_gram(_lib.dptr(xd), P, Cin, _lib.dptr(wd), C, ctypes.c_float(eps), _lib.dptr(mean),
+                                               _lib.dptr(invstd), _lib.stream_handle()), "orbit_op_bn_stats_from_gram")
+    got_var = 1.0 / invstd.cpu().double() ** 2 - eps
+    assert (mean.cpu().double() - want_mean).abs().max().item() <= 2e-6 * max(1.0, want_mean.abs().max().item())
+    assert ((got_var - want_var).abs() / (want_var + eps)).max().item() <= 2e-5
