@@ -507,7 +507,7 @@ def family_table(rows, tasks_profiled, ms_per_step):
                                 "TIMED step (two-stream overlap on)"}
 
 
-def lite_train_block(args, device, lib, tasks, ckpt, steps=10, warmup=6):
+def lite_train_block(args, device, lib, tasks, ckpt, steps=10, warmup=8):
     """the LITE meta-training step (reference single-step-learner.py:212-243) in the DEFAULT run's line:
     >= 10 optimizer steps of the headline extractor timed after the inference legs - forward passes (cache pass, H-subset,
     query batch), backward, fused Adam, one task per step - then the same steps with per-launch events for the dense-conv
@@ -526,7 +526,8 @@ def lite_train_block(args, device, lib, tasks, ckpt, steps=10, warmup=6):
         return [dict(tasks[i % len(tasks)],
                      context_labels=unpack_task({"context_labels": host_labels[i % len(tasks)], "target_labels": None,
                                                  "context_clips": None, "target_clips": None}, device)[2]) for i in range(n)]
-    for t in stream(warmup):  # (first sight of a call runs eagerly, the second captures its graph, later ones replay)
+    for t in stream(warmup):  # (first sight of a call runs eagerly, the second captures its graph, later ones replay: with
+        #                        four resident tasks every call has been seen twice after eight steps)
         step(model, t)
     torch.cuda.synchronize()
     step.step_losses = []

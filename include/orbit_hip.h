@@ -87,7 +87,7 @@ int orbit_device_count(void);
  *                   (raw depthwise outputs + their column sums): the 6x-expanded tensor never reaches HBM; 2 = every shape the
  *                   fused front serves; 0 = never (conv + depthwise pair); 3 = as 2, with the first BatchNorm's statistics from a
  *                   statistics sweep of the conv itself (bit-identical to the pair's) instead of the Gram matrix of the block
- *                   input (launch_bn_stats_from_gram: Cin = 16 / 24 / 40). Statistics agree to summation order
+ *                   input (launch_bn_stats_from_gram: Cin = 16 / 24). Statistics agree to summation order
  *  dense convolutions (csrc/conv_igemm.hip, pw_rgemm.hip, conv_bf3.hip):
  *   "conv_tile"     0 = heuristic (default); 3 = 64x64, 4 = 128x32, 6 = 32x32 with K split over the four waves (the three
  *                   tilings the heuristic chooses from)
@@ -403,7 +403,7 @@ int orbit_op_bn_train_forward(const float* y, int M, int C, const float* gamma, 
                               float momentum, float* running_mean, float* running_var, const float* residual, int act,
                               float* out, float* save_mean, float* save_invstd, orbit_stream_t stream);
 /* Batch statistics (mean, 1/sqrt(biased var + eps)) of y = W x for a POINTWISE conv (W [C][Cin], torch's 1x1 filter layout;
- * x [P][Cin] NHWC pixels; Cin = 16, 24 or 40) from the Gram matrix of x - without forming y (csrc/train_ops.hip): the first
+ * x [P][Cin] NHWC pixels; Cin = 16 or 24) from the Gram matrix of x - without forming y (csrc/train_ops.hip): the first
  * sweep of the two-sweep fused MBConv front on the no-grad cache pass of the LITE step (few_shot_recognisers.py:404-408). */
 int orbit_op_bn_stats_from_gram(const float* x, int P, int Cin, const float* w, int C, float eps, float* save_mean,
                                 float* save_invstd, orbit_stream_t stream);

@@ -205,7 +205,7 @@ int launch_bn_stats(const float* y, int M, int C, float eps, float momentum, con
 // bn_partial_floats(nblk, C) floats (room for the compaction stage of very long partial lists)
 size_t bn_partial_floats(size_t nblk, int C);
 int launch_sum_partials(const float* partial, int nblk, int C, float* stats /* [2][C] */, hipStream_t s);
-// batch statistics of a POINTWISE conv's output y = W x from the Gram matrix of its input x [P][Cin] (Cin = 16, 24, 40;
+// batch statistics of a POINTWISE conv's output y = W x from the Gram matrix of its input x [P][Cin] (Cin = 16 or 24;
 // W [C][Cin] as torch stores a 1x1 filter): no pass over y, no y at all. scratch: bn_gram_scratch_floats(P, Cin) floats
 bool bn_gram_supported(int Cin);
 size_t bn_gram_scratch_floats(int P, int Cin);

@@ -142,7 +142,7 @@ static size_t max_bn_partial_floats(const orbit_extractor* fe, int B) {
                 // (the two-sweep fused front writes one row per frame and strip-band tile instead; its first sweep's Gram
                 // partials of the block input live here too)
                 m = std::max(m, bn_partial_floats((size_t)B * 16, o.Cout));
-                m = std::max(m, bn_gram_scratch_floats(B * o.H * o.W, 40));
+                m = std::max(m, bn_gram_scratch_floats(B * o.H * o.W, 24));
             }
             // backward of a depthwise BatchNorm whose reduction rides on the squeeze-excite backward (+ 3*C coefficients)
             if (o.kind == OP_DWCONV)

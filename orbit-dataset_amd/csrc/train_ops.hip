@@ -153,6 +153,21 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
 // 112x112). Sums: fp32 per thread over <= ~64 pixels, fp32 over a block's 256 threads in a fixed order, double over the
 // blocks and through the quadratic form; the variance is E[y^2] - mean^2 in double, as in bn_stats_finalize_kernel.
 // partial[blk][CIN * CIN + CIN]: G row-major, then the column sums. Grid (nblk, CIN / RS): a block owns RS rows of G.
+// wave64 sum on the VALU with DPP lane permutes (as csrc/head.hip wave_sum: no LDS round trips), returned wave-uniform
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float gram_dpp_add(float v) {
+    return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float gram_wave_sum(float v) {
+    v = gram_dpp_add<0xB1, 0xf>(v);   // quad_perm [1,0,3,2]
+    v = gram_dpp_add<0x4E, 0xf>(v);   // quad_perm [2,3,0,1]
+    v = gram_dpp_add<0x141, 0xf>(v);  // row_half_mirror
+    v = gram_dpp_add<0x140, 0xf>(v);  // row_mirror
+    v = gram_dpp_add<0x142, 0xa>(v);  // row_bcast:15
+    v = gram_dpp_add<0x143, 0xc>(v);  // row_bcast:31: lane 63 holds the wave sum
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+
 template <int CIN, int RS>
 __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restrict__ x, int P, int pixels_per_block,
                                                            float* __restrict__ partial) {
@@ -168,38 +183,44 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < CIN; ++j) acc[i][j] = 0.f;
     }
-#pragma unroll 2
-    for (int p = p0 + tid; p < p1; p += 256) {
-        f32x4 v[Q];
+    // four pixels' loads in flight per thread (a pixel at a time, every pixel paid an HBM round trip of its own: the first form
+    // of this kernel took 115 us for the 160 MB of block 1.0's input)
+    constexpr int U = 4;
+    for (int pb = p0 + tid; pb < p1; pb += 256 * U) {
+        f32x4 v[U][Q];
+        float xr[U][RS];
 #pragma unroll
-        for (int q = 0; q < Q; ++q) v[q] = *reinterpret_cast<const f32x4*>(x + (size_t)p * CIN + 4 * q);
-        // the block's own RS row values come through loads of their own (same cache lines as v: L1 hits) - indexing the
-        // register array v with the block-uniform r0 would send it through scratch memory
-        float xr[RS];
+        for (int u = 0; u < U; ++u) {
+            const int p = min(pb + 256 * u, p1 - 1);  // (a clamped pixel is loaded and not accumulated)
 #pragma unroll
-        for (int i = 0; i < RS; ++i) xr[i] = x[(size_t)p * CIN + r0 + i];
+            for (int q = 0; q < Q; ++q) v[u][q] = *reinterpret_cast<const f32x4*>(x + (size_t)p * CIN + 4 * q);
+            // the block's own RS row values come through loads of their own (same cache lines as v: L1 hits) - indexing the
+            // register array v with the block-uniform r0 would send it through scratch memory
 #pragma unroll
-        for (int i = 0; i < RS; ++i) {
-            const float xi = xr[i];
-            rs[i] += xi;
+            for (int i = 0; i < RS; ++i) xr[u][i] = x[(size_t)p * CIN + r0 + i];
+        }
 #pragma unroll
-            for (int j = 0; j < CIN; ++j) acc[i][j] += xi * v[j >> 2][j & 3];
+        for (int u = 0; u < U; ++u) {
+            if (pb + 256 * u < p1) {
+#pragma unroll
+                for (int i = 0; i < RS; ++i) {
+                    const float xi = xr[u][i];
+                    rs[i] += xi;
+#pragma unroll
+                    for (int j = 0; j < CIN; ++j) acc[i][j] += xi * v[u][j >> 2][j & 3];
+                }
+            }
         }
     }
-    // block sum in a fixed order: a butterfly over the wave's lanes, then the four waves in wave order
-    auto wave_total = [&](float t) {
-#pragma unroll
-        for (int off = 32; off; off >>= 1) t += __shfl_xor(t, off);
-        return t;
-    };
+    // block sum in a fixed order: DPP reduction over the wave's lanes, then the four waves in wave order
 #pragma unroll
     for (int i = 0; i < RS; ++i) {
 #pragma unroll
         for (int j = 0; j < CIN; ++j) {
-            const float t = wave_total(acc[i][j]);
+            const float t = gram_wave_sum(acc[i][j]);
             if (lane == 0) red[wave][i * CIN + j] = t;
         }
-        const float t = wave_total(rs[i]);
+        const float t = gram_wave_sum(rs[i]);
         if (lane == 0) red[wave][RS * CIN + i] = t;
     }
     __syncthreads();
@@ -211,24 +232,28 @@ __global__ __launch_bounds__(256) void gram_partial_kernel(const float* __restri
     }
 }
 
-// one block per 64 output channels: the partials are summed in double (every block re-sums them: <= 1640 entries x nblk
-// L2-resident floats), then thread c evaluates its channel's mean and quadratic form and finishes like bn_stats_finalize_kernel
+// one block (1024 threads) per 64 output channels: the partials are summed in double - every entry by four lanes that take
+// every fourth block, combined in lane order (every block of this kernel re-sums them: <= 1640 entries x nblk L2-resident
+// floats) - then thread c evaluates its channel's mean and quadratic form and finishes like bn_stats_finalize_kernel
 template <int CIN>
-__global__ __launch_bounds__(256) void gram_bn_finalize_kernel(const float* __restrict__ partial, int nblk, int P,
-                                                               const float* __restrict__ w /* [C][CIN] */, int C, float eps,
-                                                               float momentum, const float* __restrict__ gamma,
-                                                               const float* __restrict__ beta, float* __restrict__ mean_out,
-                                                               float* __restrict__ invstd_out, float* __restrict__ scale,
-                                                               float* __restrict__ shift, float* __restrict__ running_mean,
-                                                               float* __restrict__ running_var) {
+__global__ __launch_bounds__(1024) void gram_bn_finalize_kernel(const float* __restrict__ partial, int nblk, int P,
+                                                                const float* __restrict__ w /* [C][CIN] */, int C, float eps,
+                                                                float momentum, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, float* __restrict__ mean_out,
+                                                                float* __restrict__ invstd_out, float* __restrict__ scale,
+                                                                float* __restrict__ shift, float* __restrict__ running_mean,
+                                                                float* __restrict__ running_var) {
     constexpr int NE = CIN * CIN + CIN;
-    __shared__ double G[NE];
-    for (int e = threadIdx.x; e < NE; e += 256) {
+    __shared__ double G[4][NE];
+    for (int idx = threadIdx.x; idx < 4 * NE; idx += 1024) {
+        const int part = idx / NE, e = idx - part * NE;
         double a = 0.0;
 #pragma unroll 8
-        for (int b = 0; b < nblk; ++b) a += (double)partial[(size_t)b * NE + e];
-        G[e] = a;
+        for (int b = part; b < nblk; b += 4) a += (double)partial[(size_t)b * NE + e];
+        G[part][e] = a;
     }
+    __syncthreads();
+    for (int e = threadIdx.x; e < NE; e += 1024) G[0][e] = (G[0][e] + G[1][e]) + (G[2][e] + G[3][e]);
     __syncthreads();
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (threadIdx.x >= 64 || c >= C) return;
@@ -241,10 +266,10 @@ __global__ __launch_bounds__(256) void gram_bn_finalize_kernel(const float* __re
     double m = 0.0, q2 = 0.0;
 #pragma unroll
     for (int i = 0; i < CIN; ++i) {
-        m += (double)wc[i] * G[CIN * CIN + i];
+        m += (double)wc[i] * G[0][CIN * CIN + i];
         double row = 0.0;
 #pragma unroll
-        for (int j = 0; j < CIN; ++j) row += G[i * CIN + j] * (double)wc[j];
+        for (int j = 0; j < CIN; ++j) row += G[0][i * CIN + j] * (double)wc[j];
         q2 += (double)wc[i] * row;
     }
     const double mean = m / P;
@@ -575,10 +600,10 @@ int launch_bn_stats_from_partials(float* partial, int nblk, int M, int C, float 
 }
 
 // batch statistics of y = W x (pointwise conv, W = [C][Cin] as torch stores it) from the Gram matrix of x [P][Cin]
-bool bn_gram_supported(int Cin) { return Cin == 16 || Cin == 24 || Cin == 40; }
-static int gram_blocks(int P) {
+bool bn_gram_supported(int Cin) { return Cin == 16 || Cin == 24; }  // (the 112x112 / 56x56 blocks; wider inputs take the conv's statistics sweep)
+static int gram_blocks(int P) {  // ~one block per CU and row slice: a thread walks ~40 pixels, four at a time
     const int b = cdiv(P, 256 * 32);
-    return b > 1024 ? 1024 : (b ? b : 1);
+    return b > 256 ? 256 : (b ? b : 1);
 }
 size_t bn_gram_scratch_floats(int P, int Cin) { return (size_t)gram_blocks(P) * ((size_t)Cin * Cin + Cin); }
 int launch_bn_stats_from_gram(const float* x, int P, int Cin, const float* w, int C, float eps, float momentum,
@@ -592,12 +617,11 @@ int launch_bn_stats_from_gram(const float* x, int P, int Cin, const float* w, in
 #define ORBIT_GRAM(CI, RS_)                                                                                                  \
     do {                                                                                                                     \
         gram_partial_kernel<CI, RS_><<<dim3(cdiv(P, ppb), CI / RS_), 256, 0, s>>>(x, P, ppb, scratch);                       \
-        gram_bn_finalize_kernel<CI><<<cdiv(C, 64), 256, 0, s>>>(scratch, cdiv(P, ppb), P, w, C, eps, momentum, gamma, beta,  \
+        gram_bn_finalize_kernel<CI><<<cdiv(C, 64), 1024, 0, s>>>(scratch, cdiv(P, ppb), P, w, C, eps, momentum, gamma, beta, \
                                                                 mean, invstd, scale, shift, running_mean, running_var);      \
     } while (0)
     if (Cin == 16) ORBIT_GRAM(16, 8);
-    else if (Cin == 24) ORBIT_GRAM(24, 6);
-    else ORBIT_GRAM(40, 4);
+    else ORBIT_GRAM(24, 6);
 #undef ORBIT_GRAM
     prof_stop(rec, s);
     ORBIT_LAUNCH_CHECK();

@@ -630,7 +630,7 @@ def test_no_backward_forward_on_two_sweep_fused_fronts(device, B, size):
         not torch.equal(outs[2][0], base)
 
 
-@pytest.mark.parametrize("Cin,C,P", [(16, 96, 50_000), (24, 144, 31_337), (40, 240, 9_999), (16, 96, 257)])
+@pytest.mark.parametrize("Cin,C,P", [(16, 96, 50_000), (24, 144, 31_337), (24, 144, 9_999), (16, 96, 257)])
 def test_bn_statistics_of_a_pointwise_conv_from_the_gram_matrix_of_its_input(device, Cin, C, P):
     """launch_bn_stats_from_gram (round 6): batch mean and 1 / sqrt(biased variance + eps) of y = W x WITHOUT forming y - mean(y_c) =
     w_c . mean(x), E[y_c^2] = w_c^T E[x x^T] w_c - against the same statistics of the materialised y in float64. x has a mean far

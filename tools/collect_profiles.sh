@@ -12,6 +12,9 @@ cd /tmp && export TMPDIR=/tmp
 # kernels must run one at a time for their durations / counters to be attributable: the support/query stream overlap of
 # the timed leg is switched off here, exactly as bench.py does for its own roofline leg
 export ORBIT_BENCH_OVERLAP=0 ORBIT_LITE_OVERLAP=0  # (LITE: the H-subset pass serial, not beside the cache pass)
+# the inference commands are profiled WITHOUT the LITE block the default line carries since round 6 (its kernels would land in the
+# inference kernel statistics); the LITE step has its own profiled command below (--mode lite_train)
+export ORBIT_BENCH_LITE_BLOCK=0
 for W in efficientnet_b0_224 resnet18_84 ${EXTRA_WORKLOADS:-}; do
   timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -- \
       python $R/bench.py --workload $W --steps 10 --warmup 3 --no-cpu-baseline > $O/${TAG}_bench_$W.json 2> $O/${TAG}_bench_$W.err
