@@ -334,13 +334,8 @@ def metric_variants(model, tasks, device, steps):
             "h2d_inclusive_fp32_prefetched_query_frames_per_s": NUM_QUERY * steps / t_pf32,
             "h2d_inclusive_uint8_query_frames_per_s": NUM_QUERY * steps / t_pf,
             "h2d_inclusive_uint8_unpipelined_query_frames_per_s": NUM_QUERY * steps / t_h2d8,
-            "note": "predict-only: predict() of 200 resident query frames after one personalise(); h2d-inclusive: whole "
-                    "task with support + query clips uploaded from pinned host memory per mini-batch inside the timed "
-                    "region; the uint8 variant uploads 8-bit frames (a quarter of the bytes) and applies to_tensor + normalize on "
-                    "the GPU (orbit_frames_from_uint8) - through data/pipeline.TaskPrefetcher (pinned ring, staging thread, copy "
-                    "stream double-buffered against the extractor; first task's upload included), and 'unpipelined' = uploaded "
-                    "per mini-batch on the compute / query stream as in round 2; fp32_prefetched: the fp32 clips of the h2d-inclusive "
-                    "variant through the same TaskPrefetcher (task i+1 uploads on the copy stream while task i runs)"}
+            "note": "predict-only: predict() after one personalise(); h2d-inclusive: clips uploaded from pinned host memory inside the "
+                    "timed region (fp32 inline / fp32 or 8-bit through data/pipeline.TaskPrefetcher / 8-bit unpipelined): DESIGN.md section 7"}
 
 
 def cpu_model_name():
@@ -495,16 +490,13 @@ def family_table(rows, tasks_profiled, ms_per_step):
                     "avg_us": round(1e3 * f["ms"] / f["launches"], 2), "gflop_per_task": round(f["flops"] / n / 1e9, 3),
                     "mb_per_task": round(f["bytes"] / n / 1e6, 2), "silu_mevals_per_task": round(f["silu"] / n / 1e6, 2),
                     "floor_us_per_task": round(fl_us, 1), "x_floor": round(us / fl_us, 2) if fl_us > 0 else None,
-                    "floor_simd_us_per_task": round(fs_us, 1), "x_floor_simd": round(us / fs_us, 2) if fs_us > 0 else None,
-                    "kernels": sorted(set(f["kernels"]))})
+                    "floor_simd_us_per_task": round(fs_us, 1), "x_floor_simd": round(us / fs_us, 2) if fs_us > 0 else None})
     return {"families": out,
             "task_kernel_ms_serial": tot_us / 1e3,  # sum of the per-launch durations of one task with every kernel running alone
             "task_floor_ms": tot_floor / 1e3, "whole_task_frac_of_floor": tot_floor / 1e3 / ms_per_step,
             "task_floor_simd_ms": tot_simd / 1e3, "whole_task_frac_of_floor_simd": tot_simd / 1e3 / ms_per_step,
-            "floor_definition": "per launch max(algorithmic bytes / 6.3e12 B/s, algorithmic FLOP / 157.3e12 FLOP/s), summed; "
-                                "floor_simd adds SiLU evaluations / 5.93e12 per s (11.06 ns of a SIMD per 64, "
-                                "profiles/r03_valu_probe.txt) to the matrix time before the max; whole_task_frac = floor / the "
-                                "TIMED step (two-stream overlap on)"}
+            "floor_definition": "sum over launches of max(bytes / 6.3e12, FLOP / 157.3e12); floor_simd: SiLU evaluations / 5.93e12 per s "
+                                "added to the matrix time (DESIGN.md section 7); frac = floor / TIMED step"}
 
 
 def lite_train_block(args, device, lib, tasks, ckpt, steps=10, warmup=8):
@@ -563,9 +555,8 @@ def lite_train_block(args, device, lib, tasks, ckpt, steps=10, warmup=8):
     fams = family_table(rows, prof_steps, 1e3 * elapsed / steps)
     return {"ms_per_step": 1e3 * elapsed / steps, "steps": steps, "warmup": warmup,
             "query_frames_per_s": NUM_QUERY * steps / elapsed,
-            "step": "one task through Learner.train_task_with_lite (200 support + 200 query frames of 224x224, H = %d, "
-                    "batch_size %d: cache pass + H-subset pass + taped query pass, backward, fused Adam), one optimizer step per "
-                    "task, train-mode BatchNorm" % (NUM_LITE, args.batch_size),
+            "step": "one task through train_task_with_lite (200 + 200 frames, H = %d: cache, H-subset and taped query pass, backward, "
+                    "fused Adam), one optimizer step per task" % NUM_LITE,
             "host_enqueue_ms_per_step": 1e3 * issued / steps,
             "train_loss_per_step": losses,
             # calls of the native training entry points INSIDE the timed steps: replayed from captured HIP graphs / run eagerly
@@ -580,8 +571,10 @@ def lite_train_block(args, device, lib, tasks, ckpt, steps=10, warmup=8):
                          "kernel_time_share": conv_ms / (1e3 * prof_elapsed),
                          "measured": "per-launch HIP events over %d further steps, the three forward passes serial, graphs "
                                      "bypassed (%.1f ms/step)" % (prof_steps, 1e3 * prof_elapsed / prof_steps),
-                         "variants": variants},
-            "instrumented_families": fams["families"]}
+                         "variants_in": "python bench.py --mode lite_train (same kernels, per-variant rows)"},
+            # (the step's kernels that carry event records: the MFMA families, depthwise, gates, head - not its elementwise passes)
+            "instrumented_families": [{k: f[k] for k in ("family", "launches_per_task", "us_per_task", "floor_us_per_task", "x_floor")}
+                                      for f in fams["families"] if f["family"] != "other"]}
 
 
 def pmc_traffic(workload_tag):
@@ -1089,7 +1082,7 @@ def main():
                      "measured": "per-launch HIP events on the launch stream over a repeat of the %d timed steps with the "
                                  "support/query overlap switched off, so every kernel runs alone (instrumented repeat took "
                                  "%.1f ms/step)" % (args.steps, 1e3 * elapsed_prof / args.steps),
-                     "variants": variants, "other_profiled_kernels": other,
+                     "variants": variants,  # (the kernels outside this family: `families` below)
                      # round 6: every kernel family of the task against its own floor
                      "families": fam["families"], "task_kernel_ms_serial": fam["task_kernel_ms_serial"],
                      "task_floor_ms": fam["task_floor_ms"], "whole_task_frac_of_floor": fam["whole_task_frac_of_floor"],
